@@ -1,0 +1,78 @@
+"""ctypes binding of libdispu_hip.so (the C ABI declared in include/dispu_hip.h).
+
+There is NO CPU fallback: if the library is missing or a call fails, the op raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libdispu_hip.so")
+
+ARITH_PLAIN = 0
+ARITH_CONTRACT = 1
+
+_vp, _i, _sz = C.c_void_p, C.c_int, C.c_size_t
+
+# name -> (restype, argtypes); must list every symbol of include/dispu_hip.h (tests check this)
+SIGNATURES = {
+    "dispu_version": (_i, []),
+    "dispu_error_string": (C.c_char_p, [_i]),
+    "dispu_fps_scratch_bytes": (_sz, [_i, _i, _i]),
+    "dispu_fps": (_i, [_i, _i, _i, _vp, _vp, _vp, _i, _vp]),
+    "dispu_gather_point": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp]),
+    "dispu_gather_point_grad": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp]),
+    "dispu_query_ball": (_i, [_i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp]),
+    "dispu_group_point": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "dispu_group_point_grad": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "dispu_knn_point": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "dispu_knn_feat": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "dispu_knn_xyz": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp]),
+    "dispu_three_nn": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp]),
+    "dispu_three_interpolate": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "dispu_three_interpolate_grad": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "dispu_nn_distance": (_i, [_i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
+    "dispu_nn_distance_grad": (_i, [_i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "dispu_approx_match_scratch_bytes": (_sz, [_i, _i, _i]),
+    "dispu_approx_match": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp]),
+    "dispu_match_cost": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp]),
+    "dispu_match_cost_grad": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
+}
+
+_LIB = None
+
+
+class DispuError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libdispu_hip.so (after torch, so both share one HIP runtime).  Raises if absent."""
+    global _LIB
+    if _LIB is None:
+        import torch  # noqa: F401  -- must come first: the runtime torch loaded is reused by soname
+        if not os.path.exists(LIB_PATH):
+            raise DispuError(
+                "libdispu_hip.so not found at %s -- build it with `python dis-pu_amd/build.py` "
+                "(there is no CPU fallback for the dis-pu_amd ops)" % LIB_PATH)
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)
+            fn.restype = res
+            fn.argtypes = args
+        _LIB = l
+    return _LIB
+
+
+def check(code, what):
+    if code != 0:
+        msg = lib().dispu_error_string(code)
+        raise DispuError("%s failed: hip error %d (%s)" % (what, code, msg.decode() if msg else "?"))
+
+
+def stream_ptr(device=None):
+    import torch
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)

@@ -1,0 +1,80 @@
+// Shared device helpers for libdispu_hip.so (gfx950 / CDNA4 only, wave64).
+// Compiled with -ffp-contract=off: every fused multiply-add in this library is an explicit
+// __builtin_fmaf, so the arithmetic is pinned (see DESIGN.md "Pinned arithmetic").
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define DISPU_EXPORT extern "C" __attribute__((visibility("default")))
+
+// Arithmetic flavour flags shared with include/dispu_hip.h
+#define DISPU_ARITH_PLAIN 0     // ((dx*dx + dy*dy) + dz*dz): the reference's CPU functions
+#define DISPU_ARITH_CONTRACT 1  // fmaf(dz,dz, fmaf(dx,dx, dy*dy)): nvcc-contracted GPU kernels
+
+#define DISPU_CHECK_LAUNCH()                         \
+    do {                                             \
+        hipError_t e__ = hipGetLastError();          \
+        if (e__ != hipSuccess) return (int)e__;      \
+    } while (0)
+
+#define DISPU_TRY(expr)                              \
+    do {                                             \
+        hipError_t e__ = (expr);                     \
+        if (e__ != hipSuccess) return (int)e__;      \
+    } while (0)
+
+namespace dispu {
+
+constexpr int kWave = 64;
+
+template <bool FMA>
+__device__ __forceinline__ float sqdist3(float dx, float dy, float dz) {
+    if constexpr (FMA) {
+        return __builtin_fmaf(dz, dz, __builtin_fmaf(dx, dx, dy * dy));
+    } else {
+        const float s = dx * dx + dy * dy;
+        return s + dz * dz;
+    }
+}
+
+// ---- DPP wave64 reductions (result valid in lane 63; use readlane to broadcast) ---------------
+// row_shr:1,2,4,8 leave each 16-lane row's reduction in its lane 15; row_bcast:15 / :31 fold the
+// four rows into lane 63.  `old` (identity) fills lanes that have no DPP source.
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ uint32_t dpp_u32(uint32_t identity, uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)identity, (int)v, CTRL, ROW_MASK, 0xF, false);
+}
+
+constexpr int DPP_ROW_SHR1 = 0x111, DPP_ROW_SHR2 = 0x112, DPP_ROW_SHR4 = 0x114, DPP_ROW_SHR8 = 0x118,
+              DPP_ROW_BCAST15 = 0x142, DPP_ROW_BCAST31 = 0x143;
+
+__device__ __forceinline__ uint64_t u64_max(uint64_t a, uint64_t b) { return a > b ? a : b; }
+
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ uint64_t dpp_step_max_u64(uint64_t v) {
+    const uint32_t hi = dpp_u32<CTRL, ROW_MASK>(0u, (uint32_t)(v >> 32));
+    const uint32_t lo = dpp_u32<CTRL, ROW_MASK>(0u, (uint32_t)v);
+    return u64_max(v, ((uint64_t)hi << 32) | lo);
+}
+
+// Wave-wide maximum of an unsigned 64-bit key, returned wave-uniform (in SGPRs).
+__device__ __forceinline__ uint64_t wave_max_u64(uint64_t v) {
+    v = dpp_step_max_u64<DPP_ROW_SHR1>(v);
+    v = dpp_step_max_u64<DPP_ROW_SHR2>(v);
+    v = dpp_step_max_u64<DPP_ROW_SHR4>(v);
+    v = dpp_step_max_u64<DPP_ROW_SHR8>(v);
+    v = dpp_step_max_u64<DPP_ROW_BCAST15, 0xA>(v);
+    v = dpp_step_max_u64<DPP_ROW_BCAST31, 0xC>(v);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), 63);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, 63);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+__device__ __forceinline__ float wave_sum_f32(float v) {
+    // butterfly; order fixed (xor 32,16,8,4,2,1) so the result is deterministic
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+}  // namespace dispu

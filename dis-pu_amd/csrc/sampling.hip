@@ -1,0 +1,219 @@
+// Farthest point sampling, gather_point and its gradient for gfx950.
+// Replaces the launchers of tf_ops/sampling/tf_sampling_g.cu:194-211 (reference) behind
+// dispu_fps / dispu_gather_point / dispu_gather_point_grad (include/dispu_hip.h).
+//
+// FPS design (MI355X): one workgroup per cloud, the cloud's coordinates AND the running
+// min-distance array live in VGPRs for the whole kernel (the reference round-trips `temp`
+// through global memory every round and keeps 3072 points in shared memory).  A round is
+//   P x (3 sub, mul, 2 fma, min, 64-bit key compare)  ->  DPP wave arg-max  ->  one LDS slot per
+//   wave, ONE barrier (double-buffered slots)  ->  scalar load of the winner's coordinates.
+// The reference's winner rule (max d, ties -> lowest k mod 512, then lowest k; see
+// tf_sampling_g.cu:146,158) is reproduced arithmetically with a 64-bit key
+//   key = float_bits(d) << 32 | (0xFFFFFFFF - ((k & 511) << 22 | k >> 9))
+// whose unsigned maximum is exactly that winner, independent of this kernel's thread layout.
+#include "common.h"
+
+namespace dispu {
+
+__device__ __forceinline__ uint32_t fps_tiekey(int k) {
+    return 0xFFFFFFFFu - ((((uint32_t)k & 511u) << 22) | ((uint32_t)k >> 9));
+}
+__device__ __forceinline__ int fps_key_to_index(uint64_t key) {
+    const uint32_t t = 0xFFFFFFFFu - (uint32_t)key;
+    return (int)(((t & 0x3FFFFFu) << 9) | (t >> 22));
+}
+
+// Visit order of a thread's P points such that the reference tie priority (k mod 512, then k) is
+// non-decreasing along the visit: then a strict '>' update keeps exactly the reference's winner
+// among equal distances inside the thread, and the 64-bit key is only built once per round.
+//   BS = 64  (P <= 8):  k = tid + 64 i < 512          -> natural order
+//   BS = 256 (P <= 8):  k mod 512 alternates tid / tid+256 -> even i first, then odd i
+//   BS = 1024:          k mod 512 is the same for all i    -> natural order
+template <int BS, int P>
+__device__ __forceinline__ constexpr int fps_visit(int s) {
+    if (BS == 256 && P > 2) return (s < P / 2) ? 2 * s : 2 * (s - P / 2) + 1;
+    return s;
+}
+
+// BS threads, P points per thread (thread t owns k = t + i*BS), FMA = arithmetic flavour.
+template <int BS, int P, bool FMA>
+__global__ __launch_bounds__(BS) void fps_reg_kernel(int n, int m, const float* __restrict__ xyz,
+                                                      int* __restrict__ out) {
+    static_assert(BS == 64 || BS == 256 || BS == 1024, "visit order is derived for these block sizes");
+    static_assert(BS != 64 || P <= 8, "BS=64 needs k < 512");
+    constexpr int W = BS / kWave;
+    __shared__ uint64_t slot[2][W > 1 ? W : 1];
+    const int cloud = blockIdx.x;
+    const float* __restrict__ p = xyz + (size_t)cloud * n * 3;
+    int* __restrict__ o = out + (size_t)cloud * m;
+    const int tid = threadIdx.x;
+
+    float x[P], y[P], z[P], td[P];
+#pragma unroll
+    for (int i = 0; i < P; ++i) {
+        const int k = tid + i * BS;
+        const bool ok = k < n;
+        x[i] = ok ? p[k * 3 + 0] : 0.f;
+        y[i] = ok ? p[k * 3 + 1] : 0.f;
+        z[i] = ok ? p[k * 3 + 2] : 0.f;
+        td[i] = ok ? 1e38f : -1.0f;  // -1 never beats the initial best of -1: "no point here"
+    }
+    if (tid == 0) o[0] = 0;
+    int old = 0;
+    for (int j = 1; j < m; ++j) {
+        const int so = __builtin_amdgcn_readfirstlane(old);
+        const float x1 = p[so * 3 + 0], y1 = p[so * 3 + 1], z1 = p[so * 3 + 2];
+        float bd = -1.0f;
+        int bi = 0;
+#pragma unroll
+        for (int s = 0; s < P; ++s) {
+            const int i = fps_visit<BS, P>(s);
+            const float d = sqdist3<FMA>(x[i] - x1, y[i] - y1, z[i] - z1);
+            const float d2 = fminf(d, td[i]);
+            td[i] = d2;
+            if (d2 > bd) { bd = d2; bi = i; }
+        }
+        uint64_t best = (bd < 0.f) ? 0ull : (((uint64_t)__float_as_uint(bd) << 32) | fps_tiekey(tid + bi * BS));
+        best = wave_max_u64(best);
+        if constexpr (W > 1) {
+            const int par = j & 1;
+            if ((tid & (kWave - 1)) == 0) slot[par][tid / kWave] = best;
+            __syncthreads();
+#pragma unroll
+            for (int w = 0; w < W; ++w) best = u64_max(best, slot[par][w]);
+        }
+        old = fps_key_to_index(best);
+        if (tid == 0) o[j] = old;
+    }
+}
+
+// Fallback for clouds that do not fit the register-resident variants: running distances in
+// caller scratch `temp` [b,n] (same role as the reference's temp, tf_sampling.cpp:115).
+template <bool FMA>
+__global__ __launch_bounds__(1024) void fps_mem_kernel(int n, int m, const float* __restrict__ xyz,
+                                                        float* __restrict__ temp, int* __restrict__ out) {
+    constexpr int BS = 1024, W = BS / kWave;
+    __shared__ uint64_t slot[2][W];
+    const int cloud = blockIdx.x;
+    const float* __restrict__ p = xyz + (size_t)cloud * n * 3;
+    float* __restrict__ t = temp + (size_t)cloud * n;
+    int* __restrict__ o = out + (size_t)cloud * m;
+    const int tid = threadIdx.x;
+    for (int k = tid; k < n; k += BS) t[k] = 1e38f;
+    if (tid == 0) o[0] = 0;
+    int old = 0;
+    for (int j = 1; j < m; ++j) {
+        const int so = __builtin_amdgcn_readfirstlane(old);
+        const float x1 = p[so * 3 + 0], y1 = p[so * 3 + 1], z1 = p[so * 3 + 2];
+        float bd = -1.0f;
+        int bk = 0;
+        for (int k = tid; k < n; k += BS) {  // k mod 512 is constant per thread: ascending k == tie priority
+            const float d = sqdist3<FMA>(p[k * 3 + 0] - x1, p[k * 3 + 1] - y1, p[k * 3 + 2] - z1);
+            const float d2 = fminf(d, t[k]);
+            t[k] = d2;
+            if (d2 > bd) { bd = d2; bk = k; }
+        }
+        uint64_t best = (bd < 0.f) ? 0ull : (((uint64_t)__float_as_uint(bd) << 32) | fps_tiekey(bk));
+        best = wave_max_u64(best);
+        const int par = j & 1;
+        if ((tid & (kWave - 1)) == 0) slot[par][tid / kWave] = best;
+        __syncthreads();
+#pragma unroll
+        for (int w = 0; w < W; ++w) best = u64_max(best, slot[par][w]);
+        old = fps_key_to_index(best);
+        if (tid == 0) o[j] = old;
+    }
+}
+
+template <int BS, int P>
+static int launch_fps_reg(int b, int n, int m, const float* xyz, int* out, int arith, hipStream_t s) {
+    if (arith == DISPU_ARITH_CONTRACT)
+        hipLaunchKernelGGL((fps_reg_kernel<BS, P, true>), dim3(b), dim3(BS), 0, s, n, m, xyz, out);
+    else
+        hipLaunchKernelGGL((fps_reg_kernel<BS, P, false>), dim3(b), dim3(BS), 0, s, n, m, xyz, out);
+    return (int)hipGetLastError();
+}
+
+// out[i,j,:] = inp[i, idx[i,j], :]   (c == 3, like the reference kernel tf_sampling_g.cu:172-181)
+__global__ void gather_point_kernel(int n, int m, size_t total, const float* __restrict__ inp,
+                                    const int* __restrict__ idx, float* __restrict__ out) {
+    for (size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x; r < total; r += (size_t)gridDim.x * blockDim.x) {
+        const size_t cloud = r / m;
+        const float* src = inp + (cloud * n + idx[r]) * 3;
+        const float a = src[0], b = src[1], c = src[2];
+        float* dst = out + r * 3;
+        dst[0] = a; dst[1] = b; dst[2] = c;
+    }
+}
+
+// inp_g[i, idx[i,j], :] += out_g[i,j,:]  on a zero-filled buffer (tf_sampling_g.cu:183-192, tf_sampling.cpp:174)
+__global__ void gather_point_grad_kernel(int n, int m, size_t total, const float* __restrict__ out_g,
+                                         const int* __restrict__ idx, float* __restrict__ inp_g) {
+    for (size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x; r < total; r += (size_t)gridDim.x * blockDim.x) {
+        const size_t cloud = r / m;
+        float* dst = inp_g + (cloud * n + idx[r]) * 3;
+        const float* src = out_g + r * 3;
+        unsafeAtomicAdd(dst + 0, src[0]);
+        unsafeAtomicAdd(dst + 1, src[1]);
+        unsafeAtomicAdd(dst + 2, src[2]);
+    }
+}
+
+}  // namespace dispu
+
+using namespace dispu;
+
+DISPU_EXPORT size_t dispu_fps_scratch_bytes(int b, int n, int m) {
+    (void)m;
+    return n > 24576 ? (size_t)b * n * sizeof(float) : 0;
+}
+
+DISPU_EXPORT int dispu_fps(int b, int n, int m, const float* inp, float* temp, int* out, int arith, void* stream) {
+    if (b < 0 || n <= 0 || m <= 0 || !inp || !out) return (int)hipErrorInvalidValue;
+    if (b == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    if (n <= 64) return launch_fps_reg<64, 1>(b, n, m, inp, out, arith, s);
+    if (n <= 128) return launch_fps_reg<64, 2>(b, n, m, inp, out, arith, s);
+    if (n <= 256) return launch_fps_reg<64, 4>(b, n, m, inp, out, arith, s);
+    if (n <= 512) return launch_fps_reg<256, 2>(b, n, m, inp, out, arith, s);
+    if (n <= 1024) return launch_fps_reg<256, 4>(b, n, m, inp, out, arith, s);
+    if (n <= 2048) return launch_fps_reg<256, 8>(b, n, m, inp, out, arith, s);
+    if (n <= 4096) return launch_fps_reg<1024, 4>(b, n, m, inp, out, arith, s);
+    if (n <= 8192) return launch_fps_reg<1024, 8>(b, n, m, inp, out, arith, s);
+    if (n <= 16384) return launch_fps_reg<1024, 16>(b, n, m, inp, out, arith, s);
+    if (n <= 24576) return launch_fps_reg<1024, 24>(b, n, m, inp, out, arith, s);
+    if (!temp) return (int)hipErrorInvalidValue;
+    if (arith == DISPU_ARITH_CONTRACT)
+        hipLaunchKernelGGL((fps_mem_kernel<true>), dim3(b), dim3(1024), 0, s, n, m, inp, temp, out);
+    else
+        hipLaunchKernelGGL((fps_mem_kernel<false>), dim3(b), dim3(1024), 0, s, n, m, inp, temp, out);
+    return (int)hipGetLastError();
+}
+
+static inline int grid_for(size_t total, int bs) {
+    size_t g = (total + bs - 1) / bs;
+    if (g > 8192) g = 8192;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+DISPU_EXPORT int dispu_gather_point(int b, int n, int m, const float* inp, const int* idx, float* out, void* stream) {
+    if (b < 0 || n <= 0 || m < 0) return (int)hipErrorInvalidValue;
+    const size_t total = (size_t)b * m;
+    if (total == 0) return 0;
+    hipLaunchKernelGGL(gather_point_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, n, m, total,
+                       inp, idx, out);
+    return (int)hipGetLastError();
+}
+
+DISPU_EXPORT int dispu_gather_point_grad(int b, int n, int m, const float* out_g, const int* idx, float* inp_g,
+                                         void* stream) {
+    if (b < 0 || n <= 0 || m < 0) return (int)hipErrorInvalidValue;
+    hipStream_t s = (hipStream_t)stream;
+    if ((size_t)b * n) DISPU_TRY(hipMemsetAsync(inp_g, 0, sizeof(float) * (size_t)b * n * 3, s));
+    const size_t total = (size_t)b * m;
+    if (total == 0) return 0;
+    hipLaunchKernelGGL(gather_point_grad_kernel, dim3(grid_for(total, 256)), dim3(256), 0, s, n, m, total, out_g, idx,
+                       inp_g);
+    return (int)hipGetLastError();
+}

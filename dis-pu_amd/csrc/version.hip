@@ -1,0 +1,5 @@
+// Version / error-string entry points of libdispu_hip.so.
+#include "common.h"
+
+DISPU_EXPORT int dispu_version(void) { return 1; }
+DISPU_EXPORT const char* dispu_error_string(int code) { return hipGetErrorString((hipError_t)code); }

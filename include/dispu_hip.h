@@ -1,0 +1,135 @@
+/*
+ * dispu_hip.h -- C ABI of libdispu_hip.so, the MI355X (gfx950) implementation of the Dis-PU
+ * point-sampling / grouping / distance hot path.
+ *
+ * This is the drop-in boundary: every entry point below replaces one plain-pointer "Launcher"
+ * that the reference's TensorFlow op kernels call from Compute() (or, for the three CPU-only
+ * ops and the nanoflann k-NN, the CPU function itself).  The reference interface each one
+ * replaces is cited as file:line in the upstream tree (liruihui/Dis-PU).
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes; no torch / TF types.
+ *   - every pointer is a DEVICE pointer owned by the caller; the library never allocates.
+ *     Scratch is passed in; `*_scratch_bytes` tells how much an op needs (0 = none).
+ *   - row-major fp32 data, int32 indices; clouds are AoS [b, n, 3].
+ *   - the last argument is the hipStream_t to launch on (as void*; NULL = default stream);
+ *     launches are asynchronous w.r.t. the host, exactly like the reference launchers.
+ *   - return value: 0 (hipSuccess) or the hipError_t code of the failing call.  The reference
+ *     launchers return void and never check errors (tf_sampling_g.cu:194-211).
+ *   - gradient entry points zero-fill their outputs first (the reference ops do the memset
+ *     before calling the launcher: tf_sampling.cpp:174, tf_grouping.cpp:208,
+ *     tf_nndistance_g.cu:153-154).
+ *   - `arith` selects the pinned floating-point flavour of d2 = dx*dx + dy*dy + dz*dz:
+ *       DISPU_ARITH_PLAIN    ((dx*dx + dy*dy) + dz*dz)             the reference's CPU functions
+ *       DISPU_ARITH_CONTRACT fmaf(dz,dz, fmaf(dx,dx, dy*dy))       nvcc-contracted GPU kernels
+ *     Index results are identical between the two except on near-ties.
+ */
+#ifndef DISPU_HIP_H
+#define DISPU_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DISPU_ARITH_PLAIN 0
+#define DISPU_ARITH_CONTRACT 1
+
+/* Library / ABI version (1 = round 1). */
+int dispu_version(void);
+/* hipGetErrorString for the codes returned below. */
+const char* dispu_error_string(int code);
+
+/* ---- tf_ops/sampling ------------------------------------------------------------------------ */
+
+/* farthestpointsamplingLauncher(b,n,m,inp,temp,out)   tf_ops/sampling/tf_sampling.cpp:94,118;
+ * kernel tf_sampling_g.cu:105-170.  out[b,m] int32; out[:,0] = 0.  `temp` ([b,n] floats) is only
+ * touched when n > 24576 (dispu_fps_scratch_bytes says how much); pass NULL otherwise. */
+size_t dispu_fps_scratch_bytes(int b, int n, int m);
+int dispu_fps(int b, int n, int m, const float* inp, float* temp, int* out, int arith, void* stream);
+
+/* gatherpointLauncher(b,n,m,inp,idx,out)   tf_sampling.cpp:125; kernel tf_sampling_g.cu:172-181. */
+int dispu_gather_point(int b, int n, int m, const float* inp, const int* idx, float* out, void* stream);
+
+/* scatteraddpointLauncher(b,n,m,out_g,idx,inp_g)   tf_sampling.cpp:150,174; kernel :183-192. */
+int dispu_gather_point_grad(int b, int n, int m, const float* out_g, const int* idx, float* inp_g, void* stream);
+
+/* ---- tf_ops/grouping ------------------------------------------------------------------------ */
+
+/* queryBallPointLauncher(b,n,m,radius,nsample,xyz1,xyz2,idx,pts_cnt)   tf_ops/grouping/tf_grouping.cpp:67;
+ * kernel tf_grouping_g.cu:3-36.  radius is a device pointer; only radius[0] is read.  Rows of idx
+ * whose query has no neighbour are left untouched (reference behaviour). */
+int dispu_query_ball(int b, int n, int m, const float* radius, int nsample, const float* xyz1, const float* xyz2,
+                     int* idx, int* pts_cnt, int arith, void* stream);
+
+/* groupPointLauncher(b,n,c,m,nsample,points,idx,out)   tf_grouping.cpp:146; kernel tf_grouping_g.cu:40-57. */
+int dispu_group_point(int b, int n, int c, int m, int nsample, const float* points, const int* idx, float* out,
+                      void* stream);
+
+/* groupPointGradLauncher(b,n,c,m,nsample,grad_out,idx,grad_points)   tf_grouping.cpp:177,208; kernel :61-78. */
+int dispu_group_point_grad(int b, int n, int c, int m, int nsample, const float* grad_out, const int* idx,
+                           float* grad_points, void* stream);
+
+/* tf_grouping.knn_point(k, xyz1[b,n,c], xyz2[b,m,c]) -> (val = -d2 [b,m,k], idx [b,m,k])
+ * tf_ops/grouping/tf_grouping.py:116-141 (pure TF: broadcast-subtract, reduce_sum, top_k).  k <= 32, c <= 128. */
+int dispu_knn_point(int b, int n, int m, int c, int k, const float* xyz1, const float* xyz2, float* val, int* idx,
+                    void* stream);
+
+/* tf_grouping.knn_point_2(k, points[b,n,c], queries[b,m,c]) -> (dist [b,m,k] = +D, idx [b,m,k])
+ * tf_grouping.py:61-66,95-114 (D = rA - 2 A.B^T + rB; top_k(-D)).  The (batch,point) pair tensor of
+ * the reference is assembled by the Python shim.  dist may be NULL.  k <= 32, c <= 128. */
+int dispu_knn_feat(int b, int n, int m, int c, int k, const float* points, const float* queries, float* dist,
+                   int* idx, void* stream);
+
+/* ---- libs/nearest_neighbors ----------------------------------------------------------------- */
+
+/* cpp_knn_batch_omp(batch_data,batch_size,npts,dim=3,queries,nqueries,K,indices)
+ * libs/nearest_neighbors/knn_.cxx:104-135 (nanoflann KD-tree on the host, int64 output).  Device-side
+ * exact brute force; idx int32 [b,m,k] ascending distance, ties -> lower index; dist (squared, may be
+ * NULL).  k <= 32 and k <= n. */
+int dispu_knn_xyz(int b, int n, int m, int k, const float* support, const float* query, int* idx, float* dist,
+                  int arith, void* stream);
+
+/* ---- tf_ops/interpolation (CPU-only ops in the reference) ------------------------------------- */
+
+/* threenn_cpu(b,n,m,xyz1,xyz2,dist,idx)   tf_ops/interpolation/tf_interpolate.cpp:60-103. */
+int dispu_three_nn(int b, int n, int m, const float* xyz1, const float* xyz2, float* dist, int* idx, int arith,
+                   void* stream);
+/* threeinterpolate_cpu(b,m,c,n,points,idx,weight,out)   tf_interpolate.cpp:107-127. */
+int dispu_three_interpolate(int b, int m, int c, int n, const float* points, const int* idx, const float* weight,
+                            float* out, void* stream);
+/* threeinterpolate_grad_cpu(b,n,c,m,grad_out,idx,weight,grad_points)   tf_interpolate.cpp:131-153. */
+int dispu_three_interpolate_grad(int b, int n, int c, int m, const float* grad_out, const int* idx,
+                                 const float* weight, float* grad_points, void* stream);
+
+/* ---- tf_ops/nn_distance --------------------------------------------------------------------- */
+
+/* NmDistanceKernelLauncher(b,n,xyz,m,xyz2,result,result_i,result2,result2_i)
+ * tf_ops/nn_distance/tf_nndistance.cpp:168; kernel tf_nndistance_g.cu:5-131. */
+int dispu_nn_distance(int b, int n, const float* xyz1, int m, const float* xyz2, float* dist1, int* idx1, float* dist2,
+                      int* idx2, int arith, void* stream);
+/* NmDistanceGradKernelLauncher(b,n,xyz1,m,xyz2,grad_dist1,idx1,grad_dist2,idx2,grad_xyz1,grad_xyz2)
+ * tf_nndistance.cpp:208; kernel tf_nndistance_g.cu:132-157. */
+int dispu_nn_distance_grad(int b, int n, const float* xyz1, int m, const float* xyz2, const float* grad_dist1,
+                           const int* idx1, const float* grad_dist2, const int* idx2, float* grad_xyz1,
+                           float* grad_xyz2, void* stream);
+
+/* ---- tf_ops/approxmatch --------------------------------------------------------------------- */
+
+/* approxmatchLauncher(b,n,m,xyz1,xyz2,match,temp)   tf_ops/approxmatch/tf_approxmatch.cpp:141,164-170;
+ * kernel tf_approxmatch_g.cu:1-182.  match [b,m,n]; temp [b, 2*(n+m)] floats. */
+size_t dispu_approx_match_scratch_bytes(int b, int n, int m);
+int dispu_approx_match(int b, int n, int m, const float* xyz1, const float* xyz2, float* match, float* temp, int arith,
+                       void* stream);
+/* matchcostLauncher(b,n,m,xyz1,xyz2,match,out)   tf_approxmatch.cpp:142; kernel tf_approxmatch_g.cu:183-228. */
+int dispu_match_cost(int b, int n, int m, const float* xyz1, const float* xyz2, const float* match, float* cost,
+                     int arith, void* stream);
+/* matchcostgradLauncher(b,n,m,xyz1,xyz2,match,grad1,grad2)   tf_approxmatch.cpp:143; kernels :229-295. */
+int dispu_match_cost_grad(int b, int n, int m, const float* xyz1, const float* xyz2, const float* match, float* grad1,
+                          float* grad2, int arith, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DISPU_HIP_H */

@@ -1,0 +1,321 @@
+"""GPU parity tests (pytest -m gpu): every HIP op, called through the reference-named Python shims ->
+ctypes -> the C ABI of libdispu_hip.so, against (a) the golden vectors produced by the reference's own
+CPU functions, (b) the CPU oracle on seeded inputs.  Indices / gathers / plain-arithmetic distances are
+bit-exact; approxmatch & reductions use the stated tolerances."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+PLAIN, CONTRACT = 0, 1
+
+
+def T(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def N(t):
+    return t.detach().cpu().numpy()
+
+
+def g(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+@pytest.fixture(scope="module")
+def ops(dev):
+    import dispu_amd.tf_sampling as S
+    import dispu_amd.tf_grouping as G
+    import dispu_amd.tf_interpolate as I
+    import dispu_amd.tf_nndistance as D
+    import dispu_amd.tf_approxmatch as A
+    import dispu_amd.nearest_neighbors as K
+    from dispu_amd import _lib
+    _lib.lib()  # fail loudly here if the HIP library is missing
+    return dict(S=S, G=G, I=I, D=D, A=A, K=K)
+
+
+def synth_patches(b, n, seed):
+    from dispu_amd import synth
+    return synth.patches(b, n, seed=seed)
+
+
+# ---------------------------------------------------------------------------------- golden (reference) ----
+def test_nn_distance_vs_reference_golden(ops, dev, golden_dir):
+    z = g(golden_dir, "ref_nndistance.npz")
+    d1, i1, d2, i2 = ops["D"].nn_distance(T(z["xyz1"], dev), T(z["xyz2"], dev), arith=PLAIN)
+    assert np.array_equal(N(i1), z["idx1"]) and np.array_equal(N(i2), z["idx2"])
+    assert np.array_equal(N(d1), z["dist1"]) and np.array_equal(N(d2), z["dist2"])
+
+
+def test_interpolate_vs_reference_golden(ops, dev, golden_dir):
+    z = g(golden_dir, "ref_interpolate.npz")
+    d, i = ops["I"].three_nn(T(z["xyz1"], dev), T(z["xyz2"], dev))
+    assert np.array_equal(N(i), z["idx"]) and np.array_equal(N(d), z["dist"])
+    out = ops["I"].three_interpolate(T(z["points"], dev), T(z["idx"], dev), T(z["weight"], dev))
+    assert np.array_equal(N(out), z["out"])
+    gp = ops["I"].three_interpolate_grad(T(z["points"], dev), T(z["idx"], dev), T(z["weight"], dev), T(z["grad_out"], dev))
+    assert np.allclose(N(gp), z["grad_points"], rtol=1e-5, atol=1e-5)      # atomic order differs
+
+
+def test_grouping_vs_reference_golden(ops, dev, golden_dir):
+    z = g(golden_dir, "ref_grouping.npz")
+    idx, cnt = ops["G"].query_ball_point(float(z["radius"]), int(z["nsample"]), T(z["xyz1"], dev), T(z["xyz2"], dev), arith=PLAIN)
+    assert np.array_equal(N(idx), z["idx"])
+    out = ops["G"].group_point(T(z["points"], dev), T(z["idx"], dev))
+    assert np.array_equal(N(out), z["out"])
+    gp = ops["G"].group_point_grad(T(z["points"], dev), T(z["idx"], dev), T(z["grad_out"], dev))
+    assert np.allclose(N(gp), z["grad_points"], rtol=1e-5, atol=1e-5)
+
+
+def test_knn_vs_nanoflann_golden(ops, dev, golden_dir):
+    z = g(golden_dir, "ref_knn.npz")
+    k = int(z["k"])
+    s, q = T(z["support"], dev), T(z["query"], dev)
+    out = ops["K"].knn_batch(s, s, k, omp=True)
+    assert out.dtype == torch.int64 and np.array_equal(N(out).astype(np.int32), z["idx_self"])
+    assert np.array_equal(N(ops["K"].knn_batch(s, q, k)).astype(np.int32), z["idx_query"])
+    assert np.array_equal(N(ops["K"].knn_query(k, s, q)), z["idx_query"])
+
+
+def test_approxmatch_vs_golden(ops, dev, golden_dir):
+    z = g(golden_dir, "ref_approxmatch.npz")
+    x1, x2 = T(z["xyz1"], dev), T(z["xyz2"], dev)
+    m = ops["A"].approx_match(x1, x2)
+    mo = z["oracle_match"]
+    assert N(m).shape == mo.shape
+    assert np.allclose(N(m), mo, atol=2e-5)                                 # fast exp vs libm expf
+    assert np.allclose(N(m).sum(1), 1.0, atol=5e-5) and np.allclose(N(m).sum(2), 1.0, atol=5e-5)
+    cost = ops["A"].match_cost(x1, x2, m)
+    assert np.allclose(N(cost), z["ref_matchcost_on_oracle_match"], rtol=1e-5)    # north-star tolerance on EMD
+    cost_o = ops["A"].match_cost(x1, x2, T(mo, dev))
+    assert np.allclose(N(cost_o), z["ref_matchcost_on_oracle_match"], rtol=2e-6)
+    g1, g2 = ops["A"].match_cost_grad(x1, x2, T(mo, dev))
+    assert np.allclose(N(g1), z["ref_grad1_on_oracle_match"], atol=2e-5)
+    assert np.allclose(N(g2), z["ref_grad2_on_oracle_match"], atol=2e-5)
+
+
+def test_gpu_only_pins(ops, dev, golden_dir):
+    z = g(golden_dir, "oracle_gpu_only.npz")
+    f = T(z["fps_inp"], dev)
+    assert np.array_equal(N(ops["S"].farthest_point_sample(96, f)), z["fps_idx_contract"])
+    assert np.array_equal(N(ops["S"].farthest_point_sample(96, f, arith=PLAIN)), z["fps_idx_plain"])
+    d, i = ops["G"].knn_point_2(17, T(z["feat"], dev), T(z["feat"], dev))
+    assert np.array_equal(N(i)[..., 1], z["knn2_idx"]) and np.array_equal(N(i)[..., 0], np.broadcast_to(np.arange(2)[:, None, None], (2, 256, 17)))
+    assert np.array_equal(N(d), z["knn2_dist"])
+
+
+# ---------------------------------------------------------------------------------- oracle, seeded ----
+@pytest.mark.parametrize("b,n,m", [(1, 1, 1), (2, 3, 3), (3, 64, 17), (2, 255, 64), (4, 256, 64), (2, 511, 100),
+                                   (2, 512, 128), (2, 513, 128), (3, 1024, 384), (1, 2048, 24), (2, 3073, 40),
+                                   (1, 5000, 33), (1, 9000, 20), (1, 20000, 12), (1, 24576, 10), (1, 30000, 8)])
+@pytest.mark.parametrize("arith", [PLAIN, CONTRACT])
+def test_fps_index_exact(ops, dev, b, n, m, arith):
+    x = np.random.default_rng(n * 7 + m).random((b, n, 3)).astype(np.float32)
+    got = N(ops["S"].farthest_point_sample(m, T(x, dev), arith=arith))
+    assert np.array_equal(got, O.farthest_point_sample(m, x, contract=arith))
+
+
+def test_fps_ties_and_duplicates(ops, dev):
+    """Adversarial: grids (many exact ties), duplicated points, more samples than distinct points."""
+    gx = np.stack(np.meshgrid(np.arange(10), np.arange(10), np.arange(7), indexing="ij"), -1).reshape(1, -1, 3).astype(np.float32)
+    for m in (5, 64, 700):
+        assert np.array_equal(N(ops["S"].farthest_point_sample(m, T(gx, dev))), O.farthest_point_sample(m, gx))
+    dup = np.repeat(np.random.default_rng(0).random((2, 150, 3)).astype(np.float32), 5, axis=1)   # n = 750
+    assert np.array_equal(N(ops["S"].farthest_point_sample(200, T(dup, dev))), O.farthest_point_sample(200, dup))
+    big = np.zeros((1, 1300, 3), np.float32)
+    big[0, [3, 515, 1027, 600], 1] = 2.0
+    assert np.array_equal(N(ops["S"].farthest_point_sample(6, T(big, dev))), O.farthest_point_sample(6, big))
+
+
+def test_gather_point_and_grad(ops, dev):
+    rng = np.random.default_rng(5)
+    inp = rng.standard_normal((3, 300, 3)).astype(np.float32)
+    idx = rng.integers(0, 300, (3, 1000)).astype(np.int32)
+    assert np.array_equal(N(ops["S"].gather_point(T(inp, dev), T(idx, dev))), O.gather_point(inp, idx))
+    og = rng.standard_normal((3, 1000, 3)).astype(np.float32)
+    got = N(ops["S"].gather_point_grad(T(inp, dev), T(idx, dev), T(og, dev)))
+    assert np.allclose(got, O.gather_point_grad(inp, idx, og), rtol=1e-5, atol=1e-5)
+    # autograd wiring == registered gradient (tf_sampling.py:43-47)
+    ti = T(inp, dev).requires_grad_(True)
+    ops["S"].gather_point(ti, T(idx, dev)).backward(T(og, dev))
+    assert np.allclose(N(ti.grad), got, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("arith", [PLAIN, CONTRACT])
+@pytest.mark.parametrize("b,n,m,r,ns", [(2, 1024, 1024, 0.07, 20), (3, 1500, 300, 0.2, 32), (1, 5, 7, 0.5, 4), (2, 2500, 64, 0.1, 64)])
+def test_query_ball_index_exact(ops, dev, b, n, m, r, ns, arith):
+    x = synth_patches(b, n, seed=n)
+    q = x[:, :m] if m <= n else np.concatenate([x, x[:, : m - n]], 1)
+    idx, cnt = ops["G"].query_ball_point(r, ns, T(x, dev), T(q, dev), arith=arith)
+    oi, oc = O.query_ball_point(r, ns, x, q, contract=arith)
+    assert np.array_equal(N(cnt), oc) and np.array_equal(N(idx), oi)
+
+
+def test_query_ball_no_hit_rows_and_radius_tensor(ops, dev):
+    x = np.random.default_rng(1).random((2, 50, 3)).astype(np.float32)
+    q = x[:, :9] + 100.0
+    idx, cnt = ops["G"].query_ball_point(torch.tensor([0.3, 9999.0], device=dev), 5, T(x, dev), T(q, dev))
+    assert (N(cnt) == 0).all() and (N(idx) == 0).all()      # only radius[0] is read: cloud 1 also finds nothing
+
+
+@pytest.mark.parametrize("c", [1, 3, 4, 7, 16, 64, 128, 134])
+def test_group_point_bit_exact(ops, dev, c):
+    rng = np.random.default_rng(c)
+    pts = rng.standard_normal((3, 257, c)).astype(np.float32)
+    idx = rng.integers(0, 257, (3, 100, 16)).astype(np.int32)
+    assert np.array_equal(N(ops["G"].group_point(T(pts, dev), T(idx, dev))), O.group_point(pts, idx))
+    go = rng.standard_normal((3, 100, 16, c)).astype(np.float32)
+    assert np.allclose(N(ops["G"].group_point_grad(T(pts, dev), T(idx, dev), T(go, dev))), O.group_point_grad(pts, idx, go),
+                       rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("b,n,m,k", [(2, 1024, 1024, 16), (3, 300, 77, 8), (1, 40, 40, 32), (2, 2500, 130, 20), (1, 5, 5, 5), (2, 64, 64, 1)])
+def test_knn_xyz_index_exact(ops, dev, b, n, m, k):
+    s = synth_patches(b, n, seed=k)
+    q = s[:, :m] if m <= n else synth_patches(b, m, seed=k + 1)
+    idx, dist = ops["K"].knn_batch(T(s, dev), T(q, dev), k, return_dist=True)
+    oi, od = O.knn_batch(s, q, k, return_dist=True)
+    assert np.array_equal(N(idx), oi) and np.array_equal(N(dist), od)
+
+
+def test_knn_xyz_ties_lower_index_first(ops, dev):
+    s = np.zeros((1, 100, 3), np.float32)
+    s[0, 50:, 0] = 1.0
+    idx = N(ops["K"].knn_batch(T(s, dev), T(s[:, :1], dev), 8))
+    assert idx[0, 0].tolist() == list(range(8))
+
+
+@pytest.mark.parametrize("c,k", [(3, 5), (3, 16), (24, 17), (48, 17), (64, 20), (5, 3), (128, 32)])
+def test_knn_point_variants(ops, dev, c, k):
+    rng = np.random.default_rng(c * 31 + k)
+    a = rng.standard_normal((2, 256, c)).astype(np.float32)
+    q = rng.standard_normal((2, 90, c)).astype(np.float32)
+    val, idx = ops["G"].knn_point(k, T(a, dev), T(q, dev))
+    ov, oi = O.knn_point(k, a, q)
+    assert np.array_equal(N(idx), oi) and np.array_equal(N(val), ov)
+    assert (N(val) <= 0).all()                                            # NEGATIVE squared distances
+    d2, i2 = ops["G"].knn_point_2(k, T(a, dev), T(q, dev))
+    od, oi2 = O.knn_point_2(k, a, q)
+    assert np.array_equal(N(i2), oi2) and np.array_equal(N(d2), od)
+
+
+@pytest.mark.parametrize("arith", [PLAIN, CONTRACT])
+@pytest.mark.parametrize("b,n,m", [(2, 1024, 384), (3, 384, 128), (2, 128, 1), (1, 2, 2), (2, 1500, 2500)])
+def test_three_nn_exact(ops, dev, b, n, m, arith):
+    x1, x2 = synth_patches(b, n, seed=n + 1), synth_patches(b, m, seed=m + 2)
+    d, i = ops["I"].three_nn(T(x1, dev), T(x2, dev), arith=arith)
+    od, oi = O.three_nn(x1, x2, contract=arith)
+    assert np.array_equal(N(i), oi) and np.array_equal(N(d), od)
+
+
+@pytest.mark.parametrize("arith", [PLAIN, CONTRACT])
+@pytest.mark.parametrize("b,n,m", [(4, 1024, 1024), (2, 4096, 4096), (3, 100, 777), (1, 1, 1), (2, 2049, 513)])
+def test_nn_distance_exact(ops, dev, b, n, m, arith):
+    x1, x2 = synth_patches(b, n, seed=3 * n), synth_patches(b, m, seed=5 * m)
+    d1, i1, d2, i2 = ops["D"].nn_distance(T(x1, dev), T(x2, dev), arith=arith)
+    o = O.nn_distance(x1, x2, contract=arith)
+    for got, want in zip((d1, i1, d2, i2), o):
+        assert np.array_equal(N(got), want)
+
+
+def test_nn_distance_grad_and_autograd(ops, dev):
+    x1, x2 = synth_patches(2, 300, seed=1), synth_patches(2, 200, seed=2)
+    rng = np.random.default_rng(0)
+    gd1, gd2 = rng.standard_normal((2, 300)).astype(np.float32), rng.standard_normal((2, 200)).astype(np.float32)
+    _, i1, _, i2 = O.nn_distance(x1, x2)
+    want = O.nn_distance_grad(x1, x2, gd1, i1, gd2, i2)
+    got = ops["D"].nn_distance_grad(T(x1, dev), T(x2, dev), T(gd1, dev), T(i1, dev), T(gd2, dev), T(i2, dev))
+    assert np.allclose(N(got[0]), want[0], atol=1e-5) and np.allclose(N(got[1]), want[1], atol=1e-5)
+    t1, t2 = T(x1, dev).requires_grad_(True), T(x2, dev).requires_grad_(True)
+    d1, _, d2, _ = ops["D"].nn_distance(t1, t2)
+    ((d1 * T(gd1, dev)).sum() + (d2 * T(gd2, dev)).sum()).backward()
+    assert np.allclose(N(t1.grad), want[0], atol=1e-5) and np.allclose(N(t2.grad), want[1], atol=1e-5)
+
+
+@pytest.mark.parametrize("b,n,m", [(2, 256, 256), (1, 1024, 1024), (2, 100, 300), (2, 300, 100), (1, 1100, 1030)])
+def test_approx_match_and_cost(ops, dev, b, n, m):
+    x1, x2 = synth_patches(b, n, seed=n), synth_patches(b, m, seed=m + 1)
+    match = ops["A"].approx_match(T(x1, dev), T(x2, dev))
+    mo = O.approx_match(x1, x2)
+    assert np.allclose(N(match), mo, atol=3e-5)
+    cost = N(ops["A"].match_cost(T(x1, dev), T(x2, dev), match))
+    co = O.match_cost(x1, x2, mo)
+    assert np.allclose(cost, co, rtol=1e-5)                                # <= 1e-5 on EMD (north star)
+    g1, g2 = ops["A"].match_cost_grad(T(x1, dev), T(x2, dev), T(mo, dev))
+    o1, o2 = O.match_cost_grad(x1, x2, mo)
+    assert np.allclose(N(g1), o1, atol=3e-5) and np.allclose(N(g2), o2, atol=3e-5)
+
+
+def test_match_cost_autograd_scaling(ops, dev):
+    x1, x2 = synth_patches(2, 128, seed=9), synth_patches(2, 128, seed=10)
+    t1, t2 = T(x1, dev).requires_grad_(True), T(x2, dev).requires_grad_(True)
+    match = ops["A"].approx_match(t1.detach(), t2.detach())
+    w = torch.tensor([2.0, -3.0], device=dev)
+    (ops["A"].match_cost(t1, t2, match) * w).sum().backward()
+    g1, g2 = ops["A"].match_cost_grad(t1.detach(), t2.detach(), match)
+    assert torch.allclose(t1.grad, g1 * w.view(2, 1, 1)) and torch.allclose(t2.grad, g2 * w.view(2, 1, 1))
+
+
+def test_gradient_checks_of_the_reference_tests(ops, dev):
+    """tf_grouping_op_test.py:9-25 and tf_interpolate_op_test.py:9-22 restated: the analytic gradient of
+    group_point / three_interpolate w.r.t. `points` equals a finite-difference gradient (< 1e-4... the ops are
+    linear in `points`, so the check is exact up to fp32 rounding)."""
+    rng = np.random.default_rng(0)
+    pts = rng.random((1, 128, 16)).astype(np.float32)
+    xyz1, xyz2 = rng.random((1, 128, 3)).astype(np.float32), rng.random((1, 8, 3)).astype(np.float32)
+    idx, _ = ops["G"].query_ball_point(0.3, 32, T(xyz1, dev), T(xyz2, dev))
+    tp = T(pts, dev).requires_grad_(True)
+    w = torch.randn(1, 8, 32, 16, device=dev)
+    (ops["G"].group_point(tp, idx) * w).sum().backward()
+    eps = 1e-2
+    for (i, c) in [(0, 0), (17, 3), (127, 15)]:
+        e = torch.zeros_like(tp); e[0, i, c] = eps
+        num = ((ops["G"].group_point(tp.detach() + e, idx) - ops["G"].group_point(tp.detach() - e, idx)) * w).sum() / (2 * eps)
+        assert abs(float(num) - float(tp.grad[0, i, c])) < 1e-3
+    pts2 = rng.random((1, 8, 16)).astype(np.float32)
+    idx3 = T(rng.integers(0, 8, (1, 128, 3)).astype(np.int32), dev)
+    w3 = torch.full((1, 128, 3), 1.0 / 3.0, device=dev)
+    tp2 = T(pts2, dev).requires_grad_(True)
+    wo = torch.randn(1, 128, 16, device=dev)
+    (ops["I"].three_interpolate(tp2, idx3, w3) * wo).sum().backward()
+    for (i, c) in [(0, 0), (5, 7)]:
+        e = torch.zeros_like(tp2); e[0, i, c] = eps
+        num = ((ops["I"].three_interpolate(tp2.detach() + e, idx3, w3) - ops["I"].three_interpolate(tp2.detach() - e, idx3, w3)) * wo).sum() / (2 * eps)
+        assert abs(float(num) - float(tp2.grad[0, i, c])) < 1e-3
+
+
+# ---------------------------------------------------------------------------------- full-size properties ----
+def test_full_size_properties(ops, dev):
+    """BASELINE sizes where the CPU oracle would take too long: size-independent properties."""
+    b, n = 32, 1024
+    x = T(synth_patches(b, n, seed=77), dev)
+    # k-NN: self first, distances ascending, idx consistent with distances, symmetric count sanity
+    idx, dist = ops["K"].knn_batch(x, x, 16, return_dist=True)
+    assert (idx[:, :, 0] == torch.arange(n, device=dev)).all() and (dist[:, :, 0] == 0).all()
+    assert (dist[:, :, 1:] >= dist[:, :, :-1]).all()
+    nb = torch.gather(x.unsqueeze(1).expand(b, n, n, 3), 2, idx.unsqueeze(-1).expand(b, n, 16, 3))
+    d_chk = ((nb - x.unsqueeze(2)) ** 2).sum(-1)
+    assert torch.allclose(d_chk, dist, atol=1e-6)
+    # Chamfer of a cloud with itself is zero with identity matches
+    d1, i1, d2, i2 = ops["D"].nn_distance(x, x)
+    assert (d1 == 0).all() and (i1 == torch.arange(n, device=dev)).all() and (i2 == i1).all()
+    # FPS of 8 x 24576 points (test-time shape): a permutation prefix, first index 0
+    big = torch.rand(2, 24576, 3, device=dev)
+    fi = ops["S"].farthest_point_sample(2048, big)
+    assert (fi[:, 0] == 0).all() and all(len(set(r.tolist())) == 2048 for r in fi)
+    # gather(idx) round trip: gather_point(FPS idx) == advanced indexing
+    assert torch.equal(ops["S"].gather_point(big, fi), torch.gather(big, 1, fi.long().unsqueeze(-1).expand(-1, -1, 3)))
+    # EMD: match rows/cols sum to one at 1024^2; cost(x, x) is ~0 relative to cost(x, y)
+    y = T(synth_patches(4, n, seed=78), dev)
+    m = ops["A"].approx_match(x[:4], y)
+    assert torch.allclose(m.sum(1), torch.ones(4, n, device=dev), atol=1e-4)
+    assert torch.allclose(m.sum(2), torch.ones(4, n, device=dev), atol=1e-4)
+    c_xy = ops["A"].match_cost(x[:4], y, m)
+    c_xx = ops["A"].match_cost(x[:4], x[:4], ops["A"].approx_match(x[:4], x[:4]))
+    assert (c_xx < 0.05 * c_xy).all()
