@@ -10,6 +10,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libdispu_hip.so")
 
 ARITH_PLAIN = 0
 ARITH_CONTRACT = 1
+ARITH_PINNED_EXP = 2   # OR-able, approx_match only (bit-reproducible exp; parity mode)
 
 _vp, _i, _sz = C.c_void_p, C.c_int, C.c_size_t
 

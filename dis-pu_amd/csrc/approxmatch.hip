@@ -16,7 +16,27 @@ namespace dispu {
 constexpr int AM_BS = 256;
 constexpr int AM_TILE = 1024;
 
-__device__ __forceinline__ float fast_exp(float x) { return __expf(x); }
+// PINNED = false: hardware v_exp_f32 like the reference's __expf.  PINNED = true: the same fmaf-chain
+// sequence as oracle/dispu_oracle.c:pinned_exp, bit-identical on CPU and GPU (parity mode).
+template <bool PINNED>
+__device__ __forceinline__ float am_exp(float x) {
+    if constexpr (!PINNED) {
+        return __expf(x);
+    } else {
+        if (!(x > -86.0f)) return 0.0f;
+        const float t = x * 1.44269504088896341f;
+        const float n = __builtin_rintf(t);
+        const float f = t - n;
+        float p = 1.5403530393381609954e-4f;
+        p = __builtin_fmaf(p, f, 1.3333558146428443423e-3f);
+        p = __builtin_fmaf(p, f, 9.6181291076284771619e-3f);
+        p = __builtin_fmaf(p, f, 5.5504108664821579953e-2f);
+        p = __builtin_fmaf(p, f, 2.4022650695910071233e-1f);
+        p = __builtin_fmaf(p, f, 6.9314718055994530942e-1f);
+        p = __builtin_fmaf(p, f, 1.0f);
+        return __int_as_float(__float_as_int(p) + (((int)n) << 23));
+    }
+}
 
 __global__ void am_init_kernel(int n, int m, float multiL, float multiR, float* __restrict__ temp,
                                float* __restrict__ match) {
@@ -32,7 +52,7 @@ __global__ void am_init_kernel(int n, int m, float multiL, float multiR, float* 
 // PASS 1: ratioL[k] = remainL[k] / (1e-9 + sum_l exp(level*d2)*remainR[l])
 // PASS 2: sumr = (sum_k exp(level*d2)*ratioL[k]) * remainR[l]; ratioR, remainR update
 // PASS 3: w = exp(level*d2)*ratioL[k]*ratioR[l]; match[l*n+k] += w; remainL update
-template <int PASS, bool FMA>
+template <int PASS, bool FMA, bool PINNED>
 __global__ __launch_bounds__(AM_BS) void am_pass_kernel(int n, int m, float level, const float* __restrict__ xyz1,
                                                          const float* __restrict__ xyz2, float* __restrict__ temp,
                                                          float* __restrict__ match) {
@@ -67,7 +87,7 @@ __global__ __launch_bounds__(AM_BS) void am_pass_kernel(int n, int m, float leve
         for (int t = 0; t < len; ++t) {
             const float4 q = tile[t];
             const float d2 = OVER_N ? sqdist3<FMA>(q.x - xa, q.y - ya, q.z - za) : sqdist3<FMA>(xa - q.x, ya - q.y, za - q.z);
-            const float e = fast_exp(level * d2);
+            const float e = am_exp<PINNED>(level * d2);
             if constexpr (PASS == 3) {
                 const float w = e * rl * q.w;
                 mt[(size_t)(t0 + t) * n + a] += w;
@@ -192,7 +212,7 @@ __global__ __launch_bounds__(AM_BS) void match_cost_grad_kernel(int n, int m, co
     }
 }
 
-template <bool FMA>
+template <bool FMA, bool PINNED>
 static int run_approx_match(int b, int n, int m, const float* xyz1, const float* xyz2, float* match, float* temp,
                             hipStream_t s) {
     const float multiL = (n >= m) ? 1.0f : (float)(m / n);
@@ -205,9 +225,9 @@ static int run_approx_match(int b, int n, int m, const float* xyz1, const float*
             level = -1.0f;
             for (int t = 0; t < (j < 0 ? -j : j); ++t) level = (j < 0) ? level * 0.25f : level * 4.0f;  // -(4^j), exact
         }
-        hipLaunchKernelGGL((am_pass_kernel<1, FMA>), gn, dim3(AM_BS), 0, s, n, m, level, xyz1, xyz2, temp, match);
-        hipLaunchKernelGGL((am_pass_kernel<2, FMA>), gm, dim3(AM_BS), 0, s, n, m, level, xyz1, xyz2, temp, match);
-        hipLaunchKernelGGL((am_pass_kernel<3, FMA>), gn, dim3(AM_BS), 0, s, n, m, level, xyz1, xyz2, temp, match);
+        hipLaunchKernelGGL((am_pass_kernel<1, FMA, PINNED>), gn, dim3(AM_BS), 0, s, n, m, level, xyz1, xyz2, temp, match);
+        hipLaunchKernelGGL((am_pass_kernel<2, FMA, PINNED>), gm, dim3(AM_BS), 0, s, n, m, level, xyz1, xyz2, temp, match);
+        hipLaunchKernelGGL((am_pass_kernel<3, FMA, PINNED>), gn, dim3(AM_BS), 0, s, n, m, level, xyz1, xyz2, temp, match);
     }
     return (int)hipGetLastError();
 }
@@ -224,15 +244,19 @@ DISPU_EXPORT int dispu_approx_match(int b, int n, int m, const float* xyz1, cons
                                     float* temp, int arith, void* stream) {
     if (b < 0 || n <= 0 || m <= 0 || !temp) return (int)hipErrorInvalidValue;
     if (b == 0) return 0;
-    if (arith == DISPU_ARITH_CONTRACT) return run_approx_match<true>(b, n, m, xyz1, xyz2, match, temp, (hipStream_t)stream);
-    return run_approx_match<false>(b, n, m, xyz1, xyz2, match, temp, (hipStream_t)stream);
+    hipStream_t s = (hipStream_t)stream;
+    const bool fma = (arith & DISPU_ARITH_CONTRACT) != 0, pin = (arith & DISPU_ARITH_PINNED_EXP) != 0;
+    if (fma && pin) return run_approx_match<true, true>(b, n, m, xyz1, xyz2, match, temp, s);
+    if (fma) return run_approx_match<true, false>(b, n, m, xyz1, xyz2, match, temp, s);
+    if (pin) return run_approx_match<false, true>(b, n, m, xyz1, xyz2, match, temp, s);
+    return run_approx_match<false, false>(b, n, m, xyz1, xyz2, match, temp, s);
 }
 
 DISPU_EXPORT int dispu_match_cost(int b, int n, int m, const float* xyz1, const float* xyz2, const float* match,
                                   float* cost, int arith, void* stream) {
     if (b < 0 || n <= 0 || m <= 0) return (int)hipErrorInvalidValue;
     if (b == 0) return 0;
-    if (arith == DISPU_ARITH_CONTRACT)
+    if ((arith & DISPU_ARITH_CONTRACT))
         hipLaunchKernelGGL((match_cost_kernel<true>), dim3(b), dim3(1024), 0, (hipStream_t)stream, n, m, xyz1, xyz2, match, cost);
     else
         hipLaunchKernelGGL((match_cost_kernel<false>), dim3(b), dim3(1024), 0, (hipStream_t)stream, n, m, xyz1, xyz2, match, cost);
@@ -245,7 +269,7 @@ DISPU_EXPORT int dispu_match_cost_grad(int b, int n, int m, const float* xyz1, c
     if (b == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
     dim3 g1((n + AM_BS - 1) / AM_BS, b), g2((m + AM_BS / kWave - 1) / (AM_BS / kWave), b);
-    if (arith == DISPU_ARITH_CONTRACT) {
+    if ((arith & DISPU_ARITH_CONTRACT)) {
         hipLaunchKernelGGL((match_cost_grad_kernel<1, true>), g1, dim3(AM_BS), 0, s, n, m, xyz1, xyz2, match, grad1);
         hipLaunchKernelGGL((match_cost_grad_kernel<2, true>), g2, dim3(AM_BS), 0, s, n, m, xyz1, xyz2, match, grad2);
     } else {

@@ -10,6 +10,7 @@
 // Arithmetic flavour flags shared with include/dispu_hip.h
 #define DISPU_ARITH_PLAIN 0     // ((dx*dx + dy*dy) + dz*dz): the reference's CPU functions
 #define DISPU_ARITH_CONTRACT 1  // fmaf(dz,dz, fmaf(dx,dx, dy*dy)): nvcc-contracted GPU kernels
+#define DISPU_ARITH_PINNED_EXP 2  // OR-able: approx_match uses the bit-reproducible exp (parity mode)
 
 #define DISPU_CHECK_LAUNCH()                         \
     do {                                             \

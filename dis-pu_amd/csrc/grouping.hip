@@ -105,7 +105,7 @@ DISPU_EXPORT int dispu_query_ball(int b, int n, int m, const float* radius, int 
     if (b < 0 || n <= 0 || m < 0 || nsample <= 0 || !radius) return (int)hipErrorInvalidValue;
     if (b == 0 || m == 0) return 0;
     dim3 grid((m + QB_BS - 1) / QB_BS, b);
-    if (arith == DISPU_ARITH_CONTRACT)
+    if ((arith & DISPU_ARITH_CONTRACT))
         hipLaunchKernelGGL((query_ball_kernel<true>), grid, dim3(QB_BS), 0, (hipStream_t)stream, n, m, radius, nsample,
                            xyz1, xyz2, idx, pts_cnt);
     else

@@ -97,7 +97,7 @@ DISPU_EXPORT int dispu_three_nn(int b, int n, int m, const float* xyz1, const fl
     if (b < 0 || n < 0 || m <= 0) return (int)hipErrorInvalidValue;
     if (b == 0 || n == 0) return 0;
     dim3 grid((n + NN3_BS - 1) / NN3_BS, b);
-    if (arith == DISPU_ARITH_CONTRACT)
+    if ((arith & DISPU_ARITH_CONTRACT))
         hipLaunchKernelGGL((three_nn_kernel<true>), grid, dim3(NN3_BS), 0, (hipStream_t)stream, n, m, xyz1, xyz2, dist, idx);
     else
         hipLaunchKernelGGL((three_nn_kernel<false>), grid, dim3(NN3_BS), 0, (hipStream_t)stream, n, m, xyz1, xyz2, dist, idx);

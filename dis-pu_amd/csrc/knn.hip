@@ -168,7 +168,7 @@ template <int K>
 static int launch_xyz(int b, int n, int m, int k, const float* s, const float* q, int* idx, float* dist, int arith,
                       hipStream_t st) {
     dim3 grid((m + KNN_BS - 1) / KNN_BS, b);
-    if (arith == DISPU_ARITH_CONTRACT)
+    if ((arith & DISPU_ARITH_CONTRACT))
         hipLaunchKernelGGL((knn_xyz_kernel<K, true>), grid, dim3(KNN_BS), 0, st, n, m, k, s, q, idx, dist);
     else
         hipLaunchKernelGGL((knn_xyz_kernel<K, false>), grid, dim3(KNN_BS), 0, st, n, m, k, s, q, idx, dist);

@@ -31,7 +31,9 @@ __global__ __launch_bounds__(NND_BS) void nn_distance_kernel(int n, int m, const
     const bool active = j < nf;
     float x1 = 0.f, y1 = 0.f, z1 = 0.f;
     if (active) { x1 = from[j * 3 + 0]; y1 = from[j * 3 + 1]; z1 = from[j * 3 + 2]; }
-    float best = __builtin_inff();
+    // `if (k == 0 || d < best)` of the reference (tf_nndistance_g.cu:29): candidate 0 is taken unconditionally
+    // (matters only for inf / NaN distances); it is revisited in the loop where d < d is false.
+    float best = sqdist3<FMA>(to[0] - x1, to[1] - y1, to[2] - z1);
     int besti = 0;
     for (int k0 = 0; k0 < nt; k0 += NND_TILE) {
         const int len = min(NND_TILE, nt - k0);
@@ -85,7 +87,7 @@ DISPU_EXPORT int dispu_nn_distance(int b, int n, const float* xyz1, int m, const
     if (b == 0) return 0;
     const int mx = n > m ? n : m;
     dim3 grid((mx + NND_BS - 1) / NND_BS, b, 2);
-    if (arith == DISPU_ARITH_CONTRACT)
+    if ((arith & DISPU_ARITH_CONTRACT))
         hipLaunchKernelGGL((nn_distance_kernel<true>), grid, dim3(NND_BS), 0, (hipStream_t)stream, n, m, xyz1, xyz2, dist1,
                            idx1, dist2, idx2);
     else

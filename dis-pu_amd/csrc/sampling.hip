@@ -127,7 +127,7 @@ __global__ __launch_bounds__(1024) void fps_mem_kernel(int n, int m, const float
 
 template <int BS, int P>
 static int launch_fps_reg(int b, int n, int m, const float* xyz, int* out, int arith, hipStream_t s) {
-    if (arith == DISPU_ARITH_CONTRACT)
+    if ((arith & DISPU_ARITH_CONTRACT))
         hipLaunchKernelGGL((fps_reg_kernel<BS, P, true>), dim3(b), dim3(BS), 0, s, n, m, xyz, out);
     else
         hipLaunchKernelGGL((fps_reg_kernel<BS, P, false>), dim3(b), dim3(BS), 0, s, n, m, xyz, out);
@@ -183,7 +183,7 @@ DISPU_EXPORT int dispu_fps(int b, int n, int m, const float* inp, float* temp, i
     if (n <= 16384) return launch_fps_reg<1024, 16>(b, n, m, inp, out, arith, s);
     if (n <= 24576) return launch_fps_reg<1024, 24>(b, n, m, inp, out, arith, s);
     if (!temp) return (int)hipErrorInvalidValue;
-    if (arith == DISPU_ARITH_CONTRACT)
+    if ((arith & DISPU_ARITH_CONTRACT))
         hipLaunchKernelGGL((fps_mem_kernel<true>), dim3(b), dim3(1024), 0, s, n, m, inp, temp, out);
     else
         hipLaunchKernelGGL((fps_mem_kernel<false>), dim3(b), dim3(1024), 0, s, n, m, inp, temp, out);

@@ -35,6 +35,10 @@ extern "C" {
 
 #define DISPU_ARITH_PLAIN 0
 #define DISPU_ARITH_CONTRACT 1
+/* OR-able with the above, dispu_approx_match only: evaluate exp() with a bit-reproducible fmaf-chain
+ * polynomial instead of the hardware v_exp_f32 (the reference uses the hardware __expf).  Parity/debug
+ * mode: results are then bit-identical to oracle/dispu_oracle.c; about 1.6x slower. */
+#define DISPU_ARITH_PINNED_EXP 2
 
 /* Library / ABI version (1 = round 1). */
 int dispu_version(void);

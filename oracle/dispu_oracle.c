@@ -42,6 +42,30 @@ static inline float sqdist3(float dx, float dy, float dz, int contract) {
     return s + dz * dz;
 }
 
+/* Pinned exponential: exp(x) for x <= 0 as 2^(x*log2e) with round-to-nearest-even range reduction
+ * and a degree-6 Taylor polynomial of 2^f evaluated as an fmaf chain (|f| <= 0.5, remainder 1.2e-7).
+ * The HIP library has the SAME sequence (v_rndne_f32 + v_fma_f32), so in DISPU_ARITH_PINNED_EXP mode
+ * approx_match is bit-reproducible between CPU and GPU.  The production default uses the hardware
+ * v_exp_f32 like the reference's __expf (tf_approxmatch_g.cu:52,97,151). */
+static inline float pinned_exp(float x) {
+    if (!(x > -86.0f)) return 0.0f;
+    const float t = x * 1.44269504088896341f;
+    const float n = rintf(t);
+    const float f = t - n;
+    float p = 1.5403530393381609954e-4f;
+    p = fmaf(p, f, 1.3333558146428443423e-3f);
+    p = fmaf(p, f, 9.6181291076284771619e-3f);
+    p = fmaf(p, f, 5.5504108664821579953e-2f);
+    p = fmaf(p, f, 2.4022650695910071233e-1f);
+    p = fmaf(p, f, 6.9314718055994530942e-1f);
+    p = fmaf(p, f, 1.0f);
+    union { float f; int32_t i; } u;
+    u.f = p;
+    u.i += ((int32_t)n) << 23;
+    return u.f;
+}
+#define ORC_EXP(x) (pinned ? pinned_exp(x) : expf(x))
+
 ORC_API int orc_version(void) { return 1; }
 
 ORC_API void orc_set_threads(int t) {
@@ -417,11 +441,12 @@ ORC_API void orc_nn_distance_grad(int b, int n, int m, const float *xyz1, const 
  *                    remainL[k] = max(0, remainL[k] - sum_l w)
  * match layout is [b][m][n] (l-major, :152).  All sums are per-thread sequential in the
  * reference, so they are layout independent.  The reference uses the fast __expf; the oracle
- * uses expf (tolerance-tested, SURVEY 8a A11: <= 1e-5 on match_cost).  d2 here is the
+ * uses libm expf (pinned = 0; tolerance-tested, SURVEY 8a A11: <= 1e-5 on match_cost) or the
+ * bit-reproducible pinned_exp above (pinned = 1; bit-exact against the HIP library in the same mode).  d2 here is the
  * (x2-x1) form; the products level*d2 and exp*weight are plain multiplies, the running sums
  * are fused (suml += w with w a product -> fma) only in contract mode. */
 ORC_API void orc_approx_match(int b, int n, int m, const float *xyz1, const float *xyz2, float *match,
-                              int contract) {
+                              int contract, int pinned) {
     const float multiL = (n >= m) ? 1.0f : (float)(m / n);
     const float multiR = (n >= m) ? (float)(n / m) : 1.0f;
 #pragma omp parallel for schedule(dynamic)
@@ -442,7 +467,7 @@ ORC_API void orc_approx_match(int b, int n, int m, const float *xyz1, const floa
                 float suml = 1e-9f;
                 for (int l = 0; l < m; ++l) {
                     const float d2 = sqdist3(p2[l * 3] - x1, p2[l * 3 + 1] - y1, p2[l * 3 + 2] - z1, contract);
-                    const float e = expf(level * d2);
+                    const float e = ORC_EXP(level * d2);
                     suml = contract ? fmaf(e, remainR[l], suml) : suml + e * remainR[l];
                 }
                 ratioL[k] = remainL[k] / suml;
@@ -452,7 +477,7 @@ ORC_API void orc_approx_match(int b, int n, int m, const float *xyz1, const floa
                 float sumr = 0.0f;
                 for (int k = 0; k < n; ++k) {
                     const float d2 = sqdist3(x2 - p1[k * 3], y2 - p1[k * 3 + 1], z2 - p1[k * 3 + 2], contract);
-                    const float e = expf(level * d2);
+                    const float e = ORC_EXP(level * d2);
                     sumr = contract ? fmaf(e, ratioL[k], sumr) : sumr + e * ratioL[k];
                 }
                 sumr *= remainR[l];
@@ -466,7 +491,7 @@ ORC_API void orc_approx_match(int b, int n, int m, const float *xyz1, const floa
                 float suml = 0.0f;
                 for (int l = 0; l < m; ++l) {
                     const float d2 = sqdist3(p2[l * 3] - x1, p2[l * 3 + 1] - y1, p2[l * 3 + 2] - z1, contract);
-                    const float w = expf(level * d2) * rl * ratioR[l];
+                    const float w = ORC_EXP(level * d2) * rl * ratioR[l];
                     mt[(size_t)l * n + k] += w;
                     suml += w;
                 }

@@ -202,12 +202,12 @@ def nn_distance_grad(xyz1, xyz2, grad_dist1, idx1, grad_dist2, idx2):
 
 
 # ---- A11/A12 approxmatch (tf_ops/approxmatch/tf_approxmatch.py:13-51) ----------------------------
-def approx_match(xyz1, xyz2, contract=1):
+def approx_match(xyz1, xyz2, contract=1, pinned_exp=False):
     xyz1, xyz2 = _f(xyz1), _f(xyz2)
     b, n, _ = xyz1.shape
     m = xyz2.shape[1]
     match = np.empty((b, m, n), np.float32)
-    lib().orc_approx_match(b, n, m, _p(xyz1), _p(xyz2), _p(match), int(contract))
+    lib().orc_approx_match(b, n, m, _p(xyz1), _p(xyz2), _p(match), int(contract), int(bool(pinned_exp)))
     return match
 
 
