@@ -12,7 +12,7 @@ ARITH_PLAIN = 0
 ARITH_CONTRACT = 1
 ARITH_PINNED_EXP = 2   # OR-able, approx_match only (bit-reproducible exp; parity mode)
 
-_vp, _i, _sz = C.c_void_p, C.c_int, C.c_size_t
+_vp, _i, _sz, _l = C.c_void_p, C.c_int, C.c_size_t, C.c_long
 
 # name -> (restype, argtypes); must list every symbol of include/dispu_hip.h (tests check this)
 SIGNATURES = {
@@ -27,6 +27,7 @@ SIGNATURES = {
     "dispu_group_point_grad": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "dispu_knn_point": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "dispu_knn_feat": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "dispu_knn_feat_strided": (_i, [_i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp]),
     "dispu_knn_xyz": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp]),
     "dispu_three_nn": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp]),
     "dispu_three_interpolate": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
@@ -37,6 +38,17 @@ SIGNATURES = {
     "dispu_approx_match": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp]),
     "dispu_match_cost": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp]),
     "dispu_match_cost_grad": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
+    "dispu_linear": (_i, [_i, _i, _i, _i, _vp, _l, _l, _vp, _l, _l, _i, _vp, _i, _vp, _l, _l, _vp, _l, _l, _vp, _l, _l, _vp]),
+    "dispu_linear_small_k": (_i, [_l, _i, _i, _vp, _l, _vp, _vp, _i, _vp, _l, _vp]),
+    "dispu_linear_small_n": (_i, [_l, _i, _i, _vp, _l, _vp, _vp, _i, _vp, _l, _vp, _l, _vp]),
+    "dispu_edge_dense_conv": (_i, [_i, _i, _i, _vp, _l, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _l, _vp]),
+    "dispu_dup_grid": (_i, [_i, _i, _i, _i, _vp, _l, _vp, _vp, _vp, _vp, _l, _vp]),
+    "dispu_ps_prep": (_i, [_l, _i, _vp, _vp, _vp, _vp, _l, _vp, _l, _vp]),
+    "dispu_ps_gather_sub_relu": (_i, [_l, _i, _i, _i, _vp, _vp, _l, _vp, _l, _vp, _l, _vp]),
+    "dispu_ps_skip_max": (_i, [_l, _i, _i, _i, _vp, _vp, _vp, _l, _vp, _l, _vp]),
+    "dispu_ps_weight_net": (_i, [_l, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "dispu_ps_point_matmul": (_i, [_l, _i, _i, _i, _vp, _l, _vp, _vp, _l, _vp]),
+    "dispu_softmax_rows": (_i, [_l, _i, C.c_float, _vp, _l, _vp]),
 }
 
 _LIB = None

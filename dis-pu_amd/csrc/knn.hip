@@ -85,7 +85,7 @@ __global__ __launch_bounds__(KNN_BS) void knn_xyz_kernel(int n, int m, int k, co
 // ascending order (bit-identical to a v_mfma_f32 k-loop); otherwise sum((p-q)^2) left to right
 // with every op rounded.  NEG: store -d (knn_point returns top_k values of -dist).
 template <int CP, int K, bool GEMM_FORM, bool NEG>
-__global__ __launch_bounds__(KNN_BS) void knn_feat_kernel(int n, int m, int c, int k,
+__global__ __launch_bounds__(KNN_BS) void knn_feat_kernel(int n, int m, int c, int k, int ldp, int ldq,
                                                            const float* __restrict__ points,
                                                            const float* __restrict__ queries,
                                                            float* __restrict__ dist, int* __restrict__ idx) {
@@ -93,13 +93,13 @@ __global__ __launch_bounds__(KNN_BS) void knn_feat_kernel(int n, int m, int c, i
     __shared__ float tile[TILE * CP];
     __shared__ float tnorm[TILE];
     const int cloud = blockIdx.y;
-    const float* __restrict__ sp = points + (size_t)cloud * n * c;
-    const float* __restrict__ qp = queries + (size_t)cloud * m * c;
+    const float* __restrict__ sp = points + (size_t)cloud * n * ldp;   // row strides ldp / ldq (floats):
+    const float* __restrict__ qp = queries + (size_t)cloud * m * ldq;  // inputs may be column slices
     const int j = blockIdx.x * KNN_BS + threadIdx.x;
     const bool active = j < m;
     float q[CP];
 #pragma unroll
-    for (int l = 0; l < CP; ++l) q[l] = (active && l < c) ? qp[(size_t)j * c + l] : 0.f;
+    for (int l = 0; l < CP; ++l) q[l] = (active && l < c) ? qp[(size_t)j * ldq + l] : 0.f;
     float rq = 0.f;
     if constexpr (GEMM_FORM) {
 #pragma unroll
@@ -112,7 +112,7 @@ __global__ __launch_bounds__(KNN_BS) void knn_feat_kernel(int n, int m, int c, i
         __syncthreads();
         for (int e = threadIdx.x; e < len * CP; e += KNN_BS) {
             const int t = e / CP, l = e - t * CP;
-            tile[e] = (l < c) ? sp[(size_t)(k0 + t) * c + l] : 0.f;
+            tile[e] = (l < c) ? sp[(size_t)(k0 + t) * ldp + l] : 0.f;
         }
         __syncthreads();
         if constexpr (GEMM_FORM) {
@@ -176,29 +176,29 @@ static int launch_xyz(int b, int n, int m, int k, const float* s, const float* q
 }
 
 template <int CP, bool GEMM_FORM, bool NEG>
-static int launch_feat_k(int b, int n, int m, int c, int k, const float* p, const float* q, float* dist, int* idx,
+static int launch_feat_k(int b, int n, int m, int c, int k, int ldp, int ldq, const float* p, const float* q, float* dist, int* idx,
                          hipStream_t st) {
     dim3 grid((m + KNN_BS - 1) / KNN_BS, b);
     if (k <= 8)
-        hipLaunchKernelGGL((knn_feat_kernel<CP, 8, GEMM_FORM, NEG>), grid, dim3(KNN_BS), 0, st, n, m, c, k, p, q, dist, idx);
+        hipLaunchKernelGGL((knn_feat_kernel<CP, 8, GEMM_FORM, NEG>), grid, dim3(KNN_BS), 0, st, n, m, c, k, ldp, ldq, p, q, dist, idx);
     else if (k <= 20)
-        hipLaunchKernelGGL((knn_feat_kernel<CP, 20, GEMM_FORM, NEG>), grid, dim3(KNN_BS), 0, st, n, m, c, k, p, q, dist, idx);
+        hipLaunchKernelGGL((knn_feat_kernel<CP, 20, GEMM_FORM, NEG>), grid, dim3(KNN_BS), 0, st, n, m, c, k, ldp, ldq, p, q, dist, idx);
     else
-        hipLaunchKernelGGL((knn_feat_kernel<CP, 32, GEMM_FORM, NEG>), grid, dim3(KNN_BS), 0, st, n, m, c, k, p, q, dist, idx);
+        hipLaunchKernelGGL((knn_feat_kernel<CP, 32, GEMM_FORM, NEG>), grid, dim3(KNN_BS), 0, st, n, m, c, k, ldp, ldq, p, q, dist, idx);
     return (int)hipGetLastError();
 }
 
 template <bool GEMM_FORM, bool NEG>
-static int launch_feat(int b, int n, int m, int c, int k, const float* p, const float* q, float* dist, int* idx,
+static int launch_feat(int b, int n, int m, int c, int k, int ldp, int ldq, const float* p, const float* q, float* dist, int* idx,
                        hipStream_t st) {
-    if (c <= 4) return launch_feat_k<4, GEMM_FORM, NEG>(b, n, m, c, k, p, q, dist, idx, st);
-    if (c <= 8) return launch_feat_k<8, GEMM_FORM, NEG>(b, n, m, c, k, p, q, dist, idx, st);
-    if (c <= 16) return launch_feat_k<16, GEMM_FORM, NEG>(b, n, m, c, k, p, q, dist, idx, st);
-    if (c <= 24) return launch_feat_k<24, GEMM_FORM, NEG>(b, n, m, c, k, p, q, dist, idx, st);
-    if (c <= 32) return launch_feat_k<32, GEMM_FORM, NEG>(b, n, m, c, k, p, q, dist, idx, st);
-    if (c <= 48) return launch_feat_k<48, GEMM_FORM, NEG>(b, n, m, c, k, p, q, dist, idx, st);
-    if (c <= 64) return launch_feat_k<64, GEMM_FORM, NEG>(b, n, m, c, k, p, q, dist, idx, st);
-    if (c <= 128) return launch_feat_k<128, GEMM_FORM, NEG>(b, n, m, c, k, p, q, dist, idx, st);
+    if (c <= 4) return launch_feat_k<4, GEMM_FORM, NEG>(b, n, m, c, k, ldp, ldq, p, q, dist, idx, st);
+    if (c <= 8) return launch_feat_k<8, GEMM_FORM, NEG>(b, n, m, c, k, ldp, ldq, p, q, dist, idx, st);
+    if (c <= 16) return launch_feat_k<16, GEMM_FORM, NEG>(b, n, m, c, k, ldp, ldq, p, q, dist, idx, st);
+    if (c <= 24) return launch_feat_k<24, GEMM_FORM, NEG>(b, n, m, c, k, ldp, ldq, p, q, dist, idx, st);
+    if (c <= 32) return launch_feat_k<32, GEMM_FORM, NEG>(b, n, m, c, k, ldp, ldq, p, q, dist, idx, st);
+    if (c <= 48) return launch_feat_k<48, GEMM_FORM, NEG>(b, n, m, c, k, ldp, ldq, p, q, dist, idx, st);
+    if (c <= 64) return launch_feat_k<64, GEMM_FORM, NEG>(b, n, m, c, k, ldp, ldq, p, q, dist, idx, st);
+    if (c <= 128) return launch_feat_k<128, GEMM_FORM, NEG>(b, n, m, c, k, ldp, ldq, p, q, dist, idx, st);
     return (int)hipErrorInvalidValue;
 }
 
@@ -222,12 +222,21 @@ DISPU_EXPORT int dispu_knn_feat(int b, int n, int m, int c, int k, const float* 
                                 float* dist, int* idx, void* stream) {
     if (b < 0 || n <= 0 || m < 0 || c <= 0 || k <= 0 || k > n || k > 32 || !idx) return (int)hipErrorInvalidValue;
     if (b == 0 || m == 0) return 0;
-    return launch_feat<true, false>(b, n, m, c, k, points, queries, dist, idx, (hipStream_t)stream);
+    return launch_feat<true, false>(b, n, m, c, k, c, c, points, queries, dist, idx, (hipStream_t)stream);
+}
+
+// Same as dispu_knn_feat with explicit row strides (floats): points / queries may be column slices of a wider
+// activation buffer (the generator keeps its dense-block features inside one [rows, 480] buffer).
+DISPU_EXPORT int dispu_knn_feat_strided(int b, int n, int m, int c, int k, const float* points, int ldp,
+                                        const float* queries, int ldq, float* dist, int* idx, void* stream) {
+    if (b < 0 || n <= 0 || m < 0 || c <= 0 || k <= 0 || k > n || k > 32 || !idx || ldp < c || ldq < c) return (int)hipErrorInvalidValue;
+    if (b == 0 || m == 0) return 0;
+    return launch_feat<true, false>(b, n, m, c, k, ldp, ldq, points, queries, dist, idx, (hipStream_t)stream);
 }
 
 DISPU_EXPORT int dispu_knn_point(int b, int n, int m, int c, int k, const float* xyz1, const float* xyz2, float* val,
                                  int* idx, void* stream) {
     if (b < 0 || n <= 0 || m < 0 || c <= 0 || k <= 0 || k > n || k > 32 || !idx) return (int)hipErrorInvalidValue;
     if (b == 0 || m == 0) return 0;
-    return launch_feat<false, true>(b, n, m, c, k, xyz1, xyz2, val, idx, (hipStream_t)stream);
+    return launch_feat<false, true>(b, n, m, c, k, c, c, xyz1, xyz2, val, idx, (hipStream_t)stream);
 }

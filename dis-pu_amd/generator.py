@@ -1,0 +1,235 @@
+"""Dis-PU generator forward pass (inference) on MI355X.
+
+Counterpart of DisPU/generator.py:21-88 (`Generator(opts, is_training)(inputs) -> (coarse, fine)`), issuing the
+same op sequence as the reference graph (Common/ops.py: feature_extraction_GCN :1437, dense_conv :1897,
+duplicate_up :1152, coordinate_regressor :1089, PointShuffle2 :1012, PointNonLocalCell :302) through the C ABI
+of libdispu_hip.so.  torch is used for device memory and the launch stream only.
+
+What is different from the reference's execution (not its results):
+  * no tf.concat / tf.tile / gather_nd tensors: dense-block outputs are written straight into one
+    [rows, 480] feature buffer, prep convs read column slices of it;
+  * the xyz k-NN of PointShuffle2 runs on the device (reference: tf.py_func -> nanoflann on the host);
+  * duplicate_up's 482-wide conv is evaluated once per SOURCE point (same fmaf chain, 4x fewer FLOPs);
+  * PointShuffle2's conv0 over [B,N,16,134] is evaluated per source point (linear in its input groups,
+    16x fewer FLOPs; reassociated -> tolerance-checked).
+Everything up to and including `coarse` is bit-identical to oracle/generator.py (fp32 MFMA == fmaf chain).
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import _lib
+
+K_NEIGH = 16
+GROWTH = 24
+DENSE_BLOCKS = 4
+BN_EPS = 1e-3
+
+
+def gen_grid(up_ratio):
+    """Common/ops.py:60-76."""
+    sq = int(math.sqrt(up_ratio)) + 1
+    for i in range(sq, 0, -1):
+        if up_ratio % i == 0:
+            num_x, num_y = i, up_ratio // i
+            break
+    gx = np.linspace(-0.2, 0.2, num_x, dtype=np.float32)
+    gy = np.linspace(-0.2, 0.2, num_y, dtype=np.float32)
+    x, y = np.meshgrid(gx, gy)
+    return np.stack([x, y], -1).reshape(-1, 2).astype(np.float32)
+
+
+class _Opts(object):
+    patch_num_point = 256
+    up_ratio = 4
+
+
+class Generator(object):
+    """Generator(opts, is_training=False)(inputs[B,N,3]) -> (coarse[B,4N,3], fine[B,4N,3]).
+
+    `params` maps the TF variable names of the reference graph ('generator/feature_extraction_coarse/layer0/weights',
+    ..., see oracle/generator.py:layer_shapes) to arrays: weights [C_in_total, C_out], biases [C_out], plus the
+    four BatchNorm vectors of 'refine/PointShuffle/weight_net/wconv0/bn/'."""
+
+    def __init__(self, opts=None, is_training=False, name="Generator", params=None, device=None):
+        if is_training:
+            raise NotImplementedError("round 1 implements the inference graph (is_training=False)")
+        self.opts = opts if opts is not None else _Opts()
+        self.is_training = is_training
+        self.name = name
+        self.num_point = int(self.opts.patch_num_point)
+        self.up_ratio = int(self.opts.up_ratio)
+        if self.up_ratio != 4:
+            raise NotImplementedError("the shipped generator graph is built for up_ratio 4 (DisPU/configs.py)")
+        self.out_num_point = self.num_point * self.up_ratio
+        self.device = torch.device(device if device is not None else "cuda:0")
+        self.P = {}
+        self._ws = {}
+        if params is not None:
+            self.load_params(params)
+
+    # ------------------------------------------------------------------------------------------ weights ----
+    def load_params(self, params):
+        dev = self.device
+        self.P = {k: torch.from_numpy(np.ascontiguousarray(v, np.float32)).to(dev) for k, v in params.items()}
+        bn = "refine/PointShuffle/weight_net/wconv0/bn/"
+        g, b = params[bn + "gamma"].astype(np.float64), params[bn + "beta"].astype(np.float64)
+        mu, var = params[bn + "moving_mean"].astype(np.float64), params[bn + "moving_variance"].astype(np.float64)
+        scale = g / np.sqrt(var + BN_EPS)
+        self.bn_scale = torch.from_numpy(scale.astype(np.float32)).to(dev)
+        self.bn_shift = torch.from_numpy((b - mu * scale).astype(np.float32)).to(dev)
+        self.grid = torch.from_numpy(gen_grid(self.up_ratio)).to(dev)
+        w1 = self.P["generator/upshuffle_0/conv1/weights"]
+        self.w_up_feat = w1[:480].contiguous()
+        self.w_up_grid = w1[480:482].contiguous()
+        w0 = self.P["refine/PointShuffle/conv0/weights"]
+        self.w_c0_feat = w0[6:134].contiguous()
+
+    def _w(self, scope):
+        return self.P[scope + "/weights"], self.P[scope + "/biases"]
+
+    # ---------------------------------------------------------------------------------------- workspace ----
+    def _workspace(self, B, N):
+        key = (B, N)
+        ws = self._ws.get(key)
+        if ws is not None:
+            return ws
+        dev, f32, i32 = self.device, torch.float32, torch.int32
+        M = N * self.up_ratio
+        rn, rm, k = B * N, B * M, K_NEIGH
+
+        def E(*shape, dtype=f32):
+            return torch.empty(shape, dtype=dtype, device=dev)
+
+        ws = dict(
+            feat=E(rn, 480), prep=E(rn, 48), kidx=E(rn, k + 1, dtype=i32), h256=E(rn, 256),
+            up256=E(rm, 256), up128=E(rm, 128), c256=E(rm, 256), c64=E(rm, 64), coarse=E(B, M, 3),
+            psidx=E(rm, k, dtype=i32), kv=E(rm, 128), q=E(rm, 64), s=E(B, M, M), att=E(rm, 64), nl=E(rm, 256),
+            skipin=torch.zeros((rm, 136), dtype=f32, device=dev), skip=E(rm, 256), gm=E(rm, 128), am=E(rm, 128),
+            x1=E(rm * k, 128), x2=E(rm * k, 128), wv=E(rm * k, 16), fp=E(rm, 2048), aft=E(rm, 256), agg=E(rm, 256),
+            f256=E(rm, 256), f64=E(rm, 64), fine=E(B, M, 3))
+        self._ws[key] = ws
+        return ws
+
+    # ------------------------------------------------------------------------------------------- launch ----
+    def _linear(self, st, X, K, W, bias, act, Y, N, M=None, ldx=None, ldw=None, ldy=None, batch=1, sx=0, sw=0, sy=0,
+                transb=0, R1=None, R2=None, xoff=0, woff=0, yoff=0):
+        """Y[:, yoff:yoff+N] = R2 + R1 + act(X[:, xoff:xoff+K] . W + bias) via dispu_linear (element offsets in floats)."""
+        L = _lib.lib()
+        M = X.shape[0] if M is None else M
+        ldx = X.stride(0) if ldx is None else ldx
+        ldw = W.stride(0) if ldw is None else ldw
+        ldy = Y.stride(0) if ldy is None else ldy
+        p = lambda t, off=0: _lib.C.c_void_p(t.data_ptr() + 4 * off) if t is not None else _lib.C.c_void_p(0)
+        _lib.check(L.dispu_linear(batch, M, K, N, p(X, xoff), ldx, sx, p(W, woff), ldw, sw, transb, p(bias), act,
+                                  p(Y, yoff), ldy, sy, p(R1), R1.stride(0) if R1 is not None else 0, 0,
+                                  p(R2), R2.stride(0) if R2 is not None else 0, 0, st), "dispu_linear")
+
+    def __call__(self, inputs):
+        return self.forward(inputs)
+
+    def forward(self, inputs):
+        if not self.P:
+            raise RuntimeError("Generator has no parameters: call load_params() first")
+        if not (isinstance(inputs, torch.Tensor) and inputs.is_cuda and inputs.dtype == torch.float32 and inputs.dim() == 3
+                and inputs.shape[2] == 3):
+            raise ValueError("Generator expects a float32 [B,N,3] tensor on a ROCm device")
+        inputs = inputs.contiguous()
+        B, N, _ = inputs.shape
+        M = N * self.up_ratio
+        rn, rm, k = B * N, B * M, K_NEIGH
+        ws = self._workspace(B, N)
+        L = _lib.lib()
+        st = _lib.stream_ptr(inputs.device)
+        ptr, chk = _lib.ptr, _lib.check
+        off = lambda t, o: _lib.C.c_void_p(t.data_ptr() + 4 * o)
+        feat = ws["feat"]
+        fe = "generator/feature_extraction_coarse/"
+
+        # ---- feature_extraction_GCN (ops.py:1437-1486): features accumulate right-to-left inside feat[:, 0:480]
+        w, b = self._w(fe + "layer0")
+        chk(L.dispu_linear_small_k(rn, 3, 24, ptr(inputs), 3, ptr(w), ptr(b), 0, off(feat, 456), 480, st), "layer0")
+        col = 456          # left edge of the features produced so far
+        for d in range(1, DENSE_BLOCKS + 1):
+            if d == 1:
+                F, ldf, foff, C = feat, 480, 456, 24
+            else:
+                w, b = self._w(fe + "layer%d_prep" % d)
+                self._linear(st, feat, 480 - col, w, b, 1, ws["prep"], 48, xoff=col)
+                F, ldf, foff, C = ws["prep"], 48, 0, 48
+            chk(L.dispu_knn_feat_strided(B, N, N, C, k + 1, off(F, foff), ldf, off(F, foff), ldf, None, ptr(ws["kidx"]), st),
+                "knn_feat")
+            w0, b0 = self._w(fe + "layer%d/l0" % d)
+            w1, b1 = self._w(fe + "layer%d/l1" % d)
+            w2, b2 = self._w(fe + "layer%d/l2" % d)
+            width = 3 * GROWTH + C
+            col -= width
+            chk(L.dispu_edge_dense_conv(rn, N, C, off(F, foff), ldf, ptr(ws["kidx"]), k + 1, 1, ptr(w0), ptr(b0), ptr(w1),
+                                        ptr(b1), ptr(w2), ptr(b2), off(feat, col), 480, st), "edge_dense_conv")
+        assert col == 0
+
+        # ---- duplicate_up (ops.py:1152-1199) + coarse coordinate_regressor (:1089-1110)
+        _, b1 = self._w("generator/upshuffle_0/conv1")
+        self._linear(st, feat, 480, self.w_up_feat, None, 0, ws["h256"], 256)
+        chk(L.dispu_dup_grid(B, N, 256, self.up_ratio, ptr(ws["h256"]), 256, ptr(self.w_up_grid), ptr(b1), ptr(self.grid),
+                             ptr(ws["up256"]), 256, st), "dup_grid")
+        w, b = self._w("generator/upshuffle_0/conv2")
+        self._linear(st, ws["up256"], 256, w, b, 1, ws["up128"], 128)
+        cs = "generator/coarse_coordinate_regressor/"
+        w, b = self._w(cs + "fc_layer0")
+        self._linear(st, ws["up128"], 128, w, b, 1, ws["c256"], 256)
+        w, b = self._w(cs + "fc_layer1")
+        self._linear(st, ws["c256"], 256, w, b, 1, ws["c64"], 64)
+        w, b = self._w(cs + "fc_layer2")
+        coarse = ws["coarse"]
+        chk(L.dispu_linear_small_n(rm, 64, 3, ptr(ws["c64"]), 64, ptr(w), ptr(b), 0, None, 0, ptr(coarse), 3, st), "coarse")
+
+        # ---- PointShuffle2 (ops.py:1012-1087)
+        ps = "refine/PointShuffle/"
+        up128 = ws["up128"]
+        chk(L.dispu_knn_xyz(B, M, M, k, ptr(coarse), ptr(coarse), ptr(ws["psidx"]), None, _lib.ARITH_PLAIN, st), "knn_xyz")
+        # PointNonLocalCell (ops.py:302-346)
+        w, b = self._w(ps + "PointShuffle/conv_kv")
+        self._linear(st, up128, 128, w, b, 0, ws["kv"], 128)
+        w, b = self._w(ps + "PointShuffle/conv_query")
+        self._linear(st, up128, 128, w, b, 0, ws["q"], 64)
+        self._linear(st, ws["q"], 64, ws["kv"], None, 0, ws["s"], M, M=M, ldx=64, ldw=128, ldy=M, batch=B, sx=M * 64,
+                     sw=M * 128, sy=M * M, transb=1)
+        chk(L.dispu_softmax_rows(rm, M, 0.125, ptr(ws["s"]), M, st), "softmax")
+        self._linear(st, ws["s"], M, ws["kv"], None, 0, ws["att"], 64, M=M, ldx=M, ldw=128, ldy=64, batch=B, sx=M * M,
+                     sw=M * 128, sy=M * 64, woff=64)
+        w, b = self._w(ps + "PointShuffle/conv_back_project")
+        self._linear(st, ws["att"], 64, w, b, 1, ws["nl"], 256)
+        # skip connection
+        chk(L.dispu_ps_skip_max(rm, M, k, 128, ptr(ws["psidx"]), ptr(coarse), ptr(up128), 128, ptr(ws["skipin"]), 136, st),
+            "skip_max")
+        w, b = self._w(ps + "skip")
+        self._linear(st, ws["skipin"], 134, w, b, 1, ws["skip"], 256)
+        # local cell: conv0 per source point, conv1 per pair
+        w0, b0 = self._w(ps + "conv0")
+        self._linear(st, up128, 128, self.w_c0_feat, None, 0, ws["gm"], 128)
+        chk(L.dispu_ps_prep(rm, 128, ptr(coarse), ptr(w0), ptr(b0), ptr(ws["gm"]), 128, ptr(ws["am"]), 128, st), "ps_prep")
+        chk(L.dispu_ps_gather_sub_relu(rm, M, k, 128, ptr(ws["psidx"]), ptr(ws["gm"]), 128, ptr(ws["am"]), 128,
+                                       ptr(ws["x1"]), 128, st), "gather_sub_relu")
+        w, b = self._w(ps + "conv1")
+        self._linear(st, ws["x1"], 128, w, b, 1, ws["x2"], 128)
+        w, b = self._w(ps + "weight_net/wconv0")
+        chk(L.dispu_ps_weight_net(rm, M, k, 16, ptr(ws["psidx"]), ptr(coarse), ptr(w), ptr(b), ptr(self.bn_scale),
+                                  ptr(self.bn_shift), ptr(ws["wv"]), st), "weight_net")
+        chk(L.dispu_ps_point_matmul(rm, k, 128, 16, ptr(ws["x2"]), 128, ptr(ws["wv"]), ptr(ws["fp"]), 2048, st), "point_matmul")
+        w, b = self._w(ps + "after_conv")
+        self._linear(st, ws["fp"], 2048, w, b, 1, ws["aft"], 256, R1=ws["skip"], R2=ws["nl"])
+        w, b = self._w(ps + "aggregation")
+        self._linear(st, ws["aft"], 256, w, b, 1, ws["agg"], 256)
+
+        # ---- fine coordinate_regressor (is_off) + residual (generator.py:76-81)
+        fs = "refine/fine_coordinate_regressor/"
+        w, b = self._w(fs + "fc_layer0")
+        self._linear(st, ws["agg"], 256, w, b, 1, ws["f256"], 256)
+        w, b = self._w(fs + "fc_layer1")
+        self._linear(st, ws["f256"], 256, w, b, 1, ws["f64"], 64)
+        w, b = self._w(fs + "fc_layer2")
+        chk(L.dispu_linear_small_n(rm, 64, 3, ptr(ws["f64"]), 64, ptr(w), ptr(b), 1, ptr(coarse), 3, ptr(ws["fine"]), 3, st),
+            "fine")
+        return coarse, ws["fine"]

@@ -86,6 +86,10 @@ int dispu_knn_point(int b, int n, int m, int c, int k, const float* xyz1, const 
 int dispu_knn_feat(int b, int n, int m, int c, int k, const float* points, const float* queries, float* dist,
                    int* idx, void* stream);
 
+/* dispu_knn_feat with explicit row strides (in floats) so points/queries can be column slices of a wider buffer. */
+int dispu_knn_feat_strided(int b, int n, int m, int c, int k, const float* points, int ldp, const float* queries,
+                           int ldq, float* dist, int* idx, void* stream);
+
 /* ---- libs/nearest_neighbors ----------------------------------------------------------------- */
 
 /* cpp_knn_batch_omp(batch_data,batch_size,npts,dim=3,queries,nqueries,K,indices)
@@ -132,6 +136,48 @@ int dispu_match_cost(int b, int n, int m, const float* xyz1, const float* xyz2, 
 /* matchcostgradLauncher(b,n,m,xyz1,xyz2,match,grad1,grad2)   tf_approxmatch.cpp:143; kernels :229-295. */
 int dispu_match_cost_grad(int b, int n, int m, const float* xyz1, const float* xyz2, const float* match, float* grad1,
                           float* grad2, int arith, void* stream);
+
+/* ---- per-point MLP stacks (Common/tf_util.py conv1d/conv2d 1x1, Common/ops.py blocks) --------------
+ * The reference builds these from TensorFlow core ops (conv2d -> bias_add -> relu, matmul, softmax,
+ * gather_nd, concat); there is no native launcher to replace, so each entry point cites the Python block
+ * whose arithmetic it implements.  Matrices are (pointer, row stride `ld*` in floats[, batch stride `s*`]). */
+
+/* Y[z][m,n] = R2 + R1 + act( sum_k X[z][m,k] * W[z][k,n] + bias[n] ), k ascending, fp32 MFMA (bit-equal to an
+ * fmaf chain).  transb != 0: W is given as [n][k].  act: 0 none, 1 ReLU.  bias/R1/R2 may be NULL.
+ * conv1d/conv2d with 1x1 kernels: Common/tf_util.py:52-115,120-185; tf.matmul of PointNonLocalCell ops.py:326,339. */
+int dispu_linear(int batch, int M, int K, int N, const float* X, long ldx, long sx, const float* W, long ldw, long sw,
+                 int transb, const float* bias, int act, float* Y, long ldy, long sy, const float* R1, long ldr1,
+                 long sr1, const float* R2, long ldr2, long sr2, void* stream);
+/* K <= 4 inputs, N in {16, 24} outputs (feature_extraction layer0, ops.py:1449-1451). */
+int dispu_linear_small_k(long rows, int K, int N, const float* X, long ldx, const float* W, const float* bias, int act,
+                         float* Y, long ldy, void* stream);
+/* N == 3 outputs (coordinate_regressor fc_layer2, ops.py:1101-1104); mode 1: Y = R + (sigmoid(.) - 0.5), the fine
+ * branch's offset fused with `fine = coarse + offset` (ops.py:1106-1108, DisPU/generator.py:80-81). */
+int dispu_linear_small_n(long rows, int K, int N, const float* X, long ldx, const float* W, const float* bias, int mode,
+                         const float* R, long ldr, float* Y, long ldy, void* stream);
+/* dense_conv + get_edge_feature fused (ops.py:1856-1877,1897-1915): F [npoints, C] (C in {24,48}), idx[npoints, ldi]
+ * neighbour ids (columns ioff..ioff+15, cloud-local), three 1x1 convs with dense concat, max over the 16 neighbours.
+ * Y[p, 0:72+C] = [max l2 | max l1 | max l0 | F_p]. */
+int dispu_edge_dense_conv(int npoints, int n_per_cloud, int C, const float* F, long ldf, const int* idx, int ldi, int ioff,
+                          const float* W0, const float* b0, const float* W1, const float* b1, const float* W2,
+                          const float* b2, float* Y, long ldy, void* stream);
+/* duplicate_up conv1 tail (ops.py:1161-1191): continues the per-source-point chain H with the two grid-code channels of
+ * each of the `up` copies, + bias, ReLU.  Output rows are copy-major: (cloud*up + r)*n + i. */
+int dispu_dup_grid(int nclouds, int n, int co, int up, const float* H, long ldh, const float* Wg, const float* bias,
+                   const float* grid, float* Y, long ldy, void* stream);
+/* PointShuffle2 (ops.py:1012-1087) pieces; idx [rows, k] int32 cloud-local neighbour ids from dispu_knn_xyz. */
+int dispu_ps_prep(long rows, int co, const float* xyz, const float* W0, const float* bias, float* G, long ldg, float* A,
+                  long lda, void* stream);
+int dispu_ps_gather_sub_relu(long rows, int n_per_cloud, int k, int c, const int* idx, const float* G, long ldg,
+                             const float* A, long lda, float* X1, long ldx1, void* stream);
+int dispu_ps_skip_max(long rows, int n_per_cloud, int k, int cf, const int* idx, const float* xyz, const float* feat,
+                      long ldf, float* out, long ldo, void* stream);
+int dispu_ps_weight_net(long rows, int n_per_cloud, int k, int t_n, const int* idx, const float* xyz, const float* Ww,
+                        const float* bw, const float* scale, const float* shift, float* wv, void* stream);
+int dispu_ps_point_matmul(long rows, int k, int c, int t_n, const float* X2, long ldx2, const float* wv, float* out,
+                          long ldo, void* stream);
+/* S <- softmax(S * mul) per row, in place (tf.nn.softmax of PointNonLocalCell, ops.py:338). */
+int dispu_softmax_rows(long rows, int n, float mul, float* S, long lds, void* stream);
 
 #ifdef __cplusplus
 }

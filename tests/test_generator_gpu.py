@@ -1,0 +1,94 @@
+"""GPU parity of the generator forward (DisPU/generator.py:31-88 counterpart) against oracle/generator.py.
+Everything that feeds an index decision (feature k-NN inside the dense blocks, xyz k-NN on `coarse`) is
+bit-exact; the refinement branch (softmax / sigmoid / reassociated conv0) is checked at 1e-5."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import generator as OG
+
+pytestmark = pytest.mark.gpu
+
+
+def N(t):
+    return t.detach().cpu().numpy()
+
+
+@pytest.fixture(scope="module")
+def setup(dev):
+    from dispu_amd import synth
+    from dispu_amd.generator import Generator
+    P = OG.init_params(seed=1234, bias_scale=0.05, bn_random=True)   # exercise biases and the BN fold
+    gen = Generator(params=P, device=dev)
+    x = synth.patches(3, 256, seed=5)
+    tap = {}
+    coarse, fine = OG.generator_forward(P, x, tap)
+    c, f = gen(torch.from_numpy(x).to(dev))
+    torch.cuda.synchronize()
+    return dict(gen=gen, P=P, x=x, tap=tap, coarse=coarse, fine=fine, c=N(c), f=N(f), ws=gen._ws[(3, 256)])
+
+
+def test_feature_extraction_bit_exact(setup):
+    ws, tap = setup["ws"], setup["tap"]
+    assert np.array_equal(N(ws["kidx"])[:, 1:].reshape(3, 256, 16), tap["fe_idx4"])   # last dense block's neighbours
+    assert np.array_equal(N(ws["feat"]).reshape(3, 256, 480), tap["feat480"])
+
+
+def test_coarse_bit_exact(setup):
+    assert np.array_equal(N(setup["ws"]["up128"]).reshape(3, 1024, 128), setup["tap"]["up128"])
+    assert np.array_equal(setup["c"], setup["coarse"])
+
+
+def test_pointshuffle_neighbours_index_exact(setup):
+    assert np.array_equal(N(setup["ws"]["psidx"]).reshape(3, 1024, 16), setup["tap"]["ps_idx"])
+
+
+def test_fine_within_tolerance(setup):
+    ff = N(setup["ws"]["agg"]).reshape(3, 1024, 256)
+    ref = setup["tap"]["fine_feat"]
+    assert np.abs(ff - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max())
+    assert np.abs(setup["f"] - setup["fine"]).max() <= 1e-5
+
+
+def test_default_init_and_batch_independence(dev):
+    """Xavier / zero-bias default init (the benchmark's weights); per-patch results do not depend on the batch."""
+    from dispu_amd import synth
+    from dispu_amd.generator import Generator
+    P = OG.init_params()
+    gen = Generator(params=P, device=dev)
+    x = synth.patches(4, 256, seed=9)
+    c4, f4 = gen(torch.from_numpy(x).to(dev))
+    c4, f4 = N(c4).copy(), N(f4).copy()
+    c1, f1 = gen(torch.from_numpy(x[2:3]).to(dev))
+    assert np.array_equal(N(c1)[0], c4[2]) and np.array_equal(N(f1)[0], f4[2])
+    co, fo = OG.generator_forward(P, x[2:3])
+    assert np.array_equal(N(c1), co) and np.abs(N(f1) - fo).max() <= 1e-5
+
+
+def test_linear_matches_chain_exactly(dev):
+    """dispu_linear (fp32 MFMA) against the pinned fmaf chain for awkward shapes: K tail, N tail, M tail,
+    strided operands, residuals, transposed B, batching."""
+    from dispu_amd import _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(0)
+    for (M, K, Nn, act) in [(300, 134, 256, 1), (257, 482, 48, 0), (1024, 64, 64, 1), (70, 2048, 256, 1), (513, 120, 128, 0)]:
+        x = rng.standard_normal((M, K + 3)).astype(np.float32)
+        w = (rng.standard_normal((K, Nn)) * 0.1).astype(np.float32)
+        b = rng.standard_normal(Nn).astype(np.float32)
+        r1 = rng.standard_normal((M, Nn)).astype(np.float32)
+        want = OG.linear(x[:, 1:K + 1], w, b, relu=bool(act)) + r1
+        tx, tw, tb, tr = (torch.from_numpy(a).to(dev) for a in (x, w, b, r1))
+        y = torch.zeros((M, Nn + 5), device=dev)
+        _lib.check(L.dispu_linear(1, M, K, Nn, tx.data_ptr() + 4, K + 3, 0, tw.data_ptr(), Nn, 0, 0, tb.data_ptr(), act,
+                                  y.data_ptr() + 8, Nn + 5, 0, tr.data_ptr(), Nn, 0, None, 0, 0,
+                                  _lib.stream_ptr(dev)), "dispu_linear")
+        got = N(y)
+        assert np.array_equal(got[:, 2:Nn + 2], want), (M, K, Nn)
+        assert (got[:, :2] == 0).all() and (got[:, Nn + 2:] == 0).all()
+    q = rng.standard_normal((2, 96, 64)).astype(np.float32)
+    kk = rng.standard_normal((2, 130, 64)).astype(np.float32)
+    s = torch.empty((2, 96, 130), device=dev)
+    tq, tk = torch.from_numpy(q).to(dev), torch.from_numpy(kk).to(dev)
+    _lib.check(L.dispu_linear(2, 96, 64, 130, tq.data_ptr(), 64, 96 * 64, tk.data_ptr(), 64, 130 * 64, 1, None, 0,
+                              s.data_ptr(), 130, 96 * 130, None, 0, 0, None, 0, 0, _lib.stream_ptr(dev)), "qk^t")
+    assert np.array_equal(N(s), OG.matmul_nt(q, kk))
