@@ -1,0 +1,198 @@
+#!/usr/bin/env python3
+"""Headline benchmark: upsampled points/s of the Dis-PU generator forward, 256 -> 1024 (4x), fp32.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]          (N > 1: launched by torch.distributed.run)
+
+A step = one pass of the hot path over one batch of synthetic patches that already live in HBM:
+BASELINE.json configs[1] (B = 32 patches of 256 points per GPU, generator forward -> 32 x 1024 points),
+and for N > 1 configs[2]: the patch batch is sharded 32 per rank (weak scaling, no data-path collective)
+followed by ONE RCCL all-gather that reassembles the upsampled clouds on every rank.
+Rank 0 prints one JSON line (contract in the task brief) including `roofline` for the dominant kernel
+(HIP events on the launch stream) and `cpu_baseline` (the CPU oracle timed on the host cores, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PATCHES_PER_GPU = 32
+NPOINT = 256
+UP = 4
+FP32_MFMA_PEAK_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+DOMINANT = "linear["                 # every launch of linear_mfma_kernel<...> (dis-pu_amd/csrc/linear.hip)
+
+
+def linear_flops(name):
+    # "linear[MxKxN]" -> algorithmic flops of that launch: 2*M*K*N
+    dims = name[name.index("[") + 1:name.index("]")].rstrip("^T").split("x")
+    m, k, n = (int(v) for v in dims)
+    return 2.0 * m * k * n
+
+
+def cpu_baseline(params, target_seconds=12.0):
+    """The CPU oracle (oracle/generator.py, a port of the reference algorithm; OpenMP over rows) on the host."""
+    import numpy as np
+    from dispu_amd import synth
+    from oracle import generator as OG
+    from oracle import oracle as O
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    x = synth.patches(256, NPOINT, seed=1000)
+    OG.generator_forward(params, x[:1])                       # warm-up / page-in
+    # the oracle's OpenMP loops are short; more threads are not always faster -> pick the best of a few counts
+    best = None
+    for c in sorted({avail, min(avail, 64), min(avail, 16), 1}, reverse=True):
+        O.set_threads(c)
+        t = time.perf_counter()
+        OG.generator_forward(params, x[:2])
+        pp = (time.perf_counter() - t) / 2
+        if best is None or pp < best[0]:
+            best = (pp, c)
+    per_patch, cores = best
+    O.set_threads(cores)
+    n = int(max(2, min(256, target_seconds / max(per_patch, 1e-3))))
+    t = time.perf_counter()
+    OG.generator_forward(params, x[:n])
+    dt = time.perf_counter() - t
+    return {"value": n * NPOINT * UP / dt, "unit": "points/s", "cores": cores, "kind": "port",
+            "sample": "%d patches of %d points (same synthetic workload), oracle/generator.py with %d OpenMP threads "
+                      "(best of a few thread counts on a host with %d cores), %.1f s" % (n, NPOINT, cores, avail, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--eager", action="store_true", help="do not capture the forward in a hipGraph")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from dispu_amd import synth
+    from dispu_amd.generator import Generator
+    from oracle import generator as OG   # parameter initialiser + cpu_baseline only; never on the measured path
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d"
+                         % (args.gpus, world, args.gpus))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    params = OG.init_params(seed=1234)                        # Xavier-uniform, zero biases (reference init)
+    gen = Generator(params=params, device=dev)
+    x = torch.from_numpy(synth.patches(PATCHES_PER_GPU, NPOINT, seed=1000 * 2 + rank)).to(dev)   # 1000*config + rank
+    gathered = torch.empty((world * PATCHES_PER_GPU, NPOINT * UP, 3), dtype=torch.float32, device=dev) if world > 1 else None
+
+    def step_eager():
+        _, fine = gen(x)
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, fine)
+        return fine
+
+    step_eager()
+    torch.cuda.synchronize()
+    launch = "eager"
+    graph = None
+    if not args.eager:
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                gen(x)
+            torch.cuda.current_stream().wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                gen(x)                                         # generator only; the collective stays outside the graph
+            launch = "hipgraph"
+        except Exception as e:                                 # noqa: BLE001
+            graph = None
+            launch = "eager (graph capture failed: %s)" % type(e).__name__
+            torch.cuda.synchronize()
+
+    fine_buf = gen._ws[(PATCHES_PER_GPU, NPOINT)]["fine"]
+
+    def step():
+        if graph is not None:
+            graph.replay()
+            if world > 1:
+                dist.all_gather_into_tensor(gathered, fine_buf)
+        else:
+            step_eager()
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    # ---- roofline of the dominant kernel: HIP events around every launch, on the launch stream (eager pass)
+    roof = None
+    if rank == 0:
+        reps = 5
+        acc = {}
+        for _ in range(reps):
+            gen.profile = []
+            gen(x)
+            torch.cuda.synchronize()
+            for name, e0, e1 in gen.profile:
+                a = acc.setdefault(name, [0.0, 0])
+                a[0] += e0.elapsed_time(e1) * 1e-3
+                a[1] += 1
+        gen.profile = None
+        lin = {k: v for k, v in acc.items() if k.startswith(DOMINANT)}
+        t_lin = sum(v[0] for v in lin.values()) / reps                      # seconds per forward in the GEMM kernel
+        n_lin = sum(v[1] for v in lin.values()) / reps
+        fl_lin = sum(linear_flops(k) * v[1] for k, v in lin.items()) / reps
+        t_all = sum(v[0] for v in acc.values()) / reps
+        achieved = fl_lin / t_lin / 1e12
+        top = sorted(acc.items(), key=lambda kv: -kv[1][0])[:6]
+        roof = {"bound": "mfma", "kernel": "dispu::linear_mfma_kernel (all %d launches per step)" % round(n_lin),
+                "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                "avg_launch_us": t_lin / n_lin * 1e6, "flops_per_launch": fl_lin / n_lin,
+                "share_of_step": t_lin / t_all,
+                "top_launches_us": {k: v[0] / v[1] * 1e6 for k, v in top}}
+
+    if rank == 0:
+        pts = world * PATCHES_PER_GPU * NPOINT * UP
+        out = {"metric": "upsampled points/sec (256->1024, 4x)", "value": pts * args.steps / dt, "unit": "points/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": "BASELINE configs[%d]: %d patches x %d points per GPU, generator forward 256->1024 (4x), "
+                                      "fp32%s" % (1 if world == 1 else 2, PATCHES_PER_GPU, NPOINT,
+                                                  "" if world == 1 else ", + RCCL all-gather of the upsampled clouds"),
+                          "patches_per_gpu": PATCHES_PER_GPU, "global_patches": world * PATCHES_PER_GPU,
+                          "points_out_per_step": pts, "launch": launch, "weights": "xavier-uniform seed 1234, zero bias",
+                          "parallelism": "patch-sharded x%d" % world},
+               "roofline": roof}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(params)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

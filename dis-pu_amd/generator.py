@@ -66,6 +66,7 @@ class Generator(object):
         self.device = torch.device(device if device is not None else "cuda:0")
         self.P = {}
         self._ws = {}
+        self.profile = None          # set to [] to collect (name, start_event, end_event) per launch
         if params is not None:
             self.load_params(params)
 
@@ -113,6 +114,17 @@ class Generator(object):
         return ws
 
     # ------------------------------------------------------------------------------------------- launch ----
+    def _call(self, name, fn, *args):
+        """One C-ABI launch; when self.profile is a list, bracket it with HIP events on the launch stream."""
+        if self.profile is None:
+            _lib.check(fn(*args), name)
+            return
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        _lib.check(fn(*args), name)
+        e1.record()
+        self.profile.append((name, e0, e1))
+
     def _linear(self, st, X, K, W, bias, act, Y, N, M=None, ldx=None, ldw=None, ldy=None, batch=1, sx=0, sw=0, sy=0,
                 transb=0, R1=None, R2=None, xoff=0, woff=0, yoff=0):
         """Y[:, yoff:yoff+N] = R2 + R1 + act(X[:, xoff:xoff+K] . W + bias) via dispu_linear (element offsets in floats)."""
@@ -122,9 +134,9 @@ class Generator(object):
         ldw = W.stride(0) if ldw is None else ldw
         ldy = Y.stride(0) if ldy is None else ldy
         p = lambda t, off=0: _lib.C.c_void_p(t.data_ptr() + 4 * off) if t is not None else _lib.C.c_void_p(0)
-        _lib.check(L.dispu_linear(batch, M, K, N, p(X, xoff), ldx, sx, p(W, woff), ldw, sw, transb, p(bias), act,
-                                  p(Y, yoff), ldy, sy, p(R1), R1.stride(0) if R1 is not None else 0, 0,
-                                  p(R2), R2.stride(0) if R2 is not None else 0, 0, st), "dispu_linear")
+        self._call("linear[%dx%dx%d%s]" % (M * batch, K, N, "^T" if transb else ""), L.dispu_linear, batch, M, K, N,
+                   p(X, xoff), ldx, sx, p(W, woff), ldw, sw, transb, p(bias), act, p(Y, yoff), ldy, sy, p(R1),
+                   R1.stride(0) if R1 is not None else 0, 0, p(R2), R2.stride(0) if R2 is not None else 0, 0, st)
 
     def __call__(self, inputs):
         return self.forward(inputs)
@@ -142,14 +154,14 @@ class Generator(object):
         ws = self._workspace(B, N)
         L = _lib.lib()
         st = _lib.stream_ptr(inputs.device)
-        ptr, chk = _lib.ptr, _lib.check
+        ptr = _lib.ptr
         off = lambda t, o: _lib.C.c_void_p(t.data_ptr() + 4 * o)
         feat = ws["feat"]
         fe = "generator/feature_extraction_coarse/"
 
         # ---- feature_extraction_GCN (ops.py:1437-1486): features accumulate right-to-left inside feat[:, 0:480]
         w, b = self._w(fe + "layer0")
-        chk(L.dispu_linear_small_k(rn, 3, 24, ptr(inputs), 3, ptr(w), ptr(b), 0, off(feat, 456), 480, st), "layer0")
+        self._call("layer0", L.dispu_linear_small_k, rn, 3, 24, ptr(inputs), 3, ptr(w), ptr(b), 0, off(feat, 456), 480, st)
         col = 456          # left edge of the features produced so far
         for d in range(1, DENSE_BLOCKS + 1):
             if d == 1:
@@ -158,22 +170,21 @@ class Generator(object):
                 w, b = self._w(fe + "layer%d_prep" % d)
                 self._linear(st, feat, 480 - col, w, b, 1, ws["prep"], 48, xoff=col)
                 F, ldf, foff, C = ws["prep"], 48, 0, 48
-            chk(L.dispu_knn_feat_strided(B, N, N, C, k + 1, off(F, foff), ldf, off(F, foff), ldf, None, ptr(ws["kidx"]), st),
-                "knn_feat")
+            self._call("knn_feat", L.dispu_knn_feat_strided, B, N, N, C, k + 1, off(F, foff), ldf, off(F, foff), ldf, None, ptr(ws["kidx"]), st)
             w0, b0 = self._w(fe + "layer%d/l0" % d)
             w1, b1 = self._w(fe + "layer%d/l1" % d)
             w2, b2 = self._w(fe + "layer%d/l2" % d)
             width = 3 * GROWTH + C
             col -= width
-            chk(L.dispu_edge_dense_conv(rn, N, C, off(F, foff), ldf, ptr(ws["kidx"]), k + 1, 1, ptr(w0), ptr(b0), ptr(w1),
-                                        ptr(b1), ptr(w2), ptr(b2), off(feat, col), 480, st), "edge_dense_conv")
+            self._call("edge_dense_conv", L.dispu_edge_dense_conv, rn, N, C, off(F, foff), ldf, ptr(ws["kidx"]), k + 1, 1, ptr(w0), ptr(b0), ptr(w1),
+                                        ptr(b1), ptr(w2), ptr(b2), off(feat, col), 480, st)
         assert col == 0
 
         # ---- duplicate_up (ops.py:1152-1199) + coarse coordinate_regressor (:1089-1110)
         _, b1 = self._w("generator/upshuffle_0/conv1")
         self._linear(st, feat, 480, self.w_up_feat, None, 0, ws["h256"], 256)
-        chk(L.dispu_dup_grid(B, N, 256, self.up_ratio, ptr(ws["h256"]), 256, ptr(self.w_up_grid), ptr(b1), ptr(self.grid),
-                             ptr(ws["up256"]), 256, st), "dup_grid")
+        self._call("dup_grid", L.dispu_dup_grid, B, N, 256, self.up_ratio, ptr(ws["h256"]), 256, ptr(self.w_up_grid), ptr(b1), ptr(self.grid),
+                             ptr(ws["up256"]), 256, st)
         w, b = self._w("generator/upshuffle_0/conv2")
         self._linear(st, ws["up256"], 256, w, b, 1, ws["up128"], 128)
         cs = "generator/coarse_coordinate_regressor/"
@@ -183,12 +194,12 @@ class Generator(object):
         self._linear(st, ws["c256"], 256, w, b, 1, ws["c64"], 64)
         w, b = self._w(cs + "fc_layer2")
         coarse = ws["coarse"]
-        chk(L.dispu_linear_small_n(rm, 64, 3, ptr(ws["c64"]), 64, ptr(w), ptr(b), 0, None, 0, ptr(coarse), 3, st), "coarse")
+        self._call("coarse", L.dispu_linear_small_n, rm, 64, 3, ptr(ws["c64"]), 64, ptr(w), ptr(b), 0, None, 0, ptr(coarse), 3, st)
 
         # ---- PointShuffle2 (ops.py:1012-1087)
         ps = "refine/PointShuffle/"
         up128 = ws["up128"]
-        chk(L.dispu_knn_xyz(B, M, M, k, ptr(coarse), ptr(coarse), ptr(ws["psidx"]), None, _lib.ARITH_PLAIN, st), "knn_xyz")
+        self._call("knn_xyz", L.dispu_knn_xyz, B, M, M, k, ptr(coarse), ptr(coarse), ptr(ws["psidx"]), None, _lib.ARITH_PLAIN, st)
         # PointNonLocalCell (ops.py:302-346)
         w, b = self._w(ps + "PointShuffle/conv_kv")
         self._linear(st, up128, 128, w, b, 0, ws["kv"], 128)
@@ -196,28 +207,27 @@ class Generator(object):
         self._linear(st, up128, 128, w, b, 0, ws["q"], 64)
         self._linear(st, ws["q"], 64, ws["kv"], None, 0, ws["s"], M, M=M, ldx=64, ldw=128, ldy=M, batch=B, sx=M * 64,
                      sw=M * 128, sy=M * M, transb=1)
-        chk(L.dispu_softmax_rows(rm, M, 0.125, ptr(ws["s"]), M, st), "softmax")
+        self._call("softmax", L.dispu_softmax_rows, rm, M, 0.125, ptr(ws["s"]), M, st)
         self._linear(st, ws["s"], M, ws["kv"], None, 0, ws["att"], 64, M=M, ldx=M, ldw=128, ldy=64, batch=B, sx=M * M,
                      sw=M * 128, sy=M * 64, woff=64)
         w, b = self._w(ps + "PointShuffle/conv_back_project")
         self._linear(st, ws["att"], 64, w, b, 1, ws["nl"], 256)
         # skip connection
-        chk(L.dispu_ps_skip_max(rm, M, k, 128, ptr(ws["psidx"]), ptr(coarse), ptr(up128), 128, ptr(ws["skipin"]), 136, st),
-            "skip_max")
+        self._call("skip_max", L.dispu_ps_skip_max, rm, M, k, 128, ptr(ws["psidx"]), ptr(coarse), ptr(up128), 128, ptr(ws["skipin"]), 136, st)
         w, b = self._w(ps + "skip")
         self._linear(st, ws["skipin"], 134, w, b, 1, ws["skip"], 256)
         # local cell: conv0 per source point, conv1 per pair
         w0, b0 = self._w(ps + "conv0")
         self._linear(st, up128, 128, self.w_c0_feat, None, 0, ws["gm"], 128)
-        chk(L.dispu_ps_prep(rm, 128, ptr(coarse), ptr(w0), ptr(b0), ptr(ws["gm"]), 128, ptr(ws["am"]), 128, st), "ps_prep")
-        chk(L.dispu_ps_gather_sub_relu(rm, M, k, 128, ptr(ws["psidx"]), ptr(ws["gm"]), 128, ptr(ws["am"]), 128,
-                                       ptr(ws["x1"]), 128, st), "gather_sub_relu")
+        self._call("ps_prep", L.dispu_ps_prep, rm, 128, ptr(coarse), ptr(w0), ptr(b0), ptr(ws["gm"]), 128, ptr(ws["am"]), 128, st)
+        self._call("gather_sub_relu", L.dispu_ps_gather_sub_relu, rm, M, k, 128, ptr(ws["psidx"]), ptr(ws["gm"]), 128, ptr(ws["am"]), 128,
+                                       ptr(ws["x1"]), 128, st)
         w, b = self._w(ps + "conv1")
         self._linear(st, ws["x1"], 128, w, b, 1, ws["x2"], 128)
         w, b = self._w(ps + "weight_net/wconv0")
-        chk(L.dispu_ps_weight_net(rm, M, k, 16, ptr(ws["psidx"]), ptr(coarse), ptr(w), ptr(b), ptr(self.bn_scale),
-                                  ptr(self.bn_shift), ptr(ws["wv"]), st), "weight_net")
-        chk(L.dispu_ps_point_matmul(rm, k, 128, 16, ptr(ws["x2"]), 128, ptr(ws["wv"]), ptr(ws["fp"]), 2048, st), "point_matmul")
+        self._call("weight_net", L.dispu_ps_weight_net, rm, M, k, 16, ptr(ws["psidx"]), ptr(coarse), ptr(w), ptr(b), ptr(self.bn_scale),
+                                  ptr(self.bn_shift), ptr(ws["wv"]), st)
+        self._call("point_matmul", L.dispu_ps_point_matmul, rm, k, 128, 16, ptr(ws["x2"]), 128, ptr(ws["wv"]), ptr(ws["fp"]), 2048, st)
         w, b = self._w(ps + "after_conv")
         self._linear(st, ws["fp"], 2048, w, b, 1, ws["aft"], 256, R1=ws["skip"], R2=ws["nl"])
         w, b = self._w(ps + "aggregation")
@@ -230,6 +240,5 @@ class Generator(object):
         w, b = self._w(fs + "fc_layer1")
         self._linear(st, ws["f256"], 256, w, b, 1, ws["f64"], 64)
         w, b = self._w(fs + "fc_layer2")
-        chk(L.dispu_linear_small_n(rm, 64, 3, ptr(ws["f64"]), 64, ptr(w), ptr(b), 1, ptr(coarse), 3, ptr(ws["fine"]), 3, st),
-            "fine")
+        self._call("fine", L.dispu_linear_small_n, rm, 64, 3, ptr(ws["f64"]), 64, ptr(w), ptr(b), 1, ptr(coarse), 3, ptr(ws["fine"]), 3, st)
         return coarse, ws["fine"]
