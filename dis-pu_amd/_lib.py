@@ -39,6 +39,7 @@ SIGNATURES = {
     "dispu_match_cost": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp]),
     "dispu_match_cost_grad": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "dispu_linear": (_i, [_i, _i, _i, _i, _vp, _l, _l, _vp, _l, _l, _i, _vp, _i, _vp, _l, _l, _vp, _l, _l, _vp, _l, _l, _vp]),
+    "dispu_linear_tile": (_i, [_i, _i, _i]),
     "dispu_linear_small_k": (_i, [_l, _i, _i, _vp, _l, _vp, _vp, _i, _vp, _l, _vp]),
     "dispu_linear_small_n": (_i, [_l, _i, _i, _vp, _l, _vp, _vp, _i, _vp, _l, _vp, _l, _vp]),
     "dispu_edge_dense_conv": (_i, [_i, _i, _i, _vp, _l, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _l, _vp]),

@@ -196,6 +196,15 @@ static int launch_linear(const LinearArgs& a, int batch, bool transb, hipStream_
 
 using namespace dispu;
 
+// Block-tile choice of dispu_linear as BM*1000 + BN (128128, 64128, 128064, 64064): large tiles when they still
+// give >= 256 workgroups (one per CU), smaller ones otherwise.  Exported so a profiler can name the instantiation.
+DISPU_EXPORT int dispu_linear_tile(int batch, int M, int N) {
+    const long blocks_big = (long)((M + 127) / 128) * ((N + 127) / 128) * batch;
+    if (N > 64) return blocks_big >= 256 ? 128128 : 64128;
+    const long blocks_mid = (long)((M + 127) / 128) * batch;
+    return blocks_mid >= 256 ? 128064 : 64064;
+}
+
 // Y = R2 + R1 + act(X.W + bias); see include/dispu_hip.h for the argument contract.
 DISPU_EXPORT int dispu_linear(int batch, int M, int K, int N, const float* X, long ldx, long sx, const float* W,
                               long ldw, long sw, int transb, const float* bias, int act, float* Y, long ldy, long sy,
@@ -204,10 +213,10 @@ DISPU_EXPORT int dispu_linear(int batch, int M, int K, int N, const float* X, lo
     if (batch == 0 || M == 0) return 0;
     LinearArgs a{M, K, N, X, ldx, sx, W, ldw, sw, bias, Y, ldy, sy, R1, ldr1, sr1, R2, ldr2, sr2, act};
     hipStream_t s = (hipStream_t)stream;
-    const long blocks_big = (long)((M + 127) / 128) * ((N + 127) / 128) * batch;
-    if (N > 64 && blocks_big >= 256) return launch_linear<128, 128>(a, batch, transb != 0, s);
-    if (N > 64) return launch_linear<64, 128>(a, batch, transb != 0, s);
-    const long blocks_mid = (long)((M + 127) / 128) * batch;
-    if (blocks_mid >= 256) return launch_linear<128, 64>(a, batch, transb != 0, s);
-    return launch_linear<64, 64>(a, batch, transb != 0, s);
+    switch (dispu_linear_tile(batch, M, N)) {
+        case 128128: return launch_linear<128, 128>(a, batch, transb != 0, s);
+        case 64128: return launch_linear<64, 128>(a, batch, transb != 0, s);
+        case 128064: return launch_linear<128, 64>(a, batch, transb != 0, s);
+        default: return launch_linear<64, 64>(a, batch, transb != 0, s);
+    }
 }

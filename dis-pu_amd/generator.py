@@ -134,7 +134,11 @@ class Generator(object):
         ldw = W.stride(0) if ldw is None else ldw
         ldy = Y.stride(0) if ldy is None else ldy
         p = lambda t, off=0: _lib.C.c_void_p(t.data_ptr() + 4 * off) if t is not None else _lib.C.c_void_p(0)
-        self._call("linear[%dx%dx%d%s]" % (M * batch, K, N, "^T" if transb else ""), L.dispu_linear, batch, M, K, N,
+        name = "linear"
+        if self.profile is not None:     # "linear<BM,BN,transb>[MxKxN]": the instantiation name rocprofv3 reports
+            t = L.dispu_linear_tile(batch, M, N)
+            name = "linear<%d,%d,%s>[%dx%dx%d]" % (t // 1000, t % 1000, "true" if transb else "false", M * batch, K, N)
+        self._call(name, L.dispu_linear, batch, M, K, N,
                    p(X, xoff), ldx, sx, p(W, woff), ldw, sw, transb, p(bias), act, p(Y, yoff), ldy, sy, p(R1),
                    R1.stride(0) if R1 is not None else 0, 0, p(R2), R2.stride(0) if R2 is not None else 0, 0, st)
 

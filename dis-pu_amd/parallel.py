@@ -1,0 +1,46 @@
+"""Patch-level data parallelism: the reference has no distributed code at all; patches are
+independent, so the batch of patches is split contiguously over the ranks (one process per GPU, no
+data-path collective) and ONE all-gather reassembles the upsampled clouds on every rank
+(`torch.distributed` backend "nccl" == RCCL over xGMI on ROCm; "gloo" in the CPU tests)."""
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(n_items, rank, world):
+    """Contiguous [lo, hi) of `n_items` for `rank`: the first (n_items % world) ranks get one extra item."""
+    base, rem = divmod(int(n_items), int(world))
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def all_gather_clouds(local, n_items=None, out=None, group=None):
+    """local [b_local, M, 3] -> [n_items, M, 3] on every rank, in global patch order.
+    Equal shards use one all_gather_into_tensor (a single ring/direct collective of b_local*M*12 bytes per
+    rank); ragged shards are padded to the largest shard and trimmed."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return local
+    world = dist.get_world_size(group)
+    n_items = local.shape[0] * world if n_items is None else int(n_items)
+    sizes = [shard_bounds(n_items, r, world)[1] - shard_bounds(n_items, r, world)[0] for r in range(world)]
+    if len(set(sizes)) == 1:
+        if out is None:
+            out = torch.empty((n_items,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        dist.all_gather_into_tensor(out, local.contiguous(), group=group)
+        return out
+    mx = max(sizes)
+    pad = torch.zeros((mx,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    pad[: local.shape[0]] = local
+    buf = torch.empty((world * mx,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(buf, pad, group=group)
+    parts = [buf[r * mx: r * mx + sizes[r]] for r in range(world)]
+    return torch.cat(parts, dim=0)
+
+
+def upsample_sharded(forward, patches, group=None):
+    """Run `forward(local_patches) -> local_clouds` on this rank's contiguous shard of `patches`
+    ([n_items, N, 3], identical on every rank) and return all clouds [n_items, M, 3] on every rank."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return forward(patches)
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    lo, hi = shard_bounds(patches.shape[0], rank, world)
+    return all_gather_clouds(forward(patches[lo:hi]), n_items=patches.shape[0], group=group)

@@ -148,6 +148,9 @@ int dispu_match_cost_grad(int b, int n, int m, const float* xyz1, const float* x
 int dispu_linear(int batch, int M, int K, int N, const float* X, long ldx, long sx, const float* W, long ldw, long sw,
                  int transb, const float* bias, int act, float* Y, long ldy, long sy, const float* R1, long ldr1,
                  long sr1, const float* R2, long ldr2, long sr2, void* stream);
+/* Which block tile dispu_linear picks for (batch, M, N), as BM*1000 + BN (e.g. 128128): lets a profiler map a
+ * launch to the kernel instantiation name rocprofv3 reports (linear_mfma_kernel<BM, BN, transb>). */
+int dispu_linear_tile(int batch, int M, int N);
 /* K <= 4 inputs, N in {16, 24} outputs (feature_extraction layer0, ops.py:1449-1451). */
 int dispu_linear_small_k(long rows, int K, int N, const float* X, long ldx, const float* W, const float* bias, int act,
                          float* Y, long ldy, void* stream);
