@@ -11,6 +11,7 @@
 #define DISPU_ARITH_PLAIN 0     // ((dx*dx + dy*dy) + dz*dz): the reference's CPU functions
 #define DISPU_ARITH_CONTRACT 1  // fmaf(dz,dz, fmaf(dx,dx, dy*dy)): nvcc-contracted GPU kernels
 #define DISPU_ARITH_PINNED_EXP 2  // OR-able: approx_match uses the bit-reproducible exp (parity mode)
+#define DISPU_KNN_LANE_PER_QUERY 4  // OR-able, dispu_knn_xyz: force the lane-per-query kernel (A/B tests)
 
 #define DISPU_CHECK_LAUNCH()                         \
     do {                                             \
@@ -69,6 +70,38 @@ __device__ __forceinline__ uint64_t wave_max_u64(uint64_t v) {
     const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), 63);
     const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, 63);
     return ((uint64_t)hi << 32) | lo;
+}
+
+__device__ __forceinline__ uint64_t u64_min(uint64_t a, uint64_t b) { return a < b ? a : b; }
+
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ uint64_t dpp_step_min_u64(uint64_t v) {
+    const uint32_t hi = dpp_u32<CTRL, ROW_MASK>(0xFFFFFFFFu, (uint32_t)(v >> 32));
+    const uint32_t lo = dpp_u32<CTRL, ROW_MASK>(0xFFFFFFFFu, (uint32_t)v);
+    return u64_min(v, ((uint64_t)hi << 32) | lo);
+}
+
+// Wave-wide minimum of an unsigned 64-bit key, returned wave-uniform.
+__device__ __forceinline__ uint64_t wave_min_u64(uint64_t v) {
+    v = dpp_step_min_u64<DPP_ROW_SHR1>(v);
+    v = dpp_step_min_u64<DPP_ROW_SHR2>(v);
+    v = dpp_step_min_u64<DPP_ROW_SHR4>(v);
+    v = dpp_step_min_u64<DPP_ROW_SHR8>(v);
+    v = dpp_step_min_u64<DPP_ROW_BCAST15, 0xA>(v);
+    v = dpp_step_min_u64<DPP_ROW_BCAST31, 0xC>(v);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), 63);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, 63);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+// float <-> unsigned key whose unsigned order is the float order (handles negative values)
+__device__ __forceinline__ uint32_t f32_to_ordered(float f) {
+    const uint32_t b = __float_as_uint(f);
+    return b ^ ((uint32_t)((int32_t)b >> 31) | 0x80000000u);
+}
+__device__ __forceinline__ float ordered_to_f32(uint32_t u) {
+    const uint32_t b = (u & 0x80000000u) ? (u ^ 0x80000000u) : ~u;
+    return __uint_as_float(b);
 }
 
 __device__ __forceinline__ float wave_sum_f32(float v) {

@@ -1,0 +1,142 @@
+// dense_conv (Common/ops.py:1897-1915) + get_edge_feature (:1856-1877) on the fp32 matrix cores.
+//
+// For every point p and each of its 16 feature-space neighbours j (one "pair row"):
+//   y0 = [F_p, F_j - F_p] -> l0 = relu(y0.W0 + b0);  y1 = [l0, F_p] -> l1 = relu(y1.W1 + b1);
+//   y2 = [l1, l0, F_p]    -> l2 = y2.W2 + b2;        out[p] = max_j [l2 | l1 | l0 | F_p]      (72 + C channels)
+//
+// MI355X mapping.  A wave owns 32 pair rows (2 points x 16 neighbours) and computes the TRANSPOSED products
+// D[channel][row] = sum_k W^T[channel][k] * y[row][k] with v_mfma_f32_32x32x2_f32, so the pair row is the
+// MFMA *column*: lane (row = lane & 31, h = lane >> 5) feeds its own row's element k = 2s + h at step s and
+// receives, in the C/D layout, accumulator register r <-> A-row (r&3) + 8(r>>2) + 4h.  The weight rows are
+// loaded PERMUTED so that this A-row is output channel 2r + h: the 24 outputs of a layer then sit in the lane as
+// "channel 2r + h in register r" - exactly the operand layout the next layer's k-loop needs.  The three chained
+// layers therefore run register-to-register (no LDS round trip, no concat), 132 MFMAs per 32 rows at C = 48.
+// Weight fragments live in LDS, one conflict-free ds_read_b32 per MFMA.  The max over the 16 neighbours is a
+// DPP row reduction (a DPP row of 16 lanes is one point).  k ascends through the concatenated input exactly as
+// in oracle/generator.py, so the result is bit-identical to the fmaf-chain restatement.
+#include "common.h"
+
+namespace dispu {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int CTRL>
+__device__ __forceinline__ float edge_dpp(float identity, float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(identity), __float_as_int(v), CTRL, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float edge_row16_max(float v) {   // valid in lane 15 of each 16-lane DPP row
+    const float ninf = -__builtin_inff();
+    v = fmaxf(v, edge_dpp<DPP_ROW_SHR1>(ninf, v));
+    v = fmaxf(v, edge_dpp<DPP_ROW_SHR2>(ninf, v));
+    v = fmaxf(v, edge_dpp<DPP_ROW_SHR4>(ninf, v));
+    v = fmaxf(v, edge_dpp<DPP_ROW_SHR8>(ninf, v));
+    return v;
+}
+
+// LDS image of one layer's A operand: frag[s*64 + lane] = W[k = 2s + (lane>>5)][channel(lane & 31)], 0 for padding.
+__device__ __forceinline__ void edge_fill_frag(float* frag, const float* __restrict__ W, int K, int tid) {
+    const int total = (K / 2) * 64;
+    for (int e = tid; e < total; e += 256) {
+        const int s = e >> 6, l = e & 63;
+        const int i = l & 31, kh = l >> 5;
+        const int r = (i & 3) + 4 * (i >> 3), hp = (i >> 2) & 1;
+        frag[e] = (r < 12) ? W[(2 * s + kh) * 24 + 2 * r + hp] : 0.f;
+    }
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void edge_dense_conv_mfma_kernel(int npoints, int n_per_cloud, const float* __restrict__ F,
+                                                                    long ldf, const int* __restrict__ idx, int ldi, int ioff,
+                                                                    const float* __restrict__ W0, const float* __restrict__ b0,
+                                                                    const float* __restrict__ W1, const float* __restrict__ b1,
+                                                                    const float* __restrict__ W2, const float* __restrict__ b2,
+                                                                    float* __restrict__ Y, long ldy) {
+    constexpr int G = 24, H = C / 2, K0 = 2 * C, K1 = G + C, K2 = 2 * G + C;
+    constexpr int S0 = K0 / 2, S1 = K1 / 2, S2 = K2 / 2;
+    __shared__ float frag[(S0 + S1 + S2) * 64];
+    float* f0 = frag;
+    float* f1 = frag + S0 * 64;
+    float* f2 = f1 + S1 * 64;
+    edge_fill_frag(f0, W0, K0, threadIdx.x);
+    edge_fill_frag(f1, W1, K1, threadIdx.x);
+    edge_fill_frag(f2, W2, K2, threadIdx.x);
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row = lane & 31, h = lane >> 5;
+    const int ngroups = (npoints + 1) / 2;                       // 2 points per wave
+    for (int grp = blockIdx.x * 4 + wave; grp < ngroups; grp += gridDim.x * 4) {
+        const int p = grp * 2 + (row >> 4);
+        const bool ok = p < npoints;
+        const int pp = ok ? p : npoints - 1;
+        const int s_nb = row & 15;
+        const int j = (pp / n_per_cloud) * n_per_cloud + idx[(size_t)pp * ldi + ioff + s_nb];
+        float fp[H], df[H];                                      // elements k = 2t + h of F_p and of F_j - F_p
+#pragma unroll
+        for (int q = 0; q < C / 4; ++q) {
+            const float4 a = *reinterpret_cast<const float4*>(F + (size_t)pp * ldf + q * 4);
+            const float4 b = *reinterpret_cast<const float4*>(F + (size_t)j * ldf + q * 4);
+            const float a0 = h ? a.y : a.x, a1 = h ? a.w : a.z;
+            const float b0v = h ? b.y : b.x, b1v = h ? b.w : b.z;
+            fp[2 * q] = a0; fp[2 * q + 1] = a1;
+            df[2 * q] = b0v - a0; df[2 * q + 1] = b1v - a1;
+        }
+        f32x16 l0, l1, l2;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { l0[r] = 0.f; l1[r] = 0.f; l2[r] = 0.f; }
+        // layer 0: k over [F_p (C), F_j - F_p (C)]
+#pragma unroll
+        for (int s = 0; s < S0; ++s) {
+            const float bv = (s < H) ? fp[s < H ? s : 0] : df[s < H ? 0 : s - H];
+            l0 = __builtin_amdgcn_mfma_f32_32x32x2f32(f0[s * 64 + lane], bv, l0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 12; ++r) l0[r] = fmaxf(l0[r] + b0[2 * r + h], 0.f);
+        // layer 1: k over [l0 (24), F_p (C)]
+#pragma unroll
+        for (int s = 0; s < S1; ++s) {
+            const float bv = (s < 12) ? l0[s < 12 ? s : 0] : fp[s < 12 ? 0 : s - 12];
+            l1 = __builtin_amdgcn_mfma_f32_32x32x2f32(f1[s * 64 + lane], bv, l1, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 12; ++r) l1[r] = fmaxf(l1[r] + b1[2 * r + h], 0.f);
+        // layer 2: k over [l1 (24), l0 (24), F_p (C)], no activation
+#pragma unroll
+        for (int s = 0; s < S2; ++s) {
+            const float bv = (s < 12) ? l1[s < 12 ? s : 0] : ((s < 24) ? l0[(s >= 12 && s < 24) ? s - 12 : 0] : fp[s >= 24 ? s - 24 : 0]);
+            l2 = __builtin_amdgcn_mfma_f32_32x32x2f32(f2[s * 64 + lane], bv, l2, 0, 0, 0);
+        }
+        // max over the 16 neighbours (one DPP row) and store [l2 | l1 | l0 | F_p]; lane 15 of each row writes
+        float* __restrict__ yr = Y + (size_t)pp * ldy;
+        const bool writer = ok && s_nb == 15;
+#pragma unroll
+        for (int r = 0; r < 12; ++r) {
+            const float m2 = edge_row16_max(l2[r] + b2[2 * r + h]);
+            const float m1 = edge_row16_max(l1[r]);
+            const float m0 = edge_row16_max(l0[r]);
+            if (writer) { yr[2 * r + h] = m2; yr[G + 2 * r + h] = m1; yr[2 * G + 2 * r + h] = m0; }
+        }
+        if (writer) {
+#pragma unroll
+            for (int t = 0; t < H; ++t) yr[3 * G + 2 * t + h] = fp[t];
+        }
+    }
+}
+
+}  // namespace dispu
+
+using namespace dispu;
+
+DISPU_EXPORT int dispu_edge_dense_conv(int npoints, int n_per_cloud, int C, const float* F, long ldf, const int* idx, int ldi,
+                                       int ioff, const float* W0, const float* b0, const float* W1, const float* b1,
+                                       const float* W2, const float* b2, float* Y, long ldy, void* stream) {
+    if (npoints < 0 || n_per_cloud <= 0 || !(C == 24 || C == 48) || (ldf & 3) || (((uintptr_t)F) & 15)) return (int)hipErrorInvalidValue;
+    if (npoints == 0) return 0;
+    int g = (npoints + 7) / 8;          // 8 points (4 waves x 2) per workgroup pass
+    if (g > 2048) g = 2048;
+    if (C == 24)
+        hipLaunchKernelGGL((edge_dense_conv_mfma_kernel<24>), dim3(g), dim3(256), 0, (hipStream_t)stream, npoints, n_per_cloud, F, ldf, idx, ldi, ioff, W0, b0, W1, b1, W2, b2, Y, ldy);
+    else
+        hipLaunchKernelGGL((edge_dense_conv_mfma_kernel<48>), dim3(g), dim3(256), 0, (hipStream_t)stream, npoints, n_per_cloud, F, ldf, idx, ldi, ioff, W0, b0, W1, b1, W2, b2, Y, ldy);
+    return (int)hipGetLastError();
+}

@@ -123,7 +123,14 @@ __global__ __launch_bounds__(KNN_BS) void knn_feat_kernel(int n, int m, int c, i
             }
             __syncthreads();
         }
-        for (int t = 0; t < len; ++t) {
+        // U candidates per iteration: their fmaf chains are independent, which hides the FMA latency of the
+        // (bit-pinned, strictly sequential) per-candidate chain; insertion stays in index order.
+        constexpr int U = 4;
+        for (int t0 = 0; t0 < len; t0 += U) {
+          float du[U];
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            const int t = (t0 + u < len) ? t0 + u : t0;
             const float4* __restrict__ row = reinterpret_cast<const float4*>(tile + t * CP);
             float d;
             if constexpr (GEMM_FORM) {
@@ -136,8 +143,8 @@ __global__ __launch_bounds__(KNN_BS) void knn_feat_kernel(int n, int m, int c, i
                     dot = __builtin_fmaf(q[l4 * 4 + 2], v.z, dot);
                     dot = __builtin_fmaf(q[l4 * 4 + 3], v.w, dot);
                 }
-                const float t0 = rq - 2.0f * dot;
-                d = t0 + tnorm[t];
+                const float rq_m2dot = rq - 2.0f * dot;
+                d = rq_m2dot + tnorm[t];
             } else {
                 d = 0.f;
 #pragma unroll
@@ -150,7 +157,11 @@ __global__ __launch_bounds__(KNN_BS) void knn_feat_kernel(int n, int m, int c, i
                     df = v.w - q[l4 * 4 + 3]; d = d + df * df;
                 }
             }
-            if (__any(d < best.worst())) best.insert(d, k0 + t);
+            du[u] = (t0 + u < len) ? d : __builtin_inff();
+          }
+#pragma unroll
+          for (int u = 0; u < U; ++u)
+            if (__any(du[u] < best.worst())) best.insert(du[u], k0 + t0 + u);
         }
     }
     if (active) {
@@ -202,6 +213,12 @@ static int launch_feat(int b, int n, int m, int c, int k, int ldp, int ldq, cons
     return (int)hipErrorInvalidValue;
 }
 
+// wave-per-query fast paths (knn_wave.hip); return -1 when the shape is outside their range
+int knn_xyz_wave_dispatch(int b, int n, int m, int k, const float* s, const float* q, int* idx, float* dist, int arith,
+                          hipStream_t st);
+int knn_feat_wave_dispatch(int b, int n, int m, int c, int k, int ldp, int ldq, const float* p, const float* q, float* dist,
+                           int* idx, hipStream_t st);
+
 }  // namespace dispu
 
 using namespace dispu;
@@ -211,6 +228,10 @@ DISPU_EXPORT int dispu_knn_xyz(int b, int n, int m, int k, const float* support,
     if (b < 0 || n <= 0 || m < 0 || k <= 0 || k > n || k > 32 || !idx) return (int)hipErrorInvalidValue;
     if (b == 0 || m == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
+    if (!(arith & DISPU_KNN_LANE_PER_QUERY)) {       // fast path: wave-per-query (knn_wave.hip), n <= 1024
+        const int rc = knn_xyz_wave_dispatch(b, n, m, k, support, query, idx, dist, arith, st);
+        if (rc >= 0) return rc;
+    }
     if (k <= 4) return launch_xyz<4>(b, n, m, k, support, query, idx, dist, arith, st);
     if (k <= 8) return launch_xyz<8>(b, n, m, k, support, query, idx, dist, arith, st);
     if (k <= 16) return launch_xyz<16>(b, n, m, k, support, query, idx, dist, arith, st);
@@ -222,6 +243,8 @@ DISPU_EXPORT int dispu_knn_feat(int b, int n, int m, int c, int k, const float* 
                                 float* dist, int* idx, void* stream) {
     if (b < 0 || n <= 0 || m < 0 || c <= 0 || k <= 0 || k > n || k > 32 || !idx) return (int)hipErrorInvalidValue;
     if (b == 0 || m == 0) return 0;
+    const int rc = knn_feat_wave_dispatch(b, n, m, c, k, c, c, points, queries, dist, idx, (hipStream_t)stream);
+    if (rc >= 0) return rc;
     return launch_feat<true, false>(b, n, m, c, k, c, c, points, queries, dist, idx, (hipStream_t)stream);
 }
 
@@ -231,6 +254,8 @@ DISPU_EXPORT int dispu_knn_feat_strided(int b, int n, int m, int c, int k, const
                                         const float* queries, int ldq, float* dist, int* idx, void* stream) {
     if (b < 0 || n <= 0 || m < 0 || c <= 0 || k <= 0 || k > n || k > 32 || !idx || ldp < c || ldq < c) return (int)hipErrorInvalidValue;
     if (b == 0 || m == 0) return 0;
+    const int rc = knn_feat_wave_dispatch(b, n, m, c, k, ldp, ldq, points, queries, dist, idx, (hipStream_t)stream);
+    if (rc >= 0) return rc;
     return launch_feat<true, false>(b, n, m, c, k, ldp, ldq, points, queries, dist, idx, (hipStream_t)stream);
 }
 

@@ -1,0 +1,260 @@
+// Wave-per-query exact k-NN for gfx950 (small clouds: n <= 1024), the fast path behind dispu_knn_xyz and
+// dispu_knn_feat(_strided).  Reference semantics and citations are in knn.hip; results are bit-identical to the
+// lane-per-query kernels there (same pinned distance arithmetic, ascending distance, ties -> lower index).
+//
+// Why a second formulation: with one lane per query the sorted-insert (~4 VALU ops per list slot) runs for
+// nearly every candidate, because SOME lane of the 64 accepts it; at the generator's sizes (8 K - 32 K queries)
+// that also leaves most of the 1024 SIMDs idle.  Here a WAVE owns a query: lane l evaluates candidates
+// l, l+64, ... (R per lane), packs (ordered distance bits << 32 | index) into a 64-bit key, sorts its R keys with
+// an odd-even merge network in registers, parks them in LDS, and the k results are k rounds of a DPP wave-min
+// over the lanes' current heads (the winner advances its head).  All lanes do useful work in every step and
+// every CU is busy.  xyz: candidates stay in VGPRs for all queries of the wave, the query sits in SGPRs.
+// Feature space: the cloud's features are staged once per workgroup in LDS, channel-quad major
+// ([C/4][n] float4 -> conflict-free ds_read_b128), dots are the same ascending-channel fmaf chains.
+#include "common.h"
+
+namespace dispu {
+
+constexpr uint64_t KEY_MAX = ~0ull;
+
+__device__ __forceinline__ void cswap(uint64_t& a, uint64_t& b) {
+    const bool c = a > b;
+    const uint64_t lo = c ? b : a, hi = c ? a : b;
+    a = lo; b = hi;
+}
+
+// Batcher odd-even merge sort, fully unrolled (R a power of two): ascending.
+template <int R>
+__device__ __forceinline__ void sort_keys(uint64_t (&a)[R]) {
+#pragma unroll
+    for (int p = 1; p < R; p <<= 1)
+#pragma unroll
+        for (int k = p; k >= 1; k >>= 1)
+#pragma unroll
+            for (int j = k % p; j <= R - 1 - k; j += 2 * k)
+#pragma unroll
+                for (int i = 0; i < k; ++i)
+                    if (i + j + k < R && (i + j) / (2 * p) == (i + j + k) / (2 * p)) cswap(a[i + j], a[i + j + k]);
+}
+
+// k rounds of wave-min over the lanes' heads; lane t keeps result t.  sorted: this wave's [R][64] key columns.
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+    v = min(v, dpp_u32<DPP_ROW_SHR1>(0xFFFFFFFFu, v));
+    v = min(v, dpp_u32<DPP_ROW_SHR2>(0xFFFFFFFFu, v));
+    v = min(v, dpp_u32<DPP_ROW_SHR4>(0xFFFFFFFFu, v));
+    v = min(v, dpp_u32<DPP_ROW_SHR8>(0xFFFFFFFFu, v));
+    v = min(v, dpp_u32<DPP_ROW_BCAST15, 0xA>(0xFFFFFFFFu, v));
+    v = min(v, dpp_u32<DPP_ROW_BCAST31, 0xC>(0xFFFFFFFFu, v));
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+// The round is a serial dependency chain, so it is kept short: a 32-bit DPP min over the heads' distance words,
+// a ballot to find the owner (the index word only matters when two heads tie on the distance - rare), and the
+// winner's next key is already in a register (prefetched from LDS one advance ahead).
+template <int R>
+__device__ __forceinline__ uint64_t select_k(const uint64_t (&key)[R], uint64_t* sorted, int lane, int k) {
+#pragma unroll
+    for (int i = 1; i < R; ++i) sorted[i * 64 + lane] = key[i];
+    uint32_t hd = (uint32_t)(key[0] >> 32), hi = (uint32_t)key[0];
+    uint64_t nk = (R > 1) ? key[R > 1 ? 1 : 0] : KEY_MAX;         // head + 1, kept in registers
+    int hp = 0;
+    uint64_t res = 0;
+    for (int t = 0; t < k; ++t) {
+        const uint32_t md = wave_min_u32(hd);
+        unsigned long long mask = __ballot(hd == md);
+        if (__popcll(mask) != 1) {                                  // wave-uniform; equal distances: lowest index wins
+            const uint32_t mi = wave_min_u32(hd == md ? hi : 0xFFFFFFFFu);
+            mask = __ballot(hd == md && hi == mi);
+        }
+        const int win = __builtin_ctzll(mask);
+        const uint32_t wi = (uint32_t)__builtin_amdgcn_readlane((int)hi, win);
+        if (lane == t) res = ((uint64_t)md << 32) | wi;
+        if (lane == win) {
+            hd = (uint32_t)(nk >> 32); hi = (uint32_t)nk;
+            ++hp;
+            nk = (hp + 1 < R) ? sorted[(hp + 1) * 64 + lane] : KEY_MAX;
+        }
+    }
+    return res;
+}
+
+template <int R, bool FMA>
+__global__ __launch_bounds__(256) void knn_xyz_wave_kernel(int n, int m, int k, int qpb, const float* __restrict__ support,
+                                                            const float* __restrict__ query, int* __restrict__ idx,
+                                                            float* __restrict__ dist) {
+    __shared__ uint64_t sorted[4][R * 64];
+    const int cloud = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const float* __restrict__ s = support + (size_t)cloud * n * 3;
+    const float* __restrict__ q = query + (size_t)cloud * m * 3;
+    float cx[R], cy[R], cz[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int p = lane + 64 * r;
+        const bool ok = p < n;
+        cx[r] = ok ? s[p * 3 + 0] : 0.f;
+        cy[r] = ok ? s[p * 3 + 1] : 0.f;
+        cz[r] = ok ? s[p * 3 + 2] : 0.f;
+    }
+    const int q0 = blockIdx.x * qpb, q1 = min(m, q0 + qpb);
+    for (int qv = q0 + wave; qv < q1; qv += 4) {
+        const int qi = __builtin_amdgcn_readfirstlane(qv);
+        const float qx = q[qi * 3 + 0], qy = q[qi * 3 + 1], qz = q[qi * 3 + 2];
+        uint64_t key[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int p = lane + 64 * r;
+            const float d = sqdist3<FMA>(qx - cx[r], qy - cy[r], qz - cz[r]) + 0.0f;
+            key[r] = (p < n) ? (((uint64_t)f32_to_ordered(d) << 32) | (uint32_t)p) : KEY_MAX;
+        }
+        sort_keys<R>(key);
+        const uint64_t res = select_k<R>(key, sorted[wave], lane, k);
+        if (lane < k) {
+            const size_t o = ((size_t)cloud * m + qi) * k + lane;
+            idx[o] = (int)(uint32_t)res;
+            if (dist) dist[o] = ordered_to_f32((uint32_t)(res >> 32));
+        }
+    }
+}
+
+// Feature-space (GEMM-form) variant: D = (rq - 2 q.p) + rp, fma chains over ascending channels.
+// LDS: feats[(c4 * n + p)] float4 = channels 4c4..4c4+3 of candidate p (zero padded to CP), norms[p].
+template <int R, int CP>
+__global__ __launch_bounds__(256) void knn_feat_wave_kernel(int n, int m, int c, int k, int qpb, int ldp, int ldq,
+                                                             const float* __restrict__ points,
+                                                             const float* __restrict__ queries, float* __restrict__ dist,
+                                                             int* __restrict__ idx) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float4* feats = reinterpret_cast<float4*>(smem);                                  // [CP/4][n]
+    float* norms = reinterpret_cast<float*>(smem + (size_t)(CP / 4) * n * 16);        // [n]
+    uint64_t* sorted = reinterpret_cast<uint64_t*>(smem + (size_t)(CP / 4) * n * 16 + (((size_t)n * 4 + 15) & ~15ull));
+    const int cloud = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const float* __restrict__ sp = points + (size_t)cloud * n * ldp;
+    const float* __restrict__ qp = queries + (size_t)cloud * m * ldq;
+    for (int e = threadIdx.x; e < (CP / 4) * n; e += 256) {
+        const int c4 = e / n, p = e - c4 * n;
+        float4 v;
+        const float* src = sp + (size_t)p * ldp + c4 * 4;
+        v.x = (c4 * 4 + 0 < c) ? src[0] : 0.f;
+        v.y = (c4 * 4 + 1 < c) ? src[1] : 0.f;
+        v.z = (c4 * 4 + 2 < c) ? src[2] : 0.f;
+        v.w = (c4 * 4 + 3 < c) ? src[3] : 0.f;
+        feats[e] = v;
+    }
+    __syncthreads();
+    for (int p = threadIdx.x; p < n; p += 256) {
+        float r = 0.f;
+#pragma unroll
+        for (int c4 = 0; c4 < CP / 4; ++c4) {
+            const float4 v = feats[c4 * n + p];
+            r = __builtin_fmaf(v.x, v.x, r); r = __builtin_fmaf(v.y, v.y, r);
+            r = __builtin_fmaf(v.z, v.z, r); r = __builtin_fmaf(v.w, v.w, r);
+        }
+        norms[p] = r;
+    }
+    __syncthreads();
+    float rp[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) rp[r] = (lane + 64 * r < n) ? norms[lane + 64 * r] : 0.f;
+
+    const int q0 = blockIdx.x * qpb, q1 = min(m, q0 + qpb);
+    for (int qv = q0 + wave; qv < q1; qv += 4) {
+        const int qi = __builtin_amdgcn_readfirstlane(qv);
+        const float* __restrict__ qrow = qp + (size_t)qi * ldq;       // wave-uniform -> scalar loads
+        float dot[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) dot[r] = 0.f;
+        float rq = 0.f;
+#pragma unroll
+        for (int c4 = 0; c4 < CP / 4; ++c4) {
+            const float q0v = (c4 * 4 + 0 < c) ? qrow[c4 * 4 + 0] : 0.f;
+            const float q1v = (c4 * 4 + 1 < c) ? qrow[c4 * 4 + 1] : 0.f;
+            const float q2v = (c4 * 4 + 2 < c) ? qrow[c4 * 4 + 2] : 0.f;
+            const float q3v = (c4 * 4 + 3 < c) ? qrow[c4 * 4 + 3] : 0.f;
+            rq = __builtin_fmaf(q0v, q0v, rq); rq = __builtin_fmaf(q1v, q1v, rq);
+            rq = __builtin_fmaf(q2v, q2v, rq); rq = __builtin_fmaf(q3v, q3v, rq);
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int p = lane + 64 * r;
+                const float4 v = feats[c4 * n + (p < n ? p : 0)];
+                dot[r] = __builtin_fmaf(q0v, v.x, dot[r]); dot[r] = __builtin_fmaf(q1v, v.y, dot[r]);
+                dot[r] = __builtin_fmaf(q2v, v.z, dot[r]); dot[r] = __builtin_fmaf(q3v, v.w, dot[r]);
+            }
+        }
+        uint64_t key[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int p = lane + 64 * r;
+            const float t0 = rq - 2.0f * dot[r];
+            const float d = (t0 + rp[r]) + 0.0f;
+            key[r] = (p < n) ? (((uint64_t)f32_to_ordered(d) << 32) | (uint32_t)p) : KEY_MAX;
+        }
+        sort_keys<R>(key);
+        const uint64_t res = select_k<R>(key, sorted + (size_t)wave * R * 64, lane, k);
+        if (lane < k) {
+            const size_t o = ((size_t)cloud * m + qi) * k + lane;
+            idx[o] = (int)(uint32_t)res;
+            if (dist) dist[o] = ordered_to_f32((uint32_t)(res >> 32));
+        }
+    }
+}
+
+template <int R>
+static int launch_xyz_wave(int b, int n, int m, int k, const float* s, const float* q, int* idx, float* dist, int arith,
+                           hipStream_t st) {
+    // queries per workgroup: a wave's queries are a serial chain, so keep it short while the total stays >= ~4 waves/SIMD
+    const int qpb = ((long)b * m >= 32768) ? 32 : 16;
+    dim3 grid((m + qpb - 1) / qpb, b);
+    if (arith & DISPU_ARITH_CONTRACT)
+        hipLaunchKernelGGL((knn_xyz_wave_kernel<R, true>), grid, dim3(256), 0, st, n, m, k, qpb, s, q, idx, dist);
+    else
+        hipLaunchKernelGGL((knn_xyz_wave_kernel<R, false>), grid, dim3(256), 0, st, n, m, k, qpb, s, q, idx, dist);
+    return (int)hipGetLastError();
+}
+
+template <int R, int CP>
+static int launch_feat_wave(int b, int n, int m, int c, int k, int ldp, int ldq, const float* p, const float* q, float* dist,
+                            int* idx, hipStream_t st) {
+    const int qpb = 16;         // 4 queries per wave; the cloud's features are re-staged per workgroup (L2-resident)
+    dim3 grid((m + qpb - 1) / qpb, b);
+    const size_t lds = (size_t)(CP / 4) * n * 16 + (((size_t)n * 4 + 15) & ~15ull) + (size_t)4 * R * 64 * 8;
+    hipLaunchKernelGGL((knn_feat_wave_kernel<R, CP>), grid, dim3(256), lds, st, n, m, c, k, qpb, ldp, ldq, p, q, dist, idx);
+    return (int)hipGetLastError();
+}
+
+// Returns -1 when the shape is outside the fast path (caller falls back to the lane-per-query kernels).
+int knn_xyz_wave_dispatch(int b, int n, int m, int k, const float* s, const float* q, int* idx, float* dist, int arith,
+                          hipStream_t st) {
+    if (n > 1024 || k > 64) return -1;
+    if (n <= 64) return launch_xyz_wave<1>(b, n, m, k, s, q, idx, dist, arith, st);
+    if (n <= 128) return launch_xyz_wave<2>(b, n, m, k, s, q, idx, dist, arith, st);
+    if (n <= 256) return launch_xyz_wave<4>(b, n, m, k, s, q, idx, dist, arith, st);
+    if (n <= 512) return launch_xyz_wave<8>(b, n, m, k, s, q, idx, dist, arith, st);
+    return launch_xyz_wave<16>(b, n, m, k, s, q, idx, dist, arith, st);
+}
+
+template <int CP>
+static int feat_wave_r(int b, int n, int m, int c, int k, int ldp, int ldq, const float* p, const float* q, float* dist,
+                       int* idx, hipStream_t st) {
+    if (n <= 64) return launch_feat_wave<1, CP>(b, n, m, c, k, ldp, ldq, p, q, dist, idx, st);
+    if (n <= 128) return launch_feat_wave<2, CP>(b, n, m, c, k, ldp, ldq, p, q, dist, idx, st);
+    if (n <= 256) return launch_feat_wave<4, CP>(b, n, m, c, k, ldp, ldq, p, q, dist, idx, st);
+    return launch_feat_wave<8, CP>(b, n, m, c, k, ldp, ldq, p, q, dist, idx, st);
+}
+
+int knn_feat_wave_dispatch(int b, int n, int m, int c, int k, int ldp, int ldq, const float* p, const float* q, float* dist,
+                           int* idx, hipStream_t st) {
+    if (n > 512 || c > 64 || k > 64) return -1;
+    const int cp = (c + 3) & ~3;
+    const int r = n <= 64 ? 1 : (n <= 128 ? 2 : (n <= 256 ? 4 : 8));
+    const size_t lds = (size_t)(cp / 4) * n * 16 + (((size_t)n * 4 + 15) & ~15ull) + (size_t)4 * r * 64 * 8;
+    if (lds > 64 * 1024) return -1;
+    if (c <= 4) return feat_wave_r<4>(b, n, m, c, k, ldp, ldq, p, q, dist, idx, st);
+    if (c <= 8) return feat_wave_r<8>(b, n, m, c, k, ldp, ldq, p, q, dist, idx, st);
+    if (c <= 16) return feat_wave_r<16>(b, n, m, c, k, ldp, ldq, p, q, dist, idx, st);
+    if (c <= 24) return feat_wave_r<24>(b, n, m, c, k, ldp, ldq, p, q, dist, idx, st);
+    if (c <= 32) return feat_wave_r<32>(b, n, m, c, k, ldp, ldq, p, q, dist, idx, st);
+    if (c <= 48) return feat_wave_r<48>(b, n, m, c, k, ldp, ldq, p, q, dist, idx, st);
+    return feat_wave_r<64>(b, n, m, c, k, ldp, ldq, p, q, dist, idx, st);
+}
+
+}  // namespace dispu

@@ -333,7 +333,8 @@ DISPU_EXPORT int dispu_linear_small_n(long rows, int K, int N, const float* X, l
     return (int)hipGetLastError();
 }
 
-DISPU_EXPORT int dispu_edge_dense_conv(int npoints, int n_per_cloud, int C, const float* F, long ldf, const int* idx, int ldi,
+// VALU formulation (lane = pair, weights through scalar loads); kept as the A/B twin of the MFMA kernel in edge.hip.
+DISPU_EXPORT int dispu_edge_dense_conv_valu(int npoints, int n_per_cloud, int C, const float* F, long ldf, const int* idx, int ldi,
                                        int ioff, const float* W0, const float* b0, const float* W1, const float* b1,
                                        const float* W2, const float* b2, float* Y, long ldy, void* stream) {
     if (npoints < 0 || n_per_cloud <= 0 || !(C == 24 || C == 48) || (ldf & 3) || (((uintptr_t)F) & 15)) return (int)hipErrorInvalidValue;

@@ -39,6 +39,9 @@ extern "C" {
  * polynomial instead of the hardware v_exp_f32 (the reference uses the hardware __expf).  Parity/debug
  * mode: results are then bit-identical to oracle/dispu_oracle.c; about 1.6x slower. */
 #define DISPU_ARITH_PINNED_EXP 2
+/* OR-able, dispu_knn_xyz only: force the lane-per-query kernel instead of the wave-per-query fast path that is
+ * used for n <= 1024 (identical results; A/B tests and profiling). */
+#define DISPU_KNN_LANE_PER_QUERY 4
 
 /* Library / ABI version (1 = round 1). */
 int dispu_version(void);
@@ -164,6 +167,11 @@ int dispu_linear_small_n(long rows, int K, int N, const float* X, long ldx, cons
 int dispu_edge_dense_conv(int npoints, int n_per_cloud, int C, const float* F, long ldf, const int* idx, int ldi, int ioff,
                           const float* W0, const float* b0, const float* W1, const float* b1, const float* W2,
                           const float* b2, float* Y, long ldy, void* stream);
+/* Same contract as dispu_edge_dense_conv, VALU formulation (one lane per pair, weights through scalar loads).
+ * Bit-identical results; kept as the A/B twin of the MFMA kernel for tests and profiling. */
+int dispu_edge_dense_conv_valu(int npoints, int n_per_cloud, int C, const float* F, long ldf, const int* idx, int ldi,
+                               int ioff, const float* W0, const float* b0, const float* W1, const float* b1,
+                               const float* W2, const float* b2, float* Y, long ldy, void* stream);
 /* duplicate_up conv1 tail (ops.py:1161-1191): continues the per-source-point chain H with the two grid-code channels of
  * each of the `up` copies, + bias, ReLU.  Output rows are copy-major: (cloud*up + r)*n + i. */
 int dispu_dup_grid(int nclouds, int n, int co, int up, const float* H, long ldh, const float* Wg, const float* bias,

@@ -92,3 +92,37 @@ def test_linear_matches_chain_exactly(dev):
     _lib.check(L.dispu_linear(2, 96, 64, 130, tq.data_ptr(), 64, 96 * 64, tk.data_ptr(), 64, 130 * 64, 1, None, 0,
                               s.data_ptr(), 130, 96 * 130, None, 0, 0, None, 0, 0, _lib.stream_ptr(dev)), "qk^t")
     assert np.array_equal(N(s), OG.matmul_nt(q, kk))
+
+
+@pytest.mark.parametrize("C,npts", [(24, 512), (48, 512), (48, 777)])
+def test_edge_dense_conv_mfma_equals_valu_and_oracle(dev, C, npts):
+    """dense_conv on the matrix cores vs its VALU twin vs the oracle chain: all three bit-identical."""
+    from dispu_amd import _lib
+    from oracle import oracle as O
+    L = _lib.lib()
+    rng = np.random.default_rng(C + npts)
+    n_cloud = npts if npts % 256 else 256
+    nb = npts // n_cloud
+    F = rng.standard_normal((nb, n_cloud, C)).astype(np.float32)
+    _, idx2 = O.knn_point_2(17, F, F)
+    idx = idx2[..., 1].astype(np.int32)                                     # [nb, n, 17]
+    P = {k: (rng.standard_normal(s) * 0.2).astype(np.float32) for k, s in
+         dict(W0=(2 * C, 24), b0=(24,), W1=(24 + C, 24), b1=(24,), W2=(48 + C, 24), b2=(24,)).items()}
+    # oracle: the dense_conv restatement with these weights
+    scope = "x"
+    PP = {scope + "/l0/weights": P["W0"], scope + "/l0/biases": P["b0"], scope + "/l1/weights": P["W1"],
+          scope + "/l1/biases": P["b1"], scope + "/l2/weights": P["W2"], scope + "/l2/biases": P["b2"]}
+    want, widx = OG.dense_conv(PP, scope, F)
+    assert np.array_equal(widx, idx[:, :, 1:])
+    t = {k: torch.from_numpy(v).to(dev) for k, v in P.items()}
+    tF, tI = torch.from_numpy(F).to(dev), torch.from_numpy(idx).to(dev)
+    outs = []
+    for fn in (L.dispu_edge_dense_conv, L.dispu_edge_dense_conv_valu):
+        y = torch.zeros((npts, 72 + C + 3), device=dev)
+        _lib.check(fn(npts, n_cloud, C, tF.data_ptr(), C, tI.data_ptr(), 17, 1, t["W0"].data_ptr(), t["b0"].data_ptr(),
+                      t["W1"].data_ptr(), t["b1"].data_ptr(), t["W2"].data_ptr(), t["b2"].data_ptr(), y.data_ptr(), 72 + C + 3,
+                      _lib.stream_ptr(dev)), "edge")
+        outs.append(N(y))
+    assert np.array_equal(outs[0], outs[1])
+    assert np.array_equal(outs[0][:, :72 + C].reshape(nb, n_cloud, 72 + C), want)
+    assert (outs[0][:, 72 + C:] == 0).all()

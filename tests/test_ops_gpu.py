@@ -332,3 +332,22 @@ def test_full_size_properties(ops, dev):
     c_xy = ops["A"].match_cost(x[:4], y, m)
     c_xx = ops["A"].match_cost(x[:4], x[:4], ops["A"].approx_match(x[:4], x[:4]))
     assert (c_xx < 0.05 * c_xy).all()
+
+
+@pytest.mark.parametrize("b,n,m,k", [(4, 1024, 1024, 16), (2, 700, 333, 20), (3, 65, 65, 32), (2, 1000, 50, 1)])
+def test_knn_xyz_wave_path_equals_lane_path(ops, dev, b, n, m, k):
+    """dispu_knn_xyz has two formulations (wave-per-query for n <= 1024, lane-per-query otherwise): identical output."""
+    from dispu_amd import _lib
+    rng = np.random.default_rng(n + k)
+    s = rng.random((b, n, 3)).astype(np.float32)
+    s[:, 5] = s[:, 17]                                        # exact duplicates -> ties must resolve to the lower index
+    q = np.concatenate([s[:, : m // 2], rng.random((b, m - m // 2, 3)).astype(np.float32)], 1)
+    ts, tq = T(s, dev), T(q, dev)
+    res = []
+    for arith in (PLAIN, PLAIN | 4, CONTRACT, CONTRACT | 4):
+        i, d = ops["K"].knn_batch(ts, tq, k, return_dist=True, arith=arith)
+        res.append((N(i), N(d)))
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+    assert np.array_equal(res[2][0], res[3][0]) and np.array_equal(res[2][1], res[3][1])
+    oi, od = O.knn_batch(s, q, k, return_dist=True)
+    assert np.array_equal(res[0][0], oi) and np.array_equal(res[0][1], od)
