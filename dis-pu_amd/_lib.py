@@ -39,7 +39,15 @@ SIGNATURES = {
     "dispu_match_cost": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp]),
     "dispu_match_cost_grad": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "dispu_linear": (_i, [_i, _i, _i, _i, _vp, _l, _l, _vp, _l, _l, _i, _vp, _i, _vp, _l, _l, _vp, _l, _l, _vp, _l, _l, _vp]),
+    "dispu_linear_bn": (_i, [_i, _i, _i, _i, _vp, _l, _l, _vp, _l, _l, _i, _vp, _vp, _vp, _i, _vp, _l, _l, _vp, _l, _l, _vp, _l, _l,
+                             _vp]),
     "dispu_linear_tile": (_i, [_i, _i, _i]),
+    "dispu_group_center": (_i, [_l, _i, _i, _vp, _vp, _vp]),
+    "dispu_pool_nsample": (_i, [_l, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "dispu_idw_weights": (_i, [_l, _vp, _vp, _vp]),
+    "dispu_edge_feature": (_i, [_l, _i, _i, _i, _vp, _l, _vp, _i, _i, _vp, _l, _vp]),
+    "dispu_row_mean_max": (_i, [_i, _i, _vp, _vp, _vp, _vp]),
+    "dispu_repulsion": (_i, [_l, _i, _i, _i, C.c_float, _vp, _vp, _vp, _vp]),
     "dispu_linear_small_k": (_i, [_l, _i, _i, _vp, _l, _vp, _vp, _i, _vp, _l, _vp]),
     "dispu_linear_small_n": (_i, [_l, _i, _i, _vp, _l, _vp, _vp, _i, _vp, _l, _vp, _l, _vp]),
     "dispu_edge_dense_conv": (_i, [_i, _i, _i, _vp, _l, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _l, _vp]),

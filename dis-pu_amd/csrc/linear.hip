@@ -27,6 +27,8 @@ struct LinearArgs {
     const float* R1; long ldr1; long sr1;  // optional residuals added after the activation
     const float* R2; long ldr2; long sr2;
     int act;                             // 0 none, 1 relu
+    const float* scale;                  // optional inference BatchNorm folded to v*scale[n] + shift[n], applied
+    const float* shift;                  // between the bias add and the activation (tf_util.py:176-185 order)
 };
 
 constexpr int LIN_BK = 32;
@@ -166,6 +168,7 @@ __global__ __launch_bounds__(256) void linear_mfma_kernel(LinearArgs a) {
         const int col = n0 + wn * (BN / 2) + j * 32 + fi;
         if (col >= N) continue;
         const float bv = a.bias ? a.bias[col] : 0.f;
+        const float sc = a.scale ? a.scale[col] : 1.f, sh = a.scale ? a.shift[col] : 0.f;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -174,6 +177,7 @@ __global__ __launch_bounds__(256) void linear_mfma_kernel(LinearArgs a) {
                 if (row < M) {
                     float v = acc[i][j][r];
                     if (a.bias) v = v + bv;
+                    if (a.scale) v = v * sc + sh;
                     if (a.act == 1) v = fmaxf(v, 0.f);
                     if (R1) v = v + R1[(size_t)row * a.ldr1 + col];
                     if (R2) v = v + R2[(size_t)row * a.ldr2 + col];
@@ -205,13 +209,30 @@ DISPU_EXPORT int dispu_linear_tile(int batch, int M, int N) {
     return blocks_mid >= 256 ? 128064 : 64064;
 }
 
+DISPU_EXPORT int dispu_linear_bn(int batch, int M, int K, int N, const float* X, long ldx, long sx, const float* W,
+                                 long ldw, long sw, int transb, const float* bias, const float* scale, const float* shift,
+                                 int act, float* Y, long ldy, long sy, const float* R1, long ldr1, long sr1,
+                                 const float* R2, long ldr2, long sr2, void* stream);
+
 // Y = R2 + R1 + act(X.W + bias); see include/dispu_hip.h for the argument contract.
 DISPU_EXPORT int dispu_linear(int batch, int M, int K, int N, const float* X, long ldx, long sx, const float* W,
                               long ldw, long sw, int transb, const float* bias, int act, float* Y, long ldy, long sy,
                               const float* R1, long ldr1, long sr1, const float* R2, long ldr2, long sr2, void* stream) {
     if (batch < 0 || M < 0 || K <= 0 || N <= 0 || !X || !W || !Y || act < 0 || act > 1) return (int)hipErrorInvalidValue;
     if (batch == 0 || M == 0) return 0;
-    LinearArgs a{M, K, N, X, ldx, sx, W, ldw, sw, bias, Y, ldy, sy, R1, ldr1, sr1, R2, ldr2, sr2, act};
+    return dispu_linear_bn(batch, M, K, N, X, ldx, sx, W, ldw, sw, transb, bias, nullptr, nullptr, act, Y, ldy, sy, R1, ldr1,
+                           sr1, R2, ldr2, sr2, stream);
+}
+
+// dispu_linear with an inference-BatchNorm epilogue: Y = R2 + R1 + act( (X.W + bias) * scale + shift ).
+DISPU_EXPORT int dispu_linear_bn(int batch, int M, int K, int N, const float* X, long ldx, long sx, const float* W,
+                                 long ldw, long sw, int transb, const float* bias, const float* scale, const float* shift,
+                                 int act, float* Y, long ldy, long sy, const float* R1, long ldr1, long sr1,
+                                 const float* R2, long ldr2, long sr2, void* stream) {
+    if (batch < 0 || M < 0 || K <= 0 || N <= 0 || !X || !W || !Y || act < 0 || act > 1 || ((scale == nullptr) != (shift == nullptr)))
+        return (int)hipErrorInvalidValue;
+    if (batch == 0 || M == 0) return 0;
+    LinearArgs a{M, K, N, X, ldx, sx, W, ldw, sw, bias, Y, ldy, sy, R1, ldr1, sr1, R2, ldr2, sr2, act, scale, shift};
     hipStream_t s = (hipStream_t)stream;
     switch (dispu_linear_tile(batch, M, N)) {
         case 128128: return launch_linear<128, 128>(a, batch, transb != 0, s);

@@ -1,0 +1,115 @@
+"""PointNet++ set-abstraction / feature-propagation modules -- the reference's Common/pointnet_util.py:22-222 with
+torch tensors, composed from the hot-path ops (FPS, gather, ball query / k-NN, group, 3-NN, interpolate) and the
+fused 1x1-conv GEMM.  Same function names, argument order and return values; variables are passed through
+`params` (see tf_util.py) instead of TF variable scopes.  Inference mode.
+
+torch is used here only to allocate / concatenate / reshape device buffers; every arithmetic step is a HIP kernel
+of libdispu_hip.so."""
+import torch
+
+from . import _lib, tf_util
+from .tf_grouping import group_point, knn_point, query_ball_point
+from .tf_interpolate import three_interpolate, three_nn
+from .tf_sampling import farthest_point_sample, gather_point
+
+_POOL = {"max": 0, "avg": 1, "min": 2, "weighted_avg": 3, "max_and_avg": 4}
+
+
+def _center(grouped, center):
+    """grouped[b,m,ns,c] -= center[b,m,c] in place (pointnet_util.py:43)."""
+    b, m, ns, c = grouped.shape
+    _lib.check(_lib.lib().dispu_group_center(b * m, ns, c, _lib.ptr(grouped), _lib.ptr(center.contiguous()),
+                                             _lib.stream_ptr(grouped.device)), "dispu_group_center")
+    return grouped
+
+
+def _pool(x, pooling, grouped_xyz=None):
+    b, m, ns, c = x.shape
+    mode = _POOL[pooling]
+    out = torch.empty((b, m, 1, 2 * c if mode == 4 else c), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().dispu_pool_nsample(b * m, ns, c, mode, _lib.ptr(x.contiguous()),
+                                             _lib.ptr(grouped_xyz.contiguous()) if mode == 3 else None, _lib.ptr(out),
+                                             _lib.stream_ptr(x.device)), "dispu_pool_nsample")
+    return out
+
+
+def sample_and_group(npoint, radius, nsample, xyz, points, tnet_spec=None, knn=False, use_xyz=True):
+    """pointnet_util.py:22-59 -> (new_xyz[b,npoint,3], new_points[b,npoint,ns,3+c], idx[b,npoint,ns], grouped_xyz)."""
+    if tnet_spec is not None:
+        raise NotImplementedError("tnet is undefined in the reference as well (pointnet_util.py:45 calls a missing symbol)")
+    new_xyz = gather_point(xyz, farthest_point_sample(npoint, xyz))
+    if knn:
+        _, idx = knn_point(nsample, xyz, new_xyz)
+    else:
+        idx, _ = query_ball_point(radius, nsample, xyz, new_xyz)
+    grouped_xyz = _center(group_point(xyz, idx), new_xyz)
+    if points is not None:
+        grouped_points = group_point(points, idx)
+        new_points = torch.cat([grouped_xyz, grouped_points], dim=-1) if use_xyz else grouped_points
+    else:
+        new_points = grouped_xyz
+    return new_xyz, new_points, idx, grouped_xyz
+
+
+def sample_and_group_all(xyz, points, use_xyz=True):
+    """pointnet_util.py:62-88: one group holding every point, centroid (0,0,0)."""
+    b, n, _ = xyz.shape
+    new_xyz = torch.zeros((b, 1, 3), dtype=torch.float32, device=xyz.device)
+    idx = torch.arange(n, dtype=torch.int32, device=xyz.device).view(1, 1, n).expand(b, 1, n).contiguous()
+    grouped_xyz = xyz.reshape(b, 1, n, 3)
+    if points is not None:
+        new_points = (torch.cat([xyz, points], dim=2) if use_xyz else points).unsqueeze(1)
+    else:
+        new_points = grouped_xyz
+    return new_xyz, new_points, idx, grouped_xyz
+
+
+def pointnet_sa_module(xyz, points, npoint, radius, nsample, mlp, mlp2, group_all, is_training, bn_decay, scope,
+                       bn=True, pooling="max", tnet_spec=None, knn=False, use_xyz=True, params=None):
+    """pointnet_util.py:91-149 -> (new_xyz, new_points[b,npoint,mlp[-1] or mlp2[-1]], idx)."""
+    if group_all:
+        nsample = xyz.shape[1]
+        new_xyz, new_points, idx, grouped_xyz = sample_and_group_all(xyz, points, use_xyz)
+    else:
+        new_xyz, new_points, idx, grouped_xyz = sample_and_group(npoint, radius, nsample, xyz, points, tnet_spec, knn, use_xyz)
+    for i, co in enumerate(mlp):
+        new_points = tf_util.conv2d(new_points, co, (1, 1), scope + "/conv%d" % i, params, bn=bn, is_training=is_training)
+    new_points = _pool(new_points, pooling, grouped_xyz)
+    for i, co in enumerate(mlp2 or []):
+        new_points = tf_util.conv2d(new_points, co, (1, 1), scope + "/conv_post_%d" % i, params, bn=bn, is_training=is_training)
+    return new_xyz, new_points.squeeze(2), idx
+
+
+def pointnet_sa_module_msg(xyz, points, npoint, radius_list, nsample_list, mlp_list, is_training=False, bn_decay=None,
+                           scope="msg", bn=True, use_xyz=True, params=None):
+    """pointnet_util.py:152-189 (multi-scale grouping; note the [points, xyz] concat order of this variant)."""
+    new_xyz = gather_point(xyz, farthest_point_sample(npoint, xyz))
+    outs = []
+    for i, (radius, nsample) in enumerate(zip(radius_list, nsample_list)):
+        idx, _ = query_ball_point(radius, nsample, xyz, new_xyz)
+        grouped_xyz = _center(group_point(xyz, idx), new_xyz)
+        if points is not None:
+            grouped_points = group_point(points, idx)
+            if use_xyz:
+                grouped_points = torch.cat([grouped_points, grouped_xyz], dim=-1)
+        else:
+            grouped_points = grouped_xyz
+        for j, co in enumerate(mlp_list[i]):
+            grouped_points = tf_util.conv2d(grouped_points, co, (1, 1), scope + "/conv%d_%d" % (i, j), params, bn=bn,
+                                            is_training=is_training)
+        outs.append(_pool(grouped_points, "max").squeeze(2))
+    return new_xyz, torch.cat(outs, dim=-1)
+
+
+def pointnet_fp_module(xyz1, xyz2, points1, points2, mlp, is_training, bn_decay, scope, bn=True, params=None):
+    """pointnet_util.py:192-222: 3-NN inverse-distance interpolation of points2 onto xyz1, concat, MLP."""
+    dist, idx = three_nn(xyz1, xyz2)
+    weight = torch.empty_like(dist)
+    _lib.check(_lib.lib().dispu_idw_weights(dist.shape[0] * dist.shape[1], _lib.ptr(dist), _lib.ptr(weight),
+                                            _lib.stream_ptr(dist.device)), "dispu_idw_weights")
+    interpolated = three_interpolate(points2, idx, weight)
+    new_points1 = torch.cat([interpolated, points1], dim=2) if points1 is not None else interpolated
+    new_points1 = new_points1.unsqueeze(2)
+    for i, co in enumerate(mlp):
+        new_points1 = tf_util.conv2d(new_points1, co, (1, 1), scope + "/conv_%d" % i, params, bn=bn, is_training=is_training)
+    return new_points1.squeeze(2)

@@ -151,6 +151,11 @@ int dispu_match_cost_grad(int b, int n, int m, const float* xyz1, const float* x
 int dispu_linear(int batch, int M, int K, int N, const float* X, long ldx, long sx, const float* W, long ldw, long sw,
                  int transb, const float* bias, int act, float* Y, long ldy, long sy, const float* R1, long ldr1,
                  long sr1, const float* R2, long ldr2, long sr2, void* stream);
+/* dispu_linear with an inference-BatchNorm epilogue (tf_util.py:176-185: conv -> bias_add -> batch_norm -> relu):
+ * Y = R2 + R1 + act( (X.W + bias) * scale[n] + shift[n] ); scale/shift are the folded BN (gamma/sqrt(var+eps), ...). */
+int dispu_linear_bn(int batch, int M, int K, int N, const float* X, long ldx, long sx, const float* W, long ldw, long sw,
+                    int transb, const float* bias, const float* scale, const float* shift, int act, float* Y, long ldy,
+                    long sy, const float* R1, long ldr1, long sr1, const float* R2, long ldr2, long sr2, void* stream);
 /* Which block tile dispu_linear picks for (batch, M, N), as BM*1000 + BN (e.g. 128128): lets a profiler map a
  * launch to the kernel instantiation name rocprofv3 reports (linear_mfma_kernel<BM, BN, transb>). */
 int dispu_linear_tile(int batch, int M, int N);
@@ -189,6 +194,25 @@ int dispu_ps_point_matmul(long rows, int k, int c, int t_n, const float* X2, lon
                           long ldo, void* stream);
 /* S <- softmax(S * mul) per row, in place (tf.nn.softmax of PointNonLocalCell, ops.py:338). */
 int dispu_softmax_rows(long rows, int n, float mul, float* S, long lds, void* stream);
+
+/* ---- glue kernels of the PointNet++ / EdgeConv / loss compositions --------------------------------------
+ * (Common/pointnet_util.py, gcn_lib/tf_vertex.py, Common/loss_utils.py: chains of generic TF ops in the reference) */
+/* grouped[r,s,:] -= center[r,:]  ("translation normalization", pointnet_util.py:43; loss_utils.py:281). */
+int dispu_group_center(long rows, int ns, int c, float* grouped, const float* center, void* stream);
+/* pooling over nsample of X[rows,ns,c] (pointnet_util.py:121-140): mode 0 max, 1 avg, 2 "min" (= max(-x), as the
+ * reference computes it), 3 weighted_avg (needs gxyz[rows,ns,3]), 4 max_and_avg -> [max|avg] (2c outputs). */
+int dispu_pool_nsample(long rows, int ns, int c, int mode, const float* X, const float* gxyz, float* out, void* stream);
+/* pointnet_fp_module inverse-distance weights (pointnet_util.py:204-208): dist[rows,3] -> weight[rows,3]. */
+int dispu_idw_weights(long rows, const float* dist, float* weight, void* stream);
+/* tf_util.get_edge_feature (Common/tf_util.py:654-686): out[(i,s), 0:2c] = [F_i | F_j - F_i]. */
+int dispu_edge_feature(long rows, int n_per_cloud, int k, int c, const float* F, long ldf, const int* idx, int ldi, int ioff,
+                       float* out, long ldo, void* stream);
+/* per-row mean and max of x[b,n] (Chamfer / Hausdorff reductions, loss_utils.py:59-63,78-83). */
+int dispu_row_mean_max(int b, int n, const float* x, float* mean, float* mx, void* stream);
+/* get_repulsion_loss core (loss_utils.py:280-296): out[i] = sum of max(0, h - d) over the 2nd..5th smallest
+ * neighbour distances of point i among idx[i, 0:ns]. */
+int dispu_repulsion(long rows, int n_per_cloud, int ns, int use_l1, float h, const float* pred, const int* idx, float* out,
+                    void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,120 @@
+"""GPU parity of the compositions: PointNet++ SA / MSG / FP modules, EdgeConv + kNN graph,
+Chamfer / Hausdorff / EMD / repulsion losses -- dis-pu_amd/{pointnet_util,gcn_lib,loss_utils}.py vs oracle/modules.py.
+Index outputs are exact; features go through fp32 GEMM chains that are bit-equal to the oracle's fmaf chains, the
+pooling / BN / loss reductions are compared at 1e-5."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import modules as OM
+
+pytestmark = pytest.mark.gpu
+
+
+def T(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def N(t):
+    return t.detach().cpu().numpy()
+
+
+def make_params(rng, spec, bn):
+    """spec: list of (scope, cin, cout)."""
+    P = {}
+    for scope, cin, cout in spec:
+        P[scope + "/weights"] = (rng.standard_normal((cin, cout)) * (1.0 / np.sqrt(cin))).astype(np.float32)
+        P[scope + "/biases"] = (rng.standard_normal(cout) * 0.1).astype(np.float32)
+        if bn:
+            P[scope + "/bn/gamma"] = rng.uniform(0.5, 1.5, cout).astype(np.float32)
+            P[scope + "/bn/beta"] = (rng.standard_normal(cout) * 0.1).astype(np.float32)
+            P[scope + "/bn/moving_mean"] = (rng.standard_normal(cout) * 0.1).astype(np.float32)
+            P[scope + "/bn/moving_variance"] = rng.uniform(0.5, 1.5, cout).astype(np.float32)
+    return P
+
+
+def cloud(rng, b, n):
+    return rng.random((b, n, 3)).astype(np.float32)
+
+
+@pytest.mark.parametrize("pooling", ["max", "avg", "min", "weighted_avg", "max_and_avg"])
+@pytest.mark.parametrize("knn", [False, True])
+def test_pointnet_sa_module(dev, pooling, knn):
+    from dispu_amd import pointnet_util as PU
+    rng = np.random.default_rng(1)
+    xyz, pts = cloud(rng, 2, 512), rng.standard_normal((2, 512, 13)).astype(np.float32)
+    c_pool = 64 if pooling == "max_and_avg" else 32
+    P = make_params(rng, [("sa/conv0", 16, 24), ("sa/conv1", 24, 32), ("sa/conv_post_0", c_pool, 40)], bn=True)
+    want_xyz, want_pts, want_idx = OM.pointnet_sa_module(P, "sa", xyz, pts, 96, 0.2, 16, [24, 32], [40], False, bn=True,
+                                                         pooling=pooling, knn=knn)
+    got_xyz, got_pts, got_idx = PU.pointnet_sa_module(T(xyz, dev), T(pts, dev), 96, 0.2, 16, [24, 32], [40], False, False,
+                                                      None, "sa", bn=True, pooling=pooling, knn=knn, params=P)
+    assert np.array_equal(N(got_xyz), want_xyz) and np.array_equal(N(got_idx), want_idx)
+    assert np.allclose(N(got_pts), want_pts, rtol=1e-5, atol=1e-5)
+
+
+def test_pointnet_sa_group_all_and_msg(dev):
+    from dispu_amd import pointnet_util as PU
+    rng = np.random.default_rng(2)
+    xyz, pts = cloud(rng, 2, 256), rng.standard_normal((2, 256, 8)).astype(np.float32)
+    P = make_params(rng, [("ga/conv0", 11, 32), ("ga/conv1", 32, 64)], bn=False)
+    wx, wp, wi = OM.pointnet_sa_module(P, "ga", xyz, pts, None, None, None, [32, 64], None, True, bn=False)
+    gx, gp, gi = PU.pointnet_sa_module(T(xyz, dev), T(pts, dev), None, None, None, [32, 64], None, True, False, None, "ga",
+                                       bn=False, params=P)
+    assert N(gp).shape == (2, 1, 64) and np.array_equal(N(gi), wi) and np.array_equal(N(gx), wx)
+    assert np.array_equal(N(gp), wp)                       # GEMM chain + max pooling: bit-exact
+    Pm = make_params(rng, [("msg/conv0_0", 11, 16), ("msg/conv0_1", 16, 32), ("msg/conv1_0", 11, 24)], bn=True)
+    wx, wp = OM.pointnet_sa_module_msg(Pm, "msg", xyz, pts, 64, [0.1, 0.3], [8, 24], [[16, 32], [24]])
+    gx, gp = PU.pointnet_sa_module_msg(T(xyz, dev), T(pts, dev), 64, [0.1, 0.3], [8, 24], [[16, 32], [24]], params=Pm)
+    assert np.array_equal(N(gx), wx) and N(gp).shape == (2, 64, 56) and np.allclose(N(gp), wp, rtol=1e-5, atol=1e-5)
+
+
+def test_pointnet_fp_module(dev):
+    from dispu_amd import pointnet_util as PU
+    rng = np.random.default_rng(3)
+    xyz1, xyz2 = cloud(rng, 2, 384), cloud(rng, 2, 128)
+    p1, p2 = rng.standard_normal((2, 384, 10)).astype(np.float32), rng.standard_normal((2, 128, 20)).astype(np.float32)
+    P = make_params(rng, [("fp/conv_0", 30, 48), ("fp/conv_1", 48, 32)], bn=True)
+    want = OM.pointnet_fp_module(P, "fp", xyz1, xyz2, p1, p2, [48, 32], bn=True)
+    got = PU.pointnet_fp_module(T(xyz1, dev), T(xyz2, dev), T(p1, dev), T(p2, dev), [48, 32], False, None, "fp", bn=True, params=P)
+    assert np.allclose(N(got), want, rtol=1e-5, atol=1e-5)
+    want = OM.pointnet_fp_module(make_params(rng, [("f2/conv_0", 20, 16)], False) if False else P, "fp", xyz1, xyz2, p1, p2, [48, 32])
+    assert want.shape == (2, 384, 32)
+
+
+def test_edge_conv_and_knn_graph(dev):
+    from dispu_amd import gcn_lib as GL
+    rng = np.random.default_rng(4)
+    f = rng.standard_normal((3, 200, 20)).astype(np.float32)
+    P = make_params(rng, [("gcn/ec", 40, 64)], bn=False)
+    idx = OM.knn_graph(f, 16)
+    got_idx = GL.knn_graph(T(f, dev), 16)
+    assert np.array_equal(N(got_idx), idx) and np.array_equal(idx[:, :, 0], np.broadcast_to(np.arange(200), (3, 200)))
+    want = OM.edge_conv_layer(P, "gcn/ec", f, idx)
+    got = GL.edge_conv_layer(T(f, dev).unsqueeze(2), got_idx, 16, 64, scope="gcn/ec", params=P)
+    assert N(got).shape == (3, 200, 1, 64) and np.array_equal(N(got), want)
+
+
+def test_losses(dev):
+    from dispu_amd import loss_utils as LU
+    from dispu_amd import synth
+    pred, gt = synth.patch_with_gt(3, 512, 512, seed=5)
+    tp, tg = T(pred, dev).requires_grad_(True), T(gt, dev)
+    cd = LU.chamfer(tp, tg, radius=1.0)
+    assert abs(float(cd) - OM.chamfer(pred, gt)) <= 1e-5 * max(1.0, abs(OM.chamfer(pred, gt)))
+    assert abs(float(LU.hausdorff_loss(tp, tg)) - OM.hausdorff_loss(pred, gt)) <= 1e-6
+    emd = LU.earth_mover(tp, tg)
+    assert abs(float(emd) - OM.earth_mover(pred, gt)) <= 1e-5 * OM.earth_mover(pred, gt)
+    rep = LU.get_repulsion_loss(tp)
+    assert abs(float(rep) - OM.get_repulsion_loss(pred)) <= 1e-6
+    # gradients: chamfer through nn_distance_grad == finite differences of the oracle loss
+    cd.backward()
+    g = N(tp.grad)
+    eps = 1e-3
+    for (b, i, c) in [(0, 3, 0), (1, 100, 2), (2, 511, 1)]:
+        e = np.zeros_like(pred); e[b, i, c] = eps
+        num = (OM.chamfer(pred + e, gt) - OM.chamfer(pred - e, gt)) / (2 * eps)
+        assert abs(num - g[b, i, c]) < 2e-4
+    tp.grad = None
+    emd.backward()
+    assert np.isfinite(N(tp.grad)).all() and np.abs(N(tp.grad)).max() > 0
