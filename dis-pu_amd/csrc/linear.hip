@@ -1,7 +1,7 @@
 // Per-point dense layers (the reference's 1x1 conv1d/conv2d, Common/tf_util.py:52-185) and the
 // batched matmuls of PointNonLocalCell (Common/ops.py:326,339) as ONE fp32 MFMA GEMM for gfx950:
 //
-//   Y[z][m, n] = res2 + res1 + act( chain_k X[z][m, k] * W[z][k, n]  + bias[n] )
+//   Y[z][m, n] = res2 + res1 + act( (chain_k X[z][m, k] * W[z][k, n] + bias[n]) [* scale[n] + shift[n]] )
 //
 // * v_mfma_f32_32x32x2_f32: exact fp32, and bit-for-bit the ascending-k fmaf chain the oracle pins
 //   (oracle/mlp_oracle.c) -- no split-K, no reassociation, so features feeding the k-NN stages are
@@ -10,9 +10,14 @@
 //   activation buffer and outputs land directly inside concatenation buffers (the reference
 //   materialises every tf.concat).
 // * TRANSB reads W as [n][k] (k contiguous): Q.K^T without a transpose pass.
-// * Block = 4 waves (2x2), LDS tiles A[BK][BM+1] / B[BK][BN+4], register prefetch of the next
-//   K-tile while the MFMAs of the current one run.  Epilogue fuses bias, ReLU and two residual adds.
+// * Workgroup = WM x WN waves, each owning TM x TN 32x32 accumulator tiles.  Two LDS stages
+//   (A[BK][BM+1] / B[BK][BN+4], conflict-free b32 fragment reads): while the MFMAs of stage t run, the same
+//   waves park K-tile t+1 (already in registers) into the other stage and issue the global loads of tile t+2, so
+//   there is ONE barrier per K-tile and no load/store-only phase.  Interior tiles take a predicate-free path.
+//   Epilogue fuses bias, BatchNorm scale/shift, ReLU and two residual adds.
 #include "common.h"
+
+#include <cstdlib>
 
 namespace dispu {
 
@@ -31,24 +36,31 @@ struct LinearArgs {
     const float* shift;                  // between the bias add and the activation (tf_util.py:176-185 order)
 };
 
-constexpr int LIN_BK = 32;
+template <int BM, int BN, int BK, bool TRANSB>
+struct LinearLds {
+    static constexpr int LDA = BM + 1;   // A tile stored k-major [BK][BM+1]: conflict-free b32 frag reads and writes
+    static constexpr int LDB = TRANSB ? BN + 1 : BN + 4;
+    static constexpr int STAGE = ((BK * (LDA + LDB) + 3) / 4) * 4;          // floats per stage (16-byte multiple)
+    static constexpr size_t BYTES = (size_t)2 * STAGE * sizeof(float);
+};
 
-// BM x BN block tile; 4 waves arranged 2 x 2; each wave owns (BM/2) x (BN/2) = TM x TN 32x32 MFMA tiles.
-template <int BM, int BN, bool TRANSB>
-__global__ __launch_bounds__(256) void linear_mfma_kernel(LinearArgs a) {
-    constexpr int BK = LIN_BK;
-    constexpr int LDA = BM + 1;   // A tile stored k-major [BK][BM+1]: conflict-free b32 frag reads and writes
-    constexpr int LDB = TRANSB ? BN + 1 : BN + 4;
-    constexpr int TM = BM / 64, TN = BN / 64;          // 32x32 tiles per wave
-    constexpr int A_F4 = BM * BK / 4 / 256;            // float4 loads per thread for the A tile
-    constexpr int B_F4 = BN * BK / 4 / 256;
-    static_assert(A_F4 >= 1 && B_F4 >= 1, "tile too small for 256 threads");
-    __shared__ float As[BK * LDA];
-    __shared__ float Bs[BK * LDB];
+// BM x BN block tile, WM x WN waves, BK k-slab per LDS stage.
+// EDGE = false: every tile is interior and 16-byte aligned (M % BM == N % BN == K % BK == 0): no predicates at all.
+template <int BM, int BN, int WM, int WN, int BK, bool TRANSB, bool EDGE>
+__global__ __launch_bounds__(64 * WM * WN) void linear_mfma_kernel(LinearArgs a) {
+    using L = LinearLds<BM, BN, BK, TRANSB>;
+    constexpr int NT = 64 * WM * WN;
+    constexpr int LDA = L::LDA, LDB = L::LDB;
+    constexpr int TM = BM / (32 * WM), TN = BN / (32 * WN);
+    constexpr int A_F4 = BM * BK / 4 / NT;            // float4 loads per thread for the A tile
+    constexpr int B_F4 = BN * BK / 4 / NT;
+    static_assert(A_F4 >= 1 && B_F4 >= 1 && TM >= 1 && TN >= 1, "tile too small for the workgroup");
+    static_assert((BM * BK / 4) % NT == 0 && (BN * BK / 4) % NT == 0, "tile must split evenly over the threads");
+    extern __shared__ __attribute__((aligned(16))) float lds[];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
     const int z = blockIdx.z;
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
     const float* __restrict__ X = a.X + (size_t)z * a.sx;
@@ -70,9 +82,10 @@ __global__ __launch_bounds__(256) void linear_mfma_kernel(LinearArgs a) {
 
     // rows-of-k loader (A always; B when TRANSB): element (row, k) with k contiguous in memory
     auto load_rowsk = [&](const float* __restrict__ P, long ld, bool vec, int row_base, int rows, int k0, int it) -> float4 {
-        const int idx = tid + it * 256;
+        const int idx = tid + it * NT;
         const int r = idx / (BK / 4), kq = idx % (BK / 4);
         const int row = row_base + r, k = k0 + kq * 4;
+        if constexpr (!EDGE) return *reinterpret_cast<const float4*>(P + (size_t)row * ld + k);
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (row < rows && k < K) {
             const float* p = P + (size_t)row * ld + k;
@@ -88,7 +101,7 @@ __global__ __launch_bounds__(256) void linear_mfma_kernel(LinearArgs a) {
         return v;
     };
     auto store_rowsk = [&](float* S, int LD, float4 v, int it) {
-        const int idx = tid + it * 256;
+        const int idx = tid + it * NT;
         const int r = idx / (BK / 4), kq = idx % (BK / 4);
         S[(kq * 4 + 0) * LD + r] = v.x;
         S[(kq * 4 + 1) * LD + r] = v.y;
@@ -97,9 +110,10 @@ __global__ __launch_bounds__(256) void linear_mfma_kernel(LinearArgs a) {
     };
     // k-rows loader for B = W[k][n] (n contiguous)
     auto load_b = [&](int k0, int it) -> float4 {
-        const int idx = tid + it * 256;
+        const int idx = tid + it * NT;
         const int kr = idx / (BN / 4), nq = idx % (BN / 4);
         const int k = k0 + kr, n = n0 + nq * 4;
+        if constexpr (!EDGE) return *reinterpret_cast<const float4*>(W + (size_t)k * ldw + n);
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (k < K && n < N) {
             const float* p = W + (size_t)k * ldw + n;
@@ -114,49 +128,59 @@ __global__ __launch_bounds__(256) void linear_mfma_kernel(LinearArgs a) {
         }
         return v;
     };
-    auto store_b = [&](float4 v, int it) {
-        const int idx = tid + it * 256;
+    auto store_b = [&](float* S, float4 v, int it) {
+        const int idx = tid + it * NT;
         const int kr = idx / (BN / 4), nq = idx % (BN / 4);
-        *reinterpret_cast<float4*>(&Bs[kr * LDB + nq * 4]) = v;
+        *reinterpret_cast<float4*>(&S[kr * LDB + nq * 4]) = v;
     };
-
-    const int ntile = (K + BK - 1) / BK;
+    auto load_tile = [&](int k0) {
 #pragma unroll
-    for (int it = 0; it < A_F4; ++it) pa[it] = load_rowsk(X, ldx, x_vec, m0, M, 0, it);
+        for (int it = 0; it < A_F4; ++it) pa[it] = load_rowsk(X, ldx, x_vec, m0, M, k0, it);
 #pragma unroll
-    for (int it = 0; it < B_F4; ++it) pb[it] = TRANSB ? load_rowsk(W, ldw, w_vec, n0, N, 0, it) : load_b(0, it);
-
-    const int fi = lane & 31, fk = lane >> 5;
-    for (int t = 0; t < ntile; ++t) {
-        __syncthreads();   // previous tile fully consumed
+        for (int it = 0; it < B_F4; ++it) pb[it] = TRANSB ? load_rowsk(W, ldw, w_vec, n0, N, k0, it) : load_b(k0, it);
+    };
+    auto store_tile = [&](int stage) {
+        float* As = lds + stage * L::STAGE;
+        float* Bs = As + BK * LDA;
 #pragma unroll
         for (int it = 0; it < A_F4; ++it) store_rowsk(As, LDA, pa[it], it);
 #pragma unroll
         for (int it = 0; it < B_F4; ++it) {
             if constexpr (TRANSB) store_rowsk(Bs, LDB, pb[it], it);
-            else store_b(pb[it], it);
+            else store_b(Bs, pb[it], it);
         }
-        __syncthreads();
+    };
+
+    const int ntile = (K + BK - 1) / BK;
+    load_tile(0);
+    store_tile(0);
+    if (ntile > 1) load_tile(BK);
+    __syncthreads();
+
+    const int fi = lane & 31, fk = lane >> 5;
+    for (int t = 0; t < ntile; ++t) {
+        const float* As = lds + (t & 1) * L::STAGE;
+        const float* Bs = As + BK * LDA;
+        // park tile t+1 in the other stage (its last readers passed the barrier that ended iteration t-1) and
+        // start fetching tile t+2; both overlap with this stage's MFMAs
         if (t + 1 < ntile) {
-            const int k0 = (t + 1) * BK;
-#pragma unroll
-            for (int it = 0; it < A_F4; ++it) pa[it] = load_rowsk(X, ldx, x_vec, m0, M, k0, it);
-#pragma unroll
-            for (int it = 0; it < B_F4; ++it) pb[it] = TRANSB ? load_rowsk(W, ldw, w_vec, n0, N, k0, it) : load_b(k0, it);
+            store_tile((t + 1) & 1);
+            if (t + 2 < ntile) load_tile((t + 2) * BK);
         }
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 2) {
             float af[TM], bf[TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) af[i] = As[(kk + fk) * LDA + wm * (BM / 2) + i * 32 + fi];
+            for (int i = 0; i < TM; ++i) af[i] = As[(kk + fk) * LDA + wm * (TM * 32) + i * 32 + fi];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) bf[j] = Bs[(kk + fk) * LDB + wn * (BN / 2) + j * 32 + fi];
+            for (int j = 0; j < TN; ++j) bf[j] = Bs[(kk + fk) * LDB + wn * (TN * 32) + j * 32 + fi];
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
         }
+        __syncthreads();
     }
 
     // epilogue: C/D layout of the 32x32 tile: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
@@ -165,16 +189,16 @@ __global__ __launch_bounds__(256) void linear_mfma_kernel(LinearArgs a) {
     const float* __restrict__ R2 = a.R2 ? a.R2 + (size_t)z * a.sr2 : nullptr;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-        const int col = n0 + wn * (BN / 2) + j * 32 + fi;
-        if (col >= N) continue;
+        const int col = n0 + wn * (TN * 32) + j * 32 + fi;
+        if (EDGE && col >= N) continue;
         const float bv = a.bias ? a.bias[col] : 0.f;
         const float sc = a.scale ? a.scale[col] : 1.f, sh = a.scale ? a.shift[col] : 0.f;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
-                if (row < M) {
+                const int row = m0 + wm * (TM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
+                if (!EDGE || row < M) {
                     float v = acc[i][j][r];
                     if (a.bias) v = v + bv;
                     if (a.scale) v = v * sc + sh;
@@ -188,25 +212,58 @@ __global__ __launch_bounds__(256) void linear_mfma_kernel(LinearArgs a) {
     }
 }
 
-template <int BM, int BN>
+template <int BM, int BN, int WM, int WN, int BK, bool TRANSB, bool EDGE>
+static int launch_one(const LinearArgs& a, dim3 grid, hipStream_t s) {
+    constexpr size_t bytes = LinearLds<BM, BN, BK, TRANSB>::BYTES;
+    auto kern = linear_mfma_kernel<BM, BN, WM, WN, BK, TRANSB, EDGE>;
+    if (bytes > 64 * 1024) {
+        static bool done = false;       // opt in to > 64 KiB of dynamic LDS once per instantiation
+        if (!done) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+            if (e != hipSuccess) return (int)e;
+            done = true;
+        }
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), bytes, s, a);
+    return (int)hipGetLastError();
+}
+
+template <int BM, int BN, int WM, int WN, int BK>
 static int launch_linear(const LinearArgs& a, int batch, bool transb, hipStream_t s) {
     dim3 grid((a.N + BN - 1) / BN, (a.M + BM - 1) / BM, batch);
-    if (transb) hipLaunchKernelGGL((linear_mfma_kernel<BM, BN, true>), grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((linear_mfma_kernel<BM, BN, false>), grid, dim3(256), 0, s, a);
-    return (int)hipGetLastError();
+    const bool aligned = ((a.ldx & 3) == 0) && ((a.ldw & 3) == 0) && ((a.sx & 3) == 0) && ((a.sw & 3) == 0) &&
+                         ((((uintptr_t)a.X) & 15) == 0) && ((((uintptr_t)a.W) & 15) == 0);
+    const bool interior = aligned && (a.M % BM == 0) && (a.N % BN == 0) && (a.K % BK == 0);
+    if (interior) {
+        if (transb) return launch_one<BM, BN, WM, WN, BK, true, false>(a, grid, s);
+        return launch_one<BM, BN, WM, WN, BK, false, false>(a, grid, s);
+    }
+    if (transb) return launch_one<BM, BN, WM, WN, BK, true, true>(a, grid, s);
+    return launch_one<BM, BN, WM, WN, BK, false, true>(a, grid, s);
+}
+
+static int tile_override() {            // DISPU_LINEAR_TILE=<code>: force one variant (benchmarking only)
+    static int v = -2;
+    if (v == -2) {
+        const char* e = getenv("DISPU_LINEAR_TILE");
+        v = e ? atoi(e) : -1;
+    }
+    return v;
 }
 
 }  // namespace dispu
 
 using namespace dispu;
 
-// Block-tile choice of dispu_linear as BM*1000 + BN (128128, 64128, 128064, 64064): large tiles when they still
-// give >= 256 workgroups (one per CU), smaller ones otherwise.  Exported so a profiler can name the instantiation.
+// Block-tile choice of dispu_linear as BM*1000 + BN (128128, 64128, 128064, 64064): the largest tile that still
+// yields >= 256 workgroups (one per CU).  Exported so a profiler can name the kernel instantiation.
 DISPU_EXPORT int dispu_linear_tile(int batch, int M, int N) {
-    const long blocks_big = (long)((M + 127) / 128) * ((N + 127) / 128) * batch;
-    if (N > 64) return blocks_big >= 256 ? 128128 : 64128;
-    const long blocks_mid = (long)((M + 127) / 128) * batch;
-    return blocks_mid >= 256 ? 128064 : 64064;
+    const int ov = tile_override();
+    if (ov > 0) return ov;
+    const long mb128 = (long)((M + 127) / 128) * batch;
+    if (N >= 256 && N % 256 == 0 && mb128 * (N / 256) >= 256) return 128257;   // 128x256 tile, BK 16: 64x128 per wave
+    if (N > 64) return (mb128 * ((N + 127) / 128) >= 256) ? 128128 : 64128;
+    return mb128 >= 256 ? 128064 : 64064;
 }
 
 DISPU_EXPORT int dispu_linear_bn(int batch, int M, int K, int N, const float* X, long ldx, long sx, const float* W,
@@ -218,8 +275,6 @@ DISPU_EXPORT int dispu_linear_bn(int batch, int M, int K, int N, const float* X,
 DISPU_EXPORT int dispu_linear(int batch, int M, int K, int N, const float* X, long ldx, long sx, const float* W,
                               long ldw, long sw, int transb, const float* bias, int act, float* Y, long ldy, long sy,
                               const float* R1, long ldr1, long sr1, const float* R2, long ldr2, long sr2, void* stream) {
-    if (batch < 0 || M < 0 || K <= 0 || N <= 0 || !X || !W || !Y || act < 0 || act > 1) return (int)hipErrorInvalidValue;
-    if (batch == 0 || M == 0) return 0;
     return dispu_linear_bn(batch, M, K, N, X, ldx, sx, W, ldw, sw, transb, bias, nullptr, nullptr, act, Y, ldy, sy, R1, ldr1,
                            sr1, R2, ldr2, sr2, stream);
 }
@@ -234,10 +289,14 @@ DISPU_EXPORT int dispu_linear_bn(int batch, int M, int K, int N, const float* X,
     if (batch == 0 || M == 0) return 0;
     LinearArgs a{M, K, N, X, ldx, sx, W, ldw, sw, bias, Y, ldy, sy, R1, ldr1, sr1, R2, ldr2, sr2, act, scale, shift};
     hipStream_t s = (hipStream_t)stream;
+    const bool tb = transb != 0;
     switch (dispu_linear_tile(batch, M, N)) {
-        case 128128: return launch_linear<128, 128>(a, batch, transb != 0, s);
-        case 64128: return launch_linear<64, 128>(a, batch, transb != 0, s);
-        case 128064: return launch_linear<128, 64>(a, batch, transb != 0, s);
-        default: return launch_linear<64, 64>(a, batch, transb != 0, s);
+        case 128257: return launch_linear<128, 256, 2, 2, 16>(a, batch, tb, s);
+        case 128256: return launch_linear<128, 256, 2, 2, 32>(a, batch, tb, s);     // benchmarking variants
+        case 128129: return launch_linear<128, 128, 2, 2, 16>(a, batch, tb, s);
+        case 128128: return launch_linear<128, 128, 2, 2, 32>(a, batch, tb, s);
+        case 64128: return launch_linear<64, 128, 2, 2, 32>(a, batch, tb, s);
+        case 128064: return launch_linear<128, 64, 2, 2, 32>(a, batch, tb, s);
+        default: return launch_linear<64, 64, 2, 2, 32>(a, batch, tb, s);
     }
 }

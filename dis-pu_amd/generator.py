@@ -67,6 +67,7 @@ class Generator(object):
         self.P = {}
         self._ws = {}
         self.profile = None          # set to [] to collect (name, start_event, end_event) per launch
+        self.fused_local = True      # PointShuffle2 local cell in one kernel (False: the 4-kernel chain, for A/B tests)
         if params is not None:
             self.load_params(params)
 
@@ -108,10 +109,19 @@ class Generator(object):
             up256=E(rm, 256), up128=E(rm, 128), c256=E(rm, 256), c64=E(rm, 64), coarse=E(B, M, 3),
             psidx=E(rm, k, dtype=i32), kv=E(rm, 128), q=E(rm, 64), s=E(B, M, M), att=E(rm, 64), nl=E(rm, 256),
             skipin=torch.zeros((rm, 136), dtype=f32, device=dev), skip=E(rm, 256), gm=E(rm, 128), am=E(rm, 128),
-            x1=E(rm * k, 128), x2=E(rm * k, 128), wv=E(rm * k, 16), fp=E(rm, 2048), aft=E(rm, 256), agg=E(rm, 256),
+            fp=E(rm, 2048), aft=E(rm, 256), agg=E(rm, 256),
             f256=E(rm, 256), f64=E(rm, 64), fine=E(B, M, 3))
         self._ws[key] = ws
         return ws
+
+    def _pair_buffers(self, B, N):
+        """[B*M*16, .] pair tensors of the UNFUSED local cell (A/B testing only; the default path never allocates them)."""
+        key = ("pair", B, N)
+        if key not in self._ws:
+            rows = B * N * self.up_ratio * K_NEIGH
+            E = lambda c: torch.empty((rows, c), dtype=torch.float32, device=self.device)
+            self._ws[key] = (E(128), E(128), E(16))
+        return self._ws[key]
 
     # ------------------------------------------------------------------------------------------- launch ----
     def _call(self, name, fn, *args):
@@ -137,7 +147,9 @@ class Generator(object):
         name = "linear"
         if self.profile is not None:     # "linear<BM,BN,transb>[MxKxN]": the instantiation name rocprofv3 reports
             t = L.dispu_linear_tile(batch, M, N)
-            name = "linear<%d,%d,%s>[%dx%dx%d]" % (t // 1000, t % 1000, "true" if transb else "false", M * batch, K, N)
+            tile = {128257: "128, 256, 2, 2, 16", 128256: "128, 256, 2, 2, 32", 128129: "128, 128, 2, 2, 16",
+                    128128: "128, 128, 2, 2, 32", 64128: "64, 128, 2, 2, 32", 128064: "128, 64, 2, 2, 32"}.get(t, "64, 64, 2, 2, 32")
+            name = "linear<%s, %s>[%dx%dx%d]" % (tile, "true" if transb else "false", M * batch, K, N)
         self._call(name, L.dispu_linear, batch, M, K, N,
                    p(X, xoff), ldx, sx, p(W, woff), ldw, sw, transb, p(bias), act, p(Y, yoff), ldy, sy, p(R1),
                    R1.stride(0) if R1 is not None else 0, 0, p(R2), R2.stride(0) if R2 is not None else 0, 0, st)
@@ -224,14 +236,20 @@ class Generator(object):
         w0, b0 = self._w(ps + "conv0")
         self._linear(st, up128, 128, self.w_c0_feat, None, 0, ws["gm"], 128)
         self._call("ps_prep", L.dispu_ps_prep, rm, 128, ptr(coarse), ptr(w0), ptr(b0), ptr(ws["gm"]), 128, ptr(ws["am"]), 128, st)
-        self._call("gather_sub_relu", L.dispu_ps_gather_sub_relu, rm, M, k, 128, ptr(ws["psidx"]), ptr(ws["gm"]), 128, ptr(ws["am"]), 128,
-                                       ptr(ws["x1"]), 128, st)
-        w, b = self._w(ps + "conv1")
-        self._linear(st, ws["x1"], 128, w, b, 1, ws["x2"], 128)
-        w, b = self._w(ps + "weight_net/wconv0")
-        self._call("weight_net", L.dispu_ps_weight_net, rm, M, k, 16, ptr(ws["psidx"]), ptr(coarse), ptr(w), ptr(b), ptr(self.bn_scale),
-                                  ptr(self.bn_shift), ptr(ws["wv"]), st)
-        self._call("point_matmul", L.dispu_ps_point_matmul, rm, k, 128, 16, ptr(ws["x2"]), 128, ptr(ws["wv"]), ptr(ws["fp"]), 2048, st)
+        w1, b1 = self._w(ps + "conv1")
+        ww, bw = self._w(ps + "weight_net/wconv0")
+        if self.fused_local:
+            # gather_sub_relu + conv1 + weight_net + feature x weight in one kernel: only F' [rm, 2048] touches HBM
+            self._call("ps_local", L.dispu_ps_local, rm, M, k, 128, ptr(ws["psidx"]), ptr(coarse), ptr(ws["gm"]), ptr(ws["am"]),
+                       ptr(w1), ptr(b1), ptr(ww), ptr(bw), ptr(self.bn_scale), ptr(self.bn_shift), ptr(ws["fp"]), st)
+        else:
+            x1, x2, wv = self._pair_buffers(B, N)
+            self._call("gather_sub_relu", L.dispu_ps_gather_sub_relu, rm, M, k, 128, ptr(ws["psidx"]), ptr(ws["gm"]), 128,
+                       ptr(ws["am"]), 128, ptr(x1), 128, st)
+            self._linear(st, x1, 128, w1, b1, 1, x2, 128)
+            self._call("weight_net", L.dispu_ps_weight_net, rm, M, k, 16, ptr(ws["psidx"]), ptr(coarse), ptr(ww), ptr(bw),
+                       ptr(self.bn_scale), ptr(self.bn_shift), ptr(wv), st)
+            self._call("point_matmul", L.dispu_ps_point_matmul, rm, k, 128, 16, ptr(x2), 128, ptr(wv), ptr(ws["fp"]), 2048, st)
         w, b = self._w(ps + "after_conv")
         self._linear(st, ws["fp"], 2048, w, b, 1, ws["aft"], 256, R1=ws["skip"], R2=ws["nl"])
         w, b = self._w(ps + "aggregation")

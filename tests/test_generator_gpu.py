@@ -50,6 +50,22 @@ def test_fine_within_tolerance(setup):
     assert np.abs(setup["f"] - setup["fine"]).max() <= 1e-5
 
 
+def test_fused_local_cell_equals_unfused_chain(dev):
+    """dispu_ps_local (one kernel) vs gather_sub_relu -> dispu_linear -> weight_net -> point_matmul: bit-identical."""
+    from dispu_amd import synth
+    from dispu_amd.generator import Generator
+    P = OG.init_params(seed=7, bias_scale=0.05, bn_random=True)
+    x = torch.from_numpy(synth.patches(2, 256, seed=11)).to(dev)
+    outs = []
+    for fused in (True, False):
+        gen = Generator(params=P, device=dev)
+        gen.fused_local = fused
+        c, f = gen(x)
+        outs.append((N(gen._ws[(2, 256)]["fp"]).copy(), N(c).copy(), N(f).copy()))
+    for a, b in zip(outs[0], outs[1]):
+        assert np.array_equal(a, b)
+
+
 def test_default_init_and_batch_independence(dev):
     """Xavier / zero-bias default init (the benchmark's weights); per-patch results do not depend on the batch."""
     from dispu_amd import synth
