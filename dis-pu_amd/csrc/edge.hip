@@ -16,6 +16,8 @@
 // in oracle/generator.py, so the result is bit-identical to the fmaf-chain restatement.
 #include "common.h"
 
+#include <cstdlib>
+
 namespace dispu {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -25,11 +27,12 @@ __device__ __forceinline__ float edge_dpp(float identity, float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(identity), __float_as_int(v), CTRL, 0xF, 0xF, false));
 }
 __device__ __forceinline__ float edge_row16_max(float v) {   // valid in lane 15 of each 16-lane DPP row
-    const float ninf = -__builtin_inff();
-    v = fmaxf(v, edge_dpp<DPP_ROW_SHR1>(ninf, v));
-    v = fmaxf(v, edge_dpp<DPP_ROW_SHR2>(ninf, v));
-    v = fmaxf(v, edge_dpp<DPP_ROW_SHR4>(ninf, v));
-    v = fmaxf(v, edge_dpp<DPP_ROW_SHR8>(ninf, v));
+    // row_ror (rotate within the 16-lane row) has no invalid source lane: one v_max_f32_dpp per step, and every
+    // lane of the row ends up with the row maximum
+    v = fmaxf(v, edge_dpp<0x121>(v, v));
+    v = fmaxf(v, edge_dpp<0x122>(v, v));
+    v = fmaxf(v, edge_dpp<0x124>(v, v));
+    v = fmaxf(v, edge_dpp<0x128>(v, v));
     return v;
 }
 
@@ -65,17 +68,30 @@ __global__ __launch_bounds__(256) void edge_dense_conv_mfma_kernel(int npoints, 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int row = lane & 31, h = lane >> 5;
     const int ngroups = (npoints + 1) / 2;                       // 2 points per wave
-    for (int grp = blockIdx.x * 4 + wave; grp < ngroups; grp += gridDim.x * 4) {
+    const int s_nb = row & 15;
+    // the rows of the NEXT point group are fetched while the MFMAs of the current one run (ra/rb double as prefetch regs)
+    float4 ra[C / 4], rb[C / 4];
+    auto fetch = [&](int grp) {
+        int p = grp * 2 + (row >> 4);
+        if (p >= npoints) p = npoints - 1;
+        const int j = (p / n_per_cloud) * n_per_cloud + idx[(size_t)p * ldi + ioff + s_nb];
+#pragma unroll
+        for (int q = 0; q < C / 4; ++q) {
+            ra[q] = *reinterpret_cast<const float4*>(F + (size_t)p * ldf + q * 4);
+            rb[q] = *reinterpret_cast<const float4*>(F + (size_t)j * ldf + q * 4);
+        }
+    };
+    const int grp0 = blockIdx.x * 4 + wave, gstride = gridDim.x * 4;
+    if (grp0 < ngroups) fetch(grp0);
+    for (int grp = grp0; grp < ngroups; grp += gstride) {
         const int p = grp * 2 + (row >> 4);
         const bool ok = p < npoints;
         const int pp = ok ? p : npoints - 1;
-        const int s_nb = row & 15;
-        const int j = (pp / n_per_cloud) * n_per_cloud + idx[(size_t)pp * ldi + ioff + s_nb];
         float fp[H], df[H];                                      // elements k = 2t + h of F_p and of F_j - F_p
 #pragma unroll
         for (int q = 0; q < C / 4; ++q) {
-            const float4 a = *reinterpret_cast<const float4*>(F + (size_t)pp * ldf + q * 4);
-            const float4 b = *reinterpret_cast<const float4*>(F + (size_t)j * ldf + q * 4);
+            const float4 a = ra[q];
+            const float4 b = rb[q];
             const float a0 = h ? a.y : a.x, a1 = h ? a.w : a.z;
             const float b0v = h ? b.y : b.x, b1v = h ? b.w : b.z;
             fp[2 * q] = a0; fp[2 * q + 1] = a1;
@@ -120,6 +136,7 @@ __global__ __launch_bounds__(256) void edge_dense_conv_mfma_kernel(int npoints, 
 #pragma unroll
             for (int t = 0; t < H; ++t) yr[3 * G + 2 * t + h] = fp[t];
         }
+        if (grp + gstride < ngroups) fetch(grp + gstride);
     }
 }
 
@@ -133,7 +150,9 @@ DISPU_EXPORT int dispu_edge_dense_conv(int npoints, int n_per_cloud, int C, cons
     if (npoints < 0 || n_per_cloud <= 0 || !(C == 24 || C == 48) || (ldf & 3) || (((uintptr_t)F) & 15)) return (int)hipErrorInvalidValue;
     if (npoints == 0) return 0;
     int g = (npoints + 7) / 8;          // 8 points (4 waves x 2) per workgroup pass
-    if (g > 2048) g = 2048;
+    static int cap = -1;                // workgroups loop over point groups: the LDS weight image is built once per CU
+    if (cap < 0) { const char* e = getenv("DISPU_EDGE_GRID"); cap = e ? atoi(e) : 256; }
+    if (g > cap) g = cap;
     if (C == 24)
         hipLaunchKernelGGL((edge_dense_conv_mfma_kernel<24>), dim3(g), dim3(256), 0, (hipStream_t)stream, npoints, n_per_cloud, F, ldf, idx, ldi, ioff, W0, b0, W1, b1, W2, b2, Y, ldy);
     else

@@ -212,23 +212,30 @@ __global__ void ps_gather_sub_relu_kernel(long rows, int n_per_cloud, int k, int
 __global__ void ps_skip_max_kernel(long rows, int n_per_cloud, int k, int cf, const int* __restrict__ idx,
                                    const float* __restrict__ xyz, const float* __restrict__ feat, long ldf,
                                    float* __restrict__ out, long ldo) {
-    const int cw = cf + 6;
-    const long total = rows * cw;
-    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-        const int ch = (int)(e % cw);
-        const long i = e / cw;
-        const long base = (i / n_per_cloud) * n_per_cloud;
-        float m = -__builtin_inff();
-        for (int s = 0; s < k; ++s) {
-            const long j = base + idx[i * k + s];
-            float v;
-            if (ch < 3) v = xyz[j * 3 + ch] - xyz[i * 3 + ch];
-            else if (ch < 6) v = xyz[j * 3 + ch - 3];
-            else v = feat[j * ldf + ch - 6];
-            m = fmaxf(m, v);
+    // 32 lanes per point: lane q owns feature channels 4q..4q+3 (float4 loads of whole 512-byte rows, cf == 128);
+    // lanes 0..5 additionally produce the six xyz channels.  Neighbour ids are read once per point.
+    const int sub = threadIdx.x & 31;
+    const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 5;
+    if (i >= rows) return;
+    const long base = (i / n_per_cloud) * n_per_cloud;
+    const float ninf = -__builtin_inff();
+    float4 m = make_float4(ninf, ninf, ninf, ninf);
+    float mx = ninf;
+    const float ci = (sub < 3) ? xyz[i * 3 + sub] : 0.f;
+    for (int s = 0; s < k; ++s) {
+        const long j = base + idx[i * k + s];
+        for (int c4 = sub; c4 * 4 < cf; c4 += 32) {      // one pass when cf <= 128
+            const float4 v = *reinterpret_cast<const float4*>(feat + j * ldf + c4 * 4);
+            m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
         }
-        out[i * ldo + ch] = m;
+        if (sub < 6) {
+            const float pj = xyz[j * 3 + (sub < 3 ? sub : sub - 3)];
+            mx = fmaxf(mx, sub < 3 ? pj - ci : pj);
+        }
     }
+    float* o = out + i * ldo;
+    if (sub < 6) o[sub] = mx;
+    if (sub * 4 < cf) { o[6 + sub * 4] = m.x; o[7 + sub * 4] = m.y; o[8 + sub * 4] = m.z; o[9 + sub * 4] = m.w; }
 }
 
 // weight_net_hidden (ops.py:181-191, 1064): wv[(i,s), t] = relu( (cxyz . Ww[:,t] + bw[t]) * scale[t] + shift[t] ),
@@ -374,9 +381,10 @@ DISPU_EXPORT int dispu_ps_gather_sub_relu(long rows, int n_per_cloud, int k, int
 
 DISPU_EXPORT int dispu_ps_skip_max(long rows, int n_per_cloud, int k, int cf, const int* idx, const float* xyz, const float* feat,
                                    long ldf, float* out, long ldo, void* stream) {
-    if (rows < 0 || n_per_cloud <= 0 || k <= 0 || cf <= 0) return (int)hipErrorInvalidValue;
+    if (rows < 0 || n_per_cloud <= 0 || k <= 0 || cf <= 0 || cf > 128 || (cf & 3) || (ldf & 3) || (((uintptr_t)feat) & 15))
+        return (int)hipErrorInvalidValue;
     if (rows == 0) return 0;
-    hipLaunchKernelGGL(ps_skip_max_kernel, dim3(grid_for(rows * (cf + 6), 256)), dim3(256), 0, (hipStream_t)stream, rows, n_per_cloud, k, cf, idx, xyz, feat, ldf, out, ldo);
+    hipLaunchKernelGGL(ps_skip_max_kernel, dim3((unsigned)((rows * 32 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, rows, n_per_cloud, k, cf, idx, xyz, feat, ldf, out, ldo);
     return (int)hipGetLastError();
 }
 
