@@ -178,7 +178,7 @@ def main():
             kern, (t_k, n_k, fl_k) = max(((k, v) for k, v in by_kernel.items() if k.startswith("linear<")),
                                           key=lambda kv: kv[1][0])
         achieved = fl_k / t_k / 1e12
-        roof = {"bound": "mfma", "kernel": "dispu::linear_mfma_kernel" + kern[len("linear"):] + " (interior + edge instantiations)",
+        roof = {"bound": "mfma", "kernel": "dispu::linear_mfma_kernel" + kern[len("linear"):],
                 "launches_per_step": round(n_k), "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
                 "avg_launch_us": t_k / n_k * 1e6, "flops_per_launch": fl_k / n_k, "share_of_step": t_k / t_all,

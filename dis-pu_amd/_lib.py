@@ -59,6 +59,9 @@ SIGNATURES = {
     "dispu_ps_weight_net": (_i, [_l, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "dispu_ps_point_matmul": (_i, [_l, _i, _i, _i, _vp, _l, _vp, _vp, _l, _vp]),
     "dispu_ps_local": (_i, [_l, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "dispu_knn_patch": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "dispu_normalize_patches": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "dispu_denormalize_patches": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp]),
     "dispu_softmax_rows": (_i, [_l, _i, C.c_float, _vp, _l, _vp]),
 }
 

@@ -147,9 +147,12 @@ class Generator(object):
         name = "linear"
         if self.profile is not None:     # "linear<BM,BN,transb>[MxKxN]": the instantiation name rocprofv3 reports
             t = L.dispu_linear_tile(batch, M, N)
-            tile = {128257: "128, 256, 2, 2, 16", 128256: "128, 256, 2, 2, 32", 128129: "128, 128, 2, 2, 16",
-                    128128: "128, 128, 2, 2, 32", 64128: "64, 128, 2, 2, 32", 128064: "128, 64, 2, 2, 32"}.get(t, "64, 64, 2, 2, 32")
-            name = "linear<%s, %s>[%dx%dx%d]" % (tile, "true" if transb else "false", M * batch, K, N)
+            bm, bn, bk = {128257: (128, 256, 16), 128256: (128, 256, 32), 128129: (128, 128, 16), 128128: (128, 128, 32),
+                          64128: (64, 128, 32), 128064: (128, 64, 32)}.get(t, (64, 64, 32))
+            edge = not (M % bm == 0 and N % bn == 0 and K % bk == 0 and ldx % 4 == 0 and ldw % 4 == 0 and sx % 4 == 0
+                        and sw % 4 == 0 and (X.data_ptr() + 4 * xoff) % 16 == 0 and (W.data_ptr() + 4 * woff) % 16 == 0)
+            name = "linear<%d, %d, 2, 2, %d, %s, %s>[%dx%dx%d]" % (bm, bn, bk, "true" if transb else "false",
+                                                                  "true" if edge else "false", M * batch, K, N)
         self._call(name, L.dispu_linear, batch, M, K, N,
                    p(X, xoff), ldx, sx, p(W, woff), ldw, sw, transb, p(bias), act, p(Y, yoff), ldy, sy, p(R1),
                    R1.stride(0) if R1 is not None else 0, 0, p(R2), R2.stride(0) if R2 is not None else 0, 0, st)

@@ -1,0 +1,74 @@
+"""Whole-cloud upsampling (the reference's `Model.test()` data path, DisPU/model.py:306-381) on one MI355X:
+
+    normalise cloud -> FPS seeds (N/256*3) -> 256-NN patches -> per-patch normalise -> generator (ALL patches in one
+    batch; the reference feeds them one by one with batch size 1) -> de-normalise -> concat -> FPS to final_ratio*N.
+
+Every stage is a kernel of libdispu_hip.so; the cloud crosses the host boundary once in and once out
+(the reference crosses it ~2 x 24 times per 2048-point cloud plus the nanoflann hop inside every generator call)."""
+import numpy as np
+import torch
+
+from . import _lib
+from .tf_sampling import farthest_point_sample, gather_point
+
+
+def knn_patch(cloud, queries, k):
+    """pc_util.extract_knn_patch (:83-92): cloud[b,n,3], queries[b,m,3] -> idx[b,m,k] int32 (ascending distance)."""
+    b, n, _ = cloud.shape
+    m = queries.shape[1]
+    idx = torch.empty((b, m, k), dtype=torch.int32, device=cloud.device)
+    _lib.check(_lib.lib().dispu_knn_patch(b, n, m, k, _lib.ptr(cloud.contiguous()), _lib.ptr(queries.contiguous()), _lib.ptr(idx),
+                                          _lib.stream_ptr(cloud.device)), "dispu_knn_patch")
+    return idx
+
+
+def normalize_patches(p):
+    """pc_util.normalize_point_cloud (:147-161) per patch: -> (normalised [b,n,3], centroid [b,3], furthest [b])."""
+    b, n, _ = p.shape
+    out = torch.empty_like(p)
+    c = torch.empty((b, 3), dtype=torch.float32, device=p.device)
+    f = torch.empty((b,), dtype=torch.float32, device=p.device)
+    _lib.check(_lib.lib().dispu_normalize_patches(b, n, _lib.ptr(p.contiguous()), _lib.ptr(out), _lib.ptr(c), _lib.ptr(f),
+                                                  _lib.stream_ptr(p.device)), "dispu_normalize_patches")
+    return out, c, f
+
+
+def denormalize_patches(p, centroid, furthest):
+    b, m, _ = p.shape
+    out = torch.empty_like(p)
+    _lib.check(_lib.lib().dispu_denormalize_patches(b, m, _lib.ptr(p.contiguous()), _lib.ptr(centroid), _lib.ptr(furthest),
+                                                    _lib.ptr(out), _lib.stream_ptr(p.device)), "dispu_denormalize_patches")
+    return out
+
+
+def upsample_cloud(gen, pc, patch_num_point=256, patch_num_ratio=3, final_ratio=4, return_stages=False):
+    """pc: [N,3] float32 (numpy or device tensor) -> upsampled [final_ratio*N, 3] numpy array (model.py:343-381).
+    `gen` is a dispu_amd.generator.Generator with up_ratio 4 (final_ratio 4: one generator pass, model.py:117-118)."""
+    if final_ratio != 4:
+        raise NotImplementedError("final_ratio 16 chains two generator passes (model.py:117-118); round 1 ships the 4x path")
+    dev = gen.device
+    cloud = torch.as_tensor(np.ascontiguousarray(pc, np.float32) if not isinstance(pc, torch.Tensor) else pc, dtype=torch.float32,
+                            device=dev).reshape(1, -1, 3)
+    n = cloud.shape[1]
+    cloud_n, c0, f0 = normalize_patches(cloud)                                   # whole-cloud normalisation (model.py:364)
+    seed_num = int(n / patch_num_point * patch_num_ratio)
+    seeds = farthest_point_sample(seed_num, cloud_n)                             # model.py:323
+    seed_xyz = gather_point(cloud_n, seeds)
+    pidx = knn_patch(cloud_n, seed_xyz, patch_num_point)                         # pc_util.extract_knn_patch
+    patches = gather_point(cloud_n, pidx.reshape(1, -1)).reshape(seed_num, patch_num_point, 3)
+    pn, pc_c, pc_f = normalize_patches(patches)                                  # model.py:306-308
+    coarse, fine = gen(pn)
+    pred = denormalize_patches(fine, pc_c, pc_f)                                 # model.py:310
+    merged = denormalize_patches(pred.reshape(1, -1, 3), c0, f0)                 # model.py:371-372
+    out_num = int(n * final_ratio)
+    sel = farthest_point_sample(out_num, merged)                                 # model.py:375
+    result = gather_point(merged, sel)[0]
+    out = result.cpu().numpy()
+    if return_stages:
+        return out, dict(cloud_n=cloud_n, seeds=seeds, pidx=pidx, patches_n=pn, fine=fine, merged=merged, sel=sel)
+    return out
+
+
+def save_xyz(path, points):
+    """np.savetxt(path, pred_pc, fmt='%.6f') (model.py:381)."""
+    np.savetxt(path, points, fmt="%.6f")

@@ -220,6 +220,17 @@ int dispu_row_mean_max(int b, int n, const float* x, float* mean, float* mx, voi
 int dispu_repulsion(long rows, int n_per_cloud, int ns, int use_l1, float h, const float* pred, const int* idx, float* out,
                     void* stream);
 
+/* ---- whole-cloud inference glue (DisPU/model.py:306-381, Common/pc_util.py:83-92,147-161; host numpy/sklearn in
+ * the reference, one patch at a time) -------------------------------------------------------------------------- */
+/* extract_knn_patch: for each of m queries the k nearest of the cloud's n points (k up to n, n <= 8192), ascending
+ * squared distance (plain arithmetic), ties -> lower index.  idx [b, m, k]. */
+int dispu_knn_patch(int b, int n, int m, int k, const float* cloud, const float* queries, int* idx, void* stream);
+/* normalize_point_cloud per patch: out = (in - mean) / max|in - mean|; centroid [b,3], furthest [b]. */
+int dispu_normalize_patches(int b, int n, const float* in, float* out, float* centroid, float* furthest, void* stream);
+/* out = centroid + in * furthest per patch (model.py:310-311). */
+int dispu_denormalize_patches(int b, int m, const float* in, const float* centroid, const float* furthest, float* out,
+                              void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,57 @@
+"""GPU parity of the whole-cloud path (dis-pu_amd/upsample.py vs oracle/upsample.py), stage by stage: seeds and
+patch indices exact, normalised patches 1e-6, generator output / merged cloud 1e-5, the final FPS exact on the SAME
+merged cloud (a down-sampling of slightly different floats may legitimately pick different near-tie points)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import generator as OG
+from oracle import oracle as O
+from oracle import upsample as OU
+
+pytestmark = pytest.mark.gpu
+
+
+def N(t):
+    return t.detach().cpu().numpy()
+
+
+def test_knn_patch_large_k(dev):
+    from dispu_amd import upsample as U
+    rng = np.random.default_rng(0)
+    for (n, m, k) in [(2048, 24, 256), (1000, 7, 256), (300, 5, 300), (8192, 3, 256)]:
+        pc = rng.random((1, n, 3)).astype(np.float32)
+        pc[0, 10] = pc[0, 3]                                   # duplicate -> tie resolved by index
+        q = pc[:, :m].copy()
+        got = N(U.knn_patch(torch.from_numpy(pc).to(dev), torch.from_numpy(q).to(dev), k))
+        assert np.array_equal(got[0], OU.extract_knn_patch_idx(q[0], pc[0], k))
+
+
+def test_upsample_cloud_stage_parity(dev):
+    from dispu_amd import synth
+    from dispu_amd import upsample as U
+    from dispu_amd.generator import Generator
+    rng = np.random.default_rng(1)
+    g = rng.standard_normal((1024, 3))
+    pc = (g / np.linalg.norm(g, axis=1, keepdims=True) * np.array([1.0, 0.7, 0.4]) + 5.0).astype(np.float32)   # an ellipsoid, off-centre
+    P = OG.init_params(seed=3)
+    gen = Generator(params=P, device=dev)
+    out, st = U.upsample_cloud(gen, pc, return_stages=True)
+    want, ws = OU.upsample_cloud(P, pc)
+    assert out.shape == (4096, 3) and want.shape == (4096, 3)
+    assert np.allclose(N(st["cloud_n"])[0], ws["cloud_n"], atol=2e-6)      # cloud sits at +5: one float32 ulp there is 5e-7
+    # FPS / kNN run on the device's own normalised cloud; re-run the oracle ops on exactly that cloud
+    cn = N(st["cloud_n"])
+    assert np.array_equal(N(st["seeds"]), O.farthest_point_sample(12, cn))
+    seeds_xyz = cn[0][N(st["seeds"])[0]]
+    assert np.array_equal(N(st["pidx"])[0], OU.extract_knn_patch_idx(seeds_xyz, cn[0], 256))
+    pn_want = OU.normalize_point_cloud(cn[0][N(st["pidx"])[0]])[0]
+    assert np.allclose(N(st["patches_n"]), pn_want, atol=2e-6)
+    c_want, f_want = OG.generator_forward(P, N(st["patches_n"]))
+    assert np.abs(N(st["fine"]) - f_want).max() <= 1e-5
+    merged = N(st["merged"])
+    assert np.array_equal(N(st["sel"]), O.farthest_point_sample(4096, merged))
+    assert np.array_equal(out, merged[0][N(st["sel"])[0]])
+    # end to end against the independent oracle run: same point set up to float noise unless a near-tie flipped
+    d1, _, d2, _ = O.nn_distance(out[None], want[None], contract=0)
+    assert np.median(d1) < 1e-9 and np.median(d2) < 1e-9
