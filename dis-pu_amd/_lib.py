@@ -62,6 +62,7 @@ SIGNATURES = {
     "dispu_knn_patch": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "dispu_normalize_patches": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp]),
     "dispu_denormalize_patches": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "dispu_attention": (_i, [_i, _i, _i, _i, _vp, _l, _vp, _l, _vp, _l, C.c_float, _vp, _l, _vp]),
     "dispu_softmax_rows": (_i, [_l, _i, C.c_float, _vp, _l, _vp]),
 }
 

@@ -1,0 +1,149 @@
+// PointNonLocalCell attention (Common/ops.py:326-339: softmax(Q.K^T / sqrt(64)) . V) fused on gfx950, fp32.
+//
+// The reference (and the unfused path here) materialises the [B, 1024, 1024] logits in HBM (134 MB at B = 32),
+// runs a softmax pass over them and reads them again for the second matmul.  This kernel keeps everything on
+// chip, flash-attention style, with the products on v_mfma_f32_32x32x2_f32 in the TRANSPOSED orientation:
+//
+//   S^T[key][q] = sum_d K[key][d] Q[q][d]        A operand = K tile (LDS), B operand = Q (registers, per wave)
+//   O^T[d][q]  += sum_key V[key][d] P^T[key][q]   A operand = V tile (LDS), B operand = P^T
+//
+// so a query is an MFMA *column*: lane (q = lane & 31, h = lane >> 5) holds, for its query, 16 of the tile's 32
+// logits in its accumulator registers.  The online softmax is therefore per-lane arithmetic plus ONE exchange with
+// the partner lane (lane ^ 32), the rescale of O^T is a per-lane multiply, and the exponentiated registers are
+// fed back UNMOVED as the B operand of the second product (step r pairs key rows r' and r'+4 - exactly the rows
+// the two half-waves hold in register r).  A workgroup = 4 waves = 128 queries of one cloud; K|V tiles of 32 keys
+// stream through two LDS stages with register prefetch (one barrier per tile).
+#include "common.h"
+
+namespace dispu {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int FA_D = 64, FA_TK = 32, FA_LDK = FA_D + 1;
+constexpr int FA_STAGE = FA_TK * FA_LDK + FA_TK * FA_D;     // floats: K tile [32][65] + V tile [32][64]
+
+__global__ __launch_bounds__(256) void flash_attention_kernel(int m, int nk, const float* __restrict__ Q, long ldq,
+                                                               const float* __restrict__ K, long ldk,
+                                                               const float* __restrict__ V, long ldv, float scale,
+                                                               float* __restrict__ O, long ldo) {
+    __shared__ __attribute__((aligned(16))) float lds[2 * FA_STAGE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int cloud = blockIdx.y;
+    const int qrow = blockIdx.x * 128 + wave * 32 + (lane & 31);
+    const int kh = lane >> 5, li = lane & 31;
+    const bool qok = qrow < m;
+    const float* __restrict__ qp = Q + ((size_t)cloud * m + (qok ? qrow : 0)) * ldq;
+    const float* __restrict__ kb = K + (size_t)cloud * nk * ldk;
+    const float* __restrict__ vb = V + (size_t)cloud * nk * ldv;
+
+    float qf[32];                                    // Q[q][2s + kh]
+#pragma unroll
+    for (int s4 = 0; s4 < 16; ++s4) {
+        const float4 v = *reinterpret_cast<const float4*>(qp + s4 * 4);
+        qf[2 * s4] = kh ? v.y : v.x;
+        qf[2 * s4 + 1] = kh ? v.w : v.z;
+    }
+
+    // tile loader: 32 keys x (64 K + 64 V) floats = 512 float4 of K and 512 of V; thread -> 2 + 2 float4
+    float4 pk[2], pv[2];
+    auto load_tile = [&](int k0) {
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int e = tid + it * 256, key = e >> 4, c4 = e & 15;
+            pk[it] = *reinterpret_cast<const float4*>(kb + (size_t)(k0 + key) * ldk + c4 * 4);
+            pv[it] = *reinterpret_cast<const float4*>(vb + (size_t)(k0 + key) * ldv + c4 * 4);
+        }
+    };
+    auto store_tile = [&](int stage) {
+        float* Kt = lds + stage * FA_STAGE;
+        float* Vt = Kt + FA_TK * FA_LDK;
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int e = tid + it * 256, key = e >> 4, c4 = e & 15;
+            Kt[key * FA_LDK + c4 * 4 + 0] = pk[it].x;
+            Kt[key * FA_LDK + c4 * 4 + 1] = pk[it].y;
+            Kt[key * FA_LDK + c4 * 4 + 2] = pk[it].z;
+            Kt[key * FA_LDK + c4 * 4 + 3] = pk[it].w;
+            *reinterpret_cast<float4*>(&Vt[key * FA_D + c4 * 4]) = pv[it];
+        }
+    };
+
+    f32x16 oacc[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[c][r] = 0.f;
+    float mrun = -__builtin_inff(), lsum = 0.f;
+
+    const int ntile = nk / FA_TK;
+    load_tile(0);
+    store_tile(0);
+    if (ntile > 1) load_tile(FA_TK);
+    __syncthreads();
+    for (int t = 0; t < ntile; ++t) {
+        const float* Kt = lds + (t & 1) * FA_STAGE;
+        const float* Vt = Kt + FA_TK * FA_LDK;
+        if (t + 1 < ntile) {
+            store_tile((t + 1) & 1);
+            if (t + 2 < ntile) load_tile((t + 2) * FA_TK);
+        }
+        // S^T tile: 32 keys x 32 queries, d ascending
+        f32x16 sacc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 32; ++s) sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(Kt[li * FA_LDK + 2 * s + kh], qf[s], sacc, 0, 0, 0);
+        // online softmax for this lane's query over the tile's 32 keys (16 here, 16 in lane ^ 32)
+        float mx = -__builtin_inff();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { sacc[r] = sacc[r] * scale; mx = fmaxf(mx, sacc[r]); }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float mnew = fmaxf(mrun, mx);
+        const float alpha = __expf(mrun - mnew);
+        float rs = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { sacc[r] = __expf(sacc[r] - mnew); rs += sacc[r]; }
+        lsum = lsum * alpha + rs;
+        mrun = mnew;
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oacc[c][r] = oacc[c][r] * alpha;
+        // O^T += V^T . P^T : step r pairs key rows kr and kr + 4 (= the rows half 0 / half 1 hold in register r)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = (r & 3) + 8 * (r >> 2) + 4 * kh;
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+                oacc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(Vt[key * FA_D + c * 32 + li], sacc[r], oacc[c], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    const float ltot = lsum + __shfl_xor(lsum, 32, 64);
+    const float inv = 1.0f / ltot;
+    if (qok) {
+        float* __restrict__ op = O + ((size_t)cloud * m + qrow) * ldo;
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) op[c * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh] = oacc[c][r] * inv;
+    }
+}
+
+}  // namespace dispu
+
+using namespace dispu;
+
+// O[b, m, 64] = softmax(scale * Q.K^T) . V per cloud;  Q [b*m, 64], K/V [b*nk, 64] with row strides ld*.
+// Requires d == 64, nk % 32 == 0, 16-byte aligned rows; returns hipErrorInvalidValue otherwise (caller falls back to
+// dispu_linear(transb) -> dispu_softmax_rows -> dispu_linear).
+DISPU_EXPORT int dispu_attention(int b, int m, int nk, int d, const float* Q, long ldq, const float* K, long ldk, const float* V,
+                                 long ldv, float scale, float* O, long ldo, void* stream) {
+    if (b < 0 || m <= 0 || nk <= 0 || d != 64 || (nk % 32) != 0 || (ldq & 3) || (ldk & 3) || (ldv & 3) ||
+        ((((uintptr_t)Q) | ((uintptr_t)K) | ((uintptr_t)V)) & 15))
+        return (int)hipErrorInvalidValue;
+    if (b == 0) return 0;
+    hipLaunchKernelGGL(flash_attention_kernel, dim3((m + 127) / 128, b), dim3(256), 0, (hipStream_t)stream, m, nk, Q, ldq, K, ldk,
+                       V, ldv, scale, O, ldo);
+    return (int)hipGetLastError();
+}

@@ -68,6 +68,7 @@ class Generator(object):
         self._ws = {}
         self.profile = None          # set to [] to collect (name, start_event, end_event) per launch
         self.fused_local = True      # PointShuffle2 local cell in one kernel (False: the 4-kernel chain, for A/B tests)
+        self.fused_attention = True  # non-local cell attention on chip (False: GEMM -> softmax -> GEMM through HBM)
         if params is not None:
             self.load_params(params)
 
@@ -107,7 +108,7 @@ class Generator(object):
         ws = dict(
             feat=E(rn, 480), prep=E(rn, 48), kidx=E(rn, k + 1, dtype=i32), h256=E(rn, 256),
             up256=E(rm, 256), up128=E(rm, 128), c256=E(rm, 256), c64=E(rm, 64), coarse=E(B, M, 3),
-            psidx=E(rm, k, dtype=i32), kv=E(rm, 128), q=E(rm, 64), s=E(B, M, M), att=E(rm, 64), nl=E(rm, 256),
+            psidx=E(rm, k, dtype=i32), kv=E(rm, 128), q=E(rm, 64), att=E(rm, 64), nl=E(rm, 256),
             skipin=torch.zeros((rm, 136), dtype=f32, device=dev), skip=E(rm, 256), gm=E(rm, 128), am=E(rm, 128),
             fp=E(rm, 2048), aft=E(rm, 256), agg=E(rm, 256),
             f256=E(rm, 256), f64=E(rm, 64), fine=E(B, M, 3))
@@ -224,11 +225,20 @@ class Generator(object):
         self._linear(st, up128, 128, w, b, 0, ws["kv"], 128)
         w, b = self._w(ps + "PointShuffle/conv_query")
         self._linear(st, up128, 128, w, b, 0, ws["q"], 64)
-        self._linear(st, ws["q"], 64, ws["kv"], None, 0, ws["s"], M, M=M, ldx=64, ldw=128, ldy=M, batch=B, sx=M * 64,
-                     sw=M * 128, sy=M * M, transb=1)
-        self._call("softmax", L.dispu_softmax_rows, rm, M, 0.125, ptr(ws["s"]), M, st)
-        self._linear(st, ws["s"], M, ws["kv"], None, 0, ws["att"], 64, M=M, ldx=M, ldw=128, ldy=64, batch=B, sx=M * M,
-                     sw=M * 128, sy=M * 64, woff=64)
+        if self.fused_attention and M % 32 == 0:
+            # softmax(Q.K^T / 8).V on chip (flash style): the [B, M, M] logits never exist in HBM
+            self._call("attention", L.dispu_attention, B, M, M, 64, ptr(ws["q"]), 64, ptr(ws["kv"]), 128, off(ws["kv"], 64), 128,
+                       0.125, ptr(ws["att"]), 64, st)
+        else:
+            key = ("scores", B, N)
+            if key not in self._ws:
+                self._ws[key] = torch.empty((B, M, M), dtype=torch.float32, device=self.device)
+            s = self._ws[key]
+            self._linear(st, ws["q"], 64, ws["kv"], None, 0, s, M, M=M, ldx=64, ldw=128, ldy=M, batch=B, sx=M * 64,
+                         sw=M * 128, sy=M * M, transb=1)
+            self._call("softmax", L.dispu_softmax_rows, rm, M, 0.125, ptr(s), M, st)
+            self._linear(st, s, M, ws["kv"], None, 0, ws["att"], 64, M=M, ldx=M, ldw=128, ldy=64, batch=B, sx=M * M,
+                         sw=M * 128, sy=M * 64, woff=64)
         w, b = self._w(ps + "PointShuffle/conv_back_project")
         self._linear(st, ws["att"], 64, w, b, 1, ws["nl"], 256)
         # skip connection

@@ -198,6 +198,10 @@ int dispu_ps_point_matmul(long rows, int k, int c, int t_n, const float* X2, lon
 int dispu_ps_local(long npoints, int n_per_cloud, int k, int c, const int* idx, const float* xyz, const float* G,
                    const float* A, const float* W1, const float* b1, const float* Ww, const float* bw, const float* scale,
                    const float* shift, float* out, void* stream);
+/* PointNonLocalCell attention fused (ops.py:326-339): O[b,m,64] = softmax(scale * Q.K^T) . V per cloud, logits never
+ * written to HBM.  d must be 64, nk % 32 == 0, rows 16-byte aligned (else hipErrorInvalidValue: use the 3-kernel path). */
+int dispu_attention(int b, int m, int nk, int d, const float* Q, long ldq, const float* K, long ldk, const float* V,
+                    long ldv, float scale, float* O, long ldo, void* stream);
 /* S <- softmax(S * mul) per row, in place (tf.nn.softmax of PointNonLocalCell, ops.py:338). */
 int dispu_softmax_rows(long rows, int n, float mul, float* S, long lds, void* stream);
 

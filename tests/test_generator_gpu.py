@@ -66,6 +66,41 @@ def test_fused_local_cell_equals_unfused_chain(dev):
         assert np.array_equal(a, b)
 
 
+@pytest.mark.parametrize("b,m", [(2, 1024), (3, 160), (1, 4096)])
+def test_fused_attention(dev, b, m):
+    """dispu_attention (flash-style, logits on chip) vs a float64 softmax(QK^T/8)V and vs the 3-kernel path."""
+    from dispu_amd import _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(m)
+    q = rng.standard_normal((b, m, 64)).astype(np.float32)
+    kv = rng.standard_normal((b, m, 128)).astype(np.float32)
+    q[0, 5] *= 6.0                                              # a peaked row: exercises the running-max rescale
+    tq, tkv = torch.from_numpy(q).to(dev), torch.from_numpy(kv).to(dev)
+    out = torch.zeros((b, m, 64), device=dev)
+    _lib.check(L.dispu_attention(b, m, m, 64, tq.data_ptr(), 64, tkv.data_ptr(), 128, tkv.data_ptr() + 256, 128, 0.125,
+                                 out.data_ptr(), 64, _lib.stream_ptr(dev)), "dispu_attention")
+    s = np.einsum("bqd,bkd->bqk", q.astype(np.float64), kv[..., :64].astype(np.float64)) / 8.0
+    s -= s.max(-1, keepdims=True)
+    p = np.exp(s)
+    want = np.einsum("bqk,bkd->bqd", p / p.sum(-1, keepdims=True), kv[..., 64:].astype(np.float64))
+    assert np.abs(N(out) - want).max() <= 2e-5 * max(1.0, np.abs(want).max())
+
+
+def test_fused_attention_path_equals_unfused_in_generator(dev):
+    from dispu_amd import synth
+    from dispu_amd.generator import Generator
+    P = OG.init_params(seed=5, bias_scale=0.05)
+    x = torch.from_numpy(synth.patches(2, 256, seed=13)).to(dev)
+    res = []
+    for fused in (True, False):
+        gen = Generator(params=P, device=dev)
+        gen.fused_attention = fused
+        c, f = gen(x)
+        res.append((N(gen._ws[(2, 256)]["nl"]).copy(), N(f).copy()))
+    assert np.abs(res[0][0] - res[1][0]).max() <= 1e-5 * max(1.0, np.abs(res[1][0]).max())
+    assert np.abs(res[0][1] - res[1][1]).max() <= 1e-6
+
+
 def test_default_init_and_batch_independence(dev):
     """Xavier / zero-bias default init (the benchmark's weights); per-patch results do not depend on the batch."""
     from dispu_amd import synth
