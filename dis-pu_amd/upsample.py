@@ -5,6 +5,8 @@
 
 Every stage is a kernel of libdispu_hip.so; the cloud crosses the host boundary once in and once out
 (the reference crosses it ~2 x 24 times per 2048-point cloud plus the nanoflann hop inside every generator call)."""
+import math
+
 import numpy as np
 import torch
 
@@ -41,11 +43,18 @@ def denormalize_patches(p, centroid, furthest):
     return out
 
 
+def generator_chain(gen, patches, final_ratio=4, step_ratio=4):
+    """Model.build_model_test (DisPU/model.py:114-118): G once, then round(final_ratio ** (1/step_ratio)) - 1 more times on
+    its own output (final_ratio 16 -> two passes: 256 -> 1024 -> 4096 points per patch)."""
+    coarse, fine = gen(patches)
+    for _ in range(round(math.pow(final_ratio, 1.0 / step_ratio)) - 1):
+        coarse, fine = gen(fine.clone())          # clone: the generator's outputs live in its reusable workspace
+    return coarse, fine
+
+
 def upsample_cloud(gen, pc, patch_num_point=256, patch_num_ratio=3, final_ratio=4, return_stages=False):
     """pc: [N,3] float32 (numpy or device tensor) -> upsampled [final_ratio*N, 3] numpy array (model.py:343-381).
     `gen` is a dispu_amd.generator.Generator with up_ratio 4 (final_ratio 4: one generator pass, model.py:117-118)."""
-    if final_ratio != 4:
-        raise NotImplementedError("final_ratio 16 chains two generator passes (model.py:117-118); round 1 ships the 4x path")
     dev = gen.device
     cloud = torch.as_tensor(np.ascontiguousarray(pc, np.float32) if not isinstance(pc, torch.Tensor) else pc, dtype=torch.float32,
                             device=dev).reshape(1, -1, 3)
@@ -57,7 +66,7 @@ def upsample_cloud(gen, pc, patch_num_point=256, patch_num_ratio=3, final_ratio=
     pidx = knn_patch(cloud_n, seed_xyz, patch_num_point)                         # pc_util.extract_knn_patch
     patches = gather_point(cloud_n, pidx.reshape(1, -1)).reshape(seed_num, patch_num_point, 3)
     pn, pc_c, pc_f = normalize_patches(patches)                                  # model.py:306-308
-    coarse, fine = gen(pn)
+    coarse, fine = generator_chain(gen, pn, final_ratio)
     pred = denormalize_patches(fine, pc_c, pc_f)                                 # model.py:310
     merged = denormalize_patches(pred.reshape(1, -1, 3), c0, f0)                 # model.py:371-372
     out_num = int(n * final_ratio)

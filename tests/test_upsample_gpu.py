@@ -27,6 +27,32 @@ def test_knn_patch_large_k(dev):
         assert np.array_equal(got[0], OU.extract_knn_patch_idx(q[0], pc[0], k))
 
 
+def test_config4_16x_with_cd_and_emd(dev):
+    """BASELINE configs[3]: 16x upsampling (256 -> 1024 -> 4096, two generator passes, DisPU/model.py:114-118) followed by
+    the Chamfer and approxmatch-EMD losses against a 4096-point ground truth, on one GPU."""
+    from dispu_amd import loss_utils as LU
+    from dispu_amd import synth
+    from dispu_amd import upsample as U
+    from dispu_amd.generator import Generator
+    from oracle import modules as OM
+    x, gt = synth.patch_with_gt(1, 256, 4096, seed=21)
+    P = OG.init_params(seed=2)
+    gen = Generator(params=P, device=dev)
+    coarse, fine = U.generator_chain(gen, torch.from_numpy(x).to(dev), final_ratio=16)
+    assert tuple(fine.shape) == (1, 4096, 3)
+    c1, f1 = OG.generator_forward(P, x)
+    c2, f2 = OG.generator_forward(P, f1)
+    # pass 1 is bit-exact up to `coarse`; pass 2 starts from fine (1e-5) so its k-NN decisions may flip on near-ties:
+    # compare the clouds as point sets through the Chamfer distance, and the losses against the oracle on the GPU cloud
+    assert np.abs(N(coarse) - c2).max() < 5e-2
+    d1, _, d2, _ = O.nn_distance(N(fine), f2, contract=0)
+    assert np.median(d1) < 1e-8 and np.median(d2) < 1e-8
+    tf, tg = fine.clone(), torch.from_numpy(gt).to(dev)
+    cd, emd = float(LU.chamfer(tf, tg)), float(LU.earth_mover(tf, tg))
+    assert abs(cd - OM.chamfer(N(tf), gt)) <= 1e-5 * max(1.0, OM.chamfer(N(tf), gt))
+    assert abs(emd - OM.earth_mover(N(tf), gt)) <= 1e-5 * OM.earth_mover(N(tf), gt)
+
+
 def test_upsample_cloud_stage_parity(dev):
     from dispu_amd import synth
     from dispu_amd import upsample as U
