@@ -83,10 +83,20 @@ def main():
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d"
                          % (args.gpus, world, args.gpus))
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    # DISPU_BENCH_BACKEND=gloo lets the N > 1 code path be smoke-tested on a box with fewer GPUs than ranks (ranks then
+    # share devices and the gather is staged through the host); the driver's real runs use nccl == RCCL, one GPU per rank.
+    backend = os.environ.get("DISPU_BENCH_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    if backend == "nccl" and local >= ndev:
+        raise SystemExit("LOCAL_RANK %d but only %d visible GPUs" % (local, ndev))
+    local_dev = local % max(ndev, 1)
+    torch.cuda.set_device(local_dev)
+    dev = torch.device("cuda", local_dev)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     params = OG.init_params(seed=1234)                        # Xavier-uniform, zero biases (reference init)
     gen = Generator(params=params, device=dev)
@@ -144,7 +154,7 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 

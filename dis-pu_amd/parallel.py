@@ -25,6 +25,13 @@ def all_gather_clouds(local, n_items=None, out=None, group=None):
     if len(set(sizes)) == 1:
         if out is None:
             out = torch.empty((n_items,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        if local.is_cuda and dist.get_backend(group) == "gloo":
+            # smoke-test configuration only (ranks sharing a GPU): gloo gathers through host memory
+            host = local.detach().cpu().contiguous()
+            parts = [torch.empty_like(host) for _ in range(world)]
+            dist.all_gather(parts, host, group=group)
+            out.copy_(torch.cat(parts, dim=0))
+            return out
         dist.all_gather_into_tensor(out, local.contiguous(), group=group)
         return out
     mx = max(sizes)
