@@ -59,21 +59,24 @@ __global__ __launch_bounds__(QB_BS) void query_ball_kernel(int n, int m, const f
 }
 
 // Flat gather: element e of out[b,m,ns,c] <- points[cloud, idx[row], e % c].  VEC = floats per lane.
+// Gather rows: out[row, :] = points[cloud(row), idx[row], :].  TX lanes (a power of two) share one output row and
+// stride over its c/VEC vectors; a workgroup covers 256/TX consecutive rows, so every wave writes whole contiguous
+// rows (coalesced) and the index / cloud arithmetic is done once per row in 32-bit (no per-element 64-bit division).
 template <int VEC>
-__global__ void group_point_kernel(int n, int c, int rows_per_cloud, size_t total_vec,
-                                   const float* __restrict__ points, const int* __restrict__ idx,
-                                   float* __restrict__ out) {
+__global__ __launch_bounds__(256) void group_point_kernel(int n, int c, int rows_per_cloud, long rows, int tx_log2,
+                                                          const float* __restrict__ points, const int* __restrict__ idx,
+                                                          float* __restrict__ out) {
+    const int TX = 1 << tx_log2;
+    const int tx = threadIdx.x & (TX - 1);
+    const int rpb = 256 >> tx_log2;                         // rows per workgroup pass
     const int cv = c / VEC;
-    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total_vec; e += (size_t)gridDim.x * blockDim.x) {
-        const size_t row = e / cv;
-        const int l = (int)(e - row * cv) * VEC;
-        const size_t cloud = row / rows_per_cloud;
-        const float* src = points + (cloud * n + idx[row]) * c + l;
-        float* dst = out + row * c + l;
-        if constexpr (VEC == 4) {
-            *reinterpret_cast<float4*>(dst) = *reinterpret_cast<const float4*>(src);
-        } else {
-            *dst = *src;
+    for (long row = (long)blockIdx.x * rpb + (threadIdx.x >> tx_log2); row < rows; row += (long)gridDim.x * rpb) {
+        const long cloud = row / rows_per_cloud;
+        const float* __restrict__ src = points + (cloud * n + idx[row]) * c;
+        float* __restrict__ dst = out + row * c;
+        for (int l = tx; l < cv; l += TX) {
+            if constexpr (VEC == 4) reinterpret_cast<float4*>(dst)[l] = reinterpret_cast<const float4*>(src)[l];
+            else dst[l] = src[l];
         }
     }
 }
@@ -120,15 +123,18 @@ DISPU_EXPORT int dispu_group_point(int b, int n, int c, int m, int nsample, cons
     const size_t rows = (size_t)b * m * nsample;
     if (rows == 0) return 0;
     const bool vec4 = (c % 4 == 0) && (((uintptr_t)points | (uintptr_t)out) % 16 == 0);
-    if (vec4) {
-        const size_t tv = rows * (c / 4);
-        hipLaunchKernelGGL((group_point_kernel<4>), dim3(grid_for(tv, 256)), dim3(256), 0, (hipStream_t)stream, n, c,
-                           m * nsample, tv, points, idx, out);
-    } else {
-        const size_t tv = rows * c;
-        hipLaunchKernelGGL((group_point_kernel<1>), dim3(grid_for(tv, 256)), dim3(256), 0, (hipStream_t)stream, n, c,
-                           m * nsample, tv, points, idx, out);
-    }
+    const int cv = vec4 ? c / 4 : c;
+    int tx_log2 = 0;
+    while ((1 << tx_log2) < cv && tx_log2 < 6) ++tx_log2;           // lanes per row: next power of two >= cv, at most 64
+    const size_t rpb = (size_t)256 >> tx_log2;
+    size_t g = (rows + rpb - 1) / rpb;
+    if (g > 65536) g = 65536;
+    if (vec4)
+        hipLaunchKernelGGL((group_point_kernel<4>), dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, n, c, m * nsample,
+                           (long)rows, tx_log2, points, idx, out);
+    else
+        hipLaunchKernelGGL((group_point_kernel<1>), dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, n, c, m * nsample,
+                           (long)rows, tx_log2, points, idx, out);
     return (int)hipGetLastError();
 }
 
