@@ -117,35 +117,41 @@ __global__ __launch_bounds__(256) void knn_xyz_wave_kernel(int n, int m, int k, 
 }
 
 // Feature-space (GEMM-form) variant: D = (rq - 2 q.p) + rp, fma chains over ascending channels.
-// LDS: feats[(c4 * n + p)] float4 = channels 4c4..4c4+3 of candidate p (zero padded to CP), norms[p].
+// LDS: feats[(c4 * (n+1) + p)] float4 = channels 4c4..4c4+3 of candidate p (zero padded to CP), norms[p].
 template <int R, int CP>
 __global__ __launch_bounds__(256) void knn_feat_wave_kernel(int n, int m, int c, int k, int qpb, int ldp, int ldq,
                                                              const float* __restrict__ points,
                                                              const float* __restrict__ queries, float* __restrict__ dist,
                                                              int* __restrict__ idx) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float4* feats = reinterpret_cast<float4*>(smem);                                  // [CP/4][n]
-    float* norms = reinterpret_cast<float*>(smem + (size_t)(CP / 4) * n * 16);        // [n]
-    uint64_t* sorted = reinterpret_cast<uint64_t*>(smem + (size_t)(CP / 4) * n * 16 + (((size_t)n * 4 + 15) & ~15ull));
+    const int ns = n + 1;                                                             // row stride of feats (float4): +1 de-conflicts the staging writes
+    float4* feats = reinterpret_cast<float4*>(smem);                                  // [CP/4][n+1]
+    float* norms = reinterpret_cast<float*>(smem + (size_t)(CP / 4) * ns * 16);       // [n]
+    uint64_t* sorted = reinterpret_cast<uint64_t*>(smem + (size_t)(CP / 4) * ns * 16 + (((size_t)n * 4 + 15) & ~15ull));
     const int cloud = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const float* __restrict__ sp = points + (size_t)cloud * n * ldp;
     const float* __restrict__ qp = queries + (size_t)cloud * m * ldq;
+    const bool vec = (c == CP) && ((ldp & 3) == 0) && ((((uintptr_t)sp) & 15) == 0);
     for (int e = threadIdx.x; e < (CP / 4) * n; e += 256) {
-        const int c4 = e / n, p = e - c4 * n;
-        float4 v;
+        const int p = e / (CP / 4), c4 = e - p * (CP / 4);       // consecutive lanes read one row's consecutive float4s
         const float* src = sp + (size_t)p * ldp + c4 * 4;
-        v.x = (c4 * 4 + 0 < c) ? src[0] : 0.f;
-        v.y = (c4 * 4 + 1 < c) ? src[1] : 0.f;
-        v.z = (c4 * 4 + 2 < c) ? src[2] : 0.f;
-        v.w = (c4 * 4 + 3 < c) ? src[3] : 0.f;
-        feats[e] = v;
+        float4 v;
+        if (vec) {
+            v = *reinterpret_cast<const float4*>(src);
+        } else {
+            v.x = (c4 * 4 + 0 < c) ? src[0] : 0.f;
+            v.y = (c4 * 4 + 1 < c) ? src[1] : 0.f;
+            v.z = (c4 * 4 + 2 < c) ? src[2] : 0.f;
+            v.w = (c4 * 4 + 3 < c) ? src[3] : 0.f;
+        }
+        feats[c4 * ns + p] = v;
     }
     __syncthreads();
     for (int p = threadIdx.x; p < n; p += 256) {
         float r = 0.f;
 #pragma unroll
         for (int c4 = 0; c4 < CP / 4; ++c4) {
-            const float4 v = feats[c4 * n + p];
+            const float4 v = feats[c4 * ns + p];
             r = __builtin_fmaf(v.x, v.x, r); r = __builtin_fmaf(v.y, v.y, r);
             r = __builtin_fmaf(v.z, v.z, r); r = __builtin_fmaf(v.w, v.w, r);
         }
@@ -164,7 +170,7 @@ __global__ __launch_bounds__(256) void knn_feat_wave_kernel(int n, int m, int c,
 #pragma unroll
         for (int r = 0; r < R; ++r) dot[r] = 0.f;
         float rq = 0.f;
-#pragma unroll
+#pragma unroll 2   // partial unroll: a full unroll keeps CP/4 x R float4 LDS loads in flight (256 VGPRs, one block per CU)
         for (int c4 = 0; c4 < CP / 4; ++c4) {
             const float q0v = (c4 * 4 + 0 < c) ? qrow[c4 * 4 + 0] : 0.f;
             const float q1v = (c4 * 4 + 1 < c) ? qrow[c4 * 4 + 1] : 0.f;
@@ -175,7 +181,7 @@ __global__ __launch_bounds__(256) void knn_feat_wave_kernel(int n, int m, int c,
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 const int p = lane + 64 * r;
-                const float4 v = feats[c4 * n + (p < n ? p : 0)];
+                const float4 v = feats[c4 * ns + (p < n ? p : 0)];
                 dot[r] = __builtin_fmaf(q0v, v.x, dot[r]); dot[r] = __builtin_fmaf(q1v, v.y, dot[r]);
                 dot[r] = __builtin_fmaf(q2v, v.z, dot[r]); dot[r] = __builtin_fmaf(q3v, v.w, dot[r]);
             }
@@ -216,7 +222,7 @@ static int launch_feat_wave(int b, int n, int m, int c, int k, int ldp, int ldq,
                             int* idx, hipStream_t st) {
     const int qpb = 16;         // 4 queries per wave; the cloud's features are re-staged per workgroup (L2-resident)
     dim3 grid((m + qpb - 1) / qpb, b);
-    const size_t lds = (size_t)(CP / 4) * n * 16 + (((size_t)n * 4 + 15) & ~15ull) + (size_t)4 * R * 64 * 8;
+    const size_t lds = (size_t)(CP / 4) * (n + 1) * 16 + (((size_t)n * 4 + 15) & ~15ull) + (size_t)4 * R * 64 * 8;
     hipLaunchKernelGGL((knn_feat_wave_kernel<R, CP>), grid, dim3(256), lds, st, n, m, c, k, qpb, ldp, ldq, p, q, dist, idx);
     return (int)hipGetLastError();
 }
@@ -246,7 +252,7 @@ int knn_feat_wave_dispatch(int b, int n, int m, int c, int k, int ldp, int ldq, 
     if (n > 512 || c > 64 || k > 64) return -1;
     const int cp = (c + 3) & ~3;
     const int r = n <= 64 ? 1 : (n <= 128 ? 2 : (n <= 256 ? 4 : 8));
-    const size_t lds = (size_t)(cp / 4) * n * 16 + (((size_t)n * 4 + 15) & ~15ull) + (size_t)4 * r * 64 * 8;
+    const size_t lds = (size_t)(cp / 4) * (n + 1) * 16 + (((size_t)n * 4 + 15) & ~15ull) + (size_t)4 * r * 64 * 8;
     if (lds > 64 * 1024) return -1;
     if (c <= 4) return feat_wave_r<4>(b, n, m, c, k, ldp, ldq, p, q, dist, idx, st);
     if (c <= 8) return feat_wave_r<8>(b, n, m, c, k, ldp, ldq, p, q, dist, idx, st);

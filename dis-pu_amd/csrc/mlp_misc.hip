@@ -150,19 +150,28 @@ __global__ void dup_grid_kernel(int nclouds, int n, int co, int up, const float*
                                 const float* __restrict__ Wg /* rows 480,481 of W: [2, co] */,
                                 const float* __restrict__ bias, const float* __restrict__ grid /* [up,2] */,
                                 float* __restrict__ Y, long ldy) {
-    const long total = (long)nclouds * up * n * co;
-    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-        const int o = (int)(e % co);
-        const long row = e / co;                 // output row = (cloud*up + r)*n + i
-        const int i = (int)(row % n);
-        const long cr = row / n;
-        const int r = (int)(cr % up);
-        const long cloud = cr / up;
-        float v = H[(cloud * n + i) * ldh + o];
-        v = __builtin_fmaf(grid[r * 2 + 0], Wg[o], v);
-        v = __builtin_fmaf(grid[r * 2 + 1], Wg[co + o], v);
-        v = v + bias[o];
-        Y[row * ldy + o] = fmaxf(v, 0.f);
+    // one source row per workgroup pass: H[src, :] is read once and expanded into its `up` copies (32-bit index
+    // arithmetic once per row, float4 lanes over the channels; co % 4 == 0)
+    const int co4 = co >> 2;
+    const long nsrc = (long)nclouds * n;
+    for (long src = blockIdx.x; src < nsrc; src += gridDim.x) {
+        const long cloud = src / n;
+        const int i = (int)(src - cloud * n);
+        for (int o4 = threadIdx.x; o4 < co4; o4 += blockDim.x) {
+            const float4 h = reinterpret_cast<const float4*>(H + src * ldh)[o4];
+            const float4 w0 = reinterpret_cast<const float4*>(Wg)[o4];
+            const float4 w1 = reinterpret_cast<const float4*>(Wg + co)[o4];
+            const float4 bb = reinterpret_cast<const float4*>(bias)[o4];
+            for (int r = 0; r < up; ++r) {
+                const float g0 = grid[r * 2 + 0], g1 = grid[r * 2 + 1];
+                float4 v;
+                v.x = fmaxf(__builtin_fmaf(g1, w1.x, __builtin_fmaf(g0, w0.x, h.x)) + bb.x, 0.f);
+                v.y = fmaxf(__builtin_fmaf(g1, w1.y, __builtin_fmaf(g0, w0.y, h.y)) + bb.y, 0.f);
+                v.z = fmaxf(__builtin_fmaf(g1, w1.z, __builtin_fmaf(g0, w0.z, h.z)) + bb.z, 0.f);
+                v.w = fmaxf(__builtin_fmaf(g1, w1.w, __builtin_fmaf(g0, w0.w, h.w)) + bb.w, 0.f);
+                reinterpret_cast<float4*>(Y + ((cloud * up + r) * n + i) * ldy)[o4] = v;
+            }
+        }
     }
 }
 
@@ -356,10 +365,13 @@ DISPU_EXPORT int dispu_edge_dense_conv_valu(int npoints, int n_per_cloud, int C,
 
 DISPU_EXPORT int dispu_dup_grid(int nclouds, int n, int co, int up, const float* H, long ldh, const float* Wg, const float* bias,
                                 const float* grid, float* Y, long ldy, void* stream) {
-    if (nclouds < 0 || n <= 0 || co <= 0 || up <= 0) return (int)hipErrorInvalidValue;
-    const long total = (long)nclouds * up * n * co;
-    if (total == 0) return 0;
-    hipLaunchKernelGGL(dup_grid_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, nclouds, n, co, up, H, ldh, Wg, bias, grid, Y, ldy);
+    if (nclouds < 0 || n <= 0 || co <= 0 || up <= 0 || (co & 3) || (ldh & 3) || (ldy & 3) ||
+        ((((uintptr_t)H) | ((uintptr_t)Wg) | ((uintptr_t)bias) | ((uintptr_t)Y)) & 15))
+        return (int)hipErrorInvalidValue;
+    const long nsrc = (long)nclouds * n;
+    if (nsrc == 0) return 0;
+    const int bs = (co / 4 >= 64) ? 64 : 32;
+    hipLaunchKernelGGL(dup_grid_kernel, dim3((unsigned)(nsrc > 65536 ? 65536 : nsrc)), dim3(bs), 0, (hipStream_t)stream, nclouds, n, co, up, H, ldh, Wg, bias, grid, Y, ldy);
     return (int)hipGetLastError();
 }
 

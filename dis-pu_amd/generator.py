@@ -88,6 +88,8 @@ class Generator(object):
         self.w_up_grid = w1[480:482].contiguous()
         w0 = self.P["refine/PointShuffle/conv0/weights"]
         self.w_c0_feat = w0[6:134].contiguous()
+        wsk = self.P["refine/PointShuffle/skip/weights"]
+        self.w_skip_pad = torch.cat([wsk, torch.zeros((10, wsk.shape[1]), dtype=torch.float32, device=dev)], dim=0).contiguous()
 
     def _w(self, scope):
         return self.P[scope + "/weights"], self.P[scope + "/biases"]
@@ -109,7 +111,7 @@ class Generator(object):
             feat=E(rn, 480), prep=E(rn, 48), kidx=E(rn, k + 1, dtype=i32), h256=E(rn, 256),
             up256=E(rm, 256), up128=E(rm, 128), c256=E(rm, 256), c64=E(rm, 64), coarse=E(B, M, 3),
             psidx=E(rm, k, dtype=i32), kv=E(rm, 128), q=E(rm, 64), att=E(rm, 64), nl=E(rm, 256),
-            skipin=torch.zeros((rm, 136), dtype=f32, device=dev), skip=E(rm, 256), gm=E(rm, 128), am=E(rm, 128),
+            skipin=torch.zeros((rm, 144), dtype=f32, device=dev), skip=E(rm, 256), gm=E(rm, 128), am=E(rm, 128),
             fp=E(rm, 2048), aft=E(rm, 256), agg=E(rm, 256),
             f256=E(rm, 256), f64=E(rm, 64), fine=E(B, M, 3))
         self._ws[key] = ws
@@ -242,9 +244,10 @@ class Generator(object):
         w, b = self._w(ps + "PointShuffle/conv_back_project")
         self._linear(st, ws["att"], 64, w, b, 1, ws["nl"], 256)
         # skip connection
-        self._call("skip_max", L.dispu_ps_skip_max, rm, M, k, 128, ptr(ws["psidx"]), ptr(coarse), ptr(up128), 128, ptr(ws["skipin"]), 136, st)
-        w, b = self._w(ps + "skip")
-        self._linear(st, ws["skipin"], 134, w, b, 1, ws["skip"], 256)
+        self._call("skip_max", L.dispu_ps_skip_max, rm, M, k, 128, ptr(ws["psidx"]), ptr(coarse), ptr(up128), 128, ptr(ws["skipin"]), 144, st)
+        _, b = self._w(ps + "skip")
+        # K padded 134 -> 144 with zero columns / zero weight rows (exact) so the GEMM takes its predicate-free path
+        self._linear(st, ws["skipin"], 144, self.w_skip_pad, b, 1, ws["skip"], 256)
         # local cell: conv0 per source point, conv1 per pair
         w0, b0 = self._w(ps + "conv0")
         self._linear(st, up128, 128, self.w_c0_feat, None, 0, ws["gm"], 128)
