@@ -61,6 +61,23 @@ def cpu_baseline(params, target_seconds=20.0):
                       "(best of a few thread counts on a host with %d cores), %.1f s" % (n, NPOINT, cores, avail, dt)}
 
 
+def pmc_traffic(kern):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes of this same command
+    (tools/pmc_traffic.sh -> profiles/pmc_traffic_latest.json): (2 * FETCH_SIZE + WRITE_SIZE) * 1024, the gfx950
+    correction of MI355X_MICROARCH.md's HBM section.  Counters cannot be read from inside the process, so this is
+    the figure of the last profiled build; None when the file or the kernel is absent."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic_latest.json")
+    try:
+        with open(path) as f:
+            rows = json.load(f)
+    except (OSError, ValueError):
+        return None, None
+    row = rows.get("linear_mfma_kernel" + kern[len("linear"):])
+    if not row or "hbm_bytes_corrected" not in row:
+        return None, None
+    return row["hbm_bytes_corrected"], "profiles/pmc_traffic_latest.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -188,9 +205,10 @@ def main():
             kern, (t_k, n_k, fl_k) = max(((k, v) for k, v in by_kernel.items() if k.startswith("linear<")),
                                           key=lambda kv: kv[1][0])
         achieved = fl_k / t_k / 1e12
+        traffic, traffic_src = pmc_traffic(kern)
         roof = {"bound": "mfma", "kernel": "dispu::linear_mfma_kernel" + kern[len("linear"):],
                 "launches_per_step": round(n_k), "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
                 "avg_launch_us": t_k / n_k * 1e6, "flops_per_launch": fl_k / n_k, "share_of_step": t_k / t_all,
                 "per_kernel_us_per_step": {k: round(v[0] * 1e6, 1) for k, v in
                                            sorted(by_kernel.items(), key=lambda kv: -kv[1][0])[:8]}}

@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""Aggregate rocprofv3 counter_collection CSVs (one directory per --pmc pass) into per-kernel averages.
+
+HBM bytes per launch follow /opt/skills/guides (MI355X_MICROARCH.md, HBM section): FETCH_SIZE / WRITE_SIZE are in
+KiB, and on gfx950 FETCH_SIZE tallies the 128-B requests of wide coalesced reads at 64 B, so the read side is
+doubled: hbm_bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024.  Both the raw and the corrected figures are kept."""
+import collections
+import csv
+import glob
+import json
+import os
+import re
+import sys
+
+
+def short(name):
+    name = re.sub(r"^void ", "", name)
+    name = re.sub(r"\(.*$", "", name)
+    return name.replace("dispu::", "")
+
+
+def main():
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for d in sys.argv[1:]:
+        for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+            for r in csv.DictReader(open(f)):
+                agg[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    out = {}
+    for k, cs in sorted(agg.items()):
+        row = {"dispatches": max(len(v) for v in cs.values())}
+        for c, v in cs.items():
+            row[c] = sum(v) / len(v)
+        if "FETCH_SIZE" in row and "WRITE_SIZE" in row:
+            row["hbm_bytes_raw"] = (row["FETCH_SIZE"] + row["WRITE_SIZE"]) * 1024
+            row["hbm_bytes_corrected"] = (2 * row["FETCH_SIZE"] + row["WRITE_SIZE"]) * 1024
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in row and row.get("SQ_BUSY_CYCLES"):
+            row["mfma_busy_over_sq_busy"] = row["SQ_VALU_MFMA_BUSY_CYCLES"] / row["SQ_BUSY_CYCLES"]
+        out[k] = row
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()
