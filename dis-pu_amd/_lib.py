@@ -64,6 +64,27 @@ SIGNATURES = {
     "dispu_denormalize_patches": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp]),
     "dispu_attention": (_i, [_i, _i, _i, _i, _vp, _l, _vp, _l, _vp, _l, C.c_float, _vp, _l, _vp]),
     "dispu_softmax_rows": (_i, [_l, _i, C.c_float, _vp, _l, _vp]),
+    "dispu_linear_tn_scratch_floats": (_l, [_i, _i, _i, _i]),
+    "dispu_linear_tn": (_i, [_i, _i, _i, _i, _vp, _l, _l, _vp, _l, _l, _vp, _l, _l, _i, _vp, _l, _vp]),
+    "dispu_act_bias_grad_scratch_floats": (_l, [_l, _i]),
+    "dispu_act_bias_grad": (_i, [_l, _i, _vp, _l, _vp, _l, _i, _vp, _l, _vp, _i, _vp, _l, _vp]),
+    "dispu_max_k": (_i, [_l, _i, _i, _vp, _l, _vp, _l, _vp]),
+    "dispu_max_k_grad": (_i, [_l, _i, _i, _vp, _l, _vp, _l, _vp, _l, _vp, _l, _i, _vp]),
+    "dispu_edge_feature_grad": (_i, [_l, _i, _i, _i, _vp, _l, _vp, _i, _i, _vp, _l, _vp]),
+    "dispu_dup_sum_grad": (_i, [_i, _i, _i, _i, _vp, _l, _vp, _l, _vp]),
+    "dispu_ps_group": (_i, [_l, _i, _i, _i, _vp, _vp, _vp, _l, _vp, _l, _vp]),
+    "dispu_ps_group_grad": (_i, [_l, _i, _i, _i, _vp, _vp, _l, _vp, _vp, _l, _vp]),
+    "dispu_ps_point_matmul_grad": (_i, [_l, _i, _i, _i, _vp, _l, _vp, _vp, _l, _vp, _l, _vp, _vp]),
+    "dispu_softmax_rows_grad": (_i, [_l, _i, C.c_float, _vp, _l, _vp, _l, _vp]),
+    "dispu_bn_scratch_bytes": (_l, [_l, _i]),
+    "dispu_bn_train": (_i, [_l, _i, _vp, _l, _vp, _vp, C.c_float, C.c_float, _i, _vp, _l, _vp, _vp, _vp, _vp, _l, _vp]),
+    "dispu_bn_train_grad": (_i, [_l, _i, _vp, _l, _vp, _l, _vp, _l, _vp, _vp, _i, _vp, _l, _vp, _vp, _vp, _vp, _l, _vp]),
+    "dispu_sigmoid_offset": (_i, [_l, _vp, _vp, _vp, _vp]),
+    "dispu_sigmoid_offset_grad": (_i, [_l, _vp, _vp, _vp, _vp, _vp]),
+    "dispu_repulsion_grad": (_i, [_l, _i, _i, C.c_float, C.c_float, _vp, _vp, _vp, _vp]),
+    "dispu_add3": (_i, [_l, _vp, _vp, _vp, _vp, _vp]),
+    "dispu_fill_rows": (_i, [_i, _i, _vp, C.c_float, _vp, _vp]),
+    "dispu_adam": (_i, [_l, _vp, _vp, _vp, _vp, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _vp]),
 }
 
 _LIB = None

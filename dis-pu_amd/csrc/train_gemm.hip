@@ -1,0 +1,256 @@
+// Weight-gradient GEMM and the column reductions of the training step for gfx950.
+//
+// The reference gets its gradients from TF1 autodiff (DisPU/model.py:178 `AdamOptimizer.minimize`): for every
+// 1x1 conv / matmul  Y = act(X.W + b)  that is  dW = X^T.dZ,  db = colsum(dZ),  dX = dZ.W^T  with dZ = dY * act'(Y)
+// (tf_util.py:52-185 layers; conv2d_backprop_filter / bias_add_grad / relu_grad).  dX is an ordinary NT product and
+// reuses dispu_linear (transb = 1); this file holds the TN product and the reductions.
+//
+// linear_tn: out[k][n] (+)= sum_m X[m][k] * Z[m][n].  M (points x neighbours) is 10^4..10^6 while K x N is at most
+// 2048 x 256, so the M axis is split over the grid: every workgroup owns one (K-tile, N-tile, M-split), streams its
+// M range through LDS in 32-row slabs and feeds v_mfma_f32_32x32x2_f32 straight from the row-major slabs (A operand
+// = a row pair of X, B operand = the same row pair of Z: neither needs a transpose).  Splits write partial tiles to
+// a scratch buffer and a second kernel sums them in split order, so the result is deterministic (no float atomics).
+#include "common.h"
+
+namespace dispu {
+
+typedef float v16f __attribute__((ext_vector_type(16)));
+
+struct TnArgs {
+    int M, K, N;
+    const float* X; long ldx; long sx;
+    const float* Z; long ldz; long sz;
+    float* out; long ldo; long so;       // final destination [K][N] (row stride ldo, batch stride so)
+    float* part;                         // scratch [batch][splits][K][N] (compact) when splits > 1 or accumulate
+    int splits, rows_per_split, direct;  // direct: single split, no accumulate -> write `out` from the GEMM kernel
+};
+
+constexpr int TN_SLAB = 32;              // rows of X / Z per LDS stage
+
+// block = 2 x 2 waves; wave tile (32*TK) x (32*TN); block tile (64*TK) x (64*TN)
+template <int TK, int TNN>
+__global__ __launch_bounds__(256) void linear_tn_kernel(TnArgs a) {
+    constexpr int BKT = 64 * TK, BNT = 64 * TNN;
+    constexpr int LDXS = BKT + 32, LDZS = BNT + 32;      // +32 floats: the two half-waves of an operand read hit disjoint banks
+    __shared__ float xs[TN_SLAB * LDXS];
+    __shared__ float zs[TN_SLAB * LDZS];
+    const int ntn = (a.N + BNT - 1) / BNT;
+    const int tk = blockIdx.x / ntn, tn = blockIdx.x - tk * ntn;
+    const int k0 = tk * BKT, n0 = tn * BNT;
+    const int split = blockIdx.y, z = blockIdx.z;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wk = wave >> 1, wn = wave & 1;
+    const float* __restrict__ X = a.X + (size_t)z * a.sx;
+    const float* __restrict__ Z = a.Z + (size_t)z * a.sz;
+    const int m_begin = split * a.rows_per_split;
+    const int m_end = min(a.M, m_begin + a.rows_per_split);
+
+    v16f acc[TK][TNN];
+#pragma unroll
+    for (int i = 0; i < TK; ++i)
+#pragma unroll
+        for (int j = 0; j < TNN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    for (int m0 = m_begin; m0 < m_end; m0 += TN_SLAB) {
+        // stage the slab: lanes run along the columns (coalesced), zero fill outside the matrix
+        for (int e = threadIdx.x; e < TN_SLAB * BKT; e += 256) {
+            const int r = e / BKT, c = e - r * BKT;
+            const int m = m0 + r, k = k0 + c;
+            xs[r * LDXS + c] = (m < m_end && k < a.K) ? X[(size_t)m * a.ldx + k] : 0.f;
+        }
+        for (int e = threadIdx.x; e < TN_SLAB * BNT; e += 256) {
+            const int r = e / BNT, c = e - r * BNT;
+            const int m = m0 + r, n = n0 + c;
+            zs[r * LDZS + c] = (m < m_end && n < a.N) ? Z[(size_t)m * a.ldz + n] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int j = 0; j < TN_SLAB / 2; ++j) {
+            const int row = 2 * j + (lane >> 5);
+            float af[TK], bf[TNN];
+#pragma unroll
+            for (int i = 0; i < TK; ++i) af[i] = xs[row * LDXS + (wk * TK + i) * 32 + (lane & 31)];
+#pragma unroll
+            for (int i = 0; i < TNN; ++i) bf[i] = zs[row * LDZS + (wn * TNN + i) * 32 + (lane & 31)];
+#pragma unroll
+            for (int i = 0; i < TK; ++i)
+#pragma unroll
+                for (int jn = 0; jn < TNN; ++jn)
+                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[jn], acc[i][jn], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    // C/D layout: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+    float* __restrict__ dst;
+    long ldd;
+    if (a.direct) {
+        dst = a.out + (size_t)z * a.so;
+        ldd = a.ldo;
+    } else {
+        dst = a.part + ((size_t)z * a.splits + split) * (size_t)a.K * a.N;
+        ldd = a.N;
+    }
+#pragma unroll
+    for (int i = 0; i < TK; ++i)
+#pragma unroll
+        for (int jn = 0; jn < TNN; ++jn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int k = k0 + (wk * TK + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int n = n0 + (wn * TNN + jn) * 32 + (lane & 31);
+                if (k < a.K && n < a.N) dst[(size_t)k * ldd + n] = acc[i][jn][r];
+            }
+}
+
+// out[z][k][n] = (accumulate ? out : 0) + sum_s part[z][s][k][n], s ascending.
+__global__ void tn_reduce_kernel(int batch, int K, int N, int splits, const float* __restrict__ part, float* __restrict__ out,
+                                 long ldo, long so, int accumulate) {
+    const size_t kn = (size_t)K * N, total = kn * batch;
+    for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const size_t z = e / kn, r = e - z * kn;
+        const int k = (int)(r / N), n = (int)(r - (size_t)k * N);
+        float* o = out + z * so + (size_t)k * ldo + n;
+        float v = accumulate ? *o : 0.f;
+        const float* p = part + z * splits * kn + r;
+        for (int s = 0; s < splits; ++s) v += p[(size_t)s * kn];
+        *o = v;
+    }
+}
+
+static void tn_plan(int batch, int M, int K, int N, int& tk, int& tnn, int& splits, int& rows) {
+    tk = (K > 64) ? 2 : 1;
+    tnn = (N > 64) ? 2 : 1;
+    const int tiles = ((K + 64 * tk - 1) / (64 * tk)) * ((N + 64 * tnn - 1) / (64 * tnn)) * batch;
+    int want = (1024 + tiles - 1) / tiles;                        // aim at ~1024 workgroups (4 per CU)
+    const int max_splits = (M + 4 * TN_SLAB - 1) / (4 * TN_SLAB);  // at least 4 slabs per split
+    splits = want < 1 ? 1 : want;
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    rows = (M + splits - 1) / splits;
+    rows = ((rows + TN_SLAB - 1) / TN_SLAB) * TN_SLAB;
+    splits = (M + rows - 1) / rows;
+}
+
+// ---- column sums with the activation mask ------------------------------------------------------------------
+// dZ[r][j] = dY[r][j] * (act ? Y[r][j] > 0 : 1);  part[blk][j] = sum over the block's rows of dZ[r][j].
+// block (64, 4): x runs over columns (coalesced), y over 4 interleaved rows.
+__global__ __launch_bounds__(256) void act_bias_grad_kernel(long rows, int n, int rows_per_block, const float* __restrict__ dY,
+                                                             long lddy, const float* __restrict__ Y, long ldy, int act,
+                                                             float* __restrict__ dZ, long lddz, float* __restrict__ part) {
+    __shared__ float red[4][64];
+    const long r0 = (long)blockIdx.x * rows_per_block;
+    const long r1 = min(rows, r0 + rows_per_block);
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int c0 = 0; c0 < n; c0 += 64) {
+        const int c = c0 + tx;
+        float s = 0.f;
+        if (c < n) {
+            for (long r = r0 + ty; r < r1; r += 4) {
+                float g = dY[r * lddy + c];
+                if (act && !(Y[r * ldy + c] > 0.f)) g = 0.f;
+                if (dZ) dZ[r * lddz + c] = g;
+                s += g;
+            }
+        }
+        red[ty][tx] = s;
+        __syncthreads();
+        if (ty == 0 && c < n && part) part[(size_t)blockIdx.x * n + c] = ((red[0][tx] + red[1][tx]) + red[2][tx]) + red[3][tx];
+        __syncthreads();
+    }
+}
+
+// out[j] = (accumulate ? out[j] : 0) + sum_s part[s][j]  (s ascending)
+__global__ void colsum_reduce_kernel(int n, int nparts, const float* __restrict__ part, float* __restrict__ out, int accumulate) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    float v = accumulate ? out[j] : 0.f;
+    for (int s = 0; s < nparts; ++s) v += part[(size_t)s * n + j];
+    out[j] = v;
+}
+
+static int bias_blocks(long rows, int& rows_per_block) {
+    rows_per_block = 256;
+    long nb = (rows + rows_per_block - 1) / rows_per_block;
+    if (nb > 2048) {
+        rows_per_block = (int)((rows + 2047) / 2048);
+        rows_per_block = (rows_per_block + 3) & ~3;
+        nb = (rows + rows_per_block - 1) / rows_per_block;
+    }
+    return (int)nb;
+}
+
+}  // namespace dispu
+
+using namespace dispu;
+
+DISPU_EXPORT long dispu_linear_tn_scratch_floats(int batch, int M, int K, int N) {
+    if (batch <= 0 || M <= 0 || K <= 0 || N <= 0) return 0;
+    int tk, tnn, splits, rows;
+    tn_plan(batch, M, K, N, tk, tnn, splits, rows);
+    return (long)batch * splits * K * N;
+}
+
+DISPU_EXPORT int dispu_linear_tn(int batch, int M, int K, int N, const float* X, long ldx, long sx, const float* Z, long ldz,
+                                 long sz, float* out, long ldo, long so, int accumulate, float* scratch, long scratch_floats,
+                                 void* stream) {
+    if (batch < 0 || M < 0 || K < 0 || N < 0) return (int)hipErrorInvalidValue;
+    if (batch == 0 || K == 0 || N == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    if (M == 0) {
+        if (!accumulate)
+            for (int z = 0; z < batch; ++z)
+                DISPU_TRY(hipMemset2DAsync(out + (size_t)z * so, sizeof(float) * ldo, 0, sizeof(float) * N, K, s));
+        return 0;
+    }
+    int tk, tnn, splits, rows;
+    tn_plan(batch, M, K, N, tk, tnn, splits, rows);
+    const int direct = (splits == 1 && !accumulate) ? 1 : 0;
+    if (!direct && (scratch == nullptr || scratch_floats < (long)batch * splits * K * N)) return (int)hipErrorInvalidValue;
+    TnArgs a{M, K, N, X, ldx, sx, Z, ldz, sz, out, ldo, so, scratch, splits, rows, direct};
+    const int tiles = ((K + 64 * tk - 1) / (64 * tk)) * ((N + 64 * tnn - 1) / (64 * tnn));
+    dim3 grid(tiles, splits, batch);
+    if (tk == 1 && tnn == 1) hipLaunchKernelGGL((linear_tn_kernel<1, 1>), grid, dim3(256), 0, s, a);
+    else if (tk == 2 && tnn == 1) hipLaunchKernelGGL((linear_tn_kernel<2, 1>), grid, dim3(256), 0, s, a);
+    else if (tk == 1 && tnn == 2) hipLaunchKernelGGL((linear_tn_kernel<1, 2>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((linear_tn_kernel<2, 2>), grid, dim3(256), 0, s, a);
+    DISPU_CHECK_LAUNCH();
+    if (!direct) {
+        const size_t total = (size_t)batch * K * N;
+        const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+        hipLaunchKernelGGL(tn_reduce_kernel, dim3(blocks), dim3(256), 0, s, batch, K, N, splits, scratch, out, ldo, so, accumulate);
+        DISPU_CHECK_LAUNCH();
+    }
+    return 0;
+}
+
+DISPU_EXPORT long dispu_act_bias_grad_scratch_floats(long rows, int n) {
+    if (rows <= 0 || n <= 0) return 0;
+    int rpb;
+    return (long)bias_blocks(rows, rpb) * n;
+}
+
+DISPU_EXPORT int dispu_act_bias_grad(long rows, int n, const float* dY, long lddy, const float* Y, long ldy, int act, float* dZ,
+                                     long lddz, float* dbias, int accumulate, float* scratch, long scratch_floats,
+                                     void* stream) {
+    if (rows < 0 || n < 0 || (act && Y == nullptr)) return (int)hipErrorInvalidValue;
+    if (n == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    if (rows == 0) {
+        if (dbias && !accumulate) DISPU_TRY(hipMemsetAsync(dbias, 0, sizeof(float) * n, s));
+        return 0;
+    }
+    int rpb;
+    const int nb = bias_blocks(rows, rpb);
+    if (dbias && (scratch == nullptr || scratch_floats < (long)nb * n)) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(act_bias_grad_kernel, dim3(nb), dim3(256), 0, s, rows, n, rpb, dY, lddy, Y, ldy, act, dZ, lddz,
+                       dbias ? scratch : nullptr);
+    DISPU_CHECK_LAUNCH();
+    if (dbias) {
+        hipLaunchKernelGGL(colsum_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, nb, scratch, dbias, accumulate);
+        DISPU_CHECK_LAUNCH();
+    }
+    return 0;
+}

@@ -1,0 +1,475 @@
+"""Dis-PU training step on MI355X: generator forward in training mode, the reference's loss, hand-written backward,
+gradient all-reduce and Adam.
+
+Counterpart of DisPU/model.py: `Model.build_model` (:68-87: coarse/fine = G(input); pu_loss = 1000 CD(coarse) +
+weight_fine(epoch) * 1000 CD(fine) + repulsion_w * repulsion(fine)), `setup_optimizer` (:158-178: staircase LR decay
+over epochs, Adam beta1 = opts.beta on every generator variable) and the per-batch body of `train` (:215-232).
+The reference obtains gradients from TF1 autodiff; here every backward op is an explicit C-ABI launch
+(include/dispu_hip.h, "training step").  torch supplies device memory, the stream and torch.distributed only.
+
+Execution differences from the reference (not results):
+  * parameters, gradients and both Adam moments live in four flat fp32 buffers (1.05 M floats each): ONE RCCL
+    all-reduce and ONE Adam launch per step;
+  * concat / tile tensors are column slices of wide buffers (the dense blocks' edge tensor is one
+    [B*N*16, 72+2C] matrix whose slices are the inputs and outputs of l0/l1/l2), their gradients likewise;
+  * duplicate_up's 482-wide conv is evaluated per source point (as in inference) and differentiated in that form.
+Training-mode forward values equal the inference path's except for BatchNorm (batch statistics here).
+"""
+import math
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from . import _lib
+from .generator import BN_EPS, DENSE_BLOCKS, GROWTH, K_NEIGH, _Opts, gen_grid
+
+BN_DECAY = 0.95      # DisPU/generator.py:39 bn_decay
+BN = "refine/PointShuffle/weight_net/wconv0/bn/"
+
+
+class TrainOpts(_Opts):
+    """the training-side defaults of DisPU/configs.py"""
+    base_lr_g = 0.001
+    beta = 0.9
+    lr_decay = True
+    decay_step = 30
+    lr_decay_rate = 0.7
+    lr_clip = 1e-6
+    use_repulse = True
+    repulsion_w = 1.0
+
+
+def weight_fine(epoch):
+    """model.py:52-54 piecewise_constant(epoch, [10, 20, 30], [0.01, 0.1, 0.5, 1.0])."""
+    return 0.01 if epoch <= 10 else 0.1 if epoch <= 20 else 0.5 if epoch <= 30 else 1.0
+
+
+def learning_rate(opts, epoch):
+    """model.py:160-170."""
+    lr = opts.base_lr_g
+    if opts.lr_decay:
+        lr = max(opts.base_lr_g * opts.lr_decay_rate ** math.floor(epoch / opts.decay_step), opts.lr_clip)
+    return lr
+
+
+def _p(t, off=0):
+    return _lib.C.c_void_p(t.data_ptr() + 4 * off) if t is not None else _lib.C.c_void_p(0)
+
+
+class Trainer(object):
+    """Trainer(opts, params).train_step(input[B,N,3], gt[B,4N,3], radius[B]) -> dict of loss terms.
+
+    `params`: the same name -> array mapping Generator.load_params takes (oracle/generator.py:layer_shapes names)."""
+
+    def __init__(self, opts=None, params=None, device=None, process_group=None):
+        self.opts = opts if opts is not None else TrainOpts()
+        self.device = torch.device(device if device is not None else "cuda:0")
+        self.up_ratio = int(self.opts.up_ratio)
+        if self.up_ratio != 4:
+            raise NotImplementedError("the shipped generator graph is built for up_ratio 4")
+        self.pg = process_group
+        self.epoch = 0
+        self.global_step = 0
+        self._ws = {}
+        self._scratch = None
+        self._bn_scratch = None
+        self.P = None
+        if params is not None:
+            self.load_params(params)
+
+    # --------------------------------------------------------------------------------------------- parameters ----
+    def load_params(self, params):
+        dev = self.device
+        names = [k for k in params if k.endswith(("/weights", "/biases", "/gamma", "/beta"))]
+        sizes = [int(np.asarray(params[k]).size) for k in names]
+        # every tensor starts on a 16-byte boundary inside the flat buffers
+        offs, total = [], 0
+        for s in sizes:
+            offs.append(total)
+            total += (s + 3) & ~3
+        self.flat_p = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.flat_g = torch.zeros_like(self.flat_p)
+        self.flat_m = torch.zeros_like(self.flat_p)
+        self.flat_v = torch.zeros_like(self.flat_p)
+        self.P, self.G, self.names = OrderedDict(), OrderedDict(), names
+        for k, o, s in zip(names, offs, sizes):
+            shp = np.asarray(params[k]).shape
+            self.P[k] = self.flat_p[o:o + s].view(shp)
+            self.G[k] = self.flat_g[o:o + s].view(shp)
+            self.P[k].copy_(torch.from_numpy(np.ascontiguousarray(params[k], np.float32)))
+        self.moving_mean = torch.from_numpy(np.ascontiguousarray(params[BN + "moving_mean"], np.float32)).to(dev)
+        self.moving_var = torch.from_numpy(np.ascontiguousarray(params[BN + "moving_variance"], np.float32)).to(dev)
+        self.grid = torch.from_numpy(gen_grid(self.up_ratio)).to(dev)
+        self.adam_t = 0
+
+    def params(self):
+        """current parameters as the name -> numpy mapping Generator.load_params / the oracle take."""
+        out = OrderedDict((k, v.detach().cpu().numpy().copy()) for k, v in self.P.items())
+        out[BN + "moving_mean"] = self.moving_mean.cpu().numpy().copy()
+        out[BN + "moving_variance"] = self.moving_var.cpu().numpy().copy()
+        return out
+
+    def grads(self):
+        return OrderedDict((k, v.detach().cpu().numpy().copy()) for k, v in self.G.items())
+
+    # ---------------------------------------------------------------------------------------------- workspace ----
+    def _workspace(self, B, N):
+        key = (B, N)
+        if key in self._ws:
+            return self._ws[key]
+        dev, f32, i32 = self.device, torch.float32, torch.int32
+        M = N * self.up_ratio
+        rn, rm, k = B * N, B * M, K_NEIGH
+        E = lambda *shape, dtype=f32: torch.empty(shape, dtype=dtype, device=dev)
+        Z = lambda *shape: torch.zeros(shape, dtype=f32, device=dev)
+        ws = dict(
+            feat=E(rn, 480), dfeat=E(rn, 480),
+            prep=[None, None] + [E(rn, 48) for _ in range(2, DENSE_BLOCKS + 1)], dprep=E(rn, 48),
+            kidx=[None] + [E(rn, k + 1, dtype=i32) for _ in range(DENSE_BLOCKS)],
+            edge=[None, E(rn * k, 72 + 48)] + [E(rn * k, 72 + 96) for _ in range(2, DENSE_BLOCKS + 1)], dedge=E(rn * k, 72 + 96),
+            h256=E(rn, 256), dh256=E(rn, 256), gcode=E(rm, 2),
+            up256=E(rm, 256), dup256=E(rm, 256), up128=E(rm, 128), dup128=E(rm, 128),
+            c256=E(rm, 256), dc256=E(rm, 256), c64=E(rm, 64), dc64=E(rm, 64), coarse=E(B, M, 3), dcoarse=E(B, M, 3),
+            psidx=E(rm, k, dtype=i32), gf=E(rm * k, 134), dgf=E(rm * k, 134), gmax=E(rm, 134), dgmax=E(rm, 134),
+            skip=E(rm, 256), dskip=E(rm, 256), h0=E(rm * k, 128), dh0=E(rm * k, 128), h1=E(rm * k, 128), dh1=E(rm * k, 128),
+            wl=E(rm * k, 16), dwl=E(rm * k, 16), wv=E(rm * k, 16), dwv=E(rm * k, 16), bn_stats=E(48), bn_sums=E(32),
+            hp=E(rm, 2048), dhp=E(rm, 2048), aft=E(rm, 256), daft=E(rm, 256),
+            kv=E(rm, 128), dkv=E(rm, 128), q=E(rm, 64), dq=E(rm, 64), S=E(B, M, M), dS=E(B, M, M), att=E(rm, 64), datt=E(rm, 64),
+            nl=E(rm, 256), dnl=E(rm, 256), sum=E(rm, 256), dsum=E(rm, 256), agg=E(rm, 256), dagg=E(rm, 256),
+            f256=E(rm, 256), df256=E(rm, 256), f64=E(rm, 64), df64=E(rm, 64), z=E(rm, 3), dz=E(rm, 3), fine=E(B, M, 3), dfine=E(B, M, 3),
+            # loss
+            d_gt=E(B, M), i_gt=E(B, M, dtype=i32), d_pred=E(B, M), i_pred=E(B, M, dtype=i32), g_gt=E(B, M), g_pred=E(B, M),
+            dgt_unused=E(B, M, 3), ball=E(B, M, 20, dtype=i32), ball_cnt=E(B, M, dtype=i32), rep=E(B, M), rowmean=E(B), rowmax=E(B),
+            zeros=Z(1))
+        # grid code of duplicate_up: row (cloud*up + r)*N + i carries grid[r]
+        ws["gcode"].view(B, self.up_ratio, N, 2).copy_(self.grid.view(1, self.up_ratio, 1, 2).expand(B, self.up_ratio, N, 2))
+        self._ws[key] = ws
+        return ws
+
+    def _scratch_floats(self, n):
+        if self._scratch is None or self._scratch.numel() < n:
+            self._scratch = torch.empty(max(int(n), 1 << 20), dtype=torch.float32, device=self.device)
+        return self._scratch
+
+    # ----------------------------------------------------------------------------------------------- helpers ----
+    def _lin(self, X, xoff, K, wname, act, Y, yoff, N, M=None, bias=True, W=None, woff=0):
+        """Y[:, yoff:yoff+N] = act(X[:, xoff:xoff+K] . W + b)"""
+        L = _lib.lib()
+        M = X.shape[0] if M is None else M
+        W = self.P[wname + "/weights"] if W is None else W
+        b = self.P[wname + "/biases"] if bias else None
+        _lib.check(L.dispu_linear(1, M, K, N, _p(X, xoff), X.stride(0), 0, _p(W, woff), W.stride(0), 0, 0, _p(b), act,
+                                  _p(Y, yoff), Y.stride(0), 0, None, 0, 0, None, 0, 0, self.st), "dispu_linear")
+
+    def _tn(self, batch, M, K, N, X, xoff, ldx, sx, Zt, zoff, ldz, sz, out, ooff, ldo, so, accumulate):
+        L = _lib.lib()
+        need = L.dispu_linear_tn_scratch_floats(batch, M, K, N)
+        sc = self._scratch_floats(need)
+        _lib.check(L.dispu_linear_tn(batch, M, K, N, _p(X, xoff), ldx, sx, _p(Zt, zoff), ldz, sz, _p(out, ooff), ldo, so,
+                                     accumulate, _p(sc), sc.numel(), self.st), "dispu_linear_tn")
+
+    def _act_bias_grad(self, M, N, dY, dyoff, Y, yoff, act, dZ, dzoff, dbias):
+        L = _lib.lib()
+        need = L.dispu_act_bias_grad_scratch_floats(M, N)
+        sc = self._scratch_floats(need)
+        _lib.check(L.dispu_act_bias_grad(M, N, _p(dY, dyoff), dY.stride(0), _p(Y, yoff) if Y is not None else None,
+                                         Y.stride(0) if Y is not None else 0, act, _p(dZ, dzoff) if dZ is not None else None,
+                                         dZ.stride(0) if dZ is not None else 0, _p(dbias), 1, _p(sc), sc.numel(), self.st),
+                   "dispu_act_bias_grad")
+
+    def _lin_bwd(self, X, xoff, K, wname, act, Y, yoff, N, dY, dyoff, dX=None, dxoff=0, acc_dx=False, M=None, bias=True,
+                 W=None, dW=None, woff=0, premasked=False):
+        """backward of _lin: dY[:, dyoff:dyoff+N] is masked in place (unless premasked), db += colsum, dW += X^T dZ,
+        dX[:, dxoff:dxoff+K] (+)= dZ . W^T."""
+        L = _lib.lib()
+        M = X.shape[0] if M is None else M
+        W = self.P[wname + "/weights"] if W is None else W
+        dW = self.G[wname + "/weights"] if dW is None else dW
+        db = self.G[wname + "/biases"] if bias else None
+        if bias or (act and not premasked):
+            self._act_bias_grad(M, N, dY, dyoff, Y, yoff, 0 if premasked else act, None if premasked else dY, dyoff, db)
+        self._tn(1, M, K, N, X, xoff, X.stride(0), 0, dY, dyoff, dY.stride(0), 0, dW, woff, dW.stride(0), 0, 1)
+        if dX is not None:
+            _lib.check(L.dispu_linear(1, M, N, K, _p(dY, dyoff), dY.stride(0), 0, _p(W, woff), W.stride(0), 0, 1, None, 0,
+                                      _p(dX, dxoff), dX.stride(0), 0, _p(dX, dxoff) if acc_dx else None,
+                                      dX.stride(0) if acc_dx else 0, 0, None, 0, 0, self.st), "dispu_linear(dX)")
+
+    # ----------------------------------------------------------------------------------------------- forward ----
+    def forward(self, inputs):
+        """training-mode forward (BatchNorm batch statistics, moving averages updated); keeps every activation."""
+        if not (isinstance(inputs, torch.Tensor) and inputs.is_cuda and inputs.dtype == torch.float32 and inputs.dim() == 3
+                and inputs.shape[2] == 3):
+            raise ValueError("Trainer expects a float32 [B,N,3] tensor on a ROCm device")
+        x = inputs.contiguous()
+        B, N, _ = x.shape
+        M, k = N * self.up_ratio, K_NEIGH
+        rn, rm = B * N, B * M
+        ws = self._workspace(B, N)
+        L = _lib.lib()
+        self.st = st = _lib.stream_ptr(x.device)
+        self._shape = (B, N)
+        self._x = x
+        P = self.P
+        feat = ws["feat"]
+        fe = "generator/feature_extraction_coarse/"
+        _lib.check(L.dispu_linear_small_k(rn, 3, 24, _p(x), 3, _p(P[fe + "layer0/weights"]), _p(P[fe + "layer0/biases"]), 0,
+                                          _p(feat, 456), 480, st), "layer0")
+        col = 456
+        self._blocks = []
+        for d in range(1, DENSE_BLOCKS + 1):
+            if d == 1:
+                F, foff, C = feat, 456, 24
+            else:
+                self._lin(feat, col, 480 - col, fe + "layer%d_prep" % d, 1, ws["prep"][d], 0, 48)
+                F, foff, C = ws["prep"][d], 0, 48
+            ldf = F.stride(0)
+            kidx, Eb = ws["kidx"][d], ws["edge"][d]
+            _lib.check(L.dispu_knn_feat_strided(B, N, N, C, k + 1, _p(F, foff), ldf, _p(F, foff), ldf, None, _p(kidx), st), "knn_feat")
+            _lib.check(L.dispu_edge_feature(rn, N, k, C, _p(F, foff), ldf, _p(kidx), k + 1, 1, _p(Eb, 72), Eb.stride(0), st), "edge_feature")
+            sc = fe + "layer%d" % d
+            self._lin(Eb, 72, 2 * C, sc + "/l0", 1, Eb, 48, 24)
+            self._lin(Eb, 48, 24 + C, sc + "/l1", 1, Eb, 24, 24)
+            self._lin(Eb, 24, 48 + C, sc + "/l2", 0, Eb, 0, 24)
+            width = 3 * GROWTH + C
+            in_col = col
+            col -= width
+            _lib.check(L.dispu_max_k(rn, k, width, _p(Eb), Eb.stride(0), _p(feat, col), 480, st), "max_k")
+            self._blocks.append((d, C, col, in_col, width))
+        assert col == 0
+
+        # duplicate_up (per source point) + coarse regressor
+        w1 = P["generator/upshuffle_0/conv1/weights"]
+        self._lin(feat, 0, 480, None, 0, ws["h256"], 0, 256, bias=False, W=w1)
+        _lib.check(L.dispu_dup_grid(B, N, 256, self.up_ratio, _p(ws["h256"]), 256, _p(w1, 480 * 256),
+                                    _p(P["generator/upshuffle_0/conv1/biases"]), _p(self.grid), _p(ws["up256"]), 256, st), "dup_grid")
+        self._lin(ws["up256"], 0, 256, "generator/upshuffle_0/conv2", 1, ws["up128"], 0, 128)
+        cs = "generator/coarse_coordinate_regressor/"
+        self._lin(ws["up128"], 0, 128, cs + "fc_layer0", 1, ws["c256"], 0, 256)
+        self._lin(ws["c256"], 0, 256, cs + "fc_layer1", 1, ws["c64"], 0, 64)
+        coarse = ws["coarse"].view(rm, 3)
+        self._lin(ws["c64"], 0, 64, cs + "fc_layer2", 0, coarse, 0, 3)
+
+        # PointShuffle2
+        ps = "refine/PointShuffle/"
+        up128 = ws["up128"]
+        _lib.check(L.dispu_knn_xyz(B, M, M, k, _p(coarse), _p(coarse), _p(ws["psidx"]), None, _lib.ARITH_PLAIN, st), "knn_xyz")
+        gf = ws["gf"]
+        _lib.check(L.dispu_ps_group(rm, M, k, 128, _p(ws["psidx"]), _p(coarse), _p(up128), 128, _p(gf), 134, st), "ps_group")
+        # non-local cell with materialised attention (kept for the backward)
+        self._lin(up128, 0, 128, ps + "PointShuffle/conv_kv", 0, ws["kv"], 0, 128)
+        self._lin(up128, 0, 128, ps + "PointShuffle/conv_query", 0, ws["q"], 0, 64)
+        S = ws["S"]
+        _lib.check(L.dispu_linear(B, M, 64, M, _p(ws["q"]), 64, M * 64, _p(ws["kv"]), 128, M * 128, 1, None, 0, _p(S), M, M * M,
+                                  None, 0, 0, None, 0, 0, st), "scores")
+        _lib.check(L.dispu_softmax_rows(rm, M, 0.125, _p(S), M, st), "softmax")
+        _lib.check(L.dispu_linear(B, M, M, 64, _p(S), M, M * M, _p(ws["kv"], 64), 128, M * 128, 0, None, 0, _p(ws["att"]), 64,
+                                  M * 64, None, 0, 0, None, 0, 0, st), "att.V")
+        self._lin(ws["att"], 0, 64, ps + "PointShuffle/conv_back_project", 1, ws["nl"], 0, 256)
+        # skip
+        _lib.check(L.dispu_max_k(rm, k, 134, _p(gf), 134, _p(ws["gmax"]), 134, st), "max_k")
+        self._lin(ws["gmax"], 0, 134, ps + "skip", 1, ws["skip"], 0, 256)
+        # local cell
+        self._lin(gf, 0, 134, ps + "conv0", 1, ws["h0"], 0, 128)
+        self._lin(ws["h0"], 0, 128, ps + "conv1", 1, ws["h1"], 0, 128)
+        self._lin(gf, 0, 3, ps + "weight_net/wconv0", 0, ws["wl"], 0, 16)
+        nb = L.dispu_bn_scratch_bytes(rm * k, 16)
+        if self._bn_scratch is None or self._bn_scratch.numel() * 8 < nb:
+            self._bn_scratch = torch.empty((nb + 7) // 8, dtype=torch.float64, device=self.device)
+        _lib.check(L.dispu_bn_train(rm * k, 16, _p(ws["wl"]), 16, _p(P[BN + "gamma"]), _p(P[BN + "beta"]), BN_EPS, BN_DECAY, 1,
+                                    _p(ws["wv"]), 16, _p(ws["bn_stats"]), _p(self.moving_mean), _p(self.moving_var),
+                                    _p(self._bn_scratch), self._bn_scratch.numel() * 8, st), "bn_train")
+        _lib.check(L.dispu_ps_point_matmul(rm, k, 128, 16, _p(ws["h1"]), 128, _p(ws["wv"]), _p(ws["hp"]), 2048, st), "point_matmul")
+        self._lin(ws["hp"], 0, 2048, ps + "after_conv", 1, ws["aft"], 0, 256)
+        _lib.check(L.dispu_add3(rm * 256, _p(ws["aft"]), _p(ws["skip"]), _p(ws["nl"]), _p(ws["sum"]), st), "add3")
+        self._lin(ws["sum"], 0, 256, ps + "aggregation", 1, ws["agg"], 0, 256)
+        # fine regressor
+        fs = "refine/fine_coordinate_regressor/"
+        self._lin(ws["agg"], 0, 256, fs + "fc_layer0", 1, ws["f256"], 0, 256)
+        self._lin(ws["f256"], 0, 256, fs + "fc_layer1", 1, ws["f64"], 0, 64)
+        self._lin(ws["f64"], 0, 64, fs + "fc_layer2", 0, ws["z"], 0, 3)
+        _lib.check(L.dispu_sigmoid_offset(rm * 3, _p(ws["z"]), _p(coarse), _p(ws["fine"]), st), "sigmoid_offset")
+        return ws["coarse"], ws["fine"]
+
+    # -------------------------------------------------------------------------------------------------- loss ----
+    def _chamfer(self, pred, gt, inv_r, coef, dpred):
+        """1000-scaled-by-caller Chamfer value and d(coef * CD)/d pred written into dpred (loss_utils.py:45-64 with
+        nn_distance(gt, pred), gradient tf_nndistance.py:31-37)."""
+        L = _lib.lib()
+        ws = self._workspace(*self._shape)
+        B, n_gt, n_pred = gt.shape[0], gt.shape[1], pred.shape[1]
+        st = self.st
+        _lib.check(L.dispu_nn_distance(B, n_gt, _p(gt), n_pred, _p(pred), _p(ws["d_gt"]), _p(ws["i_gt"]), _p(ws["d_pred"]),
+                                       _p(ws["i_pred"]), _lib.ARITH_CONTRACT, st), "nn_distance")
+        _lib.check(L.dispu_row_mean_max(B, n_gt, _p(ws["d_gt"]), _p(ws["rowmean"]), _p(ws["rowmax"]), st), "row_mean")
+        fwd = ws["rowmean"].clone()
+        _lib.check(L.dispu_row_mean_max(B, n_pred, _p(ws["d_pred"]), _p(ws["rowmean"]), _p(ws["rowmax"]), st), "row_mean")
+        value = ((fwd + ws["rowmean"]) * inv_r).sum() / B
+        _lib.check(L.dispu_fill_rows(B, n_gt, _p(inv_r), coef / (n_gt * B), _p(ws["g_gt"]), st), "fill_rows")
+        _lib.check(L.dispu_fill_rows(B, n_pred, _p(inv_r), coef / (n_pred * B), _p(ws["g_pred"]), st), "fill_rows")
+        _lib.check(L.dispu_nn_distance_grad(B, n_gt, _p(gt), n_pred, _p(pred), _p(ws["g_gt"]), _p(ws["i_gt"]), _p(ws["g_pred"]),
+                                            _p(ws["i_pred"]), _p(ws["dgt_unused"]), _p(dpred), st), "nn_distance_grad")
+        return value
+
+    def loss_backward(self, gt, radius):
+        """pu_loss of model.py:75-87 at the current epoch; fills dcoarse / dfine with its gradient."""
+        L = _lib.lib()
+        B, N = self._shape
+        M = N * self.up_ratio
+        ws = self._workspace(B, N)
+        st = self.st
+        gt = gt.contiguous()
+        inv_r = (1.0 / radius.to(torch.float32)).contiguous()
+        wf = weight_fine(self.epoch)
+        cd_c = 1000.0 * self._chamfer(ws["coarse"], gt, inv_r, 1000.0, ws["dcoarse"])
+        cd_f = 1000.0 * self._chamfer(ws["fine"], gt, inv_r, 1000.0 * wf, ws["dfine"])
+        terms = {"dis_coarse_cd": cd_c, "dis_fine_cd": cd_f, "weight_fine": wf}
+        rep = torch.zeros((), dtype=torch.float32, device=self.device)
+        if self.opts.use_repulse:
+            fine = ws["fine"]
+            r07 = torch.full((B,), 0.07, dtype=torch.float32, device=self.device)
+            _lib.check(L.dispu_query_ball(B, M, M, _p(r07), 20, _p(fine), _p(fine), _p(ws["ball"]), _p(ws["ball_cnt"]),
+                                          _lib.ARITH_PLAIN, st), "query_ball")
+            _lib.check(L.dispu_repulsion(B * M, M, 20, 0, 0.001, _p(fine), _p(ws["ball"]), _p(ws["rep"]), st), "repulsion")
+            _lib.check(L.dispu_row_mean_max(B, M, _p(ws["rep"]), _p(ws["rowmean"]), _p(ws["rowmax"]), st), "row_mean")
+            rep = self.opts.repulsion_w * ws["rowmean"].sum() / (B * 4.0)
+            _lib.check(L.dispu_repulsion_grad(B * M, M, 20, 0.001, self.opts.repulsion_w / (B * M * 4.0), _p(fine), _p(ws["ball"]),
+                                              _p(ws["dfine"]), st), "repulsion_grad")
+        terms["repulsion_loss"] = rep
+        terms["pu_loss"] = cd_c + wf * cd_f + rep
+        return terms
+
+    # ---------------------------------------------------------------------------------------------- backward ----
+    def backward(self):
+        """gradients of pu_loss w.r.t. every trainable variable, accumulated into the flat gradient buffer."""
+        L = _lib.lib()
+        B, N = self._shape
+        M, k = N * self.up_ratio, K_NEIGH
+        rn, rm = B * N, B * M
+        ws = self._workspace(B, N)
+        st = self.st
+        P, G = self.P, self.G
+        coarse = ws["coarse"].view(rm, 3)
+        dcoarse, dfine = ws["dcoarse"].view(rm, 3), ws["dfine"].view(rm, 3)
+        ps = "refine/PointShuffle/"
+        fs = "refine/fine_coordinate_regressor/"
+
+        # fine = coarse + sigmoid(z) - 0.5
+        _lib.check(L.dispu_sigmoid_offset_grad(rm * 3, _p(ws["z"]), _p(dfine), _p(ws["dz"]), _p(dcoarse), st), "sigmoid_grad")
+        self._lin_bwd(ws["f64"], 0, 64, fs + "fc_layer2", 0, ws["z"], 0, 3, ws["dz"], 0, ws["df64"])
+        self._lin_bwd(ws["f256"], 0, 256, fs + "fc_layer1", 1, ws["f64"], 0, 64, ws["df64"], 0, ws["df256"])
+        self._lin_bwd(ws["agg"], 0, 256, fs + "fc_layer0", 1, ws["f256"], 0, 256, ws["df256"], 0, ws["dagg"])
+        self._lin_bwd(ws["sum"], 0, 256, ps + "aggregation", 1, ws["agg"], 0, 256, ws["dagg"], 0, ws["dsum"])
+        # sum = relu(after) + relu(skip) + relu(nl): the three branches share dsum, each masks its own copy
+        self._act_bias_grad(rm, 256, ws["dsum"], 0, ws["aft"], 0, 1, ws["daft"], 0, G[ps + "after_conv/biases"])
+        self._act_bias_grad(rm, 256, ws["dsum"], 0, ws["skip"], 0, 1, ws["dskip"], 0, G[ps + "skip/biases"])
+        self._act_bias_grad(rm, 256, ws["dsum"], 0, ws["nl"], 0, 1, ws["dnl"], 0, G[ps + "PointShuffle/conv_back_project/biases"])
+
+        # local cell
+        self._lin_bwd(ws["hp"], 0, 2048, ps + "after_conv", 1, ws["aft"], 0, 256, ws["daft"], 0, ws["dhp"], premasked=True, bias=False)
+        _lib.check(L.dispu_ps_point_matmul_grad(rm, k, 128, 16, _p(ws["h1"]), 128, _p(ws["wv"]), _p(ws["dhp"]), 2048, _p(ws["dh1"]),
+                                                128, _p(ws["dwv"]), st), "point_matmul_grad")
+        _lib.check(L.dispu_bn_train_grad(rm * k, 16, _p(ws["wl"]), 16, _p(ws["wv"]), 16, _p(ws["dwv"]), 16, _p(ws["bn_stats"]),
+                                         _p(P[BN + "gamma"]), 1, _p(ws["dwl"]), 16, _p(G[BN + "gamma"]), _p(G[BN + "beta"]),
+                                         _p(ws["bn_sums"]), _p(self._bn_scratch), self._bn_scratch.numel() * 8, st), "bn_train_grad")
+        dgf, gf = ws["dgf"], ws["gf"]
+        # skip branch first: its max_k gradient WRITES dgf, the convs then accumulate
+        self._lin_bwd(ws["gmax"], 0, 134, ps + "skip", 1, ws["skip"], 0, 256, ws["dskip"], 0, ws["dgmax"], premasked=True, bias=False)
+        _lib.check(L.dispu_max_k_grad(rm, k, 134, _p(gf), 134, _p(ws["gmax"]), 134, _p(ws["dgmax"]), 134, _p(dgf), 134, 0, st), "max_k_grad")
+        self._lin_bwd(gf, 0, 3, ps + "weight_net/wconv0", 0, ws["wl"], 0, 16, ws["dwl"], 0, dgf, 0, acc_dx=True)
+        self._lin_bwd(ws["h0"], 0, 128, ps + "conv1", 1, ws["h1"], 0, 128, ws["dh1"], 0, ws["dh0"])
+        self._lin_bwd(gf, 0, 134, ps + "conv0", 1, ws["h0"], 0, 128, ws["dh0"], 0, dgf, 0, acc_dx=True)
+
+        # non-local cell
+        self._lin_bwd(ws["att"], 0, 64, ps + "PointShuffle/conv_back_project", 1, ws["nl"], 0, 256, ws["dnl"], 0, ws["datt"],
+                      premasked=True, bias=False)
+        S, dS, kv, dkv, q = ws["S"], ws["dS"], ws["kv"], ws["dkv"], ws["q"]
+        # dP = dO . V^T
+        _lib.check(L.dispu_linear(B, M, 64, M, _p(ws["datt"]), 64, M * 64, _p(kv, 64), 128, M * 128, 1, None, 0, _p(dS), M, M * M,
+                                  None, 0, 0, None, 0, 0, st), "dP")
+        # dV = P^T . dO  -> dkv[:, 64:128]
+        self._tn(B, M, M, 64, S, 0, M, M * M, ws["datt"], 0, 64, M * 64, dkv, 64, 128, M * 128, 0)
+        _lib.check(L.dispu_softmax_rows_grad(rm, M, 0.125, _p(S), M, _p(dS), M, st), "softmax_grad")
+        # dQ = dS . K
+        _lib.check(L.dispu_linear(B, M, M, 64, _p(dS), M, M * M, _p(kv), 128, M * 128, 0, None, 0, _p(ws["dq"]), 64, M * 64,
+                                  None, 0, 0, None, 0, 0, st), "dQ")
+        # dK = dS^T . Q -> dkv[:, 0:64]
+        self._tn(B, M, M, 64, dS, 0, M, M * M, q, 0, 64, M * 64, dkv, 0, 128, M * 128, 0)
+        dup128 = ws["dup128"]
+        self._lin_bwd(ws["up128"], 0, 128, ps + "PointShuffle/conv_kv", 0, kv, 0, 128, dkv, 0, dup128)
+        self._lin_bwd(ws["up128"], 0, 128, ps + "PointShuffle/conv_query", 0, q, 0, 64, ws["dq"], 0, dup128, 0, acc_dx=True)
+        # grouping: dgf -> dcoarse, dup128
+        _lib.check(L.dispu_ps_group_grad(rm, M, k, 128, _p(ws["psidx"]), _p(dgf), 134, _p(dcoarse), _p(dup128), 128, st), "ps_group_grad")
+
+        # coarse regressor
+        cs = "generator/coarse_coordinate_regressor/"
+        self._lin_bwd(ws["c64"], 0, 64, cs + "fc_layer2", 0, coarse, 0, 3, dcoarse, 0, ws["dc64"])
+        self._lin_bwd(ws["c256"], 0, 256, cs + "fc_layer1", 1, ws["c64"], 0, 64, ws["dc64"], 0, ws["dc256"])
+        self._lin_bwd(ws["up128"], 0, 128, cs + "fc_layer0", 1, ws["c256"], 0, 256, ws["dc256"], 0, dup128, 0, acc_dx=True)
+        # duplicate_up
+        self._lin_bwd(ws["up256"], 0, 256, "generator/upshuffle_0/conv2", 1, ws["up128"], 0, 128, dup128, 0, ws["dup256"])
+        w1, dw1 = P["generator/upshuffle_0/conv1/weights"], G["generator/upshuffle_0/conv1/weights"]
+        self._act_bias_grad(rm, 256, ws["dup256"], 0, ws["up256"], 0, 1, ws["dup256"], 0, G["generator/upshuffle_0/conv1/biases"])
+        self._tn(1, rm, 2, 256, ws["gcode"], 0, 2, 0, ws["dup256"], 0, 256, 0, dw1, 480 * 256, 256, 0, 1)
+        _lib.check(L.dispu_dup_sum_grad(B, N, 256, self.up_ratio, _p(ws["dup256"]), 256, _p(ws["dh256"]), 256, st), "dup_sum_grad")
+        feat, dfeat = ws["feat"], ws["dfeat"]
+        self._lin_bwd(feat, 0, 480, None, 0, None, 0, 256, ws["dh256"], 0, dfeat, 0, bias=False, W=w1, dW=dw1)
+
+        # dense blocks, last to first
+        fe = "generator/feature_extraction_coarse/"
+        dE = ws["dedge"]
+        for (d, C, col, in_col, width) in reversed(self._blocks):
+            Eb = ws["edge"][d]
+            lde = dE.stride(0)
+            dE.zero_()
+            _lib.check(L.dispu_max_k_grad(rn, k, width, _p(Eb), Eb.stride(0), _p(feat, col), 480, _p(dfeat, col), 480, _p(dE), lde, 0, st),
+                       "max_k_grad")
+            sc = fe + "layer%d" % d
+            self._lin_bwd(Eb, 24, 48 + C, sc + "/l2", 0, Eb, 0, 24, dE, 0, dE, 24, acc_dx=True)
+            self._lin_bwd(Eb, 48, 24 + C, sc + "/l1", 1, Eb, 24, 24, dE, 24, dE, 48, acc_dx=True)
+            self._lin_bwd(Eb, 72, 2 * C, sc + "/l0", 1, Eb, 48, 24, dE, 48, dE, 72, acc_dx=True)
+            if d == 1:
+                dF, dfoff = dfeat, 456
+            else:
+                dF, dfoff = ws["dprep"], 0
+                dF.zero_()
+            _lib.check(L.dispu_edge_feature_grad(rn, N, k, C, _p(dE, 72), lde, _p(ws["kidx"][d]), k + 1, 1, _p(dF, dfoff), dF.stride(0), st),
+                       "edge_feature_grad")
+            if d > 1:
+                self._lin_bwd(feat, in_col, 480 - in_col, fe + "layer%d_prep" % d, 1, ws["prep"][d], 0, 48, ws["dprep"], 0,
+                              dfeat, in_col, acc_dx=True)
+        # layer0 (no activation, input has no gradient)
+        self._lin_bwd(self._x.view(rn, 3), 0, 3, fe + "layer0", 0, feat, 456, 24, dfeat, 456, None)
+
+    # -------------------------------------------------------------------------------------------------- step ----
+    def zero_grad(self):
+        self.flat_g.zero_()
+
+    def all_reduce_grads(self):
+        """ONE flat-bucket all-reduce (RCCL over xGMI) of the 4.2 MB gradient buffer; the 1/world average is folded
+        into the Adam launch."""
+        import torch.distributed as dist
+        if self.pg is not None or (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+            dist.all_reduce(self.flat_g, group=self.pg)
+            return dist.get_world_size(self.pg)
+        return 1
+
+    def adam(self, world=1):
+        """tf.train.AdamOptimizer(lr, beta1=opts.beta) (model.py:178)."""
+        self.adam_t += 1
+        b1, b2 = float(self.opts.beta), 0.999
+        lr = learning_rate(self.opts, self.epoch)
+        lr_t = lr * math.sqrt(1.0 - b2 ** self.adam_t) / (1.0 - b1 ** self.adam_t)
+        _lib.check(_lib.lib().dispu_adam(self.flat_p.numel(), _p(self.flat_p), _p(self.flat_g), _p(self.flat_m), _p(self.flat_v),
+                                         lr_t, b1, b2, 1e-8, 1.0 / world, _lib.stream_ptr(self.device)), "dispu_adam")
+
+    def train_step(self, inputs, gt, radius):
+        """one iteration of the loop body of Model.train (model.py:215-232) -> loss terms (device scalars)."""
+        self.zero_grad()
+        self.forward(inputs)
+        terms = self.loss_backward(gt, radius)
+        self.backward()
+        world = self.all_reduce_grads()
+        self.adam(world)
+        self.global_step += 1
+        return terms

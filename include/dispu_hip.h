@@ -224,6 +224,69 @@ int dispu_row_mean_max(int b, int n, const float* x, float* mean, float* mx, voi
 int dispu_repulsion(long rows, int n_per_cloud, int ns, int use_l1, float h, const float* pred, const int* idx, float* out,
                     void* stream);
 
+/* ---- training step (DisPU/model.py:68-87 loss, :158-178 AdamOptimizer.minimize) ---------------------------------
+ * The reference has no native code here: TF1 autodiff derives every gradient from the forward graph.  These entry
+ * points are those gradients written out; each cites the forward op it differentiates.  Convention: for a layer
+ * Y = act(X.W + b):  dZ = dY * act'(Y) (dispu_act_bias_grad, which also yields db = colsum dZ),
+ * dW = X^T.dZ (dispu_linear_tn),  dX = dZ.W^T (dispu_linear with transb = 1, R1 = dX to accumulate). */
+/* floats of scratch dispu_linear_tn needs for (batch, M, K, N). */
+long dispu_linear_tn_scratch_floats(int batch, int M, int K, int N);
+/* out[z][k][n] (+)= sum_m X[z][m][k] * Z[z][m][n]   (conv2d_backprop_filter of a 1x1 conv; the TN products of the
+ * attention backward, ops.py:326-339).  Deterministic: M-splits are summed in split order from `scratch`. */
+int dispu_linear_tn(int batch, int M, int K, int N, const float* X, long ldx, long sx, const float* Z, long ldz, long sz,
+                    float* out, long ldo, long so, int accumulate, float* scratch, long scratch_floats, void* stream);
+long dispu_act_bias_grad_scratch_floats(long rows, int n);
+/* dZ = dY * (act ? Y > 0 : 1) (relu_grad; dZ may alias dY or be NULL), dbias (+)= column sums of dZ (bias_add_grad;
+ * dbias may be NULL).  tf_util.py:100-115,170-185. */
+int dispu_act_bias_grad(long rows, int n, const float* dY, long lddy, const float* Y, long ldy, int act, float* dZ, long lddz,
+                        float* dbias, int accumulate, float* scratch, long scratch_floats, void* stream);
+/* tf.reduce_max over the neighbour axis, strided (ops.py:1915, :1049): out[i, c] = max_s X[(i*ns + s), c]. */
+int dispu_max_k(long rows, int ns, int c, const float* X, long ldx, float* out, long ldo, void* stream);
+/* its gradient (math_grad._MinOrMaxGrad: shared evenly by tied maxima). */
+int dispu_max_k_grad(long rows, int ns, int c, const float* X, long ldx, const float* Y, long ldy, const float* dY, long lddy,
+                     float* dX, long lddx, int accumulate, void* stream);
+/* gradient of get_edge_feature (ops.py:1856-1877): dF accumulates (atomics); dE [(rows*k), 2c]. */
+int dispu_edge_feature_grad(long rows, int n_per_cloud, int k, int c, const float* dE, long lde, const int* idx, int ldi,
+                            int ioff, float* dF, long lddf, void* stream);
+/* gradient of duplicate_up's tile (ops.py:1152-1199): dH[cloud*n + i] = sum_r dZ[(cloud*up + r)*n + i]. */
+int dispu_dup_sum_grad(int nclouds, int n, int co, int up, const float* dZ, long lddz, float* dH, long lddh, void* stream);
+/* PointShuffle2 grouping, materialised (ops.py:1030-1037): gf[(i,s), 0:6+cf] = [xyz_j - xyz_i | xyz_j | feat_j]. */
+int dispu_ps_group(long rows, int n_per_cloud, int k, int cf, const int* idx, const float* xyz, const float* feat, long ldf,
+                   float* gf, long ldg, void* stream);
+/* its gradient: dxyz [rows,3] and dfeat [rows, cf] accumulate (atomics). */
+int dispu_ps_group_grad(long rows, int n_per_cloud, int k, int cf, const int* idx, const float* dgf, long ldg, float* dxyz,
+                        float* dfeat, long lddf, void* stream);
+/* gradient of dispu_ps_point_matmul (tf.matmul, ops.py:1063-1064); k == t_n == 16, c == 128. */
+int dispu_ps_point_matmul_grad(long rows, int k, int c, int t_n, const float* X2, long ldx2, const float* wv, const float* dout,
+                               long ldo, float* dX2, long lddx2, float* dwv, void* stream);
+/* gradient of dispu_softmax_rows: dP <- mul * P * (dP - rowsum(dP * P)), in place. */
+int dispu_softmax_rows_grad(long rows, int n, float mul, const float* P, long ldp, float* dP, long lddp, void* stream);
+long dispu_bn_scratch_bytes(long rows, int c);
+/* contrib.layers.batch_norm in training mode (tf_util.py:512-531): batch statistics over the rows, eps, optional
+ * ReLU; stats[3c] = mean | biased var | 1/sqrt(var+eps); moving statistics updated in place with `decay`. */
+int dispu_bn_train(long rows, int c, const float* X, long ldx, const float* gamma, const float* beta, float eps, float decay,
+                   int act, float* Y, long ldy, float* stats, float* moving_mean, float* moving_var, void* scratch,
+                   long scratch_bytes, void* stream);
+/* its gradient: dX written, dgamma / dbeta accumulate, sums[2c] receives (sum dz | sum dz*xhat). */
+int dispu_bn_train_grad(long rows, int c, const float* X, long ldx, const float* Y, long ldy, const float* dY, long lddy,
+                        const float* stats, const float* gamma, int act, float* dX, long lddx, float* dgamma, float* dbeta,
+                        float* sums, void* scratch, long scratch_bytes, void* stream);
+/* out = base + sigmoid(z) - 0.5 (coordinate_regressor is_off, ops.py:1106-1108; generator.py:80-81) and its gradient
+ * (dz written; dbase accumulates when non-NULL). */
+int dispu_sigmoid_offset(long total, const float* z, const float* base, float* out, void* stream);
+int dispu_sigmoid_offset_grad(long total, const float* z, const float* dout, float* dz, float* dbase, void* stream);
+/* gradient of get_repulsion_loss (loss_utils.py:280-296) w.r.t. pred, times `scale`; dpred accumulates (atomics). */
+int dispu_repulsion_grad(long rows, int n_per_cloud, int ns, float h, float scale, const float* pred, const int* idx,
+                         float* dpred, void* stream);
+/* out = (a + b) + c  (tf.add x2, ops.py:1072-1075). */
+int dispu_add3(long total, const float* a, const float* b, const float* c, float* out, void* stream);
+/* out[b, j] = val[b] * mul (the constant rows d loss / d dist of chamfer's means, loss_utils.py:59-63). */
+int dispu_fill_rows(int b, int n, const float* val, float mul, float* out, void* stream);
+/* tf.train.AdamOptimizer update on flat buffers (model.py:178); g is scaled by gscale first (1/world after the
+ * gradient all-reduce). */
+int dispu_adam(long total, float* p, const float* g, float* m, float* v, float lr_t, float beta1, float beta2, float eps,
+               float gscale, void* stream);
+
 /* ---- whole-cloud inference glue (DisPU/model.py:306-381, Common/pc_util.py:83-92,147-161; host numpy/sklearn in
  * the reference, one patch at a time) -------------------------------------------------------------------------- */
 /* extract_knn_patch: for each of m queries the k nearest of the cloud's n points (k up to n, n <= 8192), ascending
