@@ -51,3 +51,37 @@ def upsample_sharded(forward, patches, group=None):
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     lo, hi = shard_bounds(patches.shape[0], rank, world)
     return all_gather_clouds(forward(patches[lo:hi]), n_items=patches.shape[0], group=group)
+
+
+def all_reduce_gradients(flat, group=None):
+    """Replica data parallelism of the training step (BASELINE config 5): ONE all-reduce(sum) of the
+    flat gradient bucket (every trainable variable, 4.2 MB fp32) per step.  Returns the world size; the 1/world
+    average is applied by the caller (folded into the Adam launch).  No-op without an initialised process group."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return 1
+    world = dist.get_world_size(group)
+    if world == 1:
+        return 1
+    if flat.is_cuda and dist.get_backend(group) == "gloo":
+        host = flat.detach().cpu()                       # smoke-test configuration only (ranks sharing a GPU)
+        dist.all_reduce(host, group=group)
+        flat.copy_(host)
+    else:
+        dist.all_reduce(flat, group=group)
+    return world
+
+
+def average_replica_stats(tensors, group=None):
+    """BatchNorm moving statistics are updated from per-rank batch statistics (the reference is single-GPU); averaging
+    the 2 x 16 floats after each step keeps the replicas bit-identical."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return
+    world = dist.get_world_size(group)
+    for t in tensors:
+        if t.is_cuda and dist.get_backend(group) == "gloo":
+            host = t.detach().cpu()
+            dist.all_reduce(host, group=group)
+            t.copy_(host / world)
+        else:
+            dist.all_reduce(t, group=group)
+            t.div_(world)

@@ -447,12 +447,12 @@ class Trainer(object):
 
     def all_reduce_grads(self):
         """ONE flat-bucket all-reduce (RCCL over xGMI) of the 4.2 MB gradient buffer; the 1/world average is folded
-        into the Adam launch."""
-        import torch.distributed as dist
-        if self.pg is not None or (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
-            dist.all_reduce(self.flat_g, group=self.pg)
-            return dist.get_world_size(self.pg)
-        return 1
+        into the Adam launch.  BN moving statistics (per-rank batch statistics) are averaged alongside."""
+        from . import parallel
+        world = parallel.all_reduce_gradients(self.flat_g, self.pg)
+        if world > 1:
+            parallel.average_replica_stats([self.moving_mean, self.moving_var], self.pg)
+        return world
 
     def adam(self, world=1):
         """tf.train.AdamOptimizer(lr, beta1=opts.beta) (model.py:178)."""

@@ -62,3 +62,48 @@ def test_shard_bounds_cover():
             b = [parallel.shard_bounds(n, r, w) for r in range(w)]
             assert b[0][0] == 0 and b[-1][1] == n and all(b[i][1] == b[i + 1][0] for i in range(w - 1))
             assert max(h - l for l, h in b) - min(h - l for l, h in b) <= 1
+
+
+# ---- training step: replica data parallelism (BASELINE config 5) -------------------------------------------
+def _grad_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from dispu_amd import parallel
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        # a least-squares "model": loss = mean over the batch of (x.w - y)^2; global batch 8 split contiguously
+        g = torch.Generator().manual_seed(3)
+        X, y, w = torch.randn(8, 5, generator=g, dtype=torch.float64), torch.randn(8, generator=g, dtype=torch.float64), torch.randn(5, generator=g, dtype=torch.float64)
+        lo, hi = parallel.shard_bounds(8, rank, world)
+        r = X[lo:hi] @ w - y[lo:hi]
+        flat = (2.0 * X[lo:hi].t() @ r / (hi - lo)).clone()              # gradient of this rank's mean loss
+        n = parallel.all_reduce_gradients(flat)
+        full = 2.0 * X.t() @ (X @ w - y) / 8                             # gradient of the global-batch mean loss
+        stats = [torch.full((16,), float(rank)), torch.full((16,), 10.0 + rank)]
+        parallel.average_replica_stats(stats)
+        q.put((rank, n, bool(torch.allclose(flat / n, full, rtol=1e-12, atol=1e-12)), float(stats[0][0]), float(stats[1][0])))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gradient_all_reduce_gloo_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_grad_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert [r[1] for r in res] == [2, 2]
+    assert all(r[2] for r in res)                          # averaged shard gradients == global-batch gradient
+    assert all(r[3] == 0.5 and r[4] == 10.5 for r in res)  # BN moving statistics averaged over the replicas
+
+
+def test_all_reduce_is_noop_without_process_group():
+    from dispu_amd import parallel
+    t = torch.arange(4.0)
+    assert parallel.all_reduce_gradients(t) == 1 and torch.equal(t, torch.arange(4.0))
