@@ -92,7 +92,7 @@ def main():
     import torch.distributed as dist
     from dispu_amd import synth
     from dispu_amd.generator import Generator
-    from oracle import generator as OG   # parameter initialiser + cpu_baseline only; never on the measured path
+    from dispu_amd.params import init_params
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -115,7 +115,7 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    params = OG.init_params(seed=1234)                        # Xavier-uniform, zero biases (reference init)
+    params = init_params(seed=1234)                           # Xavier-uniform, zero biases (reference init)
     gen = Generator(params=params, device=dev)
     x = torch.from_numpy(synth.patches(PATCHES_PER_GPU, NPOINT, seed=1000 * 2 + rank)).to(dev)   # 1000*config + rank
     gathered = torch.empty((world * PATCHES_PER_GPU, NPOINT * UP, 3), dtype=torch.float32, device=dev) if world > 1 else None

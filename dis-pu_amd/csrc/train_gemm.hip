@@ -21,8 +21,10 @@ struct TnArgs {
     const float* X; long ldx; long sx;
     const float* Z; long ldz; long sz;
     float* out; long ldo; long so;       // final destination [K][N] (row stride ldo, batch stride so)
-    float* part;                         // scratch [batch][splits][K][N] (compact) when splits > 1 or accumulate
-    int splits, rows_per_split, direct;  // direct: single split, no accumulate -> write `out` from the GEMM kernel
+    float* part;                         // scratch [batch][splits][K + 1][N] (compact) when splits > 1 or accumulate;
+                                         // row K of every partial = column sums of Z (the bias gradient)
+    int splits, rows_per_split, direct;  // direct: single split, no accumulate, no bias -> write `out` from the GEMM kernel
+    int want_bias;
 };
 
 constexpr int TN_SLAB = 32;              // rows of X / Z per LDS stage
@@ -53,6 +55,8 @@ __global__ __launch_bounds__(256) void linear_tn_kernel(TnArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    float bsum = 0.f;                    // column sum of Z for column n0 + threadIdx.x (K-tile 0 only)
+    const bool do_bias = a.want_bias && tk == 0 && threadIdx.x < BNT;
     for (int m0 = m_begin; m0 < m_end; m0 += TN_SLAB) {
         // stage the slab: lanes run along the columns (coalesced), zero fill outside the matrix
         for (int e = threadIdx.x; e < TN_SLAB * BKT; e += 256) {
@@ -80,6 +84,10 @@ __global__ __launch_bounds__(256) void linear_tn_kernel(TnArgs a) {
                 for (int jn = 0; jn < TNN; ++jn)
                     acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[jn], acc[i][jn], 0, 0, 0);
         }
+        if (do_bias) {
+#pragma unroll 8
+            for (int r = 0; r < TN_SLAB; ++r) bsum += zs[r * LDZS + threadIdx.x];
+        }
         __syncthreads();
     }
 
@@ -90,8 +98,9 @@ __global__ __launch_bounds__(256) void linear_tn_kernel(TnArgs a) {
         dst = a.out + (size_t)z * a.so;
         ldd = a.ldo;
     } else {
-        dst = a.part + ((size_t)z * a.splits + split) * (size_t)a.K * a.N;
+        dst = a.part + ((size_t)z * a.splits + split) * (size_t)(a.K + 1) * a.N;
         ldd = a.N;
+        if (do_bias && n0 + (int)threadIdx.x < a.N) dst[(size_t)a.K * a.N + n0 + threadIdx.x] = bsum;
     }
 #pragma unroll
     for (int i = 0; i < TK; ++i)
@@ -105,18 +114,46 @@ __global__ __launch_bounds__(256) void linear_tn_kernel(TnArgs a) {
             }
 }
 
-// out[z][k][n] = (accumulate ? out : 0) + sum_s part[z][s][k][n], s ascending.
-__global__ void tn_reduce_kernel(int batch, int K, int N, int splits, const float* __restrict__ part, float* __restrict__ out,
-                                 long ldo, long so, int accumulate) {
-    const size_t kn = (size_t)K * N, total = kn * batch;
-    for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
-        const size_t z = e / kn, r = e - z * kn;
-        const int k = (int)(r / N), n = (int)(r - (size_t)k * N);
-        float* o = out + z * so + (size_t)k * ldo + n;
-        float v = accumulate ? *o : 0.f;
-        const float* p = part + z * splits * kn + r;
-        for (int s = 0; s < splits; ++s) v += p[(size_t)s * kn];
-        *o = v;
+// out[z][k][n] = (accumulate ? out : 0) + sum_s part[z][s][k][n]; row K of the partials goes to dbias[n] (always
+// accumulating, batch 0..).  One workgroup = 64 consecutive outputs x 8 split groups: group g sums splits
+// g, g+8, ... (coalesced 256-byte rows), the 8 group sums are added in group order -> deterministic.
+__global__ __launch_bounds__(512) void tn_reduce_kernel(int batch, int K, int N, int splits, const float* __restrict__ part,
+                                                        float* __restrict__ out, long ldo, long so, int accumulate,
+                                                        float* __restrict__ dbias) {
+    __shared__ float red[8][64];
+    const size_t kn1 = (size_t)(K + 1) * N;
+    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const size_t chunks = (kn1 + 63) / 64;
+    for (size_t blk = blockIdx.x; blk < chunks * batch; blk += gridDim.x) {
+        const size_t z = blk / chunks, r = (blk - z * chunks) * 64 + lane;
+        float v = 0.f;
+        if (r < kn1) {
+            const float* p = part + z * splits * kn1 + r;
+            float v0 = 0.f, v1 = 0.f;
+            int s = grp;
+            for (; s + 8 < splits; s += 16) {
+                v0 += p[(size_t)s * kn1];
+                v1 += p[(size_t)(s + 8) * kn1];
+            }
+            if (s < splits) v0 += p[(size_t)s * kn1];
+            v = v0 + v1;
+        }
+        red[grp][lane] = v;
+        __syncthreads();
+        if (grp == 0 && r < kn1) {
+            float t = red[0][lane];
+#pragma unroll
+            for (int g = 1; g < 8; ++g) t += red[g][lane];
+            const int k = (int)(r / N), n = (int)(r - (size_t)k * N);
+            if (k < K) {
+                float* o = out + z * so + (size_t)k * ldo + n;
+                *o = accumulate ? *o + t : t;
+            } else if (dbias) {
+                if (batch == 1) dbias[n] += t;
+                else unsafeAtomicAdd(dbias + n, t);
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -124,8 +161,8 @@ static void tn_plan(int batch, int M, int K, int N, int& tk, int& tnn, int& spli
     tk = (K > 64) ? 2 : 1;
     tnn = (N > 64) ? 2 : 1;
     const int tiles = ((K + 64 * tk - 1) / (64 * tk)) * ((N + 64 * tnn - 1) / (64 * tnn)) * batch;
-    int want = (1024 + tiles - 1) / tiles;                        // aim at ~1024 workgroups (4 per CU)
-    const int max_splits = (M + 4 * TN_SLAB - 1) / (4 * TN_SLAB);  // at least 4 slabs per split
+    int want = (768 + tiles - 1) / tiles;                         // aim at ~768 workgroups (3 per CU)
+    const int max_splits = (M + 8 * TN_SLAB - 1) / (8 * TN_SLAB);  // at least 8 slabs (256 rows) per split
     splits = want < 1 ? 1 : want;
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
@@ -162,6 +199,18 @@ __global__ __launch_bounds__(256) void act_bias_grad_kernel(long rows, int n, in
     }
 }
 
+// mask only (no bias): flat, coalesced
+__global__ void act_mask_kernel(long rows, int n, const float* __restrict__ dY, long lddy, const float* __restrict__ Y, long ldy,
+                                float* __restrict__ dZ, long lddz) {
+    const size_t total = (size_t)rows * n;
+    for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const size_t r = e / n;
+        const int c = (int)(e - r * n);
+        const float g = dY[r * lddy + c];
+        dZ[r * lddz + c] = (Y[r * ldy + c] > 0.f) ? g : 0.f;
+    }
+}
+
 // out[j] = (accumulate ? out[j] : 0) + sum_s part[s][j]  (s ascending)
 __global__ void colsum_reduce_kernel(int n, int nparts, const float* __restrict__ part, float* __restrict__ out, int accumulate) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
@@ -190,16 +239,16 @@ DISPU_EXPORT long dispu_linear_tn_scratch_floats(int batch, int M, int K, int N)
     if (batch <= 0 || M <= 0 || K <= 0 || N <= 0) return 0;
     int tk, tnn, splits, rows;
     tn_plan(batch, M, K, N, tk, tnn, splits, rows);
-    return (long)batch * splits * K * N;
+    return (long)batch * splits * (K + 1) * N;
 }
 
 DISPU_EXPORT int dispu_linear_tn(int batch, int M, int K, int N, const float* X, long ldx, long sx, const float* Z, long ldz,
-                                 long sz, float* out, long ldo, long so, int accumulate, float* scratch, long scratch_floats,
-                                 void* stream) {
+                                 long sz, float* out, long ldo, long so, int accumulate, float* dbias, float* scratch,
+                                 long scratch_floats, void* stream) {
     if (batch < 0 || M < 0 || K < 0 || N < 0) return (int)hipErrorInvalidValue;
     if (batch == 0 || K == 0 || N == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
-    if (M == 0) {
+    if (M == 0) {   // nothing to add to dbias
         if (!accumulate)
             for (int z = 0; z < batch; ++z)
                 DISPU_TRY(hipMemset2DAsync(out + (size_t)z * so, sizeof(float) * ldo, 0, sizeof(float) * N, K, s));
@@ -207,9 +256,9 @@ DISPU_EXPORT int dispu_linear_tn(int batch, int M, int K, int N, const float* X,
     }
     int tk, tnn, splits, rows;
     tn_plan(batch, M, K, N, tk, tnn, splits, rows);
-    const int direct = (splits == 1 && !accumulate) ? 1 : 0;
-    if (!direct && (scratch == nullptr || scratch_floats < (long)batch * splits * K * N)) return (int)hipErrorInvalidValue;
-    TnArgs a{M, K, N, X, ldx, sx, Z, ldz, sz, out, ldo, so, scratch, splits, rows, direct};
+    const int direct = (splits == 1 && !accumulate && !dbias) ? 1 : 0;
+    if (!direct && (scratch == nullptr || scratch_floats < (long)batch * splits * (K + 1) * N)) return (int)hipErrorInvalidValue;
+    TnArgs a{M, K, N, X, ldx, sx, Z, ldz, sz, out, ldo, so, scratch, splits, rows, direct, dbias ? 1 : 0};
     const int tiles = ((K + 64 * tk - 1) / (64 * tk)) * ((N + 64 * tnn - 1) / (64 * tnn));
     dim3 grid(tiles, splits, batch);
     if (tk == 1 && tnn == 1) hipLaunchKernelGGL((linear_tn_kernel<1, 1>), grid, dim3(256), 0, s, a);
@@ -218,9 +267,10 @@ DISPU_EXPORT int dispu_linear_tn(int batch, int M, int K, int N, const float* X,
     else hipLaunchKernelGGL((linear_tn_kernel<2, 2>), grid, dim3(256), 0, s, a);
     DISPU_CHECK_LAUNCH();
     if (!direct) {
-        const size_t total = (size_t)batch * K * N;
-        const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
-        hipLaunchKernelGGL(tn_reduce_kernel, dim3(blocks), dim3(256), 0, s, batch, K, N, splits, scratch, out, ldo, so, accumulate);
+        const size_t chunks = (((size_t)(K + 1) * N + 63) / 64) * batch;
+        const int blocks = (int)(chunks > 8192 ? 8192 : chunks);
+        hipLaunchKernelGGL(tn_reduce_kernel, dim3(blocks), dim3(512), 0, s, batch, K, N, splits, scratch, out, ldo, so, accumulate,
+                           dbias);
         DISPU_CHECK_LAUNCH();
     }
     return 0;
@@ -241,6 +291,13 @@ DISPU_EXPORT int dispu_act_bias_grad(long rows, int n, const float* dY, long ldd
     if (rows == 0) {
         if (dbias && !accumulate) DISPU_TRY(hipMemsetAsync(dbias, 0, sizeof(float) * n, s));
         return 0;
+    }
+    if (!dbias) {
+        if (!act || !dZ) return 0;
+        const size_t total = (size_t)rows * n;
+        const size_t g = (total + 255) / 256;
+        hipLaunchKernelGGL(act_mask_kernel, dim3((unsigned)(g > 32768 ? 32768 : g)), dim3(256), 0, s, rows, n, dY, lddy, Y, ldy, dZ, lddz);
+        return (int)hipGetLastError();
     }
     int rpb;
     const int nb = bias_blocks(rows, rpb);

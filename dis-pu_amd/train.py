@@ -162,12 +162,12 @@ class Trainer(object):
         _lib.check(L.dispu_linear(1, M, K, N, _p(X, xoff), X.stride(0), 0, _p(W, woff), W.stride(0), 0, 0, _p(b), act,
                                   _p(Y, yoff), Y.stride(0), 0, None, 0, 0, None, 0, 0, self.st), "dispu_linear")
 
-    def _tn(self, batch, M, K, N, X, xoff, ldx, sx, Zt, zoff, ldz, sz, out, ooff, ldo, so, accumulate):
+    def _tn(self, batch, M, K, N, X, xoff, ldx, sx, Zt, zoff, ldz, sz, out, ooff, ldo, so, accumulate, dbias=None):
         L = _lib.lib()
         need = L.dispu_linear_tn_scratch_floats(batch, M, K, N)
         sc = self._scratch_floats(need)
         _lib.check(L.dispu_linear_tn(batch, M, K, N, _p(X, xoff), ldx, sx, _p(Zt, zoff), ldz, sz, _p(out, ooff), ldo, so,
-                                     accumulate, _p(sc), sc.numel(), self.st), "dispu_linear_tn")
+                                     accumulate, _p(dbias), _p(sc), sc.numel(), self.st), "dispu_linear_tn")
 
     def _act_bias_grad(self, M, N, dY, dyoff, Y, yoff, act, dZ, dzoff, dbias):
         L = _lib.lib()
@@ -187,9 +187,9 @@ class Trainer(object):
         W = self.P[wname + "/weights"] if W is None else W
         dW = self.G[wname + "/weights"] if dW is None else dW
         db = self.G[wname + "/biases"] if bias else None
-        if bias or (act and not premasked):
-            self._act_bias_grad(M, N, dY, dyoff, Y, yoff, 0 if premasked else act, None if premasked else dY, dyoff, db)
-        self._tn(1, M, K, N, X, xoff, X.stride(0), 0, dY, dyoff, dY.stride(0), 0, dW, woff, dW.stride(0), 0, 1)
+        if act and not premasked:
+            self._act_bias_grad(M, N, dY, dyoff, Y, yoff, act, dY, dyoff, None)          # relu_grad, in place
+        self._tn(1, M, K, N, X, xoff, X.stride(0), 0, dY, dyoff, dY.stride(0), 0, dW, woff, dW.stride(0), 0, 1, dbias=db)
         if dX is not None:
             _lib.check(L.dispu_linear(1, M, N, K, _p(dY, dyoff), dY.stride(0), 0, _p(W, woff), W.stride(0), 0, 1, None, 0,
                                       _p(dX, dxoff), dX.stride(0), 0, _p(dX, dxoff) if acc_dx else None,
@@ -361,12 +361,12 @@ class Trainer(object):
         self._lin_bwd(ws["agg"], 0, 256, fs + "fc_layer0", 1, ws["f256"], 0, 256, ws["df256"], 0, ws["dagg"])
         self._lin_bwd(ws["sum"], 0, 256, ps + "aggregation", 1, ws["agg"], 0, 256, ws["dagg"], 0, ws["dsum"])
         # sum = relu(after) + relu(skip) + relu(nl): the three branches share dsum, each masks its own copy
-        self._act_bias_grad(rm, 256, ws["dsum"], 0, ws["aft"], 0, 1, ws["daft"], 0, G[ps + "after_conv/biases"])
-        self._act_bias_grad(rm, 256, ws["dsum"], 0, ws["skip"], 0, 1, ws["dskip"], 0, G[ps + "skip/biases"])
-        self._act_bias_grad(rm, 256, ws["dsum"], 0, ws["nl"], 0, 1, ws["dnl"], 0, G[ps + "PointShuffle/conv_back_project/biases"])
+        self._act_bias_grad(rm, 256, ws["dsum"], 0, ws["aft"], 0, 1, ws["daft"], 0, None)
+        self._act_bias_grad(rm, 256, ws["dsum"], 0, ws["skip"], 0, 1, ws["dskip"], 0, None)
+        self._act_bias_grad(rm, 256, ws["dsum"], 0, ws["nl"], 0, 1, ws["dnl"], 0, None)
 
         # local cell
-        self._lin_bwd(ws["hp"], 0, 2048, ps + "after_conv", 1, ws["aft"], 0, 256, ws["daft"], 0, ws["dhp"], premasked=True, bias=False)
+        self._lin_bwd(ws["hp"], 0, 2048, ps + "after_conv", 1, ws["aft"], 0, 256, ws["daft"], 0, ws["dhp"], premasked=True)
         _lib.check(L.dispu_ps_point_matmul_grad(rm, k, 128, 16, _p(ws["h1"]), 128, _p(ws["wv"]), _p(ws["dhp"]), 2048, _p(ws["dh1"]),
                                                 128, _p(ws["dwv"]), st), "point_matmul_grad")
         _lib.check(L.dispu_bn_train_grad(rm * k, 16, _p(ws["wl"]), 16, _p(ws["wv"]), 16, _p(ws["dwv"]), 16, _p(ws["bn_stats"]),
@@ -374,7 +374,7 @@ class Trainer(object):
                                          _p(ws["bn_sums"]), _p(self._bn_scratch), self._bn_scratch.numel() * 8, st), "bn_train_grad")
         dgf, gf = ws["dgf"], ws["gf"]
         # skip branch first: its max_k gradient WRITES dgf, the convs then accumulate
-        self._lin_bwd(ws["gmax"], 0, 134, ps + "skip", 1, ws["skip"], 0, 256, ws["dskip"], 0, ws["dgmax"], premasked=True, bias=False)
+        self._lin_bwd(ws["gmax"], 0, 134, ps + "skip", 1, ws["skip"], 0, 256, ws["dskip"], 0, ws["dgmax"], premasked=True)
         _lib.check(L.dispu_max_k_grad(rm, k, 134, _p(gf), 134, _p(ws["gmax"]), 134, _p(ws["dgmax"]), 134, _p(dgf), 134, 0, st), "max_k_grad")
         self._lin_bwd(gf, 0, 3, ps + "weight_net/wconv0", 0, ws["wl"], 0, 16, ws["dwl"], 0, dgf, 0, acc_dx=True)
         self._lin_bwd(ws["h0"], 0, 128, ps + "conv1", 1, ws["h1"], 0, 128, ws["dh1"], 0, ws["dh0"])
@@ -382,7 +382,7 @@ class Trainer(object):
 
         # non-local cell
         self._lin_bwd(ws["att"], 0, 64, ps + "PointShuffle/conv_back_project", 1, ws["nl"], 0, 256, ws["dnl"], 0, ws["datt"],
-                      premasked=True, bias=False)
+                      premasked=True)
         S, dS, kv, dkv, q = ws["S"], ws["dS"], ws["kv"], ws["dkv"], ws["q"]
         # dP = dO . V^T
         _lib.check(L.dispu_linear(B, M, 64, M, _p(ws["datt"]), 64, M * 64, _p(kv, 64), 128, M * 128, 1, None, 0, _p(dS), M, M * M,
@@ -409,8 +409,9 @@ class Trainer(object):
         # duplicate_up
         self._lin_bwd(ws["up256"], 0, 256, "generator/upshuffle_0/conv2", 1, ws["up128"], 0, 128, dup128, 0, ws["dup256"])
         w1, dw1 = P["generator/upshuffle_0/conv1/weights"], G["generator/upshuffle_0/conv1/weights"]
-        self._act_bias_grad(rm, 256, ws["dup256"], 0, ws["up256"], 0, 1, ws["dup256"], 0, G["generator/upshuffle_0/conv1/biases"])
-        self._tn(1, rm, 2, 256, ws["gcode"], 0, 2, 0, ws["dup256"], 0, 256, 0, dw1, 480 * 256, 256, 0, 1)
+        self._act_bias_grad(rm, 256, ws["dup256"], 0, ws["up256"], 0, 1, ws["dup256"], 0, None)
+        self._tn(1, rm, 2, 256, ws["gcode"], 0, 2, 0, ws["dup256"], 0, 256, 0, dw1, 480 * 256, 256, 0, 1,
+                 dbias=G["generator/upshuffle_0/conv1/biases"])
         _lib.check(L.dispu_dup_sum_grad(B, N, 256, self.up_ratio, _p(ws["dup256"]), 256, _p(ws["dh256"]), 256, st), "dup_sum_grad")
         feat, dfeat = ws["feat"], ws["dfeat"]
         self._lin_bwd(feat, 0, 480, None, 0, None, 0, 256, ws["dh256"], 0, dfeat, 0, bias=False, W=w1, dW=dw1)

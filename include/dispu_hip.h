@@ -232,9 +232,11 @@ int dispu_repulsion(long rows, int n_per_cloud, int ns, int use_l1, float h, con
 /* floats of scratch dispu_linear_tn needs for (batch, M, K, N). */
 long dispu_linear_tn_scratch_floats(int batch, int M, int K, int N);
 /* out[z][k][n] (+)= sum_m X[z][m][k] * Z[z][m][n]   (conv2d_backprop_filter of a 1x1 conv; the TN products of the
- * attention backward, ops.py:326-339).  Deterministic: M-splits are summed in split order from `scratch`. */
+ * attention backward, ops.py:326-339);  dbias[n] += sum_m Z[m][n] when non-NULL (bias_add_grad rides along as one
+ * extra output row).  Deterministic: M-splits are summed in a fixed order from `scratch`. */
 int dispu_linear_tn(int batch, int M, int K, int N, const float* X, long ldx, long sx, const float* Z, long ldz, long sz,
-                    float* out, long ldo, long so, int accumulate, float* scratch, long scratch_floats, void* stream);
+                    float* out, long ldo, long so, int accumulate, float* dbias, float* scratch, long scratch_floats,
+                    void* stream);
 long dispu_act_bias_grad_scratch_floats(long rows, int n);
 /* dZ = dY * (act ? Y > 0 : 1) (relu_grad; dZ may alias dY or be NULL), dbias (+)= column sums of dZ (bias_add_grad;
  * dbias may be NULL).  tf_util.py:100-115,170-185. */

@@ -39,3 +39,12 @@ def test_linear_is_an_fma_chain():
                 acc = np.float32(np.float64(x[r, k]) * np.float64(w[k, o]) + np.float64(acc))   # exact product, one rounding
             want[r, o] = max(np.float32(acc + b[o]), np.float32(0))
     assert np.array_equal(got, want)
+
+
+def test_product_initialiser_matches_oracle_inventory():
+    """dis-pu_amd/params.py (what bench.py / the trainer use) lists the same variables, shapes and Xavier draws."""
+    from dispu_amd import params as PP
+    a, b = OG.init_params(1234), PP.init_params(1234)
+    assert list(a) == list(b)
+    assert all(np.array_equal(a[k], b[k]) for k in a)
+    assert PP.num_params(b) == OG.num_params(a) + 32           # + BN gamma / beta

@@ -69,11 +69,19 @@ def test_linear_tn(dev, L, batch, M, K, N, ldx, ldz, acc):
     out0 = rng.standard_normal((batch, K, N)).astype(np.float32)
     ref = np.einsum("zmk,zmn->zkn", X[:, :, :K].astype(np.float64), Z[:, :, :N].astype(np.float64)) + (out0 if acc else 0)
     x, z, o = dv(X, dev), dv(Z, dev), dv(out0, dev)
+    db0 = rng.standard_normal(N).astype(np.float32)
+    db = dv(db0, dev)
     need = L.lib().dispu_linear_tn_scratch_floats(batch, M, K, N)
     sc = torch.empty(max(need, 1), dtype=torch.float32, device=dev)
-    L.check(L.lib().dispu_linear_tn(batch, M, K, N, p(x), ldx, M * ldx, p(z), ldz, M * ldz, p(o), N, K * N, acc, p(sc), sc.numel(),
-                                    L.stream_ptr(dev)), "linear_tn")
+    L.check(L.lib().dispu_linear_tn(batch, M, K, N, p(x), ldx, M * ldx, p(z), ldz, M * ldz, p(o), N, K * N, acc, p(db), p(sc),
+                                    sc.numel(), L.stream_ptr(dev)), "linear_tn")
     close(N_(o), ref, 2e-5 if M > 2000 else 1e-5, "linear_tn")
+    close(N_(db), db0 + Z[:, :, :N].astype(np.float64).sum((0, 1)), 2e-5, "linear_tn bias row")
+    if not acc:     # without a bias request a single split writes the result directly
+        o2 = torch.empty((batch, K, N), dtype=torch.float32, device=dev)
+        L.check(L.lib().dispu_linear_tn(batch, M, K, N, p(x), ldx, M * ldx, p(z), ldz, M * ldz, p(o2), N, K * N, 0, None, p(sc),
+                                        sc.numel(), L.stream_ptr(dev)), "linear_tn")
+        assert torch.equal(o2, o)
 
 
 def N_(t):

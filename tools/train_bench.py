@@ -1,0 +1,90 @@
+#!/usr/bin/env python3
+"""Training-step benchmark (BASELINE configs[4] shape: full train step, data-parallel over the ranks, RCCL gradient
+all-reduce; fp32 here -- the reference is fp32-only).  Not the driver's headline bench (that is bench.py, configs[1]).
+
+    python tools/train_bench.py --batch 8 --steps 20                 # one GPU, 8 patches (config 5's per-GPU share)
+    python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 tools/train_bench.py --batch 8
+
+Prints one JSON line on rank 0: ms/step (max over ranks), patches/s (all ranks), and the per-phase split measured
+with HIP events on rank 0 (forward / loss+its gradient / backward / all-reduce+Adam)."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=8, help="patches per GPU")
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    args = ap.parse_args()
+    from dispu_amd import synth
+    from dispu_amd.train import Trainer
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    # weights: Xavier-uniform, seed 1234 (identical on every rank) -- generated without the oracle package
+    from dispu_amd.params import init_params
+    P = init_params(1234)
+    tr = Trainer(params=P, device=dev)
+    x, gt = synth.patch_with_gt(args.batch, 256, 1024, seed=5000 + rank)
+    x, gt = torch.from_numpy(x).to(dev), torch.from_numpy(gt).to(dev)
+    radius = torch.ones(args.batch, device=dev)
+
+    for _ in range(args.warmup):
+        tr.train_step(x, gt, radius)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        terms = tr.train_step(x, gt, radius)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    phases = {}
+    if rank == 0:
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+        acc = np.zeros(4)
+        for _ in range(5):
+            tr.zero_grad()
+            ev[0].record()
+            tr.forward(x)
+            ev[1].record()
+            tr.loss_backward(gt, radius)
+            ev[2].record()
+            tr.backward()
+            ev[3].record()
+            tr.adam(tr.all_reduce_grads())
+            ev[4].record()
+            torch.cuda.synchronize()
+            acc += [ev[i].elapsed_time(ev[i + 1]) for i in range(4)]
+        phases = dict(zip(("forward_ms", "loss_ms", "backward_ms", "allreduce_adam_ms"), (acc / 5).round(3).tolist()))
+        print(json.dumps({"metric": "training patches/sec (256->1024 generator, full step)", "value": world * args.batch * args.steps / dt,
+                          "unit": "patches/s", "n_gpus": world, "patches_per_gpu": args.batch, "steps": args.steps,
+                          "ms_per_step": dt / args.steps * 1e3, "dtype": "f32", "pu_loss": float(terms["pu_loss"]), **phases}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
