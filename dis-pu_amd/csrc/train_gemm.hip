@@ -27,25 +27,33 @@ struct TnArgs {
     int want_bias;
 };
 
-constexpr int TN_SLAB = 32;              // rows of X / Z per LDS stage
+constexpr int TN_SLAB = 16;              // rows of X / Z per LDS stage
 
-// block = 2 x 2 waves; wave tile (32*TK) x (32*TN); block tile (64*TK) x (64*TN)
-template <int TK, int TNN>
+// block = 2 x 2 waves; wave tile (32*TK) x (32*TNN); block tile (64*TK) x (64*TNN).
+// Same pipeline as the forward GEMM (linear.hip): the next slab is already in registers and is parked in the other
+// LDS stage while this stage's MFMAs run; one barrier per slab.  EDGE = false: every slab and tile is interior and
+// 16-byte aligned -> no predicates.
+template <int TK, int TNN, bool EDGE>
 __global__ __launch_bounds__(256) void linear_tn_kernel(TnArgs a) {
     constexpr int BKT = 64 * TK, BNT = 64 * TNN;
     constexpr int LDXS = BKT + 32, LDZS = BNT + 32;      // +32 floats: the two half-waves of an operand read hit disjoint banks
-    __shared__ float xs[TN_SLAB * LDXS];
-    __shared__ float zs[TN_SLAB * LDZS];
+    constexpr int STAGE = TN_SLAB * (LDXS + LDZS);
+    constexpr int X_F4 = TN_SLAB * BKT / 4 / 256, Z_F4 = TN_SLAB * BNT / 4 / 256;
+    static_assert(X_F4 >= 1 && Z_F4 >= 1, "slab too small for the workgroup");
+    extern __shared__ __attribute__((aligned(16))) float tn_lds[];
     const int ntn = (a.N + BNT - 1) / BNT;
     const int tk = blockIdx.x / ntn, tn = blockIdx.x - tk * ntn;
     const int k0 = tk * BKT, n0 = tn * BNT;
     const int split = blockIdx.y, z = blockIdx.z;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
     const int wk = wave >> 1, wn = wave & 1;
     const float* __restrict__ X = a.X + (size_t)z * a.sx;
     const float* __restrict__ Z = a.Z + (size_t)z * a.sz;
     const int m_begin = split * a.rows_per_split;
     const int m_end = min(a.M, m_begin + a.rows_per_split);
+    const bool x_vec = ((a.ldx & 3) == 0) && ((((uintptr_t)X) & 15) == 0);
+    const bool z_vec = ((a.ldz & 3) == 0) && ((((uintptr_t)Z) & 15) == 0);
 
     v16f acc[TK][TNN];
 #pragma unroll
@@ -55,29 +63,72 @@ __global__ __launch_bounds__(256) void linear_tn_kernel(TnArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    float bsum = 0.f;                    // column sum of Z for column n0 + threadIdx.x (K-tile 0 only)
-    const bool do_bias = a.want_bias && tk == 0 && threadIdx.x < BNT;
-    for (int m0 = m_begin; m0 < m_end; m0 += TN_SLAB) {
-        // stage the slab: lanes run along the columns (coalesced), zero fill outside the matrix
-        for (int e = threadIdx.x; e < TN_SLAB * BKT; e += 256) {
-            const int r = e / BKT, c = e - r * BKT;
-            const int m = m0 + r, k = k0 + c;
-            xs[r * LDXS + c] = (m < m_end && k < a.K) ? X[(size_t)m * a.ldx + k] : 0.f;
+    // one float4 of a row-major slab: element (m0 + r, c0 + 4*q)
+    auto load4 = [&](const float* __restrict__ P, long ld, bool vec, int m0, int c0, int climit, int width, int it) -> float4 {
+        const int idx = tid + it * 256;
+        const int r = idx / (width / 4), q = idx % (width / 4);
+        const int m = m0 + r, c = c0 + q * 4;
+        if constexpr (!EDGE) return *reinterpret_cast<const float4*>(P + (size_t)m * ld + c);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (m < m_end && c < climit) {
+            const float* p = P + (size_t)m * ld + c;
+            if (vec && c + 3 < climit) {
+                v = *reinterpret_cast<const float4*>(p);
+            } else {
+                v.x = p[0];
+                if (c + 1 < climit) v.y = p[1];
+                if (c + 2 < climit) v.z = p[2];
+                if (c + 3 < climit) v.w = p[3];
+            }
         }
-        for (int e = threadIdx.x; e < TN_SLAB * BNT; e += 256) {
-            const int r = e / BNT, c = e - r * BNT;
-            const int m = m0 + r, n = n0 + c;
-            zs[r * LDZS + c] = (m < m_end && n < a.N) ? Z[(size_t)m * a.ldz + n] : 0.f;
+        return v;
+    };
+    float4 px[X_F4], pz[Z_F4];
+    auto load_slab = [&](int m0) {
+#pragma unroll
+        for (int it = 0; it < X_F4; ++it) px[it] = load4(X, a.ldx, x_vec, m0, k0, a.K, BKT, it);
+#pragma unroll
+        for (int it = 0; it < Z_F4; ++it) pz[it] = load4(Z, a.ldz, z_vec, m0, n0, a.N, BNT, it);
+    };
+    auto store_slab = [&](int stage) {
+        float* xs = tn_lds + stage * STAGE;
+        float* zs = xs + TN_SLAB * LDXS;
+#pragma unroll
+        for (int it = 0; it < X_F4; ++it) {
+            const int idx = tid + it * 256;
+            *reinterpret_cast<float4*>(&xs[(idx / (BKT / 4)) * LDXS + (idx % (BKT / 4)) * 4]) = px[it];
         }
-        __syncthreads();
-#pragma unroll 4
-        for (int j = 0; j < TN_SLAB / 2; ++j) {
-            const int row = 2 * j + (lane >> 5);
+#pragma unroll
+        for (int it = 0; it < Z_F4; ++it) {
+            const int idx = tid + it * 256;
+            *reinterpret_cast<float4*>(&zs[(idx / (BNT / 4)) * LDZS + (idx % (BNT / 4)) * 4]) = pz[it];
+        }
+    };
+
+    float bsum = 0.f;                    // column sum of Z for column n0 + tid (K-tile 0 only)
+    const bool do_bias = a.want_bias && tk == 0 && tid < BNT;
+    const int nslab = (m_end - m_begin + TN_SLAB - 1) / TN_SLAB;
+    if (nslab > 0) {
+        load_slab(m_begin);
+        store_slab(0);
+        if (nslab > 1) load_slab(m_begin + TN_SLAB);
+    }
+    __syncthreads();
+    const int fi = lane & 31, fk = lane >> 5;
+    for (int t = 0; t < nslab; ++t) {
+        const float* xs = tn_lds + (t & 1) * STAGE;
+        const float* zs = xs + TN_SLAB * LDXS;
+        if (t + 1 < nslab) {
+            store_slab((t + 1) & 1);
+            if (t + 2 < nslab) load_slab(m_begin + (t + 2) * TN_SLAB);
+        }
+#pragma unroll
+        for (int kk = 0; kk < TN_SLAB; kk += 2) {
             float af[TK], bf[TNN];
 #pragma unroll
-            for (int i = 0; i < TK; ++i) af[i] = xs[row * LDXS + (wk * TK + i) * 32 + (lane & 31)];
+            for (int i = 0; i < TK; ++i) af[i] = xs[(kk + fk) * LDXS + (wk * TK + i) * 32 + fi];
 #pragma unroll
-            for (int i = 0; i < TNN; ++i) bf[i] = zs[row * LDZS + (wn * TNN + i) * 32 + (lane & 31)];
+            for (int j = 0; j < TNN; ++j) bf[j] = zs[(kk + fk) * LDZS + (wn * TNN + j) * 32 + fi];
 #pragma unroll
             for (int i = 0; i < TK; ++i)
 #pragma unroll
@@ -85,8 +136,8 @@ __global__ __launch_bounds__(256) void linear_tn_kernel(TnArgs a) {
                     acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[jn], acc[i][jn], 0, 0, 0);
         }
         if (do_bias) {
-#pragma unroll 8
-            for (int r = 0; r < TN_SLAB; ++r) bsum += zs[r * LDZS + threadIdx.x];
+#pragma unroll
+            for (int r = 0; r < TN_SLAB; ++r) bsum += zs[r * LDZS + tid];
         }
         __syncthreads();
     }
@@ -100,7 +151,7 @@ __global__ __launch_bounds__(256) void linear_tn_kernel(TnArgs a) {
     } else {
         dst = a.part + ((size_t)z * a.splits + split) * (size_t)(a.K + 1) * a.N;
         ldd = a.N;
-        if (do_bias && n0 + (int)threadIdx.x < a.N) dst[(size_t)a.K * a.N + n0 + threadIdx.x] = bsum;
+        if (do_bias && n0 + tid < a.N) dst[(size_t)a.K * a.N + n0 + tid] = bsum;
     }
 #pragma unroll
     for (int i = 0; i < TK; ++i)
@@ -108,10 +159,23 @@ __global__ __launch_bounds__(256) void linear_tn_kernel(TnArgs a) {
         for (int jn = 0; jn < TNN; ++jn)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int k = k0 + (wk * TK + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                const int n = n0 + (wn * TNN + jn) * 32 + (lane & 31);
-                if (k < a.K && n < a.N) dst[(size_t)k * ldd + n] = acc[i][jn][r];
+                const int k = k0 + (wk * TK + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
+                const int n = n0 + (wn * TNN + jn) * 32 + fi;
+                if (!EDGE || (k < a.K && n < a.N)) dst[(size_t)k * ldd + n] = acc[i][jn][r];
             }
+}
+
+template <int TK, int TNN, bool EDGE>
+static int launch_tn(const TnArgs& a, dim3 grid, hipStream_t s) {
+    constexpr size_t bytes = (size_t)2 * TN_SLAB * (64 * TK + 32 + 64 * TNN + 32) * sizeof(float);
+    static_assert(bytes <= 64 * 1024, "TN stage exceeds the default dynamic LDS limit");
+    hipLaunchKernelGGL((linear_tn_kernel<TK, TNN, EDGE>), grid, dim3(256), bytes, s, a);
+    return (int)hipGetLastError();
+}
+
+template <int TK, int TNN>
+static int launch_tn_e(const TnArgs& a, dim3 grid, bool edge, hipStream_t s) {
+    return edge ? launch_tn<TK, TNN, true>(a, grid, s) : launch_tn<TK, TNN, false>(a, grid, s);
 }
 
 // out[z][k][n] = (accumulate ? out : 0) + sum_s part[z][s][k][n]; row K of the partials goes to dbias[n] (always
@@ -159,10 +223,10 @@ __global__ __launch_bounds__(512) void tn_reduce_kernel(int batch, int K, int N,
 
 static void tn_plan(int batch, int M, int K, int N, int& tk, int& tnn, int& splits, int& rows) {
     tk = (K > 64) ? 2 : 1;
-    tnn = (N > 64) ? 2 : 1;
+    tnn = (N > 128) ? 4 : (N > 64) ? 2 : 1;
     const int tiles = ((K + 64 * tk - 1) / (64 * tk)) * ((N + 64 * tnn - 1) / (64 * tnn)) * batch;
     int want = (768 + tiles - 1) / tiles;                         // aim at ~768 workgroups (3 per CU)
-    const int max_splits = (M + 8 * TN_SLAB - 1) / (8 * TN_SLAB);  // at least 8 slabs (256 rows) per split
+    const int max_splits = (M + 16 * TN_SLAB - 1) / (16 * TN_SLAB);  // at least 16 slabs (256 rows) per split
     splits = want < 1 ? 1 : want;
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
@@ -261,11 +325,16 @@ DISPU_EXPORT int dispu_linear_tn(int batch, int M, int K, int N, const float* X,
     TnArgs a{M, K, N, X, ldx, sx, Z, ldz, sz, out, ldo, so, scratch, splits, rows, direct, dbias ? 1 : 0};
     const int tiles = ((K + 64 * tk - 1) / (64 * tk)) * ((N + 64 * tnn - 1) / (64 * tnn));
     dim3 grid(tiles, splits, batch);
-    if (tk == 1 && tnn == 1) hipLaunchKernelGGL((linear_tn_kernel<1, 1>), grid, dim3(256), 0, s, a);
-    else if (tk == 2 && tnn == 1) hipLaunchKernelGGL((linear_tn_kernel<2, 1>), grid, dim3(256), 0, s, a);
-    else if (tk == 1 && tnn == 2) hipLaunchKernelGGL((linear_tn_kernel<1, 2>), grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((linear_tn_kernel<2, 2>), grid, dim3(256), 0, s, a);
-    DISPU_CHECK_LAUNCH();
+    const bool edge = !(K % (64 * tk) == 0 && N % (64 * tnn) == 0 && M % TN_SLAB == 0 && (ldx & 3) == 0 && (ldz & 3) == 0 &&
+                        (sx & 3) == 0 && (sz & 3) == 0 && (((uintptr_t)X) & 15) == 0 && (((uintptr_t)Z) & 15) == 0);
+    int rc;
+    if (tk == 1 && tnn == 1) rc = launch_tn_e<1, 1>(a, grid, edge, s);
+    else if (tk == 1 && tnn == 2) rc = launch_tn_e<1, 2>(a, grid, edge, s);
+    else if (tk == 1) rc = launch_tn_e<1, 4>(a, grid, edge, s);
+    else if (tnn == 1) rc = launch_tn_e<2, 1>(a, grid, edge, s);
+    else if (tnn == 2) rc = launch_tn_e<2, 2>(a, grid, edge, s);
+    else rc = launch_tn_e<2, 4>(a, grid, edge, s);
+    if (rc != 0) return rc;
     if (!direct) {
         const size_t chunks = (((size_t)(K + 1) * N + 63) / 64) * batch;
         const int blocks = (int)(chunks > 8192 ? 8192 : chunks);
