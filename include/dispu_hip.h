@@ -289,6 +289,13 @@ int dispu_fill_rows(int b, int n, const float* val, float mul, float* out, void*
 int dispu_adam(long total, float* p, const float* g, float* m, float* v, float lr_t, float beta1, float beta2, float eps,
                float gscale, void* stream);
 
+/* ---- training data path (DisPU/dataset.py:118-143; Common/point_operation.py:32-123: numpy on the host in the
+ * reference) ------------------------------------------------------------------------------------------------------
+ * out[b,i,:] = ((in[b,i,:] + noise[b,i,:]) . rot[b]) * scale[b] + shift[b]   (jitter -> rotate -> scale [-> shift]);
+ * rot [b,9] row-major with p' = p . R as np.dot(points, R); noise [b,n,3] and shift [b,3] may be NULL. */
+int dispu_augment(int b, int n, const float* in, const float* noise, const float* rot, const float* scale,
+                  const float* shift, float* out, void* stream);
+
 /* ---- whole-cloud inference glue (DisPU/model.py:306-381, Common/pc_util.py:83-92,147-161; host numpy/sklearn in
  * the reference, one patch at a time) -------------------------------------------------------------------------- */
 /* extract_knn_patch: for each of m queries the k nearest of the cloud's n points (k up to n, n <= 8192), ascending

@@ -32,8 +32,26 @@ def save(name, **kw):
     print(name, {k: v.shape for k, v in kw.items()})
 
 
+def point_operation_golden():
+    """Outputs of the reference's own Common/point_operation.py (pure numpy, importable here) under a fixed seed."""
+    sys.dont_write_bytecode = True
+    sys.path.insert(0, "/root/reference")
+    from Common import point_operation as PO   # noqa: E402  (authoring container only)
+    x = synth.patches(3, 64, seed=77).astype(np.float64)
+    gt = synth.patches(3, 96, seed=78).astype(np.float64)
+    np.random.seed(4242)
+    idx = np.array(PO.nonuniform_sampling(1024, 256), np.int64)
+    jit = PO.jitter_perturbation_point_cloud(x.copy(), sigma=0.01, clip=0.03)
+    rx, rgt = PO.rotate_point_cloud_and_gt(jit.copy(), gt.copy())
+    sx, sgt, scales = PO.random_scale_point_cloud_and_gt(rx.copy(), rgt.copy(), scale_low=0.8, scale_high=1.2)
+    hx, hgt = PO.shift_point_cloud_and_gt(sx.copy(), sgt.copy(), shift_range=0.3)
+    save("ref_point_operation.npz", seed=np.array(4242), x=x, gt=gt, idx=idx, jit=jit, rx=rx, rgt=rgt, sx=sx, sgt=sgt,
+         scales=scales, hx=hx, hgt=hgt)
+
+
 def main():
     assert R.available(), "build oracle/_ref first: python oracle/build.py"
+    point_operation_golden()
     rng = np.random.default_rng(20260928)
 
     # --- nn_distance: reference CPU nnsearch, both directions -------------------------------------
