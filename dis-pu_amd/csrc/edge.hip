@@ -83,6 +83,11 @@ __global__ __launch_bounds__(256) void edge_dense_conv_mfma_kernel(int npoints, 
     };
     const int grp0 = blockIdx.x * 4 + wave, gstride = gridDim.x * 4;
     if (grp0 < ngroups) fetch(grp0);
+    constexpr int WD = 12, STOT = S0 + S1 + S2;     // ring depth must divide STOT (84, 132): the ring wraps into the next group
+    static_assert(STOT % WD == 0, "fragment ring depth must divide the step count");
+    float wq[WD];
+#pragma unroll
+    for (int i = 0; i < WD; ++i) wq[i] = frag[i * 64 + lane];
     for (int grp = grp0; grp < ngroups; grp += gstride) {
         const int p = grp * 2 + (row >> 4);
         const bool ok = p < npoints;
@@ -97,14 +102,25 @@ __global__ __launch_bounds__(256) void edge_dense_conv_mfma_kernel(int npoints, 
             fp[2 * q] = a0; fp[2 * q + 1] = a1;
             df[2 * q] = b0v - a0; df[2 * q + 1] = b1v - a1;
         }
+        // ra / rb are consumed: start the next group's index + row loads now, so both latencies hide behind this
+        // group's 132-MFMA chain instead of being exposed at the top of the next iteration
+        if (grp + gstride < ngroups) fetch(grp + gstride);
         f32x16 l0, l1, l2;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { l0[r] = 0.f; l1[r] = 0.f; l2[r] = 0.f; }
+        // The weight fragments of all three layers are one contiguous LDS array of STOT steps.  They do not depend on
+        // the data, so they run through a register ring WD steps ahead of the MFMA that consumes them (wrapping into
+        // the next point group): with one wave per SIMD nothing else would hide the ds_read latency.
+        auto step = [&](int sg, float bv, f32x16& acc) {
+            const float w = wq[sg % WD];
+            wq[sg % WD] = frag[((sg + WD) % STOT) * 64 + lane];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w, bv, acc, 0, 0, 0);
+        };
         // layer 0: k over [F_p (C), F_j - F_p (C)]
 #pragma unroll
         for (int s = 0; s < S0; ++s) {
             const float bv = (s < H) ? fp[s < H ? s : 0] : df[s < H ? 0 : s - H];
-            l0 = __builtin_amdgcn_mfma_f32_32x32x2f32(f0[s * 64 + lane], bv, l0, 0, 0, 0);
+            step(s, bv, l0);
         }
 #pragma unroll
         for (int r = 0; r < 12; ++r) l0[r] = fmaxf(l0[r] + b0[2 * r + h], 0.f);
@@ -112,7 +128,7 @@ __global__ __launch_bounds__(256) void edge_dense_conv_mfma_kernel(int npoints, 
 #pragma unroll
         for (int s = 0; s < S1; ++s) {
             const float bv = (s < 12) ? l0[s < 12 ? s : 0] : fp[s < 12 ? 0 : s - 12];
-            l1 = __builtin_amdgcn_mfma_f32_32x32x2f32(f1[s * 64 + lane], bv, l1, 0, 0, 0);
+            step(S0 + s, bv, l1);
         }
 #pragma unroll
         for (int r = 0; r < 12; ++r) l1[r] = fmaxf(l1[r] + b1[2 * r + h], 0.f);
@@ -120,7 +136,7 @@ __global__ __launch_bounds__(256) void edge_dense_conv_mfma_kernel(int npoints, 
 #pragma unroll
         for (int s = 0; s < S2; ++s) {
             const float bv = (s < 12) ? l1[s < 12 ? s : 0] : ((s < 24) ? l0[(s >= 12 && s < 24) ? s - 12 : 0] : fp[s >= 24 ? s - 24 : 0]);
-            l2 = __builtin_amdgcn_mfma_f32_32x32x2f32(f2[s * 64 + lane], bv, l2, 0, 0, 0);
+            step(S0 + S1 + s, bv, l2);
         }
         // max over the 16 neighbours (one DPP row) and store [l2 | l1 | l0 | F_p]; lane 15 of each row writes
         float* __restrict__ yr = Y + (size_t)pp * ldy;
@@ -136,7 +152,6 @@ __global__ __launch_bounds__(256) void edge_dense_conv_mfma_kernel(int npoints, 
 #pragma unroll
             for (int t = 0; t < H; ++t) yr[3 * G + 2 * t + h] = fp[t];
         }
-        if (grp + gstride < ngroups) fetch(grp + gstride);
     }
 }
 

@@ -44,30 +44,132 @@ struct LinearLds {
     static constexpr size_t BYTES = (size_t)2 * STAGE * sizeof(float);
 };
 
-// BM x BN block tile, WM x WN waves, BK k-slab per LDS stage.
+// BM x BN block tile, WM x WN MFMA waves + as many LOADER waves, BK k-slab per LDS stage.
+//
+// Wave specialisation.  v_mfma blocks the wave that issued it, and a wave that also has to wait for its global
+// loads (s_waitcnt vmcnt), write them to LDS and issue the next loads cannot keep the matrix pipe fed: measured on
+// the [32768 x 2048] x [2048 x 256] product (tools/micro/gemm_lab.hip), the single-role kernel spends ~2600 of every
+// ~7300 cycles per slab in that refill phase and reaches 82 TFLOP/s, although the same MFMA loop alone sustains
+// 135 TFLOP/s and the pipe itself 156.  So the roles are split: waves 0 .. WM*WN-1 only read operand fragments from
+// LDS and issue MFMAs; waves WM*WN .. 2*WM*WN-1 only move tiles (global -> registers -> LDS, one tile in flight).
+// One workgroup barrier per slab joins them (127 TFLOP/s on that product).  Each SIMD hosts one wave of each role.
 // EDGE = false: every tile is interior and 16-byte aligned (M % BM == N % BN == K % BK == 0): no predicates at all.
-template <int BM, int BN, int WM, int WN, int BK, bool TRANSB, bool EDGE>
-__global__ __launch_bounds__(64 * WM * WN) void linear_mfma_kernel(LinearArgs a) {
+template <int BM, int BN, int WM, int WN, int BK, bool TRANSB, bool EDGE, int EPI>
+__global__ __launch_bounds__(128 * WM * WN) void linear_mfma_kernel(LinearArgs a) {
     using L = LinearLds<BM, BN, BK, TRANSB>;
-    constexpr int NT = 64 * WM * WN;
+    constexpr int NT = 64 * WM * WN;                  // threads per role
     constexpr int LDA = L::LDA, LDB = L::LDB;
     constexpr int TM = BM / (32 * WM), TN = BN / (32 * WN);
-    constexpr int A_F4 = BM * BK / 4 / NT;            // float4 loads per thread for the A tile
+    constexpr int A_F4 = BM * BK / 4 / NT;            // float4 loads per loader thread for the A tile
     constexpr int B_F4 = BN * BK / 4 / NT;
     static_assert(A_F4 >= 1 && B_F4 >= 1 && TM >= 1 && TN >= 1, "tile too small for the workgroup");
     static_assert((BM * BK / 4) % NT == 0 && (BN * BK / 4) % NT == 0, "tile must split evenly over the threads");
     extern __shared__ __attribute__((aligned(16))) float lds[];
 
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int wm = wave / WN, wn = wave % WN;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int z = blockIdx.z;
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-    const float* __restrict__ X = a.X + (size_t)z * a.sx;
-    const float* __restrict__ W = a.W + (size_t)z * a.sw;
     const int M = a.M, K = a.K, N = a.N;
-    const long ldx = a.ldx, ldw = a.ldw;
+    const int ntile = (K + BK - 1) / BK;
 
+    if (wave >= WM * WN) {
+        // ------------------------------------------------------------------------------------ loader waves
+        const int tid = threadIdx.x - NT;
+        const float* __restrict__ X = a.X + (size_t)z * a.sx;
+        const float* __restrict__ W = a.W + (size_t)z * a.sw;
+        const long ldx = a.ldx, ldw = a.ldw;
+        float4 pa[A_F4], pb[B_F4];
+        const bool x_vec = ((ldx & 3) == 0) && ((((uintptr_t)X) & 15) == 0);
+        const bool w_vec = ((ldw & 3) == 0) && ((((uintptr_t)W) & 15) == 0);
+
+        // rows-of-k loader (A always; B when TRANSB): element (row, k) with k contiguous in memory
+        auto load_rowsk = [&](const float* __restrict__ P, long ld, bool vec, int row_base, int rows, int k0, int it) -> float4 {
+            const int idx = tid + it * NT;
+            const int r = idx / (BK / 4), kq = idx % (BK / 4);
+            const int row = row_base + r, k = k0 + kq * 4;
+            if constexpr (!EDGE) return *reinterpret_cast<const float4*>(P + (size_t)row * ld + k);
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < rows && k < K) {
+                const float* p = P + (size_t)row * ld + k;
+                if (vec && k + 3 < K) {
+                    v = *reinterpret_cast<const float4*>(p);
+                } else {
+                    v.x = p[0];
+                    if (k + 1 < K) v.y = p[1];
+                    if (k + 2 < K) v.z = p[2];
+                    if (k + 3 < K) v.w = p[3];
+                }
+            }
+            return v;
+        };
+        auto store_rowsk = [&](float* S, int LD, float4 v, int it) {
+            const int idx = tid + it * NT;
+            const int r = idx / (BK / 4), kq = idx % (BK / 4);
+            S[(kq * 4 + 0) * LD + r] = v.x;
+            S[(kq * 4 + 1) * LD + r] = v.y;
+            S[(kq * 4 + 2) * LD + r] = v.z;
+            S[(kq * 4 + 3) * LD + r] = v.w;
+        };
+        // k-rows loader for B = W[k][n] (n contiguous)
+        auto load_b = [&](int k0, int it) -> float4 {
+            const int idx = tid + it * NT;
+            const int kr = idx / (BN / 4), nq = idx % (BN / 4);
+            const int k = k0 + kr, n = n0 + nq * 4;
+            if constexpr (!EDGE) return *reinterpret_cast<const float4*>(W + (size_t)k * ldw + n);
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (k < K && n < N) {
+                const float* p = W + (size_t)k * ldw + n;
+                if (w_vec && n + 3 < N) {
+                    v = *reinterpret_cast<const float4*>(p);
+                } else {
+                    v.x = p[0];
+                    if (n + 1 < N) v.y = p[1];
+                    if (n + 2 < N) v.z = p[2];
+                    if (n + 3 < N) v.w = p[3];
+                }
+            }
+            return v;
+        };
+        auto store_b = [&](float* S, float4 v, int it) {
+            const int idx = tid + it * NT;
+            const int kr = idx / (BN / 4), nq = idx % (BN / 4);
+            *reinterpret_cast<float4*>(&S[kr * LDB + nq * 4]) = v;
+        };
+        auto load_tile = [&](int k0) {
+#pragma unroll
+            for (int it = 0; it < A_F4; ++it) pa[it] = load_rowsk(X, ldx, x_vec, m0, M, k0, it);
+#pragma unroll
+            for (int it = 0; it < B_F4; ++it) pb[it] = TRANSB ? load_rowsk(W, ldw, w_vec, n0, N, k0, it) : load_b(k0, it);
+        };
+        auto store_tile = [&](int stage) {
+            float* As = lds + stage * L::STAGE;
+            float* Bs = As + BK * LDA;
+#pragma unroll
+            for (int it = 0; it < A_F4; ++it) store_rowsk(As, LDA, pa[it], it);
+#pragma unroll
+            for (int it = 0; it < B_F4; ++it) {
+                if constexpr (TRANSB) store_rowsk(Bs, LDB, pb[it], it);
+                else store_b(Bs, pb[it], it);
+            }
+        };
+        load_tile(0);
+        store_tile(0);
+        if (ntile > 1) load_tile(BK);
+        __syncthreads();
+        // slab t: park tile t+1 in the other stage (its last readers passed the barrier that ended slab t-1) and
+        // request tile t+2, while the MFMA waves work through stage t
+        for (int t = 0; t < ntile; ++t) {
+            if (t + 1 < ntile) {
+                store_tile((t + 1) & 1);
+                if (t + 2 < ntile) load_tile((t + 2) * BK);
+            }
+            __syncthreads();
+        }
+        return;
+    }
+
+    // ------------------------------------------------------------------------------------------ MFMA waves
+    const int wm = wave / WN, wn = wave % WN;
     f32x16 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -76,97 +178,11 @@ __global__ __launch_bounds__(64 * WM * WN) void linear_mfma_kernel(LinearArgs a)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    float4 pa[A_F4], pb[B_F4];
-    const bool x_vec = ((ldx & 3) == 0) && ((((uintptr_t)X) & 15) == 0);
-    const bool w_vec = ((ldw & 3) == 0) && ((((uintptr_t)W) & 15) == 0);
-
-    // rows-of-k loader (A always; B when TRANSB): element (row, k) with k contiguous in memory
-    auto load_rowsk = [&](const float* __restrict__ P, long ld, bool vec, int row_base, int rows, int k0, int it) -> float4 {
-        const int idx = tid + it * NT;
-        const int r = idx / (BK / 4), kq = idx % (BK / 4);
-        const int row = row_base + r, k = k0 + kq * 4;
-        if constexpr (!EDGE) return *reinterpret_cast<const float4*>(P + (size_t)row * ld + k);
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (row < rows && k < K) {
-            const float* p = P + (size_t)row * ld + k;
-            if (vec && k + 3 < K) {
-                v = *reinterpret_cast<const float4*>(p);
-            } else {
-                v.x = p[0];
-                if (k + 1 < K) v.y = p[1];
-                if (k + 2 < K) v.z = p[2];
-                if (k + 3 < K) v.w = p[3];
-            }
-        }
-        return v;
-    };
-    auto store_rowsk = [&](float* S, int LD, float4 v, int it) {
-        const int idx = tid + it * NT;
-        const int r = idx / (BK / 4), kq = idx % (BK / 4);
-        S[(kq * 4 + 0) * LD + r] = v.x;
-        S[(kq * 4 + 1) * LD + r] = v.y;
-        S[(kq * 4 + 2) * LD + r] = v.z;
-        S[(kq * 4 + 3) * LD + r] = v.w;
-    };
-    // k-rows loader for B = W[k][n] (n contiguous)
-    auto load_b = [&](int k0, int it) -> float4 {
-        const int idx = tid + it * NT;
-        const int kr = idx / (BN / 4), nq = idx % (BN / 4);
-        const int k = k0 + kr, n = n0 + nq * 4;
-        if constexpr (!EDGE) return *reinterpret_cast<const float4*>(W + (size_t)k * ldw + n);
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (k < K && n < N) {
-            const float* p = W + (size_t)k * ldw + n;
-            if (w_vec && n + 3 < N) {
-                v = *reinterpret_cast<const float4*>(p);
-            } else {
-                v.x = p[0];
-                if (n + 1 < N) v.y = p[1];
-                if (n + 2 < N) v.z = p[2];
-                if (n + 3 < N) v.w = p[3];
-            }
-        }
-        return v;
-    };
-    auto store_b = [&](float* S, float4 v, int it) {
-        const int idx = tid + it * NT;
-        const int kr = idx / (BN / 4), nq = idx % (BN / 4);
-        *reinterpret_cast<float4*>(&S[kr * LDB + nq * 4]) = v;
-    };
-    auto load_tile = [&](int k0) {
-#pragma unroll
-        for (int it = 0; it < A_F4; ++it) pa[it] = load_rowsk(X, ldx, x_vec, m0, M, k0, it);
-#pragma unroll
-        for (int it = 0; it < B_F4; ++it) pb[it] = TRANSB ? load_rowsk(W, ldw, w_vec, n0, N, k0, it) : load_b(k0, it);
-    };
-    auto store_tile = [&](int stage) {
-        float* As = lds + stage * L::STAGE;
-        float* Bs = As + BK * LDA;
-#pragma unroll
-        for (int it = 0; it < A_F4; ++it) store_rowsk(As, LDA, pa[it], it);
-#pragma unroll
-        for (int it = 0; it < B_F4; ++it) {
-            if constexpr (TRANSB) store_rowsk(Bs, LDB, pb[it], it);
-            else store_b(Bs, pb[it], it);
-        }
-    };
-
-    const int ntile = (K + BK - 1) / BK;
-    load_tile(0);
-    store_tile(0);
-    if (ntile > 1) load_tile(BK);
-    __syncthreads();
-
     const int fi = lane & 31, fk = lane >> 5;
+    __syncthreads();
     for (int t = 0; t < ntile; ++t) {
         const float* As = lds + (t & 1) * L::STAGE;
         const float* Bs = As + BK * LDA;
-        // park tile t+1 in the other stage (its last readers passed the barrier that ended iteration t-1) and
-        // start fetching tile t+2; both overlap with this stage's MFMAs
-        if (t + 1 < ntile) {
-            store_tile((t + 1) & 1);
-            if (t + 2 < ntile) load_tile((t + 2) * BK);
-        }
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 2) {
             float af[TM], bf[TN];
@@ -183,39 +199,80 @@ __global__ __launch_bounds__(64 * WM * WN) void linear_mfma_kernel(LinearArgs a)
         __syncthreads();
     }
 
-    // epilogue: C/D layout of the 32x32 tile: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+    // epilogue: C/D layout of the 32x32 tile: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
+    // What the epilogue does is a TEMPLATE choice (EPI), not a per-element test: an earlier version tested
+    // bias / scale / act / R1 / R2 inside the 128-element unrolled store loop, which the compiler unswitched into
+    // ~5000 instructions with spills (9 us per launch).  EPI 0: bias + activation; 1: + BatchNorm fold;
+    // 4: BatchNorm fold and whatever residuals are given (uniform branches around the residual loads: the compiler
+    // keeps those loads in program order, whereas unconditional ones were all hoisted and spilled).
+    constexpr bool E_SCALE = (EPI == 1 || EPI == 4), E_R1 = (EPI >= 2), E_R2 = (EPI >= 3);
     float* __restrict__ Y = a.Y + (size_t)z * a.sy;
-    const float* __restrict__ R1 = a.R1 ? a.R1 + (size_t)z * a.sr1 : nullptr;
-    const float* __restrict__ R2 = a.R2 ? a.R2 + (size_t)z * a.sr2 : nullptr;
+    const float lo = (a.act == 1) ? 0.f : -__builtin_inff();
+    const bool has_bias = a.bias != nullptr;
+    const float* __restrict__ R1 = (E_R1 && a.R1) ? a.R1 + (size_t)z * a.sr1 : nullptr;
+    const float* __restrict__ R2 = (E_R2 && a.R2) ? a.R2 + (size_t)z * a.sr2 : nullptr;
+    // addresses = wave-uniform row base (scalar registers) + one per-lane offset (4*fk rows + column): the 128
+    // stores / residual loads of a lane then share three 32-bit offset registers instead of 128 64-bit pointers
+    const int wm_u = __builtin_amdgcn_readfirstlane(wm), wn_u = __builtin_amdgcn_readfirstlane(wn);
+    const int rbase = m0 + wm_u * (TM * 32), cbase = n0 + wn_u * (TN * 32);
+    const long ldy = a.ldy, ldr1 = a.ldr1, ldr2 = a.ldr2;
+    const unsigned offy = (unsigned)(4 * fk * ldy + fi), off1 = (unsigned)(4 * fk * ldr1 + fi), off2 = (unsigned)(4 * fk * ldr2 + fi);
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-        const int col = n0 + wn * (TN * 32) + j * 32 + fi;
-        if (EDGE && col >= N) continue;
-        const float bv = a.bias ? a.bias[col] : 0.f;
-        const float sc = a.scale ? a.scale[col] : 1.f, sh = a.scale ? a.shift[col] : 0.f;
+        const int colu = cbase + j * 32;                      // wave-uniform first column of this 32-wide tile
+        const int col = colu + fi;
+        const bool col_ok = !EDGE || col < N;
+        const int colc = col_ok ? col : 0;
+        const float bv = has_bias ? a.bias[colc] : 0.f;
+        float sc = 1.f, sh = 0.f;
+        if constexpr (E_SCALE) {
+            if (a.scale) { sc = a.scale[colc]; sh = a.shift[colc]; }
+        }
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
+            // residuals of one 32x32 tile are fetched as a batch (16 + 16 loads in flight), then consumed: testing
+            // R1 / R2 per element serialises load -> wait -> add -> store 128 times (+110 us on the after_conv GEMM)
+            float r1v[16], r2v[16];
+            if constexpr (EPI == 4) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * (TM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
-                if (!EDGE || row < M) {
-                    float v = acc[i][j][r];
-                    if (a.bias) v = v + bv;
-                    if (a.scale) v = v * sc + sh;
-                    if (a.act == 1) v = fmaxf(v, 0.f);
-                    if (R1) v = v + R1[(size_t)row * a.ldr1 + col];
-                    if (R2) v = v + R2[(size_t)row * a.ldr2 + col];
-                    Y[(size_t)row * a.ldy + col] = v;
+                for (int r = 0; r < 16; ++r) {
+                    const int rowu = rbase + i * 32 + (r & 3) + 8 * (r >> 2);
+                    const bool ok = col_ok && (!EDGE || rowu + 4 * fk < M);
+                    r1v[r] = (R1 && ok) ? (R1 + (size_t)rowu * ldr1 + colu)[off1] : 0.f;
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int rowu = rbase + i * 32 + (r & 3) + 8 * (r >> 2);
+                    const bool ok = col_ok && (!EDGE || rowu + 4 * fk < M);
+                    r2v[r] = (R2 && ok) ? (R2 + (size_t)rowu * ldr2 + colu)[off2] : 0.f;
                 }
             }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rowu = rbase + i * 32 + (r & 3) + 8 * (r >> 2);      // wave-uniform; the lane's row is rowu + 4*fk
+                if (col_ok && (!EDGE || rowu + 4 * fk < M)) {
+                    float v = acc[i][j][r];
+                    if (has_bias) v = v + bv;
+                    if constexpr (E_SCALE) {
+                        if (a.scale) v = v * sc + sh;
+                    }
+                    v = fmaxf(v, lo);
+                    if constexpr (EPI == 4) {
+                        if (R1) v = v + r1v[r];
+                        if (R2) v = v + r2v[r];
+                    }
+                    (Y + (size_t)rowu * ldy + colu)[offy] = v;
+                }
+            }
+            if constexpr (EPI == 4) __builtin_amdgcn_sched_barrier(0);
         }
     }
 }
 
-template <int BM, int BN, int WM, int WN, int BK, bool TRANSB, bool EDGE>
-static int launch_one(const LinearArgs& a, dim3 grid, hipStream_t s) {
+template <int BM, int BN, int WM, int WN, int BK, bool TRANSB, bool EDGE, int EPI>
+static int launch_epi(const LinearArgs& a, dim3 grid, hipStream_t s) {
     constexpr size_t bytes = LinearLds<BM, BN, BK, TRANSB>::BYTES;
-    auto kern = linear_mfma_kernel<BM, BN, WM, WN, BK, TRANSB, EDGE>;
+    auto kern = linear_mfma_kernel<BM, BN, WM, WN, BK, TRANSB, EDGE, EPI>;
     if (bytes > 64 * 1024) {
         static bool done = false;       // opt in to > 64 KiB of dynamic LDS once per instantiation
         if (!done) {
@@ -224,8 +281,15 @@ static int launch_one(const LinearArgs& a, dim3 grid, hipStream_t s) {
             done = true;
         }
     }
-    hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), bytes, s, a);
+    hipLaunchKernelGGL(kern, grid, dim3(128 * WM * WN), bytes, s, a);
     return (int)hipGetLastError();
+}
+
+template <int BM, int BN, int WM, int WN, int BK, bool TRANSB, bool EDGE>
+static int launch_one(const LinearArgs& a, dim3 grid, hipStream_t s) {
+    if (!a.scale && !a.R1 && !a.R2) return launch_epi<BM, BN, WM, WN, BK, TRANSB, EDGE, 0>(a, grid, s);
+    if (a.scale && !a.R1 && !a.R2) return launch_epi<BM, BN, WM, WN, BK, TRANSB, EDGE, 1>(a, grid, s);
+    return launch_epi<BM, BN, WM, WN, BK, TRANSB, EDGE, 4>(a, grid, s);
 }
 
 template <int BM, int BN, int WM, int WN, int BK>

@@ -69,6 +69,7 @@ class Generator(object):
         self.profile = None          # set to [] to collect (name, start_event, end_event) per launch
         self.fused_local = True      # PointShuffle2 local cell in one kernel (False: the 4-kernel chain, for A/B tests)
         self.fused_attention = True  # non-local cell attention on chip (False: GEMM -> softmax -> GEMM through HBM)
+        self.fused_residual = bool(int(__import__('os').environ.get('DISPU_FUSED_RES', '1')))
         if params is not None:
             self.load_params(params)
 
@@ -267,7 +268,12 @@ class Generator(object):
                        ptr(self.bn_scale), ptr(self.bn_shift), ptr(wv), st)
             self._call("point_matmul", L.dispu_ps_point_matmul, rm, k, 128, 16, ptr(x2), 128, ptr(wv), ptr(ws["fp"]), 2048, st)
         w, b = self._w(ps + "after_conv")
-        self._linear(st, ws["fp"], 2048, w, b, 1, ws["aft"], 256, R1=ws["skip"], R2=ws["nl"])
+        if self.fused_residual:
+            self._linear(st, ws["fp"], 2048, w, b, 1, ws["aft"], 256, R1=ws["skip"], R2=ws["nl"])
+        else:
+            # same arithmetic order ((act(.) + skip) + nl) in a separate streaming kernel
+            self._linear(st, ws["fp"], 2048, w, b, 1, ws["aft"], 256)
+            self._call("add3", L.dispu_add3, rm * 256, ptr(ws["aft"]), ptr(ws["skip"]), ptr(ws["nl"]), ptr(ws["aft"]), st)
         w, b = self._w(ps + "aggregation")
         self._linear(st, ws["aft"], 256, w, b, 1, ws["agg"], 256)
 

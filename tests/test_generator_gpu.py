@@ -145,7 +145,9 @@ def test_linear_matches_chain_exactly(dev):
     assert np.array_equal(N(s), OG.matmul_nt(q, kk))
 
 
-@pytest.mark.parametrize("C,npts", [(24, 512), (48, 512), (48, 777)])
+# 2560 / 4096 points: more than 2 x 1024 waves of the persistent grid -> several point groups per wave (the weight
+# fragment ring and the row prefetch wrap from one group into the next)
+@pytest.mark.parametrize("C,npts", [(24, 512), (48, 512), (48, 777), (24, 2560), (48, 4096)])
 def test_edge_dense_conv_mfma_equals_valu_and_oracle(dev, C, npts):
     """dense_conv on the matrix cores vs its VALU twin vs the oracle chain: all three bit-identical."""
     from dispu_amd import _lib
