@@ -104,6 +104,19 @@ __device__ __forceinline__ float ordered_to_f32(uint32_t u) {
     return __uint_as_float(b);
 }
 
+// v_mfma_f32_32x32x2_f32 with the accumulator pinned to the ACC register file.  hipcc prefers VGPR accumulators when
+// the budget allows; a wave issuing back-to-back MFMAs then reads and writes 16 VGPRs x 64 lanes per instruction and
+// keeps the VGPR ports of its SIMD busy, so that the OTHER wave on the SIMD (a loader / helper wave) needs ~340
+// cycles to issue one global load instead of ~40 (tools/micro/gemm_lab.hip, "AGPR acc").  The compiler does not see
+// an MFMA in the asm statement: call mfma_acc_settle() once before the accumulators are read.
+typedef float dispu_f32x16 __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ void mfma_acc(dispu_f32x16& acc, float a, float b) {
+    asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void mfma_acc_settle() {   // >= 18 wait states between the last 16-pass MFMA and a read of its result
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+}
+
 __device__ __forceinline__ float wave_sum_f32(float v) {
     // butterfly; order fixed (xor 32,16,8,4,2,1) so the result is deterministic
 #pragma unroll

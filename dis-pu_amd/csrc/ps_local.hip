@@ -16,6 +16,8 @@
 // in 4 slabs of 32 through two LDS stages (same pipeline as linear.hip).
 #include "common.h"
 
+#include <cstdlib>
+
 namespace dispu {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -184,6 +186,278 @@ __global__ __launch_bounds__(PL_NT) void ps_local_kernel(long npoints, int n_per
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Wave-specialised, persistent formulation (default).  The single-role kernel above keeps the matrix pipe ~39 % busy:
+// every workgroup pays the index / row gather latencies, the 16 x 16 weight-net evaluation and the VALU contraction
+// epilogue in the same waves that issue the MFMAs, and streams 192 KB per 8 points through the CU's load path
+// (16 x redundant A rows, W1 again for every group).  Here a workgroup of 8 waves loops over point groups:
+//   * waves 0-3 (MFMA waves) issue fragment reads + MFMAs only: conv1 from the staged A slabs and the LDS-RESIDENT W1,
+//     then the per-point contraction F'[c][t] = sum_s X2[s][c] * wv[s][t] on the matrix pipe as well, two points at a
+//     time as a [32 ch x 32] x [32 x (2 x 16)] product with a block-diagonal B (point q's weights in the rows of
+//     point q, zeros elsewhere);
+//   * waves 4-7 (helpers) gather the neighbour rows, form relu(G_j - A_i) into the next A slab, and evaluate the next
+//     group's weight net.
+// The pair rows of every 32-row block are laid out in the order the MFMA result layout dictates (tile row
+// (k>>1 & 3) + 8 (k>>3) + 4 (k & 1) holds contraction index k = 16 * point + s), so relu(acc + b1) is already the A
+// operand of the contraction in the lane that holds it: the [128 x 128] pair tensor never leaves the registers.
+// k ascends through (point, s) and the foreign point contributes exact zeros, so every output is the same
+// s-ascending fmaf chain as above -> bit-identical output.
+constexpr int PW_WRES = PL_K * PL_LDB;                               // resident W1 [128 k][132]
+constexpr int PW_ASTG = PL_BK * PL_LDA;                              // one A slab, k-major [32][129]
+constexpr int PW_FLOATS = PW_WRES + 2 * PW_ASTG + 2 * 2048 + 2 * 1024 + 512;
+constexpr size_t PW_LDS_BYTES = (size_t)PW_FLOATS * sizeof(float);
+
+__global__ __launch_bounds__(512) void ps_local_ws_kernel(long npoints, int n_per_cloud, const int* __restrict__ idx,
+                                                           const float* __restrict__ xyz, const float* __restrict__ Gm,
+                                                           const float* __restrict__ Am, const float* __restrict__ W1,
+                                                           const float* __restrict__ b1, const float* __restrict__ Ww,
+                                                           const float* __restrict__ bw, const float* __restrict__ scale,
+                                                           const float* __restrict__ shift, float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* wres = lds;                                               // [128][PL_LDB]
+    float* astg = wres + PW_WRES;                                    // [2][32][PL_LDA]
+    float* wvbuf = astg + 2 * PW_ASTG;                               // [2][8 points][16 s][16 t]
+    float* abuf = wvbuf + 2 * 2048;                                  // [2][8 points][128]
+    float* cxbuf = abuf + 2 * 1024;                                  // [128 pairs][4]: x_j - x_i
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int np = (int)npoints;
+    const int ng = (np + 7) / 8, gstep = (int)gridDim.x;
+    if ((int)blockIdx.x >= ng) return;
+    constexpr int NTILE = PL_K / PL_BK;                              // 4 slabs of 32
+
+    if (wave >= 4) {
+        // ------------------------------------------------------------------------------------- helper waves
+        const int ht = threadIdx.x - 256;
+        const int kq = ht & 7;
+        // A-tile rows of this thread: r = rho + 32 * it, rho = ht >> 3.  Row rho of a 32-row block holds contraction index
+        // k = 16 * q' + s  with  rho = (k>>1 & 3) + 8 (k>>3) + 4 (k & 1); block `it` holds points 2 it, 2 it + 1.
+        const int rho = ht >> 3;
+        const int kc = ((rho >> 2) & 1) | ((rho & 3) << 1) | ((rho >> 3) << 3);
+        const int rq = kc >> 4, rs = kc & 15;
+        auto clampi = [&](int i) { return i < np ? i : np - 1; };
+        auto cloud_base = [&](int i) { return (int)((unsigned)i / (unsigned)n_per_cloud) * n_per_cloud; };
+        int goff[4], goff_n[4];                                      // element offsets of the gathered G rows (+ kq * 4)
+        auto rows_of = [&](int g, int (&go)[4]) {
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int i = clampi(g * 8 + 2 * it + rq);
+                go[it] = (cloud_base(i) + idx[i * 16 + rs]) * PL_K + kq * 4;
+            }
+        };
+        float4 pg[4];
+        auto load_g = [&](int k0, const int (&go)[4]) {
+#pragma unroll
+            for (int it = 0; it < 4; ++it) pg[it] = *reinterpret_cast<const float4*>(Gm + go[it] + k0);
+        };
+        auto store_a = [&](int stage, int k0, const float* ab) {     // relu(G_j - A_i) -> slab `stage`, k-major
+            float* As = astg + stage * PW_ASTG;
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const float4 av = *reinterpret_cast<const float4*>(ab + (2 * it + rq) * PL_K + k0 + kq * 4);
+                const int r = rho + 32 * it;
+                As[(kq * 4 + 0) * PL_LDA + r] = fmaxf(pg[it].x - av.x, 0.f);
+                As[(kq * 4 + 1) * PL_LDA + r] = fmaxf(pg[it].y - av.y, 0.f);
+                As[(kq * 4 + 2) * PL_LDA + r] = fmaxf(pg[it].z - av.z, 0.f);
+                As[(kq * 4 + 3) * PL_LDA + r] = fmaxf(pg[it].w - av.w, 0.f);
+            }
+        };
+        // A rows of the 8 points of a group: 8 x 128 floats = 256 float4, one per helper thread
+        float4 arow;
+        auto load_arow = [&](int g) {
+            const int i = clampi(g * 8 + (ht >> 5));
+            arow = *reinterpret_cast<const float4*>(Am + (size_t)i * PL_K + (ht & 31) * 4);
+        };
+        auto store_arow = [&](float* ab) { *reinterpret_cast<float4*>(ab + (ht >> 5) * PL_K + (ht & 31) * 4) = arow; };
+        // weight net, staged: (a) neighbour id of pair ht (threads < 128), (b) its coordinates, (c) x_j - x_i -> cxbuf,
+        // (d) every thread: wv[u][s][t] for its (s, t) and the 8 points
+        const int wt = ht & 15, wsn = (ht >> 4) & 15;
+        const float ww0 = Ww[wt], ww1 = Ww[16 + wt], ww2 = Ww[32 + wt], wbw = bw[wt], wsc = scale[wt], wsh = shift[wt];
+        int pj = 0, pi_ = 0;
+        float px[6];
+        auto wn_a = [&](int g) {
+            if (ht < 128) {
+                pi_ = clampi(g * 8 + (ht >> 4));
+                pj = cloud_base(pi_) + idx[pi_ * 16 + (ht & 15)];
+            }
+        };
+        auto wn_b = [&]() {
+            if (ht < 128) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) { px[c] = xyz[pj * 3 + c]; px[3 + c] = xyz[pi_ * 3 + c]; }
+            }
+        };
+        auto wn_c = [&]() {
+            if (ht < 128) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) cxbuf[ht * 4 + c] = px[c] - px[3 + c];
+            }
+        };
+        auto wn_d = [&](int g, float* wv) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                float v = 0.f;
+                if (g * 8 + u < np) {
+                    const float* cx = cxbuf + (u * 16 + wsn) * 4;
+                    float acc = 0.f;
+                    acc = __builtin_fmaf(cx[0], ww0, acc);
+                    acc = __builtin_fmaf(cx[1], ww1, acc);
+                    acc = __builtin_fmaf(cx[2], ww2, acc);
+                    acc = acc + wbw;
+                    acc = acc * wsc + wsh;
+                    v = fmaxf(acc, 0.f);
+                }
+                wv[ht + u * PL_NT] = v;
+            }
+        };
+
+        // ---- prologue: W1 into LDS for the lifetime of the workgroup; first group's operands
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int e = ht + it * PL_NT;                            // 4096 float4
+            const int kr = e >> 5, nq = e & 31;
+            *reinterpret_cast<float4*>(&wres[kr * PL_LDB + nq * 4]) = *reinterpret_cast<const float4*>(W1 + (size_t)kr * PL_BN + nq * 4);
+        }
+        int g = blockIdx.x;
+        rows_of(g, goff);
+        load_arow(g);
+        store_arow(abuf);
+        wn_a(g);
+        wn_b();
+        wn_c();
+        load_g(0, goff);
+        __syncthreads();                                             // #1: abuf, cxbuf, wres visible
+        wn_d(g, wvbuf);
+        store_a(0, 0, abuf);
+        load_g(PL_BK, goff);
+        __syncthreads();                                             // #2: slab 0 and wv of the first group ready
+        int n = 0;
+        for (; g < ng; g += gstep, ++n) {
+            const int gn = g + gstep;
+            const bool has_next = gn < ng;
+            const float* ab = abuf + (n & 1) * 1024;
+            float* ab_n = abuf + ((n + 1) & 1) * 1024;
+            // slab 0 interval
+            store_a(1, PL_BK, ab);
+            load_g(2 * PL_BK, goff);
+            if (has_next) { rows_of(gn, goff_n); load_arow(gn); wn_a(gn); }
+            __syncthreads();
+            // slab 1 interval
+            store_a(0, 2 * PL_BK, ab);
+            load_g(3 * PL_BK, goff);
+            if (has_next) { store_arow(ab_n); wn_b(); }
+            __syncthreads();
+            // slab 2 interval
+            store_a(1, 3 * PL_BK, ab);
+            if (has_next) { load_g(0, goff_n); wn_c(); }
+            __syncthreads();
+            // slab 3 interval: slab buffer 0 is free again (read during slab 2) -> next group's first slab
+            if (has_next) {
+                store_a(0, 0, ab_n);
+                load_g(PL_BK, goff_n);
+                wn_d(gn, wvbuf + ((n + 1) & 1) * 2048);                // that buffer's last reader was the contraction of group n-1
+            }
+            __syncthreads();
+#pragma unroll
+            for (int it = 0; it < 4; ++it) goff[it] = goff_n[it];
+        }
+        return;
+    }
+
+    // ----------------------------------------------------------------------------------------------- MFMA waves
+    const int wm = wave >> 1, wn = wave & 1;
+    const int fi = lane & 31, fk = lane >> 5;
+    float bias[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) bias[j] = b1[wn * 64 + j * 32 + fi];
+    __syncthreads();                                                 // #1
+    __syncthreads();                                                 // #2
+    int n = 0;
+#ifdef PL_STAMPS
+    unsigned long long c_mma = 0, c_bar = 0, c_con = 0;
+#define PL_T(v) const unsigned long long v = __builtin_readcyclecounter()
+#else
+#define PL_T(v)
+#endif
+    for (int g = blockIdx.x; g < ng; g += gstep, ++n) {
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+#pragma unroll
+        for (int t = 0; t < NTILE; ++t) {
+            const float* As = astg + (t & 1) * PW_ASTG;
+            const float* Bs = wres + (t * PL_BK) * PL_LDB;
+            PL_T(s0);
+#pragma unroll
+            for (int kk = 0; kk < PL_BK; kk += 2) {
+                float af[2], bf[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) af[i] = As[(kk + fk) * PL_LDA + wm * 64 + i * 32 + fi];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) bf[j] = Bs[(kk + fk) * PL_LDB + wn * 64 + j * 32 + fi];
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+            }
+            PL_T(s1);
+            __syncthreads();
+            PL_T(s2);
+#ifdef PL_STAMPS
+            c_mma += s1 - s0; c_bar += s2 - s1;
+#endif
+        }
+        PL_T(p0s);
+        // contraction: this wave owns row blocks i (points 2 (2 wm + i) + q) and channel blocks j
+        const float* wv = wvbuf + (n & 1) * 2048;
+        const int q = fi >> 4, tt = fi & 15;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int pblk = 2 * (2 * wm + i);                        // first point of the pair
+            f32x16 o[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[j][r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks) {
+                const int k = 2 * ks + fk;                            // (q', s) = (k >> 4, k & 15)
+                const float bvv = ((k >> 4) == q) ? wv[(pblk + q) * 256 + (k & 15) * 16 + tt] : 0.f;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const float av = fmaxf(acc[i][j][ks] + bias[j], 0.f);      // X2 of tile row rho(k), channel wn*64 + j*32 + fi
+                    o[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bvv, o[j], 0, 0, 0);
+                }
+            }
+            const int pi = g * 8 + pblk + q;
+            if (pi < np) {
+                float* dst = out + (size_t)pi * 2048 + tt;
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int c = wn * 64 + j * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
+                        dst[c * 16] = o[j][r];
+                    }
+            }
+        }
+#ifdef PL_STAMPS
+        { PL_T(p2s); c_con += p2s - p0s; }
+#endif
+    }
+#ifdef PL_STAMPS
+    if (blockIdx.x == 5 && lane == 0) {
+        unsigned long long* st = reinterpret_cast<unsigned long long*>(out + (size_t)npoints * 2048) + wave * 5;
+        st[0] = c_mma; st[1] = c_bar; st[2] = 0; st[3] = c_con; st[4] = n;
+    }
+#endif
+}
+
 }  // namespace dispu
 
 using namespace dispu;
@@ -194,14 +468,26 @@ DISPU_EXPORT int dispu_ps_local(long npoints, int n_per_cloud, int k, int c, con
     if (npoints < 0 || n_per_cloud <= 0 || k != 16 || c != 128) return (int)hipErrorInvalidValue;
     if ((((uintptr_t)G) | ((uintptr_t)A) | ((uintptr_t)W1) | ((uintptr_t)out)) & 15) return (int)hipErrorInvalidValue;
     if (npoints == 0) return 0;
+    static int mode = -1;               // DISPU_PS_LOCAL=0: single-role kernel (A/B tests); default: wave-specialised persistent kernel
+    if (mode < 0) { const char* e = getenv("DISPU_PS_LOCAL"); mode = e ? atoi(e) : 1; }
     static bool attr = false;
     if (!attr) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ps_local_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)PL_LDS_BYTES);
         if (e != hipSuccess) return (int)e;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(ps_local_ws_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)PW_LDS_BYTES);
+        if (e != hipSuccess) return (int)e;
         attr = true;
     }
-    hipLaunchKernelGGL(ps_local_kernel, dim3((unsigned)((npoints + 7) / 8)), dim3(PL_NT), PL_LDS_BYTES, (hipStream_t)stream, npoints,
-                       n_per_cloud, idx, xyz, G, A, W1, b1, Ww, bw, scale, shift, out);
+    if (mode == 0) {
+        hipLaunchKernelGGL(ps_local_kernel, dim3((unsigned)((npoints + 7) / 8)), dim3(PL_NT), PL_LDS_BYTES, (hipStream_t)stream, npoints,
+                           n_per_cloud, idx, xyz, G, A, W1, b1, Ww, bw, scale, shift, out);
+    } else {
+        const long ngroups = (npoints + 7) / 8;
+        const unsigned grid = (unsigned)(ngroups < 256 ? ngroups : 256);      // one persistent workgroup per CU
+        hipLaunchKernelGGL(ps_local_ws_kernel, dim3(grid), dim3(512), PW_LDS_BYTES, (hipStream_t)stream, npoints, n_per_cloud, idx, xyz,
+                           G, A, W1, b1, Ww, bw, scale, shift, out);
+    }
     return (int)hipGetLastError();
 }

@@ -215,7 +215,7 @@ static void run(const char* name, int M, int K, int N, int ldx, const float* X, 
 
 // ---- wave-specialised variant: waves 0..3 only read fragments + issue MFMAs, waves 4..7 only move tiles
 // (global -> registers -> LDS).  One workgroup barrier per slab joins the two roles.
-template <int BM, int BN, int BK, int GD = 1>
+template <int BM, int BN, int BK, int GD = 1, bool AGPR = false>
 __global__ __launch_bounds__(512) void gemm_ws_kernel(int M, int K, int N, int ldx, const float* __restrict__ X,
                                                        const float* __restrict__ W, float* __restrict__ Y, unsigned long long* __restrict__ stamps) {
     constexpr int WM = 2, WN = 2, NT = 256;
@@ -319,8 +319,10 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(int M, int K, int N, int l
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < TN; ++j) {
+                    if constexpr (AGPR) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(af[i]), "v"(bf[j]));
+                    else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+                }
         }
         __builtin_amdgcn_sched_barrier(0);
         const unsigned long long m1s = __builtin_readcyclecounter();
@@ -344,10 +346,10 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(int M, int K, int N, int l
     }
 }
 
-template <int BM, int BN, int BK, int GD = 1>
+template <int BM, int BN, int BK, int GD = 1, bool AGPR = false>
 static void run_ws(const char* name, int M, int K, int N, int ldx, const float* X, const float* W, float* Y) {
     constexpr size_t bytes = (size_t)2 * (((BK * (BM + 1 + BN + 4) + 3) / 4) * 4) * sizeof(float);
-    auto kern = gemm_ws_kernel<BM, BN, BK, GD>;
+    auto kern = gemm_ws_kernel<BM, BN, BK, GD, AGPR>;
     hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     dim3 grid(N / BN, M / BM);
     unsigned long long* stamps;
@@ -400,6 +402,7 @@ int main() {
         hipMemcpy(W, hw.data(), hw.size() * 4, hipMemcpyHostToDevice);
         run<128, 256, 16, true, 1, 0>("128x256 bk16 fragDB full", M, K, N, ldx, X, W, Y);
         run_ws<128, 256, 16, 1>("WS 128x256 bk16", M, K, N, ldx, X, W, Y);
+        run_ws<128, 256, 16, 1, true>("WS 128x256 bk16 AGPR acc", M, K, N, ldx, X, W, Y);
         run_ws<128, 128, 16, 1>("WS 128x128 bk16", M, K, N, ldx, X, W, Y);
         hipFree(X); hipFree(W); hipFree(Y);
       }
