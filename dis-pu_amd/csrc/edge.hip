@@ -36,18 +36,33 @@ __device__ __forceinline__ float edge_row16_max(float v) {   // valid in lane 15
     return v;
 }
 
-// LDS image of one layer's A operand: frag[s*64 + lane] = W[k = 2s + (lane>>5)][channel(lane & 31)], 0 for padding.
+// LDS image of one layer's A operand: frag[s*64 + lane] = W[k = 2s + (lane>>5)][channel(lane & 31)], 0 for padding
+// (lanes whose A-row would be channel >= 24).  W [K][24] is read once, linearly (coalesced float4), and scattered
+// into place through LDS: a per-element gather from global memory was 33 vector-memory instructions per thread.
 __device__ __forceinline__ void edge_fill_frag(float* frag, const float* __restrict__ W, int K, int tid) {
-    const int total = (K / 2) * 64;
-    for (int e = tid; e < total; e += 256) {
-        const int s = e >> 6, l = e & 63;
-        const int i = l & 31, kh = l >> 5;
-        const int r = (i & 3) + 4 * (i >> 3), hp = (i >> 2) & 1;
-        frag[e] = (r < 12) ? W[(2 * s + kh) * 24 + 2 * r + hp] : 0.f;
+    const int nf4 = K * 24 / 4;                                  // W rows are 96 bytes: every float4 stays inside one row
+    for (int e = tid; e < nf4; e += 256) {
+        const float4 v = *reinterpret_cast<const float4*>(W + e * 4);
+        const int k = (e * 4) / 24, ch0 = (e * 4) - k * 24;
+        const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int ch = ch0 + u, r = ch >> 1, hp = ch & 1;
+            const int i = (r & 3) | (hp << 2) | ((r >> 2) << 3);
+            frag[(k >> 1) * 64 + (k & 1) * 32 + i] = vv[u];
+        }
+    }
+    for (int e = tid; e < K * 8; e += 256) {                     // padding lanes 24..31 of every (s, half)
+        const int sh = e >> 3;                                   // s * 2 + half
+        frag[sh * 32 + 24 + (e & 7)] = 0.f;
     }
 }
 
-template <int C>
+// LDSF = true: one workgroup works inside ONE cloud and first copies that cloud's [n_per_cloud, C] feature block into
+// LDS; the 2 x C/4 float4 row gathers per lane and group then are ds_read_b128 instead of global loads.  A wave that
+// shares its SIMD's issue with its own 64-cycle MFMAs gets a vector-memory instruction out only every ~300 cycles
+// (tools/micro/gemm_lab.hip), and the 24 gathers per group cost more than the 132 MFMAs they feed.
+template <int C, bool LDSF>
 __global__ __launch_bounds__(256) void edge_dense_conv_mfma_kernel(int npoints, int n_per_cloud, const float* __restrict__ F,
                                                                     long ldf, const int* __restrict__ idx, int ldi, int ioff,
                                                                     const float* __restrict__ W0, const float* __restrict__ b0,
@@ -56,42 +71,79 @@ __global__ __launch_bounds__(256) void edge_dense_conv_mfma_kernel(int npoints, 
                                                                     float* __restrict__ Y, long ldy) {
     constexpr int G = 24, H = C / 2, K0 = 2 * C, K1 = G + C, K2 = 2 * G + C;
     constexpr int S0 = K0 / 2, S1 = K1 / 2, S2 = K2 / 2;
-    __shared__ float frag[(S0 + S1 + S2) * 64];
+    extern __shared__ __attribute__((aligned(16))) float edge_lds[];
+    float* frag = edge_lds;                                      // (S0 + S1 + S2) * 64 weight fragments
+    float* stage = frag + (S0 + S1 + S2) * 64;                   // [4 waves][2 points][72 + C] output staging
+    float* fl = stage + 4 * 2 * (3 * G + C);                     // LDSF: [n_per_cloud][C + 4] features of this cloud
+    const bool vec_store = ((ldy & 3) == 0) && ((((uintptr_t)Y) & 15) == 0);
+    constexpr int FLD = C + 4;                                   // row stride 52 / 28 floats: 16-byte aligned, spreads the banks
     float* f0 = frag;
     float* f1 = frag + S0 * 64;
     float* f2 = f1 + S1 * 64;
     edge_fill_frag(f0, W0, K0, threadIdx.x);
     edge_fill_frag(f1, W1, K1, threadIdx.x);
     edge_fill_frag(f2, W2, K2, threadIdx.x);
+    // LDSF geometry: blockIdx.x = cloud * parts + part; the workgroup handles point groups [g_lo, g_hi) of its cloud
+    int cloud0 = 0, g_lo = 0, g_hi = (npoints + 1) / 2, gstep0 = gridDim.x * 4, gfirst = blockIdx.x * 4;
+    if constexpr (LDSF) {
+        const int parts = gridDim.y;                             // workgroups per cloud
+        const int cloud = blockIdx.x, part = blockIdx.y;
+        cloud0 = cloud * n_per_cloud;
+        const int gpc = n_per_cloud / 2;                         // groups per cloud (n_per_cloud even)
+        const int per = (gpc + parts - 1) / parts;
+        g_lo = cloud * gpc + part * per;
+        g_hi = min(cloud * gpc + gpc, g_lo + per);
+        gstep0 = 4;
+        gfirst = g_lo;
+        for (int e = threadIdx.x; e < n_per_cloud * (C / 4); e += 256) {
+            const int p = e / (C / 4), q = e - p * (C / 4);
+            *reinterpret_cast<float4*>(fl + p * FLD + q * 4) = *reinterpret_cast<const float4*>(F + (size_t)(cloud0 + p) * ldf + q * 4);
+        }
+    }
     __syncthreads();
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int row = lane & 31, h = lane >> 5;
-    const int ngroups = (npoints + 1) / 2;                       // 2 points per wave
+    const int ngroups = LDSF ? g_hi : (npoints + 1) / 2;         // 2 points per wave
     const int s_nb = row & 15;
     // the rows of the NEXT point group are fetched while the MFMAs of the current one run (ra/rb double as prefetch regs)
     float4 ra[C / 4], rb[C / 4];
     auto fetch = [&](int grp) {
         int p = grp * 2 + (row >> 4);
         if (p >= npoints) p = npoints - 1;
-        const int j = (p / n_per_cloud) * n_per_cloud + idx[(size_t)p * ldi + ioff + s_nb];
+        if constexpr (LDSF) {
+            const int jl = idx[(size_t)p * ldi + ioff + s_nb];   // cloud-local neighbour id
+            const float* fp_ = fl + (p - cloud0) * FLD;
+            const float* fj_ = fl + jl * FLD;
 #pragma unroll
-        for (int q = 0; q < C / 4; ++q) {
-            ra[q] = *reinterpret_cast<const float4*>(F + (size_t)p * ldf + q * 4);
-            rb[q] = *reinterpret_cast<const float4*>(F + (size_t)j * ldf + q * 4);
+            for (int q = 0; q < C / 4; ++q) {
+                ra[q] = *reinterpret_cast<const float4*>(fp_ + q * 4);
+                rb[q] = *reinterpret_cast<const float4*>(fj_ + q * 4);
+            }
+        } else {
+            const int j = (p / n_per_cloud) * n_per_cloud + idx[(size_t)p * ldi + ioff + s_nb];
+#pragma unroll
+            for (int q = 0; q < C / 4; ++q) {
+                ra[q] = *reinterpret_cast<const float4*>(F + (size_t)p * ldf + q * 4);
+                rb[q] = *reinterpret_cast<const float4*>(F + (size_t)j * ldf + q * 4);
+            }
         }
     };
-    const int grp0 = blockIdx.x * 4 + wave, gstride = gridDim.x * 4;
+    const int grp0 = gfirst + wave, gstride = gstep0;
     if (grp0 < ngroups) fetch(grp0);
     constexpr int WD = 12, STOT = S0 + S1 + S2;     // ring depth must divide STOT (84, 132): the ring wraps into the next group
     static_assert(STOT % WD == 0, "fragment ring depth must divide the step count");
     float wq[WD];
 #pragma unroll
     for (int i = 0; i < WD; ++i) wq[i] = frag[i * 64 + lane];
+#ifdef EDGE_STAMPS
+    unsigned long long e_conv = 0, e_l0 = 0, e_l1 = 0, e_l2 = 0, e_epi = 0, e_n = 0;
+#define ED_T(v) __builtin_amdgcn_sched_barrier(0); const unsigned long long v = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0)
+#else
+#define ED_T(v)
+#endif
     for (int grp = grp0; grp < ngroups; grp += gstride) {
-        const int p = grp * 2 + (row >> 4);
-        const bool ok = p < npoints;
-        const int pp = ok ? p : npoints - 1;
+        ED_T(t0);
         float fp[H], df[H];                                      // elements k = 2t + h of F_p and of F_j - F_p
 #pragma unroll
         for (int q = 0; q < C / 4; ++q) {
@@ -116,6 +168,7 @@ __global__ __launch_bounds__(256) void edge_dense_conv_mfma_kernel(int npoints, 
             wq[sg % WD] = frag[((sg + WD) % STOT) * 64 + lane];
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w, bv, acc, 0, 0, 0);
         };
+        ED_T(t1);
         // layer 0: k over [F_p (C), F_j - F_p (C)]
 #pragma unroll
         for (int s = 0; s < S0; ++s) {
@@ -124,6 +177,7 @@ __global__ __launch_bounds__(256) void edge_dense_conv_mfma_kernel(int npoints, 
         }
 #pragma unroll
         for (int r = 0; r < 12; ++r) l0[r] = fmaxf(l0[r] + b0[2 * r + h], 0.f);
+        ED_T(t2);
         // layer 1: k over [l0 (24), F_p (C)]
 #pragma unroll
         for (int s = 0; s < S1; ++s) {
@@ -132,27 +186,56 @@ __global__ __launch_bounds__(256) void edge_dense_conv_mfma_kernel(int npoints, 
         }
 #pragma unroll
         for (int r = 0; r < 12; ++r) l1[r] = fmaxf(l1[r] + b1[2 * r + h], 0.f);
+        ED_T(t3);
         // layer 2: k over [l1 (24), l0 (24), F_p (C)], no activation
 #pragma unroll
         for (int s = 0; s < S2; ++s) {
             const float bv = (s < 12) ? l1[s < 12 ? s : 0] : ((s < 24) ? l0[(s >= 12 && s < 24) ? s - 12 : 0] : fp[s >= 24 ? s - 24 : 0]);
             step(S0 + S1 + s, bv, l2);
         }
-        // max over the 16 neighbours (one DPP row) and store [l2 | l1 | l0 | F_p]; lane 15 of each row writes
-        float* __restrict__ yr = Y + (size_t)pp * ldy;
-        const bool writer = ok && s_nb == 15;
+        ED_T(t4);
+        // max over the 16 neighbours (one DPP row); lane 15 of each row parks [l2 | l1 | l0 | F_p] of its point in an LDS
+        // staging row, then the wave writes its two points with ONE float4 store instruction.  (60 separate 4-byte
+        // stores from four active lanes cost ~300 cycles of issue each next to the MFMAs: twice the 132-MFMA chain.)
+        constexpr int OW = 3 * G + C;                                // 96 / 120 floats per point
+        float* stg = stage + wave * (2 * OW);
+        const bool writer = s_nb == 15;
+        float* sp = stg + (row >> 4) * OW;
 #pragma unroll
         for (int r = 0; r < 12; ++r) {
             const float m2 = edge_row16_max(l2[r] + b2[2 * r + h]);
             const float m1 = edge_row16_max(l1[r]);
             const float m0 = edge_row16_max(l0[r]);
-            if (writer) { yr[2 * r + h] = m2; yr[G + 2 * r + h] = m1; yr[2 * G + 2 * r + h] = m0; }
+            if (writer) { sp[2 * r + h] = m2; sp[G + 2 * r + h] = m1; sp[2 * G + 2 * r + h] = m0; }
         }
         if (writer) {
 #pragma unroll
-            for (int t = 0; t < H; ++t) yr[3 * G + 2 * t + h] = fp[t];
+            for (int t = 0; t < H; ++t) sp[3 * G + 2 * t + h] = fp[t];
         }
+        // (LDS operations of one wave execute in order: the reads below see the writes above)
+        const int p_first = grp * 2;
+        if (vec_store) {
+            if (lane < 2 * (OW / 4)) {
+                const int pt = lane / (OW / 4), q4 = lane - pt * (OW / 4);
+                if (p_first + pt < npoints)
+                    *reinterpret_cast<float4*>(Y + (size_t)(p_first + pt) * ldy + q4 * 4) = *reinterpret_cast<const float4*>(stg + pt * OW + q4 * 4);
+            }
+        } else {
+            for (int e = lane; e < 2 * OW; e += 64) {
+                const int pt = e / OW, q = e - pt * OW;
+                if (p_first + pt < npoints) Y[(size_t)(p_first + pt) * ldy + q] = stg[e];
+            }
+        }
+#ifdef EDGE_STAMPS
+        { ED_T(t5); e_conv += t1 - t0; e_l0 += t2 - t1; e_l1 += t3 - t2; e_l2 += t4 - t3; e_epi += t5 - t4; ++e_n; }
+#endif
     }
+#ifdef EDGE_STAMPS
+    if (blockIdx.x == 3 && blockIdx.y == 0 && lane == 0) {
+        unsigned long long* st = reinterpret_cast<unsigned long long*>(Y + (size_t)npoints * ldy) + wave * 6;
+        st[0] = e_conv; st[1] = e_l0; st[2] = e_l1; st[3] = e_l2; st[4] = e_epi; st[5] = e_n;
+    }
+#endif
 }
 
 }  // namespace dispu
@@ -164,13 +247,41 @@ DISPU_EXPORT int dispu_edge_dense_conv(int npoints, int n_per_cloud, int C, cons
                                        const float* W2, const float* b2, float* Y, long ldy, void* stream) {
     if (npoints < 0 || n_per_cloud <= 0 || !(C == 24 || C == 48) || (ldf & 3) || (((uintptr_t)F) & 15)) return (int)hipErrorInvalidValue;
     if (npoints == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    const size_t frag_bytes = (size_t)((C == 24 ? 84 : 132) * 64 + 8 * (72 + C)) * sizeof(float);   // weight fragments + output staging
+    // LDS-resident cloud features when a cloud fits next to the weight fragments (n <= ~600 points at C = 48) and the
+    // points are whole clouds; each cloud is split over `parts` workgroups so that ~256 of them exist
+    const size_t feat_bytes = (size_t)n_per_cloud * (C + 4) * sizeof(float);
+    static int mode = -1;               // DISPU_EDGE_LDS=0 forces the global-gather kernel (A/B tests)
+    if (mode < 0) { const char* e = getenv("DISPU_EDGE_LDS"); mode = e ? atoi(e) : 1; }
+    if (mode != 0 && npoints % n_per_cloud == 0 && n_per_cloud % 2 == 0 && frag_bytes + feat_bytes <= 160 * 1024) {
+        const int clouds = npoints / n_per_cloud;
+        int parts = (256 + clouds - 1) / clouds;
+        const int gpc = n_per_cloud / 2;
+        if (parts > (gpc + 3) / 4) parts = (gpc + 3) / 4;                 // at least one group per wave
+        if (parts < 1) parts = 1;
+        const size_t bytes = frag_bytes + feat_bytes;
+        static bool attr = false;
+        if (!attr) {
+            DISPU_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(edge_dense_conv_mfma_kernel<24, true>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            DISPU_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(edge_dense_conv_mfma_kernel<48, true>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr = true;
+        }
+        if (C == 24)
+            hipLaunchKernelGGL((edge_dense_conv_mfma_kernel<24, true>), dim3(clouds, parts), dim3(256), bytes, s, npoints, n_per_cloud, F, ldf, idx, ldi, ioff, W0, b0, W1, b1, W2, b2, Y, ldy);
+        else
+            hipLaunchKernelGGL((edge_dense_conv_mfma_kernel<48, true>), dim3(clouds, parts), dim3(256), bytes, s, npoints, n_per_cloud, F, ldf, idx, ldi, ioff, W0, b0, W1, b1, W2, b2, Y, ldy);
+        return (int)hipGetLastError();
+    }
     int g = (npoints + 7) / 8;          // 8 points (4 waves x 2) per workgroup pass
     static int cap = -1;                // workgroups loop over point groups: the LDS weight image is built once per CU
     if (cap < 0) { const char* e = getenv("DISPU_EDGE_GRID"); cap = e ? atoi(e) : 256; }
     if (g > cap) g = cap;
     if (C == 24)
-        hipLaunchKernelGGL((edge_dense_conv_mfma_kernel<24>), dim3(g), dim3(256), 0, (hipStream_t)stream, npoints, n_per_cloud, F, ldf, idx, ldi, ioff, W0, b0, W1, b1, W2, b2, Y, ldy);
+        hipLaunchKernelGGL((edge_dense_conv_mfma_kernel<24, false>), dim3(g), dim3(256), frag_bytes, s, npoints, n_per_cloud, F, ldf, idx, ldi, ioff, W0, b0, W1, b1, W2, b2, Y, ldy);
     else
-        hipLaunchKernelGGL((edge_dense_conv_mfma_kernel<48>), dim3(g), dim3(256), 0, (hipStream_t)stream, npoints, n_per_cloud, F, ldf, idx, ldi, ioff, W0, b0, W1, b1, W2, b2, Y, ldy);
+        hipLaunchKernelGGL((edge_dense_conv_mfma_kernel<48, false>), dim3(g), dim3(256), frag_bytes, s, npoints, n_per_cloud, F, ldf, idx, ldi, ioff, W0, b0, W1, b1, W2, b2, Y, ldy);
     return (int)hipGetLastError();
 }
