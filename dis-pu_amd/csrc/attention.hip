@@ -11,8 +11,10 @@
 // logits in its accumulator registers.  The online softmax is therefore per-lane arithmetic plus ONE exchange with
 // the partner lane (lane ^ 32), the rescale of O^T is a per-lane multiply, and the exponentiated registers are
 // fed back UNMOVED as the B operand of the second product (step r pairs key rows r' and r'+4 - exactly the rows
-// the two half-waves hold in register r).  A workgroup = 4 waves = 128 queries of one cloud; K|V tiles of 32 keys
-// stream through two LDS stages with register prefetch (one barrier per tile).
+// the two half-waves hold in register r).  A workgroup = 128 queries of one cloud = 4 MFMA waves (fragment reads, MFMAs and
+// the per-lane softmax arithmetic only) + 4 loader waves that stream the K|V tiles of 32 keys through two LDS stages
+// (global -> registers -> LDS, one tile in flight, one barrier per tile): a wave that issues its own global loads
+// next to its MFMAs keeps the matrix pipe under 50 % busy (see linear.hip).
 #include "common.h"
 
 namespace dispu {
@@ -22,19 +24,62 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int FA_D = 64, FA_TK = 32, FA_LDK = FA_D + 1;
 constexpr int FA_STAGE = FA_TK * FA_LDK + FA_TK * FA_D;     // floats: K tile [32][65] + V tile [32][64]
 
-__global__ __launch_bounds__(256) void flash_attention_kernel(int m, int nk, const float* __restrict__ Q, long ldq,
+__global__ __launch_bounds__(512) void flash_attention_kernel(int m, int nk, const float* __restrict__ Q, long ldq,
                                                                const float* __restrict__ K, long ldk,
                                                                const float* __restrict__ V, long ldv, float scale,
                                                                float* __restrict__ O, long ldo) {
     __shared__ __attribute__((aligned(16))) float lds[2 * FA_STAGE];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int cloud = blockIdx.y;
+    const float* __restrict__ kb = K + (size_t)cloud * nk * ldk;
+    const float* __restrict__ vb = V + (size_t)cloud * nk * ldv;
+    const int ntile = nk / FA_TK;
+
+    if (wave >= 4) {
+        // ---------------------------------------------------------------------------------- loader waves
+        // tile: 32 keys x (64 K + 64 V) floats = 512 float4 of K and 512 of V; loader thread -> 2 + 2 float4
+        const int tid = threadIdx.x - 256;
+        float4 pk[2], pv[2];
+        auto load_tile = [&](int k0) {
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int e = tid + it * 256, key = e >> 4, c4 = e & 15;
+                pk[it] = *reinterpret_cast<const float4*>(kb + (size_t)(k0 + key) * ldk + c4 * 4);
+                pv[it] = *reinterpret_cast<const float4*>(vb + (size_t)(k0 + key) * ldv + c4 * 4);
+            }
+        };
+        auto store_tile = [&](int stage) {
+            float* Kt = lds + stage * FA_STAGE;
+            float* Vt = Kt + FA_TK * FA_LDK;
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int e = tid + it * 256, key = e >> 4, c4 = e & 15;
+                Kt[key * FA_LDK + c4 * 4 + 0] = pk[it].x;
+                Kt[key * FA_LDK + c4 * 4 + 1] = pk[it].y;
+                Kt[key * FA_LDK + c4 * 4 + 2] = pk[it].z;
+                Kt[key * FA_LDK + c4 * 4 + 3] = pk[it].w;
+                *reinterpret_cast<float4*>(&Vt[key * FA_D + c4 * 4]) = pv[it];
+            }
+        };
+        load_tile(0);
+        store_tile(0);
+        if (ntile > 1) load_tile(FA_TK);
+        __syncthreads();
+        for (int t = 0; t < ntile; ++t) {
+            if (t + 1 < ntile) {
+                store_tile((t + 1) & 1);
+                if (t + 2 < ntile) load_tile((t + 2) * FA_TK);
+            }
+            __syncthreads();
+        }
+        return;
+    }
+
+    // ------------------------------------------------------------------------------------------ MFMA waves
     const int qrow = blockIdx.x * 128 + wave * 32 + (lane & 31);
     const int kh = lane >> 5, li = lane & 31;
     const bool qok = qrow < m;
     const float* __restrict__ qp = Q + ((size_t)cloud * m + (qok ? qrow : 0)) * ldq;
-    const float* __restrict__ kb = K + (size_t)cloud * nk * ldk;
-    const float* __restrict__ vb = V + (size_t)cloud * nk * ldv;
 
     float qf[32];                                    // Q[q][2s + kh]
 #pragma unroll
@@ -44,30 +89,6 @@ __global__ __launch_bounds__(256) void flash_attention_kernel(int m, int nk, con
         qf[2 * s4 + 1] = kh ? v.w : v.z;
     }
 
-    // tile loader: 32 keys x (64 K + 64 V) floats = 512 float4 of K and 512 of V; thread -> 2 + 2 float4
-    float4 pk[2], pv[2];
-    auto load_tile = [&](int k0) {
-#pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            const int e = tid + it * 256, key = e >> 4, c4 = e & 15;
-            pk[it] = *reinterpret_cast<const float4*>(kb + (size_t)(k0 + key) * ldk + c4 * 4);
-            pv[it] = *reinterpret_cast<const float4*>(vb + (size_t)(k0 + key) * ldv + c4 * 4);
-        }
-    };
-    auto store_tile = [&](int stage) {
-        float* Kt = lds + stage * FA_STAGE;
-        float* Vt = Kt + FA_TK * FA_LDK;
-#pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            const int e = tid + it * 256, key = e >> 4, c4 = e & 15;
-            Kt[key * FA_LDK + c4 * 4 + 0] = pk[it].x;
-            Kt[key * FA_LDK + c4 * 4 + 1] = pk[it].y;
-            Kt[key * FA_LDK + c4 * 4 + 2] = pk[it].z;
-            Kt[key * FA_LDK + c4 * 4 + 3] = pk[it].w;
-            *reinterpret_cast<float4*>(&Vt[key * FA_D + c4 * 4]) = pv[it];
-        }
-    };
-
     f32x16 oacc[2];
 #pragma unroll
     for (int c = 0; c < 2; ++c)
@@ -75,18 +96,10 @@ __global__ __launch_bounds__(256) void flash_attention_kernel(int m, int nk, con
         for (int r = 0; r < 16; ++r) oacc[c][r] = 0.f;
     float mrun = -__builtin_inff(), lsum = 0.f;
 
-    const int ntile = nk / FA_TK;
-    load_tile(0);
-    store_tile(0);
-    if (ntile > 1) load_tile(FA_TK);
     __syncthreads();
     for (int t = 0; t < ntile; ++t) {
         const float* Kt = lds + (t & 1) * FA_STAGE;
         const float* Vt = Kt + FA_TK * FA_LDK;
-        if (t + 1 < ntile) {
-            store_tile((t + 1) & 1);
-            if (t + 2 < ntile) load_tile((t + 2) * FA_TK);
-        }
         // S^T tile: 32 keys x 32 queries, d ascending
         f32x16 sacc;
 #pragma unroll
@@ -143,7 +156,7 @@ DISPU_EXPORT int dispu_attention(int b, int m, int nk, int d, const float* Q, lo
         ((((uintptr_t)Q) | ((uintptr_t)K) | ((uintptr_t)V)) & 15))
         return (int)hipErrorInvalidValue;
     if (b == 0) return 0;
-    hipLaunchKernelGGL(flash_attention_kernel, dim3((m + 127) / 128, b), dim3(256), 0, (hipStream_t)stream, m, nk, Q, ldq, K, ldk,
+    hipLaunchKernelGGL(flash_attention_kernel, dim3((m + 127) / 128, b), dim3(512), 0, (hipStream_t)stream, m, nk, Q, ldq, K, ldk,
                        V, ldv, scale, O, ldo);
     return (int)hipGetLastError();
 }
