@@ -29,12 +29,12 @@ struct TnArgs {
 
 constexpr int TN_SLAB = 16;              // rows of X / Z per LDS stage
 
-// block = 2 x 2 waves; wave tile (32*TK) x (32*TNN); block tile (64*TK) x (64*TNN).
-// Same pipeline as the forward GEMM (linear.hip): the next slab is already in registers and is parked in the other
-// LDS stage while this stage's MFMAs run; one barrier per slab.  EDGE = false: every slab and tile is interior and
-// 16-byte aligned -> no predicates.
+// block = 2 x 2 MFMA waves + 4 loader waves; wave tile (32*TK) x (32*TNN); block tile (64*TK) x (64*TNN).
+// Wave-specialised like the forward GEMM (linear.hip): the loader waves move the row slabs of X and Z (global ->
+// registers -> LDS, one slab in flight), the MFMA waves only read operand fragments and issue MFMAs; one barrier
+// per slab.  EDGE = false: every slab and tile is interior and 16-byte aligned -> no predicates.
 template <int TK, int TNN, bool EDGE>
-__global__ __launch_bounds__(256) void linear_tn_kernel(TnArgs a) {
+__global__ __launch_bounds__(512) void linear_tn_kernel(TnArgs a) {
     constexpr int BKT = 64 * TK, BNT = 64 * TNN;
     constexpr int LDXS = BKT + 32, LDZS = BNT + 32;      // +32 floats: the two half-waves of an operand read hit disjoint banks
     constexpr int STAGE = TN_SLAB * (LDXS + LDZS);
@@ -45,16 +45,78 @@ __global__ __launch_bounds__(256) void linear_tn_kernel(TnArgs a) {
     const int tk = blockIdx.x / ntn, tn = blockIdx.x - tk * ntn;
     const int k0 = tk * BKT, n0 = tn * BNT;
     const int split = blockIdx.y, z = blockIdx.z;
-    const int tid = threadIdx.x;
-    const int wave = tid >> 6, lane = tid & 63;
-    const int wk = wave >> 1, wn = wave & 1;
-    const float* __restrict__ X = a.X + (size_t)z * a.sx;
-    const float* __restrict__ Z = a.Z + (size_t)z * a.sz;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int m_begin = split * a.rows_per_split;
     const int m_end = min(a.M, m_begin + a.rows_per_split);
-    const bool x_vec = ((a.ldx & 3) == 0) && ((((uintptr_t)X) & 15) == 0);
-    const bool z_vec = ((a.ldz & 3) == 0) && ((((uintptr_t)Z) & 15) == 0);
+    const int nslab = (m_end - m_begin + TN_SLAB - 1) / TN_SLAB;
 
+    if (wave >= 4) {
+        // ------------------------------------------------------------------------------------ loader waves
+        const int tid = threadIdx.x - 256;
+        const float* __restrict__ X = a.X + (size_t)z * a.sx;
+        const float* __restrict__ Z = a.Z + (size_t)z * a.sz;
+        const bool x_vec = ((a.ldx & 3) == 0) && ((((uintptr_t)X) & 15) == 0);
+        const bool z_vec = ((a.ldz & 3) == 0) && ((((uintptr_t)Z) & 15) == 0);
+        // one float4 of a row-major slab: element (m0 + r, c0 + 4*q)
+        auto load4 = [&](const float* __restrict__ P, long ld, bool vec, int m0, int c0, int climit, int width, int it) -> float4 {
+            const int idx = tid + it * 256;
+            const int r = idx / (width / 4), q = idx % (width / 4);
+            const int m = m0 + r, c = c0 + q * 4;
+            if constexpr (!EDGE) return *reinterpret_cast<const float4*>(P + (size_t)m * ld + c);
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (m < m_end && c < climit) {
+                const float* p = P + (size_t)m * ld + c;
+                if (vec && c + 3 < climit) {
+                    v = *reinterpret_cast<const float4*>(p);
+                } else {
+                    v.x = p[0];
+                    if (c + 1 < climit) v.y = p[1];
+                    if (c + 2 < climit) v.z = p[2];
+                    if (c + 3 < climit) v.w = p[3];
+                }
+            }
+            return v;
+        };
+        float4 px[X_F4], pz[Z_F4];
+        auto load_slab = [&](int m0) {
+#pragma unroll
+            for (int it = 0; it < X_F4; ++it) px[it] = load4(X, a.ldx, x_vec, m0, k0, a.K, BKT, it);
+#pragma unroll
+            for (int it = 0; it < Z_F4; ++it) pz[it] = load4(Z, a.ldz, z_vec, m0, n0, a.N, BNT, it);
+        };
+        auto store_slab = [&](int stage) {
+            float* xs = tn_lds + stage * STAGE;
+            float* zs = xs + TN_SLAB * LDXS;
+#pragma unroll
+            for (int it = 0; it < X_F4; ++it) {
+                const int idx = tid + it * 256;
+                *reinterpret_cast<float4*>(&xs[(idx / (BKT / 4)) * LDXS + (idx % (BKT / 4)) * 4]) = px[it];
+            }
+#pragma unroll
+            for (int it = 0; it < Z_F4; ++it) {
+                const int idx = tid + it * 256;
+                *reinterpret_cast<float4*>(&zs[(idx / (BNT / 4)) * LDZS + (idx % (BNT / 4)) * 4]) = pz[it];
+            }
+        };
+        if (nslab > 0) {
+            load_slab(m_begin);
+            store_slab(0);
+            if (nslab > 1) load_slab(m_begin + TN_SLAB);
+        }
+        __syncthreads();
+        for (int t = 0; t < nslab; ++t) {
+            if (t + 1 < nslab) {
+                store_slab((t + 1) & 1);
+                if (t + 2 < nslab) load_slab(m_begin + (t + 2) * TN_SLAB);
+            }
+            __syncthreads();
+        }
+        return;
+    }
+
+    // ------------------------------------------------------------------------------------------ MFMA waves
+    const int tid = threadIdx.x;
+    const int wk = wave >> 1, wn = wave & 1;
     v16f acc[TK][TNN];
 #pragma unroll
     for (int i = 0; i < TK; ++i)
@@ -63,65 +125,13 @@ __global__ __launch_bounds__(256) void linear_tn_kernel(TnArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // one float4 of a row-major slab: element (m0 + r, c0 + 4*q)
-    auto load4 = [&](const float* __restrict__ P, long ld, bool vec, int m0, int c0, int climit, int width, int it) -> float4 {
-        const int idx = tid + it * 256;
-        const int r = idx / (width / 4), q = idx % (width / 4);
-        const int m = m0 + r, c = c0 + q * 4;
-        if constexpr (!EDGE) return *reinterpret_cast<const float4*>(P + (size_t)m * ld + c);
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (m < m_end && c < climit) {
-            const float* p = P + (size_t)m * ld + c;
-            if (vec && c + 3 < climit) {
-                v = *reinterpret_cast<const float4*>(p);
-            } else {
-                v.x = p[0];
-                if (c + 1 < climit) v.y = p[1];
-                if (c + 2 < climit) v.z = p[2];
-                if (c + 3 < climit) v.w = p[3];
-            }
-        }
-        return v;
-    };
-    float4 px[X_F4], pz[Z_F4];
-    auto load_slab = [&](int m0) {
-#pragma unroll
-        for (int it = 0; it < X_F4; ++it) px[it] = load4(X, a.ldx, x_vec, m0, k0, a.K, BKT, it);
-#pragma unroll
-        for (int it = 0; it < Z_F4; ++it) pz[it] = load4(Z, a.ldz, z_vec, m0, n0, a.N, BNT, it);
-    };
-    auto store_slab = [&](int stage) {
-        float* xs = tn_lds + stage * STAGE;
-        float* zs = xs + TN_SLAB * LDXS;
-#pragma unroll
-        for (int it = 0; it < X_F4; ++it) {
-            const int idx = tid + it * 256;
-            *reinterpret_cast<float4*>(&xs[(idx / (BKT / 4)) * LDXS + (idx % (BKT / 4)) * 4]) = px[it];
-        }
-#pragma unroll
-        for (int it = 0; it < Z_F4; ++it) {
-            const int idx = tid + it * 256;
-            *reinterpret_cast<float4*>(&zs[(idx / (BNT / 4)) * LDZS + (idx % (BNT / 4)) * 4]) = pz[it];
-        }
-    };
-
     float bsum = 0.f;                    // column sum of Z for column n0 + tid (K-tile 0 only)
     const bool do_bias = a.want_bias && tk == 0 && tid < BNT;
-    const int nslab = (m_end - m_begin + TN_SLAB - 1) / TN_SLAB;
-    if (nslab > 0) {
-        load_slab(m_begin);
-        store_slab(0);
-        if (nslab > 1) load_slab(m_begin + TN_SLAB);
-    }
     __syncthreads();
     const int fi = lane & 31, fk = lane >> 5;
     for (int t = 0; t < nslab; ++t) {
         const float* xs = tn_lds + (t & 1) * STAGE;
         const float* zs = xs + TN_SLAB * LDXS;
-        if (t + 1 < nslab) {
-            store_slab((t + 1) & 1);
-            if (t + 2 < nslab) load_slab(m_begin + (t + 2) * TN_SLAB);
-        }
 #pragma unroll
         for (int kk = 0; kk < TN_SLAB; kk += 2) {
             float af[TK], bf[TNN];
@@ -169,7 +179,7 @@ template <int TK, int TNN, bool EDGE>
 static int launch_tn(const TnArgs& a, dim3 grid, hipStream_t s) {
     constexpr size_t bytes = (size_t)2 * TN_SLAB * (64 * TK + 32 + 64 * TNN + 32) * sizeof(float);
     static_assert(bytes <= 64 * 1024, "TN stage exceeds the default dynamic LDS limit");
-    hipLaunchKernelGGL((linear_tn_kernel<TK, TNN, EDGE>), grid, dim3(256), bytes, s, a);
+    hipLaunchKernelGGL((linear_tn_kernel<TK, TNN, EDGE>), grid, dim3(512), bytes, s, a);
     return (int)hipGetLastError();
 }
 
