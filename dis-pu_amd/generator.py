@@ -149,14 +149,15 @@ class Generator(object):
         ldy = Y.stride(0) if ldy is None else ldy
         p = lambda t, off=0: _lib.C.c_void_p(t.data_ptr() + 4 * off) if t is not None else _lib.C.c_void_p(0)
         name = "linear"
-        if self.profile is not None:     # "linear<BM,BN,transb>[MxKxN]": the instantiation name rocprofv3 reports
+        if self.profile is not None:     # "linear<BM, BN, 2, 2, BK, transb, edge, epi>[MxKxN]": the instantiation rocprofv3 reports
             t = L.dispu_linear_tile(batch, M, N)
             bm, bn, bk = {128257: (128, 256, 16), 128256: (128, 256, 32), 128129: (128, 128, 16), 128128: (128, 128, 32),
                           64128: (64, 128, 32), 128064: (128, 64, 32)}.get(t, (64, 64, 32))
             edge = not (M % bm == 0 and N % bn == 0 and K % bk == 0 and ldx % 4 == 0 and ldw % 4 == 0 and sx % 4 == 0
                         and sw % 4 == 0 and (X.data_ptr() + 4 * xoff) % 16 == 0 and (W.data_ptr() + 4 * woff) % 16 == 0)
-            name = "linear<%d, %d, 2, 2, %d, %s, %s>[%dx%dx%d]" % (bm, bn, bk, "true" if transb else "false",
-                                                                  "true" if edge else "false", M * batch, K, N)
+            epi = 0 if (R1 is None and R2 is None) else 4       # epilogue variant: 0 bias/act, 4 with residual inputs
+            name = "linear<%d, %d, 2, 2, %d, %s, %s, %d>[%dx%dx%d]" % (bm, bn, bk, "true" if transb else "false",
+                                                                      "true" if edge else "false", epi, M * batch, K, N)
         self._call(name, L.dispu_linear, batch, M, K, N,
                    p(X, xoff), ldx, sx, p(W, woff), ldw, sw, transb, p(bias), act, p(Y, yoff), ldy, sy, p(R1),
                    R1.stride(0) if R1 is not None else 0, 0, p(R2), R2.stride(0) if R2 is not None else 0, 0, st)
