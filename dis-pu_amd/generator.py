@@ -70,6 +70,8 @@ class Generator(object):
         self.fused_local = True      # PointShuffle2 local cell in one kernel (False: the 4-kernel chain, for A/B tests)
         self.fused_attention = True  # non-local cell attention on chip (False: GEMM -> softmax -> GEMM through HBM)
         self.fused_residual = bool(int(__import__('os').environ.get('DISPU_FUSED_RES', '1')))
+        self.fused_heads = bool(int(__import__('os').environ.get('DISPU_FUSED_HEADS', '1')))   # one launch per head chain
+        self.keep_intermediates = False   # fused heads: also write the aggregation output (tests compare it)
         if params is not None:
             self.load_params(params)
 
@@ -209,16 +211,26 @@ class Generator(object):
         self._linear(st, feat, 480, self.w_up_feat, None, 0, ws["h256"], 256)
         self._call("dup_grid", L.dispu_dup_grid, B, N, 256, self.up_ratio, ptr(ws["h256"]), 256, ptr(self.w_up_grid), ptr(b1), ptr(self.grid),
                              ptr(ws["up256"]), 256, st)
-        w, b = self._w("generator/upshuffle_0/conv2")
-        self._linear(st, ws["up256"], 256, w, b, 1, ws["up128"], 128)
         cs = "generator/coarse_coordinate_regressor/"
-        w, b = self._w(cs + "fc_layer0")
-        self._linear(st, ws["up128"], 128, w, b, 1, ws["c256"], 256)
-        w, b = self._w(cs + "fc_layer1")
-        self._linear(st, ws["c256"], 256, w, b, 1, ws["c64"], 64)
-        w, b = self._w(cs + "fc_layer2")
         coarse = ws["coarse"]
-        self._call("coarse", L.dispu_linear_small_n, rm, 64, 3, ptr(ws["c64"]), 64, ptr(w), ptr(b), 0, None, 0, ptr(coarse), 3, st)
+        heads = self.fused_heads and rm % 128 == 0
+        if heads:
+            # conv2 -> fc_layer0 -> fc_layer1 -> fc_layer2 in one launch; up128 (needed by PointShuffle2) is written on the way
+            w1, b1_ = self._w("generator/upshuffle_0/conv2")
+            w2, b2_ = self._w(cs + "fc_layer0")
+            w3, b3_ = self._w(cs + "fc_layer1")
+            w4, b4_ = self._w(cs + "fc_layer2")
+            self._call("mlp_chain[coarse]", L.dispu_mlp_chain, rm, 256, 128, 256, 64, ptr(ws["up256"]), 256, ptr(w1), ptr(b1_), ptr(w2), ptr(b2_),
+                       ptr(w3), ptr(b3_), ptr(w4), ptr(b4_), ptr(ws["up128"]), 128, 0, None, 0, ptr(coarse), 3, st)
+        else:
+            w, b = self._w("generator/upshuffle_0/conv2")
+            self._linear(st, ws["up256"], 256, w, b, 1, ws["up128"], 128)
+            w, b = self._w(cs + "fc_layer0")
+            self._linear(st, ws["up128"], 128, w, b, 1, ws["c256"], 256)
+            w, b = self._w(cs + "fc_layer1")
+            self._linear(st, ws["c256"], 256, w, b, 1, ws["c64"], 64)
+            w, b = self._w(cs + "fc_layer2")
+            self._call("coarse", L.dispu_linear_small_n, rm, 64, 3, ptr(ws["c64"]), 64, ptr(w), ptr(b), 0, None, 0, ptr(coarse), 3, st)
 
         # ---- PointShuffle2 (ops.py:1012-1087)
         ps = "refine/PointShuffle/"
@@ -275,15 +287,23 @@ class Generator(object):
             # same arithmetic order ((act(.) + skip) + nl) in a separate streaming kernel
             self._linear(st, ws["fp"], 2048, w, b, 1, ws["aft"], 256)
             self._call("add3", L.dispu_add3, rm * 256, ptr(ws["aft"]), ptr(ws["skip"]), ptr(ws["nl"]), ptr(ws["aft"]), st)
-        w, b = self._w(ps + "aggregation")
-        self._linear(st, ws["aft"], 256, w, b, 1, ws["agg"], 256)
-
-        # ---- fine coordinate_regressor (is_off) + residual (generator.py:76-81)
         fs = "refine/fine_coordinate_regressor/"
-        w, b = self._w(fs + "fc_layer0")
-        self._linear(st, ws["agg"], 256, w, b, 1, ws["f256"], 256)
-        w, b = self._w(fs + "fc_layer1")
-        self._linear(st, ws["f256"], 256, w, b, 1, ws["f64"], 64)
-        w, b = self._w(fs + "fc_layer2")
-        self._call("fine", L.dispu_linear_small_n, rm, 64, 3, ptr(ws["f64"]), 64, ptr(w), ptr(b), 1, ptr(coarse), 3, ptr(ws["fine"]), 3, st)
+        if heads:
+            w1, b1_ = self._w(ps + "aggregation")
+            w2, b2_ = self._w(fs + "fc_layer0")
+            w3, b3_ = self._w(fs + "fc_layer1")
+            w4, b4_ = self._w(fs + "fc_layer2")
+            self._call("mlp_chain[fine]", L.dispu_mlp_chain, rm, 256, 256, 256, 64, ptr(ws["aft"]), 256, ptr(w1), ptr(b1_), ptr(w2), ptr(b2_),
+                       ptr(w3), ptr(b3_), ptr(w4), ptr(b4_), ptr(ws["agg"]) if self.keep_intermediates else None, 256, 1, ptr(coarse), 3,
+                       ptr(ws["fine"]), 3, st)
+        else:
+            w, b = self._w(ps + "aggregation")
+            self._linear(st, ws["aft"], 256, w, b, 1, ws["agg"], 256)
+            # ---- fine coordinate_regressor (is_off) + residual (generator.py:76-81)
+            w, b = self._w(fs + "fc_layer0")
+            self._linear(st, ws["agg"], 256, w, b, 1, ws["f256"], 256)
+            w, b = self._w(fs + "fc_layer1")
+            self._linear(st, ws["f256"], 256, w, b, 1, ws["f64"], 64)
+            w, b = self._w(fs + "fc_layer2")
+            self._call("fine", L.dispu_linear_small_n, rm, 64, 3, ptr(ws["f64"]), 64, ptr(w), ptr(b), 1, ptr(coarse), 3, ptr(ws["fine"]), 3, st)
         return coarse, ws["fine"]

@@ -205,6 +205,15 @@ int dispu_attention(int b, int m, int nk, int d, const float* Q, long ldq, const
 /* S <- softmax(S * mul) per row, in place (tf.nn.softmax of PointNonLocalCell, ops.py:338). */
 int dispu_softmax_rows(long rows, int n, float mul, float* S, long lds, void* stream);
 
+/* Fused head chains (one launch, activations stay in LDS): X [rows, K0] -> relu(. W1 + b1) [N1] -> relu(. W2 + b2) [N2]
+ * -> relu(. W3 + b3) [N3] -> . W4 + b4 [3]; mode 1: out = R + sigmoid(.) - 0.5.  Y1 (optional) receives the first
+ * layer's output.  Coarse head: upshuffle conv2 + coordinate_regressor (ops.py:1186-1192, 1089-1104), shape
+ * (256,128,256,64); fine head: PointShuffle2 aggregation + coordinate_regressor is_off (ops.py:1079-1083, 1089-1108),
+ * shape (256,256,256,64).  rows % 128 == 0.  Bit-identical to the dispu_linear / dispu_linear_small_n launches. */
+int dispu_mlp_chain(long rows, int K0, int N1, int N2, int N3, const float* X, long ldx, const float* W1, const float* b1,
+                    const float* W2, const float* b2, const float* W3, const float* b3, const float* W4, const float* b4,
+                    float* Y1, long ldy1, int mode, const float* R, long ldr, float* out, long ldo, void* stream);
+
 /* ---- glue kernels of the PointNet++ / EdgeConv / loss compositions --------------------------------------
  * (Common/pointnet_util.py, gcn_lib/tf_vertex.py, Common/loss_utils.py: chains of generic TF ops in the reference) */
 /* grouped[r,s,:] -= center[r,:]  ("translation normalization", pointnet_util.py:43; loss_utils.py:281). */

@@ -20,6 +20,7 @@ def setup(dev):
     from dispu_amd.generator import Generator
     P = OG.init_params(seed=1234, bias_scale=0.05, bn_random=True)   # exercise biases and the BN fold
     gen = Generator(params=P, device=dev)
+    gen.keep_intermediates = True                 # the fused fine head then also writes the aggregation output
     x = synth.patches(3, 256, seed=5)
     tap = {}
     coarse, fine = OG.generator_forward(P, x, tap)
@@ -179,3 +180,22 @@ def test_edge_dense_conv_mfma_equals_valu_and_oracle(dev, C, npts):
     assert np.array_equal(outs[0], outs[1])
     assert np.array_equal(outs[0][:, :72 + C].reshape(nb, n_cloud, 72 + C), want)
     assert (outs[0][:, 72 + C:] == 0).all()
+
+
+def test_fused_head_chains_equal_separate_launches(dev):
+    """dispu_mlp_chain (one launch per head, activations in LDS) vs the dispu_linear / dispu_linear_small_n launches:
+    bit-identical coarse, fine, up128 and aggregation output."""
+    from dispu_amd import synth
+    from dispu_amd.generator import Generator
+    P = OG.init_params(seed=3, bias_scale=0.05, bn_random=True)
+    x = torch.from_numpy(synth.patches(2, 256, seed=13)).to(dev)
+    outs = []
+    for fused in (True, False):
+        gen = Generator(params=P, device=dev)
+        gen.fused_heads = fused
+        gen.keep_intermediates = True
+        c, f = gen(x)
+        ws = gen._ws[(2, 256)]
+        outs.append([N(c).copy(), N(f).copy(), N(ws["up128"]).copy(), N(ws["agg"]).copy()])
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b)
