@@ -199,3 +199,17 @@ def test_fused_head_chains_equal_separate_launches(dev):
         outs.append([N(c).copy(), N(f).copy(), N(ws["up128"]).copy(), N(ws["agg"]).copy()])
     for a, b in zip(*outs):
         assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("B", [1, 5])
+def test_odd_batch_sizes_match_oracle(dev, B):
+    """BASELINE configs[0] (a single 256-point patch) and a batch that is not a multiple of anything: persistent /
+    per-cloud kernels must cope with fewer point groups than CUs and with ragged grids."""
+    from dispu_amd import synth
+    from dispu_amd.generator import Generator
+    P = OG.init_params(seed=11, bias_scale=0.05, bn_random=True)
+    x = synth.patches(B, 256, seed=40 + B)
+    coarse, fine = OG.generator_forward(P, x)
+    c, f = Generator(params=P, device=dev)(torch.from_numpy(x).to(dev))
+    assert np.array_equal(N(c), coarse)
+    assert np.abs(N(f) - fine).max() <= 1e-5
