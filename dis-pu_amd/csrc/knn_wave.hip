@@ -78,6 +78,40 @@ __device__ __forceinline__ uint64_t select_k(const uint64_t (&key)[R], uint64_t*
     return res;
 }
 
+// Two queries at once, heads and the whole per-lane sorted list in registers (R <= 4: the next head after a win is a
+// 3-deep select on the lane's position instead of an LDS read).  The two selection chains are independent, so their
+// DPP / readlane / ballot latencies overlap; lane t keeps result t of both.
+template <int R>
+__device__ __forceinline__ void select_k2(const uint64_t (&ka)[R], const uint64_t (&kb)[R], int lane, int k, uint64_t& ra, uint64_t& rb) {
+    static_assert(R <= 4, "register-resident selection is written for up to four keys per lane");
+    uint32_t hda = (uint32_t)(ka[0] >> 32), hia = (uint32_t)ka[0], hdb = (uint32_t)(kb[0] >> 32), hib = (uint32_t)kb[0];
+    int hpa = 0, hpb = 0;
+    ra = 0; rb = 0;
+    auto nth = [&](const uint64_t (&key)[R], int hp) -> uint64_t {
+        uint64_t v = KEY_MAX;
+#pragma unroll
+        for (int i = R - 1; i >= 1; --i) v = (hp == i) ? key[i] : v;
+        return v;
+    };
+    for (int t = 0; t < k; ++t) {
+        const uint32_t mda = wave_min_u32(hda), mdb = wave_min_u32(hdb);
+        unsigned long long ma = __ballot(hda == mda), mb = __ballot(hdb == mdb);
+        if (__popcll(ma) != 1) {                                    // wave-uniform; equal distances: lowest index wins
+            const uint32_t mi = wave_min_u32(hda == mda ? hia : 0xFFFFFFFFu);
+            ma = __ballot(hda == mda && hia == mi);
+        }
+        if (__popcll(mb) != 1) {
+            const uint32_t mi = wave_min_u32(hdb == mdb ? hib : 0xFFFFFFFFu);
+            mb = __ballot(hdb == mdb && hib == mi);
+        }
+        const int wa = __builtin_ctzll(ma), wb = __builtin_ctzll(mb);
+        const uint32_t wia = (uint32_t)__builtin_amdgcn_readlane((int)hia, wa), wib = (uint32_t)__builtin_amdgcn_readlane((int)hib, wb);
+        if (lane == t) { ra = ((uint64_t)mda << 32) | wia; rb = ((uint64_t)mdb << 32) | wib; }
+        if (lane == wa) { ++hpa; const uint64_t nk = nth(ka, hpa); hda = (uint32_t)(nk >> 32); hia = (uint32_t)nk; }
+        if (lane == wb) { ++hpb; const uint64_t nk = nth(kb, hpb); hdb = (uint32_t)(nk >> 32); hib = (uint32_t)nk; }
+    }
+}
+
 template <int R, bool FMA>
 __global__ __launch_bounds__(256) void knn_xyz_wave_kernel(int n, int m, int k, int qpb, const float* __restrict__ support,
                                                             const float* __restrict__ query, int* __restrict__ idx,
@@ -118,8 +152,12 @@ __global__ __launch_bounds__(256) void knn_xyz_wave_kernel(int n, int m, int k, 
 
 // Feature-space (GEMM-form) variant: D = (rq - 2 q.p) + rp, fma chains over ascending channels.
 // LDS: feats[(c4 * (n+1) + p)] float4 = channels 4c4..4c4+3 of candidate p (zero padded to CP), norms[p].
+// NW waves per workgroup share one staged copy of the cloud: the k selection rounds are a dependent chain of ~400
+// cycles each (DPP min, readlane, ballot, LDS), so the SIMDs need several resident waves to stay busy; with 4-wave
+// workgroups the 49 KB feature image limited a CU to 8 waves.
+constexpr int KF_NW = 8;
 template <int R, int CP>
-__global__ __launch_bounds__(256) void knn_feat_wave_kernel(int n, int m, int c, int k, int qpb, int ldp, int ldq,
+__global__ __launch_bounds__(64 * KF_NW) void knn_feat_wave_kernel(int n, int m, int c, int k, int qpb, int ldp, int ldq,
                                                              const float* __restrict__ points,
                                                              const float* __restrict__ queries, float* __restrict__ dist,
                                                              int* __restrict__ idx) {
@@ -128,11 +166,21 @@ __global__ __launch_bounds__(256) void knn_feat_wave_kernel(int n, int m, int c,
     float4* feats = reinterpret_cast<float4*>(smem);                                  // [CP/4][n+1]
     float* norms = reinterpret_cast<float*>(smem + (size_t)(CP / 4) * ns * 16);       // [n]
     uint64_t* sorted = reinterpret_cast<uint64_t*>(smem + (size_t)(CP / 4) * ns * 16 + (((size_t)n * 4 + 15) & ~15ull));
+    // the workgroup's query rows, zero padded to CP: read per channel quad as one broadcast ds_read_b128.  (Scalar loads
+    // of the query row inside the channel loop exposed an s_load round trip every two quads.)
+    float4* qs = reinterpret_cast<float4*>(reinterpret_cast<char*>(sorted) + (R <= 4 ? (size_t)0 : (size_t)KF_NW * R * 64 * 8));   // R <= 4 keeps the lists in registers   // [qpb][CP/4]
     const int cloud = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const float* __restrict__ sp = points + (size_t)cloud * n * ldp;
     const float* __restrict__ qp = queries + (size_t)cloud * m * ldq;
+#ifdef KNN_STAMPS
+#define KN_T(v) __builtin_amdgcn_sched_barrier(0); const unsigned long long v = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0)
+    unsigned long long k_dot = 0, k_sort = 0, k_sel = 0, k_nq = 0;
+#else
+#define KN_T(v)
+#endif
+    KN_T(ts0);
     const bool vec = (c == CP) && ((ldp & 3) == 0) && ((((uintptr_t)sp) & 15) == 0);
-    for (int e = threadIdx.x; e < (CP / 4) * n; e += 256) {
+    for (int e = threadIdx.x; e < (CP / 4) * n; e += 64 * KF_NW) {
         const int p = e / (CP / 4), c4 = e - p * (CP / 4);       // consecutive lanes read one row's consecutive float4s
         const float* src = sp + (size_t)p * ldp + c4 * 4;
         float4 v;
@@ -146,8 +194,22 @@ __global__ __launch_bounds__(256) void knn_feat_wave_kernel(int n, int m, int c,
         }
         feats[c4 * ns + p] = v;
     }
+    {
+        const int q0s = blockIdx.x * qpb;
+        for (int e = threadIdx.x; e < qpb * (CP / 4); e += 64 * KF_NW) {
+            const int ql = e / (CP / 4), c4 = e - ql * (CP / 4);
+            const int qg = min(q0s + ql, m - 1);
+            const float* src = qp + (size_t)qg * ldq + c4 * 4;
+            float4 v;
+            v.x = (c4 * 4 + 0 < c) ? src[0] : 0.f;
+            v.y = (c4 * 4 + 1 < c) ? src[1] : 0.f;
+            v.z = (c4 * 4 + 2 < c) ? src[2] : 0.f;
+            v.w = (c4 * 4 + 3 < c) ? src[3] : 0.f;
+            qs[e] = v;
+        }
+    }
     __syncthreads();
-    for (int p = threadIdx.x; p < n; p += 256) {
+    for (int p = threadIdx.x; p < n; p += 64 * KF_NW) {
         float r = 0.f;
 #pragma unroll
         for (int c4 = 0; c4 < CP / 4; ++c4) {
@@ -163,19 +225,79 @@ __global__ __launch_bounds__(256) void knn_feat_wave_kernel(int n, int m, int c,
     for (int r = 0; r < R; ++r) rp[r] = (lane + 64 * r < n) ? norms[lane + 64 * r] : 0.f;
 
     const int q0 = blockIdx.x * qpb, q1 = min(m, q0 + qpb);
-    for (int qv = q0 + wave; qv < q1; qv += 4) {
+    KN_T(ts1);
+    if constexpr (R <= 4) {
+        // query pairs (qa, qb = qa + KF_NW): every staged float4 feeds both dot products, both selections run interleaved
+        for (int qv = q0 + wave; qv < q1; qv += 2 * KF_NW) {
+            KN_T(t0);
+            const int qa = __builtin_amdgcn_readfirstlane(qv);
+            const bool has_b = qa + KF_NW < q1;
+            const int qb = has_b ? qa + KF_NW : qa;
+            const float4* __restrict__ qra = qs + (qa - q0) * (CP / 4);
+            const float4* __restrict__ qrb = qs + (qb - q0) * (CP / 4);
+            float da[R], db[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) { da[r] = 0.f; db[r] = 0.f; }
+            float rqa = 0.f, rqb = 0.f;
+#pragma unroll 2
+            for (int c4 = 0; c4 < CP / 4; ++c4) {
+                const float4 a4 = qra[c4], b4 = qrb[c4];
+                rqa = __builtin_fmaf(a4.x, a4.x, rqa); rqa = __builtin_fmaf(a4.y, a4.y, rqa);
+                rqa = __builtin_fmaf(a4.z, a4.z, rqa); rqa = __builtin_fmaf(a4.w, a4.w, rqa);
+                rqb = __builtin_fmaf(b4.x, b4.x, rqb); rqb = __builtin_fmaf(b4.y, b4.y, rqb);
+                rqb = __builtin_fmaf(b4.z, b4.z, rqb); rqb = __builtin_fmaf(b4.w, b4.w, rqb);
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const int p = lane + 64 * r;
+                    const float4 v = feats[c4 * ns + (p < n ? p : 0)];
+                    da[r] = __builtin_fmaf(a4.x, v.x, da[r]); da[r] = __builtin_fmaf(a4.y, v.y, da[r]);
+                    da[r] = __builtin_fmaf(a4.z, v.z, da[r]); da[r] = __builtin_fmaf(a4.w, v.w, da[r]);
+                    db[r] = __builtin_fmaf(b4.x, v.x, db[r]); db[r] = __builtin_fmaf(b4.y, v.y, db[r]);
+                    db[r] = __builtin_fmaf(b4.z, v.z, db[r]); db[r] = __builtin_fmaf(b4.w, v.w, db[r]);
+                }
+            }
+            uint64_t ka[R], kb[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int p = lane + 64 * r;
+                const float ta = rqa - 2.0f * da[r], tb = rqb - 2.0f * db[r];
+                const float dda = (ta + rp[r]) + 0.0f, ddb = (tb + rp[r]) + 0.0f;
+                ka[r] = (p < n) ? (((uint64_t)f32_to_ordered(dda) << 32) | (uint32_t)p) : KEY_MAX;
+                kb[r] = (p < n) ? (((uint64_t)f32_to_ordered(ddb) << 32) | (uint32_t)p) : KEY_MAX;
+            }
+            KN_T(t1);
+            sort_keys<R>(ka);
+            sort_keys<R>(kb);
+            KN_T(t2);
+            uint64_t resa, resb;
+            select_k2<R>(ka, kb, lane, k, resa, resb);
+            if (lane < k) {
+                const size_t oa = ((size_t)cloud * m + qa) * k + lane;
+                idx[oa] = (int)(uint32_t)resa;
+                if (dist) dist[oa] = ordered_to_f32((uint32_t)(resa >> 32));
+                if (has_b) {
+                    const size_t ob = ((size_t)cloud * m + qb) * k + lane;
+                    idx[ob] = (int)(uint32_t)resb;
+                    if (dist) dist[ob] = ordered_to_f32((uint32_t)(resb >> 32));
+                }
+            }
+#ifdef KNN_STAMPS
+            { KN_T(t3); k_dot += t1 - t0; k_sort += t2 - t1; k_sel += t3 - t2; k_nq += 2; }
+#endif
+        }
+    } else {
+    for (int qv = q0 + wave; qv < q1; qv += KF_NW) {
+        KN_T(t0);
         const int qi = __builtin_amdgcn_readfirstlane(qv);
-        const float* __restrict__ qrow = qp + (size_t)qi * ldq;       // wave-uniform -> scalar loads
+        const float4* __restrict__ qrow4 = qs + (qi - q0) * (CP / 4);  // wave-uniform LDS address -> broadcast read
         float dot[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) dot[r] = 0.f;
         float rq = 0.f;
 #pragma unroll 2   // partial unroll: a full unroll keeps CP/4 x R float4 LDS loads in flight (256 VGPRs, one block per CU)
         for (int c4 = 0; c4 < CP / 4; ++c4) {
-            const float q0v = (c4 * 4 + 0 < c) ? qrow[c4 * 4 + 0] : 0.f;
-            const float q1v = (c4 * 4 + 1 < c) ? qrow[c4 * 4 + 1] : 0.f;
-            const float q2v = (c4 * 4 + 2 < c) ? qrow[c4 * 4 + 2] : 0.f;
-            const float q3v = (c4 * 4 + 3 < c) ? qrow[c4 * 4 + 3] : 0.f;
+            const float4 qv4 = qrow4[c4];
+            const float q0v = qv4.x, q1v = qv4.y, q2v = qv4.z, q3v = qv4.w;
             rq = __builtin_fmaf(q0v, q0v, rq); rq = __builtin_fmaf(q1v, q1v, rq);
             rq = __builtin_fmaf(q2v, q2v, rq); rq = __builtin_fmaf(q3v, q3v, rq);
 #pragma unroll
@@ -194,14 +316,26 @@ __global__ __launch_bounds__(256) void knn_feat_wave_kernel(int n, int m, int c,
             const float d = (t0 + rp[r]) + 0.0f;
             key[r] = (p < n) ? (((uint64_t)f32_to_ordered(d) << 32) | (uint32_t)p) : KEY_MAX;
         }
+        KN_T(t1);
         sort_keys<R>(key);
+        KN_T(t2);
         const uint64_t res = select_k<R>(key, sorted + (size_t)wave * R * 64, lane, k);
         if (lane < k) {
             const size_t o = ((size_t)cloud * m + qi) * k + lane;
             idx[o] = (int)(uint32_t)res;
             if (dist) dist[o] = ordered_to_f32((uint32_t)(res >> 32));
         }
+#ifdef KNN_STAMPS
+        { KN_T(t3); k_dot += t1 - t0; k_sort += t2 - t1; k_sel += t3 - t2; ++k_nq; }
+#endif
     }
+    }
+#ifdef KNN_STAMPS
+    if (blockIdx.x == 3 && blockIdx.y == 1 && lane == 0) {
+        unsigned long long* st = reinterpret_cast<unsigned long long*>(idx + (size_t)gridDim.y * m * k) + wave * 5;
+        st[0] = ts1 - ts0; st[1] = k_dot; st[2] = k_sort; st[3] = k_sel; st[4] = k_nq;
+    }
+#endif
 }
 
 template <int R>
@@ -220,10 +354,16 @@ static int launch_xyz_wave(int b, int n, int m, int k, const float* s, const flo
 template <int R, int CP>
 static int launch_feat_wave(int b, int n, int m, int c, int k, int ldp, int ldq, const float* p, const float* q, float* dist,
                             int* idx, hipStream_t st) {
-    const int qpb = 16;         // 4 queries per wave; the cloud's features are re-staged per workgroup (L2-resident)
+    const int qpb = 16;         // 2 queries per wave; the cloud's features are re-staged per workgroup (L2-resident)
     dim3 grid((m + qpb - 1) / qpb, b);
-    const size_t lds = (size_t)(CP / 4) * (n + 1) * 16 + (((size_t)n * 4 + 15) & ~15ull) + (size_t)4 * R * 64 * 8;
-    hipLaunchKernelGGL((knn_feat_wave_kernel<R, CP>), grid, dim3(256), lds, st, n, m, c, k, qpb, ldp, ldq, p, q, dist, idx);
+    const size_t lds = (size_t)(CP / 4) * (n + 1) * 16 + (((size_t)n * 4 + 15) & ~15ull) + (R <= 4 ? (size_t)0 : (size_t)KF_NW * R * 64 * 8) + (size_t)qpb * CP * 4;
+    static bool attr = false;           // per instantiation: opt in to more than 64 KB of dynamic LDS
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(knn_feat_wave_kernel<R, CP>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return (int)e;
+        attr = true;
+    }
+    hipLaunchKernelGGL((knn_feat_wave_kernel<R, CP>), grid, dim3(64 * KF_NW), lds, st, n, m, c, k, qpb, ldp, ldq, p, q, dist, idx);
     return (int)hipGetLastError();
 }
 
@@ -252,8 +392,8 @@ int knn_feat_wave_dispatch(int b, int n, int m, int c, int k, int ldp, int ldq, 
     if (n > 512 || c > 64 || k > 64) return -1;
     const int cp = (c + 3) & ~3;
     const int r = n <= 64 ? 1 : (n <= 128 ? 2 : (n <= 256 ? 4 : 8));
-    const size_t lds = (size_t)(cp / 4) * (n + 1) * 16 + (((size_t)n * 4 + 15) & ~15ull) + (size_t)4 * r * 64 * 8;
-    if (lds > 64 * 1024) return -1;
+    const size_t lds = (size_t)(cp / 4) * (n + 1) * 16 + (((size_t)n * 4 + 15) & ~15ull) + (r <= 4 ? (size_t)0 : (size_t)KF_NW * r * 64 * 8) + (size_t)16 * cp * 4;
+    if (lds > 160 * 1024) return -1;
     if (c <= 4) return feat_wave_r<4>(b, n, m, c, k, ldp, ldq, p, q, dist, idx, st);
     if (c <= 8) return feat_wave_r<8>(b, n, m, c, k, ldp, ldq, p, q, dist, idx, st);
     if (c <= 16) return feat_wave_r<16>(b, n, m, c, k, ldp, ldq, p, q, dist, idx, st);
