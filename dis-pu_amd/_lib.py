@@ -58,7 +58,7 @@ SIGNATURES = {
     "dispu_ps_skip_max": (_i, [_l, _i, _i, _i, _vp, _vp, _vp, _l, _vp, _l, _vp]),
     "dispu_ps_weight_net": (_i, [_l, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "dispu_ps_point_matmul": (_i, [_l, _i, _i, _i, _vp, _l, _vp, _vp, _l, _vp]),
-    "dispu_ps_local": (_i, [_l, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "dispu_ps_local": (_i, [_l, _i, _i, _i, _vp, _vp, _vp, _l, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "dispu_knn_patch": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "dispu_normalize_patches": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp]),
     "dispu_denormalize_patches": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp]),

@@ -326,6 +326,7 @@ DISPU_EXPORT int dispu_linear_tile(int batch, int M, int N) {
     if (ov > 0) return ov;
     const long mb128 = (long)((M + 127) / 128) * batch;
     if (N >= 256 && N % 256 == 0 && mb128 * (N / 256) >= 256) return 128257;   // 128x256 tile, BK 16: 64x128 per wave
+    if (N > 64 && N % 128 != 0 && N % 64 == 0 && mb128 >= 64) return 128064;   // e.g. N = 320: five full 64-wide tiles beat a half-empty edge tile
     if (N > 64) return (mb128 * ((N + 127) / 128) >= 256) ? 128128 : 64128;
     return mb128 >= 256 ? 128064 : 64064;
 }

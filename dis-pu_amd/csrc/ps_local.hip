@@ -28,7 +28,7 @@ constexpr int PL_STAGE = PL_BK * (PL_LDA + PL_LDB);                 // floats pe
 constexpr size_t PL_LDS_BYTES = (size_t)(2 * PL_STAGE + 8 * 256) * sizeof(float);   // + wv[8 points][16][16]
 
 __global__ __launch_bounds__(PL_NT) void ps_local_kernel(long npoints, int n_per_cloud, const int* __restrict__ idx,
-                                                          const float* __restrict__ xyz, const float* __restrict__ Gm,
+                                                          const float* __restrict__ xyz, const float* __restrict__ Gm, long ldg,
                                                           const float* __restrict__ Am, const float* __restrict__ W1,
                                                           const float* __restrict__ b1, const float* __restrict__ Ww,
                                                           const float* __restrict__ bw, const float* __restrict__ scale,
@@ -72,7 +72,7 @@ __global__ __launch_bounds__(PL_NT) void ps_local_kernel(long npoints, int n_per
     auto load_tile = [&](int k0) {
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
-            pg[it] = *reinterpret_cast<const float4*>(Gm + gj[it] * PL_K + k0 + kq * 4);
+            pg[it] = *reinterpret_cast<const float4*>(Gm + gj[it] * ldg + k0 + kq * 4);
             pa[it] = *reinterpret_cast<const float4*>(Am + gi[it] * PL_K + k0 + kq * 4);
         }
 #pragma unroll
@@ -209,7 +209,7 @@ constexpr int PW_FLOATS = PW_WRES + 2 * PW_ASTG + 2 * 2048 + 2 * 1024 + 512;
 constexpr size_t PW_LDS_BYTES = (size_t)PW_FLOATS * sizeof(float);
 
 __global__ __launch_bounds__(512) void ps_local_ws_kernel(long npoints, int n_per_cloud, const int* __restrict__ idx,
-                                                           const float* __restrict__ xyz, const float* __restrict__ Gm,
+                                                           const float* __restrict__ xyz, const float* __restrict__ Gm, int ldg,
                                                            const float* __restrict__ Am, const float* __restrict__ W1,
                                                            const float* __restrict__ b1, const float* __restrict__ Ww,
                                                            const float* __restrict__ bw, const float* __restrict__ scale,
@@ -242,7 +242,7 @@ __global__ __launch_bounds__(512) void ps_local_ws_kernel(long npoints, int n_pe
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
                 const int i = clampi(g * 8 + 2 * it + rq);
-                go[it] = (cloud_base(i) + idx[i * 16 + rs]) * PL_K + kq * 4;
+                go[it] = (cloud_base(i) + idx[i * 16 + rs]) * ldg + kq * 4;
             }
         };
         float4 pg[4];
@@ -463,9 +463,9 @@ __global__ __launch_bounds__(512) void ps_local_ws_kernel(long npoints, int n_pe
 using namespace dispu;
 
 DISPU_EXPORT int dispu_ps_local(long npoints, int n_per_cloud, int k, int c, const int* idx, const float* xyz, const float* G,
-                                const float* A, const float* W1, const float* b1, const float* Ww, const float* bw,
+                                long ldg, const float* A, const float* W1, const float* b1, const float* Ww, const float* bw,
                                 const float* scale, const float* shift, float* out, void* stream) {
-    if (npoints < 0 || n_per_cloud <= 0 || k != 16 || c != 128) return (int)hipErrorInvalidValue;
+    if (npoints < 0 || n_per_cloud <= 0 || k != 16 || c != 128 || ldg < 128 || (ldg & 3) || npoints * ldg > 0x7fffffffL) return (int)hipErrorInvalidValue;
     if ((((uintptr_t)G) | ((uintptr_t)A) | ((uintptr_t)W1) | ((uintptr_t)out)) & 15) return (int)hipErrorInvalidValue;
     if (npoints == 0) return 0;
     static int mode = -1;               // DISPU_PS_LOCAL=0: single-role kernel (A/B tests); default: wave-specialised persistent kernel
@@ -482,12 +482,12 @@ DISPU_EXPORT int dispu_ps_local(long npoints, int n_per_cloud, int k, int c, con
     }
     if (mode == 0) {
         hipLaunchKernelGGL(ps_local_kernel, dim3((unsigned)((npoints + 7) / 8)), dim3(PL_NT), PL_LDS_BYTES, (hipStream_t)stream, npoints,
-                           n_per_cloud, idx, xyz, G, A, W1, b1, Ww, bw, scale, shift, out);
+                           n_per_cloud, idx, xyz, G, ldg, A, W1, b1, Ww, bw, scale, shift, out);
     } else {
         const long ngroups = (npoints + 7) / 8;
         const unsigned grid = (unsigned)(ngroups < 256 ? ngroups : 256);      // one persistent workgroup per CU
         hipLaunchKernelGGL(ps_local_ws_kernel, dim3(grid), dim3(512), PW_LDS_BYTES, (hipStream_t)stream, npoints, n_per_cloud, idx, xyz,
-                           G, A, W1, b1, Ww, bw, scale, shift, out);
+                           G, (int)ldg, A, W1, b1, Ww, bw, scale, shift, out);
     }
     return (int)hipGetLastError();
 }

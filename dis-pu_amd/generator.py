@@ -91,6 +91,12 @@ class Generator(object):
         self.w_up_grid = w1[480:482].contiguous()
         w0 = self.P["refine/PointShuffle/conv0/weights"]
         self.w_c0_feat = w0[6:134].contiguous()
+        # the three 1x1 convs that read up128 (conv_kv, conv_query, the feature part of PointShuffle2's conv0) as ONE
+        # [128, 320] GEMM: columns 0:128 K|V, 128:192 Q, 192:320 conv0 features (its bias is added in ps_prep)
+        nlp = "refine/PointShuffle/PointShuffle/"
+        self.w_up3 = torch.cat([self.P[nlp + "conv_kv/weights"], self.P[nlp + "conv_query/weights"], self.w_c0_feat], dim=1).contiguous()
+        self.b_up3 = torch.cat([self.P[nlp + "conv_kv/biases"], self.P[nlp + "conv_query/biases"],
+                                torch.zeros(128, dtype=torch.float32, device=dev)]).contiguous()
         wsk = self.P["refine/PointShuffle/skip/weights"]
         self.w_skip_pad = torch.cat([wsk, torch.zeros((10, wsk.shape[1]), dtype=torch.float32, device=dev)], dim=0).contiguous()
 
@@ -113,10 +119,11 @@ class Generator(object):
         ws = dict(
             feat=E(rn, 480), prep=E(rn, 48), kidx=E(rn, k + 1, dtype=i32), h256=E(rn, 256),
             up256=E(rm, 256), up128=E(rm, 128), c256=E(rm, 256), c64=E(rm, 64), coarse=E(B, M, 3),
-            psidx=E(rm, k, dtype=i32), kv=E(rm, 128), q=E(rm, 64), att=E(rm, 64), nl=E(rm, 256),
-            skipin=torch.zeros((rm, 144), dtype=f32, device=dev), skip=E(rm, 256), gm=E(rm, 128), am=E(rm, 128),
+            psidx=E(rm, k, dtype=i32), up3=E(rm, 320), att=E(rm, 64), nl=E(rm, 256),
+            skipin=torch.zeros((rm, 144), dtype=f32, device=dev), skip=E(rm, 256), am=E(rm, 128),
             fp=E(rm, 2048), aft=E(rm, 256), agg=E(rm, 256),
             f256=E(rm, 256), f64=E(rm, 64), fine=E(B, M, 3))
+        ws["kv"], ws["q"], ws["gm"] = ws["up3"][:, 0:128], ws["up3"][:, 128:192], ws["up3"][:, 192:320]   # views, row stride 320
         self._ws[key] = ws
         return ws
 
@@ -237,24 +244,21 @@ class Generator(object):
         up128 = ws["up128"]
         self._call("knn_xyz", L.dispu_knn_xyz, B, M, M, k, ptr(coarse), ptr(coarse), ptr(ws["psidx"]), None, _lib.ARITH_PLAIN, st)
         # PointNonLocalCell (ops.py:302-346)
-        w, b = self._w(ps + "PointShuffle/conv_kv")
-        self._linear(st, up128, 128, w, b, 0, ws["kv"], 128)
-        w, b = self._w(ps + "PointShuffle/conv_query")
-        self._linear(st, up128, 128, w, b, 0, ws["q"], 64)
+        self._linear(st, up128, 128, self.w_up3, self.b_up3, 0, ws["up3"], 320)      # K|V, Q and conv0's feature part at once
         if self.fused_attention and M % 32 == 0:
             # softmax(Q.K^T / 8).V on chip (flash style): the [B, M, M] logits never exist in HBM
-            self._call("attention", L.dispu_attention, B, M, M, 64, ptr(ws["q"]), 64, ptr(ws["kv"]), 128, off(ws["kv"], 64), 128,
+            self._call("attention", L.dispu_attention, B, M, M, 64, ptr(ws["q"]), 320, ptr(ws["kv"]), 320, off(ws["kv"], 64), 320,
                        0.125, ptr(ws["att"]), 64, st)
         else:
             key = ("scores", B, N)
             if key not in self._ws:
                 self._ws[key] = torch.empty((B, M, M), dtype=torch.float32, device=self.device)
             s = self._ws[key]
-            self._linear(st, ws["q"], 64, ws["kv"], None, 0, s, M, M=M, ldx=64, ldw=128, ldy=M, batch=B, sx=M * 64,
-                         sw=M * 128, sy=M * M, transb=1)
+            self._linear(st, ws["q"], 64, ws["kv"], None, 0, s, M, M=M, ldx=320, ldw=320, ldy=M, batch=B, sx=M * 320,
+                         sw=M * 320, sy=M * M, transb=1)
             self._call("softmax", L.dispu_softmax_rows, rm, M, 0.125, ptr(s), M, st)
-            self._linear(st, s, M, ws["kv"], None, 0, ws["att"], 64, M=M, ldx=M, ldw=128, ldy=64, batch=B, sx=M * M,
-                         sw=M * 128, sy=M * 64, woff=64)
+            self._linear(st, s, M, ws["kv"], None, 0, ws["att"], 64, M=M, ldx=M, ldw=320, ldy=64, batch=B, sx=M * M,
+                         sw=M * 320, sy=M * 64, woff=64)
         w, b = self._w(ps + "PointShuffle/conv_back_project")
         self._linear(st, ws["att"], 64, w, b, 1, ws["nl"], 256)
         # skip connection
@@ -264,17 +268,16 @@ class Generator(object):
         self._linear(st, ws["skipin"], 144, self.w_skip_pad, b, 1, ws["skip"], 256)
         # local cell: conv0 per source point, conv1 per pair
         w0, b0 = self._w(ps + "conv0")
-        self._linear(st, up128, 128, self.w_c0_feat, None, 0, ws["gm"], 128)
-        self._call("ps_prep", L.dispu_ps_prep, rm, 128, ptr(coarse), ptr(w0), ptr(b0), ptr(ws["gm"]), 128, ptr(ws["am"]), 128, st)
+        self._call("ps_prep", L.dispu_ps_prep, rm, 128, ptr(coarse), ptr(w0), ptr(b0), ptr(ws["gm"]), 320, ptr(ws["am"]), 128, st)
         w1, b1 = self._w(ps + "conv1")
         ww, bw = self._w(ps + "weight_net/wconv0")
         if self.fused_local:
             # gather_sub_relu + conv1 + weight_net + feature x weight in one kernel: only F' [rm, 2048] touches HBM
-            self._call("ps_local", L.dispu_ps_local, rm, M, k, 128, ptr(ws["psidx"]), ptr(coarse), ptr(ws["gm"]), ptr(ws["am"]),
+            self._call("ps_local", L.dispu_ps_local, rm, M, k, 128, ptr(ws["psidx"]), ptr(coarse), ptr(ws["gm"]), 320, ptr(ws["am"]),
                        ptr(w1), ptr(b1), ptr(ww), ptr(bw), ptr(self.bn_scale), ptr(self.bn_shift), ptr(ws["fp"]), st)
         else:
             x1, x2, wv = self._pair_buffers(B, N)
-            self._call("gather_sub_relu", L.dispu_ps_gather_sub_relu, rm, M, k, 128, ptr(ws["psidx"]), ptr(ws["gm"]), 128,
+            self._call("gather_sub_relu", L.dispu_ps_gather_sub_relu, rm, M, k, 128, ptr(ws["psidx"]), ptr(ws["gm"]), 320,
                        ptr(ws["am"]), 128, ptr(x1), 128, st)
             self._linear(st, x1, 128, w1, b1, 1, x2, 128)
             self._call("weight_net", L.dispu_ps_weight_net, rm, M, k, 16, ptr(ws["psidx"]), ptr(coarse), ptr(ww), ptr(bw),

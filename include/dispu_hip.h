@@ -195,7 +195,7 @@ int dispu_ps_point_matmul(long rows, int k, int c, int t_n, const float* X2, lon
 /* PointShuffle2 local cell fused (ops.py:1055-1067): gather_sub_relu -> conv1 (W1 [128,128], b1) -> weight_net ->
  * per-point feature x weight product, in one kernel; out [npoints, 2048].  Bit-identical to the chain
  * dispu_ps_gather_sub_relu / dispu_linear / dispu_ps_weight_net / dispu_ps_point_matmul; k == 16, c == 128. */
-int dispu_ps_local(long npoints, int n_per_cloud, int k, int c, const int* idx, const float* xyz, const float* G,
+int dispu_ps_local(long npoints, int n_per_cloud, int k, int c, const int* idx, const float* xyz, const float* G, long ldg,
                    const float* A, const float* W1, const float* b1, const float* Ww, const float* bw, const float* scale,
                    const float* shift, float* out, void* stream);
 /* PointNonLocalCell attention fused (ops.py:326-339): O[b,m,64] = softmax(scale * Q.K^T) . V per cloud, logits never

@@ -19,11 +19,11 @@ int main() {
     hipMemcpy(G, hg.data(), hg.size() * 4, hipMemcpyHostToDevice); hipMemcpy(A, hg.data(), hg.size() * 4, hipMemcpyHostToDevice);
     hipMemcpy(W, hw.data(), hw.size() * 4, hipMemcpyHostToDevice);
     const float* W1 = W; const float* b1 = W + 16384; const float* Ww = b1 + 128; const float* bw = Ww + 48; const float* sc = bw + 16; const float* sh = sc + 16;
-    for (int rep = 0; rep < 3; ++rep) dispu_ps_local(np, n, 16, 128, idx, xyz, G, A, W1, b1, Ww, bw, sc, sh, out, nullptr);
+    for (int rep = 0; rep < 3; ++rep) dispu_ps_local(np, n, 16, 128, idx, xyz, G, 128, A, W1, b1, Ww, bw, sc, sh, out, nullptr);
     hipDeviceSynchronize();
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     hipEventRecord(e0);
-    for (int rep = 0; rep < 10; ++rep) dispu_ps_local(np, n, 16, 128, idx, xyz, G, A, W1, b1, Ww, bw, sc, sh, out, nullptr);
+    for (int rep = 0; rep < 10; ++rep) dispu_ps_local(np, n, 16, 128, idx, xyz, G, 128, A, W1, b1, Ww, bw, sc, sh, out, nullptr);
     hipEventRecord(e1); hipDeviceSynchronize();
     float ms; hipEventElapsedTime(&ms, e0, e1);
     unsigned long long st[40];
