@@ -39,9 +39,9 @@ __device__ __forceinline__ float edge_row16_max(float v) {   // valid in lane 15
 // LDS image of one layer's A operand: frag[s*64 + lane] = W[k = 2s + (lane>>5)][channel(lane & 31)], 0 for padding
 // (lanes whose A-row would be channel >= 24).  W [K][24] is read once, linearly (coalesced float4), and scattered
 // into place through LDS: a per-element gather from global memory was 33 vector-memory instructions per thread.
-__device__ __forceinline__ void edge_fill_frag(float* frag, const float* __restrict__ W, int K, int tid) {
+__device__ __forceinline__ void edge_fill_frag(float* frag, const float* __restrict__ W, int K, int tid, int nthreads) {
     const int nf4 = K * 24 / 4;                                  // W rows are 96 bytes: every float4 stays inside one row
-    for (int e = tid; e < nf4; e += 256) {
+    for (int e = tid; e < nf4; e += nthreads) {
         const float4 v = *reinterpret_cast<const float4*>(W + e * 4);
         const int k = (e * 4) / 24, ch0 = (e * 4) - k * 24;
         const float vv[4] = {v.x, v.y, v.z, v.w};
@@ -52,7 +52,7 @@ __device__ __forceinline__ void edge_fill_frag(float* frag, const float* __restr
             frag[(k >> 1) * 64 + (k & 1) * 32 + i] = vv[u];
         }
     }
-    for (int e = tid; e < K * 8; e += 256) {                     // padding lanes 24..31 of every (s, half)
+    for (int e = tid; e < K * 8; e += nthreads) {                // padding lanes 24..31 of every (s, half)
         const int sh = e >> 3;                                   // s * 2 + half
         frag[sh * 32 + 24 + (e & 7)] = 0.f;
     }
@@ -62,8 +62,10 @@ __device__ __forceinline__ void edge_fill_frag(float* frag, const float* __restr
 // LDS; the 2 x C/4 float4 row gathers per lane and group then are ds_read_b128 instead of global loads.  A wave that
 // shares its SIMD's issue with its own 64-cycle MFMAs gets a vector-memory instruction out only every ~300 cycles
 // (tools/micro/gemm_lab.hip), and the 24 gathers per group cost more than the 132 MFMAs they feed.
+// LDSF workgroups have 8 waves (two per SIMD: one wave's DPP max / store epilogue overlaps the other's MFMA chain; the
+// rows come from LDS at the top of each group, so no prefetch registers are needed and 256 registers per wave suffice).
 template <int C, bool LDSF>
-__global__ __launch_bounds__(256) void edge_dense_conv_mfma_kernel(int npoints, int n_per_cloud, const float* __restrict__ F,
+__global__ __launch_bounds__(LDSF ? 512 : 256) void edge_dense_conv_mfma_kernel(int npoints, int n_per_cloud, const float* __restrict__ F,
                                                                     long ldf, const int* __restrict__ idx, int ldi, int ioff,
                                                                     const float* __restrict__ W0, const float* __restrict__ b0,
                                                                     const float* __restrict__ W1, const float* __restrict__ b1,
@@ -74,15 +76,16 @@ __global__ __launch_bounds__(256) void edge_dense_conv_mfma_kernel(int npoints, 
     extern __shared__ __attribute__((aligned(16))) float edge_lds[];
     float* frag = edge_lds;                                      // (S0 + S1 + S2) * 64 weight fragments
     float* stage = frag + (S0 + S1 + S2) * 64;                   // [4 waves][2 points][72 + C] output staging
-    float* fl = stage + 4 * 2 * (3 * G + C);                     // LDSF: [n_per_cloud][C + 4] features of this cloud
+    float* fl = stage + (LDSF ? 8 : 4) * 2 * (3 * G + C);        // LDSF: [n_per_cloud][C + 4] features of this cloud
     const bool vec_store = ((ldy & 3) == 0) && ((((uintptr_t)Y) & 15) == 0);
     constexpr int FLD = C + 4;                                   // row stride 52 / 28 floats: 16-byte aligned, spreads the banks
     float* f0 = frag;
     float* f1 = frag + S0 * 64;
     float* f2 = f1 + S1 * 64;
-    edge_fill_frag(f0, W0, K0, threadIdx.x);
-    edge_fill_frag(f1, W1, K1, threadIdx.x);
-    edge_fill_frag(f2, W2, K2, threadIdx.x);
+    constexpr int NWAVE = LDSF ? 8 : 4;
+    edge_fill_frag(f0, W0, K0, threadIdx.x, 64 * NWAVE);
+    edge_fill_frag(f1, W1, K1, threadIdx.x, 64 * NWAVE);
+    edge_fill_frag(f2, W2, K2, threadIdx.x, 64 * NWAVE);
     // LDSF geometry: blockIdx.x = cloud * parts + part; the workgroup handles point groups [g_lo, g_hi) of its cloud
     int cloud0 = 0, g_lo = 0, g_hi = (npoints + 1) / 2, gstep0 = gridDim.x * 4, gfirst = blockIdx.x * 4;
     if constexpr (LDSF) {
@@ -93,9 +96,9 @@ __global__ __launch_bounds__(256) void edge_dense_conv_mfma_kernel(int npoints, 
         const int per = (gpc + parts - 1) / parts;
         g_lo = cloud * gpc + part * per;
         g_hi = min(cloud * gpc + gpc, g_lo + per);
-        gstep0 = 4;
+        gstep0 = NWAVE;
         gfirst = g_lo;
-        for (int e = threadIdx.x; e < n_per_cloud * (C / 4); e += 256) {
+        for (int e = threadIdx.x; e < n_per_cloud * (C / 4); e += 64 * NWAVE) {
             const int p = e / (C / 4), q = e - p * (C / 4);
             *reinterpret_cast<float4*>(fl + p * FLD + q * 4) = *reinterpret_cast<const float4*>(F + (size_t)(cloud0 + p) * ldf + q * 4);
         }
@@ -107,19 +110,13 @@ __global__ __launch_bounds__(256) void edge_dense_conv_mfma_kernel(int npoints, 
     const int ngroups = LDSF ? g_hi : (npoints + 1) / 2;         // 2 points per wave
     const int s_nb = row & 15;
     // the rows of the NEXT point group are fetched while the MFMAs of the current one run (ra/rb double as prefetch regs)
-    float4 ra[C / 4], rb[C / 4];
+    float4 ra[LDSF ? 1 : C / 4], rb[LDSF ? 1 : C / 4];
+    int jl_next = 0;                                             // LDSF: cloud-local neighbour id of the next group
     auto fetch = [&](int grp) {
         int p = grp * 2 + (row >> 4);
         if (p >= npoints) p = npoints - 1;
         if constexpr (LDSF) {
-            const int jl = idx[(size_t)p * ldi + ioff + s_nb];   // cloud-local neighbour id
-            const float* fp_ = fl + (p - cloud0) * FLD;
-            const float* fj_ = fl + jl * FLD;
-#pragma unroll
-            for (int q = 0; q < C / 4; ++q) {
-                ra[q] = *reinterpret_cast<const float4*>(fp_ + q * 4);
-                rb[q] = *reinterpret_cast<const float4*>(fj_ + q * 4);
-            }
+            jl_next = idx[(size_t)p * ldi + ioff + s_nb];
         } else {
             const int j = (p / n_per_cloud) * n_per_cloud + idx[(size_t)p * ldi + ioff + s_nb];
 #pragma unroll
@@ -145,10 +142,12 @@ __global__ __launch_bounds__(256) void edge_dense_conv_mfma_kernel(int npoints, 
     for (int grp = grp0; grp < ngroups; grp += gstride) {
         ED_T(t0);
         float fp[H], df[H];                                      // elements k = 2t + h of F_p and of F_j - F_p
+        const float* fp_ = fl + (grp * 2 + (row >> 4) - cloud0) * FLD;
+        const float* fj_ = fl + jl_next * FLD;
 #pragma unroll
         for (int q = 0; q < C / 4; ++q) {
-            const float4 a = ra[q];
-            const float4 b = rb[q];
+            const float4 a = LDSF ? *reinterpret_cast<const float4*>(fp_ + q * 4) : ra[q];
+            const float4 b = LDSF ? *reinterpret_cast<const float4*>(fj_ + q * 4) : rb[q];
             const float a0 = h ? a.y : a.x, a1 = h ? a.w : a.z;
             const float b0v = h ? b.y : b.x, b1v = h ? b.w : b.z;
             fp[2 * q] = a0; fp[2 * q + 1] = a1;
@@ -248,7 +247,7 @@ DISPU_EXPORT int dispu_edge_dense_conv(int npoints, int n_per_cloud, int C, cons
     if (npoints < 0 || n_per_cloud <= 0 || !(C == 24 || C == 48) || (ldf & 3) || (((uintptr_t)F) & 15)) return (int)hipErrorInvalidValue;
     if (npoints == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
-    const size_t frag_bytes = (size_t)((C == 24 ? 84 : 132) * 64 + 8 * (72 + C)) * sizeof(float);   // weight fragments + output staging
+    const size_t frag_bytes = (size_t)((C == 24 ? 84 : 132) * 64 + 16 * (72 + C)) * sizeof(float);  // weight fragments + output staging (up to 8 waves)
     // LDS-resident cloud features when a cloud fits next to the weight fragments (n <= ~600 points at C = 48) and the
     // points are whole clouds; each cloud is split over `parts` workgroups so that ~256 of them exist
     const size_t feat_bytes = (size_t)n_per_cloud * (C + 4) * sizeof(float);
@@ -258,7 +257,7 @@ DISPU_EXPORT int dispu_edge_dense_conv(int npoints, int n_per_cloud, int C, cons
         const int clouds = npoints / n_per_cloud;
         int parts = (256 + clouds - 1) / clouds;
         const int gpc = n_per_cloud / 2;
-        if (parts > (gpc + 3) / 4) parts = (gpc + 3) / 4;                 // at least one group per wave
+        if (parts > (gpc + 7) / 8) parts = (gpc + 7) / 8;                 // at least one group per wave
         if (parts < 1) parts = 1;
         const size_t bytes = frag_bytes + feat_bytes;
         static bool attr = false;
@@ -270,9 +269,9 @@ DISPU_EXPORT int dispu_edge_dense_conv(int npoints, int n_per_cloud, int C, cons
             attr = true;
         }
         if (C == 24)
-            hipLaunchKernelGGL((edge_dense_conv_mfma_kernel<24, true>), dim3(clouds, parts), dim3(256), bytes, s, npoints, n_per_cloud, F, ldf, idx, ldi, ioff, W0, b0, W1, b1, W2, b2, Y, ldy);
+            hipLaunchKernelGGL((edge_dense_conv_mfma_kernel<24, true>), dim3(clouds, parts), dim3(512), bytes, s, npoints, n_per_cloud, F, ldf, idx, ldi, ioff, W0, b0, W1, b1, W2, b2, Y, ldy);
         else
-            hipLaunchKernelGGL((edge_dense_conv_mfma_kernel<48, true>), dim3(clouds, parts), dim3(256), bytes, s, npoints, n_per_cloud, F, ldf, idx, ldi, ioff, W0, b0, W1, b1, W2, b2, Y, ldy);
+            hipLaunchKernelGGL((edge_dense_conv_mfma_kernel<48, true>), dim3(clouds, parts), dim3(512), bytes, s, npoints, n_per_cloud, F, ldf, idx, ldi, ioff, W0, b0, W1, b1, W2, b2, Y, ldy);
         return (int)hipGetLastError();
     }
     int g = (npoints + 7) / 8;          // 8 points (4 waves x 2) per workgroup pass
