@@ -78,6 +78,120 @@ __device__ __forceinline__ uint64_t select_k(const uint64_t (&key)[R], uint64_t*
     return res;
 }
 
+// ---- threshold prefilter + one cross-lane sort (n > 256: R >= 8 keys per lane) --------------------------------
+// Sorting 16 keys in every lane and then popping k heads costs ~1200 instructions per query although only k of the
+// 64 R candidates matter.  Instead: T = an upper bound of the k-th smallest distance, obtained from the lanes' minima
+// (the k-th smallest of the 64 lane minima: k distinct candidates are <= T); the survivors (distance <= T, typically
+// 1.2 k - 2 k of the 1024) are compacted into LDS with
+// ballot / mbcnt, and every survivor counts the survivors with a smaller (distance, index) key: that rank is its
+// position in the result.  Same result as the full sort: ascending distance, ties -> lower index.  More than 128
+// survivors (degenerate clouds: many candidates at exactly the same distance) take the full path.
+// Ascending sort of one 32-bit word per lane over the 64 lanes: the bitonic network in its "flip" form (phase K2 first
+// pairs lane i with i ^ (K2 - 1), then with i ^ J for J = K2/4 .. 1; the lower lane of a pair always keeps the
+// minimum).  21 compare-exchange steps in 56 VALU instructions: the min / max take the partner through the DPP operand
+// directly, and wherever "lower lane" is a whole DPP bank (4 lanes) the bank_mask of the two instructions does the
+// select (min written to the lower banks, max to the upper ones).  Inline asm because the compiler keeps v_mov_dpp +
+// v_min + v_max + v_cndmask per step; the leading s_nop covers the VALU-write -> DPP-read hazard it cannot see.
+#define DISPU_SORT_BANK(v, ctl_lo, ctl_hi, bm_lo, bm_hi)                                                          \
+    {                                                                                                              \
+        uint32_t t_;                                                                                               \
+        asm("s_nop 1\n\tv_min_u32_dpp %0, %1, %1 " ctl_lo " row_mask:0xf bank_mask:" bm_lo                         \
+            "\n\tv_max_u32_dpp %0, %1, %1 " ctl_hi " row_mask:0xf bank_mask:" bm_hi                                 \
+            : "=&v"(t_) : "v"(v));                                                                                 \
+        v = t_;                                                                                                    \
+    }
+#define DISPU_SORT_QUAD(v, perm, lower)                                                                           \
+    {                                                                                                              \
+        uint32_t lo_, hi_;                                                                                         \
+        asm("s_nop 1\n\tv_min_u32_dpp %0, %2, %2 quad_perm:" perm " row_mask:0xf bank_mask:0xf"                    \
+            "\n\tv_max_u32_dpp %1, %2, %2 quad_perm:" perm " row_mask:0xf bank_mask:0xf"                            \
+            : "=&v"(lo_), "=&v"(hi_) : "v"(v));                                                                    \
+        v = (lower) ? lo_ : hi_;                                                                                   \
+    }
+#define DISPU_SORT_X8(v) DISPU_SORT_BANK(v, "row_ror:8", "row_ror:8", "0x3", "0xc")
+#define DISPU_SORT_X4(v) DISPU_SORT_BANK(v, "row_shl:4", "row_shr:4", "0x5", "0xa")
+#define DISPU_SORT_X2(v) DISPU_SORT_QUAD(v, "[2,3,0,1]", e2)
+#define DISPU_SORT_X1(v) DISPU_SORT_QUAD(v, "[1,0,3,2]", e1)
+__device__ __forceinline__ uint32_t wave_bitonic_sort_u32(uint32_t v, int lane) {
+    const bool e1 = (lane & 1) == 0, e2 = (lane & 2) == 0, e16 = (lane & 16) == 0, e32 = lane < 32;
+    DISPU_SORT_X1(v);                                                                             // K2 = 2
+    DISPU_SORT_QUAD(v, "[3,2,1,0]", e2); DISPU_SORT_X1(v);                                        // K2 = 4
+    DISPU_SORT_BANK(v, "row_half_mirror", "row_half_mirror", "0x5", "0xa"); DISPU_SORT_X2(v); DISPU_SORT_X1(v);   // 8
+    DISPU_SORT_BANK(v, "row_mirror", "row_mirror", "0x3", "0xc"); DISPU_SORT_X4(v); DISPU_SORT_X2(v); DISPU_SORT_X1(v);   // 16
+    {   // K2 = 32: partner lane ^ 31 (ds_swizzle bit mode: and 0x1F, xor 0x1F)
+        const uint32_t o = (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x7C1F);
+        v = e16 ? min(v, o) : max(v, o);
+    }
+    DISPU_SORT_X8(v); DISPU_SORT_X4(v); DISPU_SORT_X2(v); DISPU_SORT_X1(v);
+    {   // K2 = 64: partner 63 - lane, then lane ^ 16
+        uint32_t o = (uint32_t)__builtin_amdgcn_ds_bpermute((63 - lane) * 4, (int)v);
+        v = e32 ? min(v, o) : max(v, o);
+        o = (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x401F);
+        v = e16 ? min(v, o) : max(v, o);
+    }
+    DISPU_SORT_X8(v); DISPU_SORT_X4(v); DISPU_SORT_X2(v); DISPU_SORT_X1(v);
+    return v;
+}
+
+// Threshold prefilter + rank (see above).  od: distance words (any encoding whose unsigned order is the distance order;
+// candidates that do not exist carry a word > tmax), cp: candidate indices, buf: this wave's LDS scratch (wave-uniform
+// pointer; CAP + 4 slots when GUARD, else room for every candidate + 4).  Writes the k results (ascending distance,
+// ties -> lower index) as idx_out[t] / word_out[t] and returns true; returns false - nothing written - when fewer than
+// k or more than 128 candidates pass the threshold (the caller then sorts everything).
+template <int R, bool GUARD, typename WORD2F>
+__device__ __forceinline__ bool prefilter_rank(const uint32_t (&od)[R], const int (&cp)[R], uint64_t* buf, int lane, int k, uint32_t tmax,
+                                               int* __restrict__ idx_out, float* __restrict__ dist_out, WORD2F word_to_float) {
+    constexpr int CAP = 128;
+    uint32_t dmin = od[0];
+#pragma unroll
+    for (int r = 1; r < R; ++r) dmin = min(dmin, od[r]);
+    // k-th smallest of the 64 lane minima: k distinct candidates are <= T, and on average only ~1.2 k candidates are
+    uint32_t T = (uint32_t)__builtin_amdgcn_readlane((int)wave_bitonic_sort_u32(dmin, lane), k - 1);
+    T = min(T, tmax);
+    int cnt = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const bool flag = od[r] <= T;
+        const unsigned long long mk = __ballot(flag);
+        const int pos = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0u));
+        if (flag && (!GUARD || cnt + pos < CAP)) (buf + cnt)[pos] = ((uint64_t)od[r] << 32) | (uint32_t)cp[r];
+        cnt += __popcll(mk);
+    }
+    if (cnt < k || cnt > CAP) return false;                             // wave-uniform
+    // rank of every survivor among the survivors (keys are distinct): broadcast reads of the compacted list, one
+    // compare + one add-with-carry per pair; the survivor of rank t < k IS result t
+    if (lane < 4) buf[cnt + lane] = KEY_MAX;                            // the loop reads in fours
+    const uint64_t m0 = (lane < cnt) ? buf[lane] : KEY_MAX;
+    if (cnt <= 64) {
+        int r0 = 0;
+        for (int j = 0; j < cnt; j += 4) {
+            const uint64_t a0 = buf[j], a1 = buf[j + 1], a2 = buf[j + 2], a3 = buf[j + 3];
+            r0 += (int)(a0 < m0) + (int)(a1 < m0) + (int)(a2 < m0) + (int)(a3 < m0);
+        }
+        if (r0 < k) {
+            idx_out[r0] = (int)(uint32_t)m0;
+            if (dist_out) dist_out[r0] = word_to_float((uint32_t)(m0 >> 32));
+        }
+    } else {
+        const uint64_t m1 = (lane + 64 < cnt) ? buf[lane + 64] : KEY_MAX;
+        int r0 = 0, r1 = 0;
+        for (int j = 0; j < cnt; j += 4) {
+            const uint64_t a0 = buf[j], a1 = buf[j + 1], a2 = buf[j + 2], a3 = buf[j + 3];
+            r0 += (int)(a0 < m0) + (int)(a1 < m0) + (int)(a2 < m0) + (int)(a3 < m0);
+            r1 += (int)(a0 < m1) + (int)(a1 < m1) + (int)(a2 < m1) + (int)(a3 < m1);
+        }
+        if (r0 < k) {
+            idx_out[r0] = (int)(uint32_t)m0;
+            if (dist_out) dist_out[r0] = word_to_float((uint32_t)(m0 >> 32));
+        }
+        if (r1 < k) {
+            idx_out[r1] = (int)(uint32_t)m1;
+            if (dist_out) dist_out[r1] = word_to_float((uint32_t)(m1 >> 32));
+        }
+    }
+    return true;
+}
+
 // Two queries at once, heads and the whole per-lane sorted list in registers (R <= 4: the next head after a win is a
 // 3-deep select on the lane's position instead of an LDS read).  The two selection chains are independent, so their
 // DPP / readlane / ballot latencies overlap; lane t keeps result t of both.
@@ -113,41 +227,77 @@ __device__ __forceinline__ void select_k2(const uint64_t (&ka)[R], const uint64_
 }
 
 template <int R, bool FMA>
-__global__ __launch_bounds__(256) void knn_xyz_wave_kernel(int n, int m, int k, int qpb, const float* __restrict__ support,
+__global__ __launch_bounds__(256, 4) void knn_xyz_wave_kernel(int n, int m, int k, int qpb, const float* __restrict__ support,
                                                             const float* __restrict__ query, int* __restrict__ idx,
                                                             float* __restrict__ dist) {
-    __shared__ uint64_t sorted[4][R * 64];
-    const int cloud = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __shared__ uint64_t sorted[4][R * 64 + 4];
+    const int cloud = blockIdx.y, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const float* __restrict__ s = support + (size_t)cloud * n * 3;
     const float* __restrict__ q = query + (size_t)cloud * m * 3;
+    // lane l holds candidate 64 r + ((l + ROT r) & 63) of every 64-block r.  ROT = 17 for the prefiltered path: clouds
+    // whose near neighbours sit a multiple of 64 apart in memory (the generator's coarse clouds: the 4 children of a
+    // parent are 256 apart) would otherwise put them all in ONE lane, where they hide behind the lane minimum and
+    // the threshold admits ~4x more survivors.  Candidates past n: +inf coordinates (prefilter) / all-ones keys.
+    constexpr int ROT = (R >= 8) ? 17 : 0;
     float cx[R], cy[R], cz[R];
+    int cp[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-        const int p = lane + 64 * r;
+        const int p = 64 * r + ((lane + ROT * r) & 63);
         const bool ok = p < n;
-        cx[r] = ok ? s[p * 3 + 0] : 0.f;
-        cy[r] = ok ? s[p * 3 + 1] : 0.f;
-        cz[r] = ok ? s[p * 3 + 2] : 0.f;
+        cp[r] = p;
+        cx[r] = ok ? s[p * 3 + 0] : __builtin_inff();
+        cy[r] = ok ? s[p * 3 + 1] : __builtin_inff();
+        cz[r] = ok ? s[p * 3 + 2] : __builtin_inff();
     }
     const int q0 = blockIdx.x * qpb, q1 = min(m, q0 + qpb);
+#ifdef KNN_STAMPS
+#define KX_T(v) __builtin_amdgcn_sched_barrier(0); const unsigned long long v = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0)
+    unsigned long long x_d = 0, x_t = 0, x_c = 0, x_s = 0, x_n = 0, x_f = 0;
+#else
+#define KX_T(v)
+#endif
     for (int qv = q0 + wave; qv < q1; qv += 4) {
+        KX_T(u0);
         const int qi = __builtin_amdgcn_readfirstlane(qv);
         const float qx = q[qi * 3 + 0], qy = q[qi * 3 + 1], qz = q[qi * 3 + 2];
-        uint64_t key[R];
+        // distance words: the raw bits of the (non-negative) squared distance order like the floats themselves
+        uint32_t od[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            const int p = lane + 64 * r;
-            const float d = sqdist3<FMA>(qx - cx[r], qy - cy[r], qz - cz[r]) + 0.0f;
-            key[r] = (p < n) ? (((uint64_t)f32_to_ordered(d) << 32) | (uint32_t)p) : KEY_MAX;
+            const float d = sqdist3<FMA>(qx - cx[r], qy - cy[r], qz - cz[r]);
+            od[r] = (R >= 8 || cp[r] < n) ? __float_as_uint(d) : 0xFFFFFFFFu;
         }
-        sort_keys<R>(key);
-        const uint64_t res = select_k<R>(key, sorted[wave], lane, k);
-        if (lane < k) {
-            const size_t o = ((size_t)cloud * m + qi) * k + lane;
-            idx[o] = (int)(uint32_t)res;
-            if (dist) dist[o] = ordered_to_f32((uint32_t)(res >> 32));
+        KX_T(u1);
+        bool done = false;
+        const size_t o = ((size_t)cloud * m + qi) * k;
+        if constexpr (R >= 8)      // tmax = largest finite float: never admits the padding (+inf / NaN)
+            done = prefilter_rank<R, false>(od, cp, sorted[wave], lane, k, 0x7F7FFFFFu, idx + o, dist ? dist + o : nullptr,
+                                            [](uint32_t w) { return __uint_as_float(w); });
+        if (!done) {
+#ifdef KNN_STAMPS
+            ++x_f;
+#endif
+            uint64_t key[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) key[r] = (cp[r] < n) ? (((uint64_t)od[r] << 32) | (uint32_t)cp[r]) : KEY_MAX;
+            sort_keys<R>(key);
+            const uint64_t res = select_k<R>(key, sorted[wave], lane, k);
+            if (lane < k) {
+                idx[o + lane] = (int)(uint32_t)res;
+                if (dist) dist[o + lane] = __uint_as_float((uint32_t)(res >> 32));
+            }
         }
+#ifdef KNN_STAMPS
+        { KX_T(u4); x_d += u1 - u0; x_s += u4 - u1; ++x_n; }
+#endif
     }
+#ifdef KNN_STAMPS
+    if (blockIdx.x == 3 && blockIdx.y == 1 && lane == 0) {
+        unsigned long long* st = reinterpret_cast<unsigned long long*>(idx + (size_t)gridDim.y * m * k) + wave * 5;
+        st[0] = x_d; st[1] = x_t; st[2] = x_c; st[3] = x_s; st[4] = x_n | (x_f << 32);
+    }
+#endif
 }
 
 // Feature-space (GEMM-form) variant: D = (rq - 2 q.p) + rp, fma chains over ascending channels.
@@ -156,6 +306,7 @@ __global__ __launch_bounds__(256) void knn_xyz_wave_kernel(int n, int m, int k, 
 // cycles each (DPP min, readlane, ballot, LDS), so the SIMDs need several resident waves to stay busy; with 4-wave
 // workgroups the 49 KB feature image limited a CU to 8 waves.
 constexpr int KF_NW = 8;
+constexpr int KF_SCRATCH = 128 + 4;          // u64 slots per wave for the prefilter's survivors (R <= 4)
 template <int R, int CP>
 __global__ __launch_bounds__(64 * KF_NW) void knn_feat_wave_kernel(int n, int m, int c, int k, int qpb, int ldp, int ldq,
                                                              const float* __restrict__ points,
@@ -168,8 +319,8 @@ __global__ __launch_bounds__(64 * KF_NW) void knn_feat_wave_kernel(int n, int m,
     uint64_t* sorted = reinterpret_cast<uint64_t*>(smem + (size_t)(CP / 4) * ns * 16 + (((size_t)n * 4 + 15) & ~15ull));
     // the workgroup's query rows, zero padded to CP: read per channel quad as one broadcast ds_read_b128.  (Scalar loads
     // of the query row inside the channel loop exposed an s_load round trip every two quads.)
-    float4* qs = reinterpret_cast<float4*>(reinterpret_cast<char*>(sorted) + (R <= 4 ? (size_t)0 : (size_t)KF_NW * R * 64 * 8));   // R <= 4 keeps the lists in registers   // [qpb][CP/4]
-    const int cloud = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float4* qs = reinterpret_cast<float4*>(reinterpret_cast<char*>(sorted) + (R <= 4 ? (size_t)KF_NW * KF_SCRATCH * 8 : (size_t)KF_NW * R * 64 * 8));   // R <= 4: prefilter scratch only   // [qpb][CP/4]
+    const int cloud = blockIdx.y, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const float* __restrict__ sp = points + (size_t)cloud * n * ldp;
     const float* __restrict__ qp = queries + (size_t)cloud * m * ldq;
 #ifdef KNN_STAMPS
@@ -256,29 +407,44 @@ __global__ __launch_bounds__(64 * KF_NW) void knn_feat_wave_kernel(int n, int m,
                     db[r] = __builtin_fmaf(b4.z, v.z, db[r]); db[r] = __builtin_fmaf(b4.w, v.w, db[r]);
                 }
             }
-            uint64_t ka[R], kb[R];
+            uint32_t oda[R], odb[R];
+            int cp[R];
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 const int p = lane + 64 * r;
                 const float ta = rqa - 2.0f * da[r], tb = rqb - 2.0f * db[r];
                 const float dda = (ta + rp[r]) + 0.0f, ddb = (tb + rp[r]) + 0.0f;
-                ka[r] = (p < n) ? (((uint64_t)f32_to_ordered(dda) << 32) | (uint32_t)p) : KEY_MAX;
-                kb[r] = (p < n) ? (((uint64_t)f32_to_ordered(ddb) << 32) | (uint32_t)p) : KEY_MAX;
+                cp[r] = p;
+                oda[r] = (p < n) ? f32_to_ordered(dda) : 0xFFFFFFFFu;
+                odb[r] = (p < n) ? f32_to_ordered(ddb) : 0xFFFFFFFFu;
             }
             KN_T(t1);
-            sort_keys<R>(ka);
-            sort_keys<R>(kb);
+            const size_t oa = ((size_t)cloud * m + qa) * k, ob = ((size_t)cloud * m + qb) * k;
+            uint64_t* buf = sorted + (size_t)wave * KF_SCRATCH;
+            const auto w2f = [](uint32_t w) { return ordered_to_f32(w); };
+            const bool done_a = prefilter_rank<R, true>(oda, cp, buf, lane, k, 0xFFFFFFFEu, idx + oa, dist ? dist + oa : nullptr, w2f);
+            const bool done_b = !has_b || prefilter_rank<R, true>(odb, cp, buf, lane, k, 0xFFFFFFFEu, idx + ob, dist ? dist + ob : nullptr, w2f);
             KN_T(t2);
-            uint64_t resa, resb;
-            select_k2<R>(ka, kb, lane, k, resa, resb);
-            if (lane < k) {
-                const size_t oa = ((size_t)cloud * m + qa) * k + lane;
-                idx[oa] = (int)(uint32_t)resa;
-                if (dist) dist[oa] = ordered_to_f32((uint32_t)(resa >> 32));
-                if (has_b) {
-                    const size_t ob = ((size_t)cloud * m + qb) * k + lane;
-                    idx[ob] = (int)(uint32_t)resb;
-                    if (dist) dist[ob] = ordered_to_f32((uint32_t)(resb >> 32));
+            if (!(done_a && done_b)) {                                    // degenerate clouds: sort everything
+                uint64_t ka[R], kb[R];
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    ka[r] = (cp[r] < n) ? (((uint64_t)oda[r] << 32) | (uint32_t)cp[r]) : KEY_MAX;
+                    kb[r] = (cp[r] < n) ? (((uint64_t)odb[r] << 32) | (uint32_t)cp[r]) : KEY_MAX;
+                }
+                sort_keys<R>(ka);
+                sort_keys<R>(kb);
+                uint64_t resa, resb;
+                select_k2<R>(ka, kb, lane, k, resa, resb);
+                if (lane < k) {
+                    if (!done_a) {
+                        idx[oa + lane] = (int)(uint32_t)resa;
+                        if (dist) dist[oa + lane] = ordered_to_f32((uint32_t)(resa >> 32));
+                    }
+                    if (!done_b) {
+                        idx[ob + lane] = (int)(uint32_t)resb;
+                        if (dist) dist[ob + lane] = ordered_to_f32((uint32_t)(resb >> 32));
+                    }
                 }
             }
 #ifdef KNN_STAMPS
@@ -356,7 +522,7 @@ static int launch_feat_wave(int b, int n, int m, int c, int k, int ldp, int ldq,
                             int* idx, hipStream_t st) {
     const int qpb = 16;         // 2 queries per wave; the cloud's features are re-staged per workgroup (L2-resident)
     dim3 grid((m + qpb - 1) / qpb, b);
-    const size_t lds = (size_t)(CP / 4) * (n + 1) * 16 + (((size_t)n * 4 + 15) & ~15ull) + (R <= 4 ? (size_t)0 : (size_t)KF_NW * R * 64 * 8) + (size_t)qpb * CP * 4;
+    const size_t lds = (size_t)(CP / 4) * (n + 1) * 16 + (((size_t)n * 4 + 15) & ~15ull) + (R <= 4 ? (size_t)KF_NW * KF_SCRATCH * 8 : (size_t)KF_NW * R * 64 * 8) + (size_t)qpb * CP * 4;
     static bool attr = false;           // per instantiation: opt in to more than 64 KB of dynamic LDS
     if (!attr) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(knn_feat_wave_kernel<R, CP>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

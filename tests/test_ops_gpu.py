@@ -351,3 +351,24 @@ def test_knn_xyz_wave_path_equals_lane_path(ops, dev, b, n, m, k):
     assert np.array_equal(res[2][0], res[3][0]) and np.array_equal(res[2][1], res[3][1])
     oi, od = O.knn_batch(s, q, k, return_dist=True)
     assert np.array_equal(res[0][0], oi) and np.array_equal(res[0][1], od)
+
+
+@pytest.mark.parametrize("n,ndup,k", [(1024, 40, 16), (1024, 100, 16), (1024, 300, 16), (600, 90, 32), (1024, 1024, 8)])
+def test_knn_xyz_prefilter_degenerate_clouds(ops, dev, n, ndup, k):
+    """The n > 256 wave kernel prefilters with a threshold and ranks the survivors (<= 64, <= 128) or falls back to the
+    full sort (> 128): clouds with `ndup` coincident points force each of the three paths; ties -> lower index."""
+    rng = np.random.default_rng(n + ndup)
+    s = rng.random((2, n, 3)).astype(np.float32)
+    where = rng.permutation(n)[:ndup]
+    s[:, where] = s[:, where[:1]]                                # ndup copies of one point
+    s[1, ::4] = s[1, 1::4] = s[1, 2::4] + np.float32(1e-3)      # and near-coincident groups 1 apart in memory
+    q = np.concatenate([s[:, where[:3]], s[:, :40], rng.random((2, 21, 3)).astype(np.float32)], 1)
+    i, d = ops["K"].knn_batch(T(s, dev), T(q, dev), k, return_dist=True)
+    oi, od = O.knn_batch(s, q, k, return_dist=True)
+    assert np.array_equal(N(i), oi) and np.array_equal(N(d), od)
+    # children of one parent 256 apart in memory (the generator's coarse clouds)
+    par = rng.random((2, 256, 3)).astype(np.float32)
+    c = (par[:, None] + 0.01 * rng.standard_normal((2, 4, 256, 3)).astype(np.float32)).reshape(2, 1024, 3)
+    i, d = ops["K"].knn_batch(T(c, dev), T(c, dev), 16, return_dist=True)
+    oi, od = O.knn_batch(c, c, 16, return_dist=True)
+    assert np.array_equal(N(i), oi) and np.array_equal(N(d), od)
