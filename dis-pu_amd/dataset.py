@@ -27,17 +27,14 @@ def nonuniform_sampling(num=4096, sample_num=1024):
 
 
 def load_patches(path, in_num=256, out_num=1024, random=True):
-    """load_h5_data (dataset.py:52-78): returns (input, gt) arrays [n, P, 3].  HDF5 needs h5py, which this image does not
-    ship; .npz / .npy files with the same dataset names ('poisson_<num>') are read directly."""
+    """load_h5_data (dataset.py:52-78): returns (input, gt) arrays [n, P, 3].  HDF5 files are read through the HDF5 C
+    library (dispu_amd.h5: ctypes binding, same library h5py wraps); .npz / .npy files with the same dataset names
+    ('poisson_<num>') are read directly."""
     if path.endswith((".h5", ".hdf5")):
-        try:
-            import h5py
-        except ImportError as e:
-            raise RuntimeError("reading %s needs h5py (not installed); convert it once to .npz with the keys "
-                               "poisson_%d / poisson_%d" % (path, in_num, out_num)) from e
-        with h5py.File(path, "r") as f:
-            gt = f["poisson_%d" % out_num][:]
-            inp = gt if random else f["poisson_%d" % in_num][:]
+        from . import h5
+        with h5.File(path) as f:
+            gt = f["poisson_%d" % out_num]
+            inp = gt if random else f["poisson_%d" % in_num]
     elif path.endswith(".npz"):
         z = np.load(path)
         gt = z["poisson_%d" % out_num]
