@@ -41,6 +41,32 @@ __global__ void linear_small_k_kernel(long rows, int K, const float* __restrict_
     }
 }
 
+// Same arithmetic, one thread per (row, 4 outputs): the row-per-thread form above runs 8192 rows on 32 workgroups with
+// 1920-byte-strided scalar stores (9 us for 0.8 MB); here a wave writes whole 96-byte row segments as float4.
+template <int N>
+__global__ __launch_bounds__(256) void linear_small_k_v4_kernel(long rows, int K, const float* __restrict__ X, long ldx,
+                                                                 const float* __restrict__ W, const float* __restrict__ bias, int act,
+                                                                 float* __restrict__ Y, long ldy) {
+    constexpr int Q = N / 4;
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long r = e / Q;
+    const int q = (int)(e - r * Q);
+    if (r >= rows) return;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = 0; k < K; ++k) {
+        const float x = X[r * ldx + k];
+        const float4 w = *reinterpret_cast<const float4*>(W + k * N + q * 4);
+        acc.x = __builtin_fmaf(x, w.x, acc.x); acc.y = __builtin_fmaf(x, w.y, acc.y);
+        acc.z = __builtin_fmaf(x, w.z, acc.z); acc.w = __builtin_fmaf(x, w.w, acc.w);
+    }
+    if (bias) {
+        const float4 b = *reinterpret_cast<const float4*>(bias + q * 4);
+        acc.x = acc.x + b.x; acc.y = acc.y + b.y; acc.z = acc.z + b.z; acc.w = acc.w + b.w;
+    }
+    if (act == 1) { acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f); }
+    *reinterpret_cast<float4*>(Y + r * ldy + q * 4) = acc;
+}
+
 // Y[r, 0:N] = chain_k X[r,k] W[k,n] + bias[n],  N <= 4 (coordinate_regressor fc_layer2, ops.py:1101-1104).
 // mode 1: Y = R + (sigmoid(.) - 0.5)  -- the fine branch's offset (ops.py:1106-1108) fused with
 // `fine = coarse + offset` (DisPU/generator.py:80-81).
@@ -199,6 +225,35 @@ __global__ void ps_prep_kernel(long rows, int co, const float* __restrict__ xyz,
     }
 }
 
+// float4 form (co % 4 == 0, 16-byte aligned rows): same per-element expressions.
+__global__ __launch_bounds__(256) void ps_prep_v4_kernel(long rows, int co4, const float* __restrict__ xyz, const float* __restrict__ W0,
+                                                          const float* __restrict__ bias, float* __restrict__ Gm, long ldg,
+                                                          float* __restrict__ A, long lda) {
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long r = e / co4;
+    const int q = (int)(e - r * co4);
+    if (r >= rows) return;
+    const int co = co4 * 4;
+    const float x = xyz[r * 3 + 0], y = xyz[r * 3 + 1], z = xyz[r * 3 + 2];
+    const float4 wc0 = *reinterpret_cast<const float4*>(W0 + 0 * co + q * 4), wc1 = *reinterpret_cast<const float4*>(W0 + 1 * co + q * 4),
+                 wc2 = *reinterpret_cast<const float4*>(W0 + 2 * co + q * 4), wr0 = *reinterpret_cast<const float4*>(W0 + 3 * co + q * 4),
+                 wr1 = *reinterpret_cast<const float4*>(W0 + 4 * co + q * 4), wr2 = *reinterpret_cast<const float4*>(W0 + 5 * co + q * 4);
+    const float4 b = *reinterpret_cast<const float4*>(bias + q * 4);
+    float4 g0 = *reinterpret_cast<const float4*>(Gm + r * ldg + q * 4);
+    float4 a;
+#define DISPU_PREP(c)                                                                                              \
+    {                                                                                                              \
+        float av = x * wc0.c; av = __builtin_fmaf(y, wc1.c, av); av = __builtin_fmaf(z, wc2.c, av);                \
+        float gv = x * (wc0.c + wr0.c); gv = __builtin_fmaf(y, wc1.c + wr1.c, gv); gv = __builtin_fmaf(z, wc2.c + wr2.c, gv); \
+        a.c = av;                                                                                                  \
+        g0.c = (g0.c + gv) + b.c;                                                                                  \
+    }
+    DISPU_PREP(x) DISPU_PREP(y) DISPU_PREP(z) DISPU_PREP(w)
+#undef DISPU_PREP
+    *reinterpret_cast<float4*>(A + r * lda + q * 4) = a;
+    *reinterpret_cast<float4*>(Gm + r * ldg + q * 4) = g0;
+}
+
 // X1[(i,s), c] = relu(G[cloud, idx[i,s], c] - A[i, c])     (float4 over c)
 __global__ void ps_gather_sub_relu_kernel(long rows, int n_per_cloud, int k, int c4n, const int* __restrict__ idx,
                                           const float* __restrict__ Gm, long ldg, const float* __restrict__ A, long lda,
@@ -245,6 +300,40 @@ __global__ void ps_skip_max_kernel(long rows, int n_per_cloud, int k, int cf, co
     float* o = out + i * ldo;
     if (sub < 6) o[sub] = mx;
     if (sub * 4 < cf) { o[6 + sub * 4] = m.x; o[7 + sub * 4] = m.y; o[8 + sub * 4] = m.z; o[9 + sub * 4] = m.w; }
+}
+
+// k = 16, cf = 128 (the generator's shape): the 16 neighbour ids of a point are fetched by 16 lanes at once and handed
+// round with ds_bpermute, so the 16 row gathers (and the xyz reads) are all in flight together instead of forming a
+// chain of 16 dependent id -> row round trips.  max is order-independent: same result as the loop above.
+__global__ __launch_bounds__(256) void ps_skip_max16_kernel(long rows, int n_per_cloud, const int* __restrict__ idx,
+                                                             const float* __restrict__ xyz, const float* __restrict__ feat, long ldf,
+                                                             float* __restrict__ out, long ldo) {
+    const int sub = threadIdx.x & 31;
+    const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 5;
+    if (i >= rows) return;                                         // whole 32-lane groups leave together
+    const long base = (i / n_per_cloud) * n_per_cloud;
+    const int mine = idx[i * 16 + (sub & 15)];
+    const float ci = (sub < 3) ? xyz[i * 3 + sub] : 0.f;
+    const int xc = sub < 3 ? sub : sub - 3;
+    float4 v[16];
+    float pj[16];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+        const long j = base + __shfl(mine, s, 32);
+        v[s] = *reinterpret_cast<const float4*>(feat + j * ldf + sub * 4);
+        pj[s] = (sub < 6) ? xyz[j * 3 + xc] : 0.f;
+    }
+    const float ninf = -__builtin_inff();
+    float4 m = make_float4(ninf, ninf, ninf, ninf);
+    float mx = ninf;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+        m.x = fmaxf(m.x, v[s].x); m.y = fmaxf(m.y, v[s].y); m.z = fmaxf(m.z, v[s].z); m.w = fmaxf(m.w, v[s].w);
+        mx = fmaxf(mx, sub < 3 ? pj[s] - ci : pj[s]);
+    }
+    float* o = out + i * ldo;
+    if (sub < 6) o[sub] = mx;
+    o[6 + sub * 4] = m.x; o[7 + sub * 4] = m.y; o[8 + sub * 4] = m.z; o[9 + sub * 4] = m.w;
 }
 
 // weight_net_hidden (ops.py:181-191, 1064): wv[(i,s), t] = relu( (cxyz . Ww[:,t] + bw[t]) * scale[t] + shift[t] ),
@@ -334,6 +423,13 @@ DISPU_EXPORT int dispu_linear_small_k(long rows, int K, int N, const float* X, l
                                       int act, float* Y, long ldy, void* stream) {
     if (rows < 0 || K <= 0 || K > 4 || !(N == 16 || N == 24) || !X || !W || !Y) return (int)hipErrorInvalidValue;
     if (rows == 0) return 0;
+    const bool v4 = ((ldy & 3) == 0) && (((((uintptr_t)Y) | ((uintptr_t)W) | ((uintptr_t)bias)) & 15) == 0);
+    if (v4) {
+        const int g4 = (int)((rows * (N / 4) + 255) / 256);
+        if (N == 24) hipLaunchKernelGGL((linear_small_k_v4_kernel<24>), dim3(g4), dim3(256), 0, (hipStream_t)stream, rows, K, X, ldx, W, bias, act, Y, ldy);
+        else hipLaunchKernelGGL((linear_small_k_v4_kernel<16>), dim3(g4), dim3(256), 0, (hipStream_t)stream, rows, K, X, ldx, W, bias, act, Y, ldy);
+        return (int)hipGetLastError();
+    }
     const int g = (int)((rows + 255) / 256);
     if (N == 24) hipLaunchKernelGGL((linear_small_k_kernel<24>), dim3(g), dim3(256), 0, (hipStream_t)stream, rows, K, X, ldx, W, bias, act, Y, ldy);
     else hipLaunchKernelGGL((linear_small_k_kernel<16>), dim3(g), dim3(256), 0, (hipStream_t)stream, rows, K, X, ldx, W, bias, act, Y, ldy);
@@ -379,6 +475,11 @@ DISPU_EXPORT int dispu_ps_prep(long rows, int co, const float* xyz, const float*
                                float* A, long lda, void* stream) {
     if (rows < 0 || co <= 0) return (int)hipErrorInvalidValue;
     if (rows == 0) return 0;
+    if ((co & 3) == 0 && (ldg & 3) == 0 && (lda & 3) == 0 && (((((uintptr_t)W0) | ((uintptr_t)bias) | ((uintptr_t)G) | ((uintptr_t)A)) & 15) == 0)) {
+        const long nt = rows * (co / 4);
+        hipLaunchKernelGGL(ps_prep_v4_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, (hipStream_t)stream, rows, co / 4, xyz, W0, bias, G, ldg, A, lda);
+        return (int)hipGetLastError();
+    }
     hipLaunchKernelGGL(ps_prep_kernel, dim3(grid_for(rows * co, 256)), dim3(256), 0, (hipStream_t)stream, rows, co, xyz, W0, bias, G, ldg, A, lda);
     return (int)hipGetLastError();
 }
@@ -396,7 +497,10 @@ DISPU_EXPORT int dispu_ps_skip_max(long rows, int n_per_cloud, int k, int cf, co
     if (rows < 0 || n_per_cloud <= 0 || k <= 0 || cf <= 0 || cf > 128 || (cf & 3) || (ldf & 3) || (((uintptr_t)feat) & 15))
         return (int)hipErrorInvalidValue;
     if (rows == 0) return 0;
-    hipLaunchKernelGGL(ps_skip_max_kernel, dim3((unsigned)((rows * 32 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, rows, n_per_cloud, k, cf, idx, xyz, feat, ldf, out, ldo);
+    if (k == 16 && cf == 128)
+        hipLaunchKernelGGL(ps_skip_max16_kernel, dim3((unsigned)((rows * 32 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, rows, n_per_cloud, idx, xyz, feat, ldf, out, ldo);
+    else
+        hipLaunchKernelGGL(ps_skip_max_kernel, dim3((unsigned)((rows * 32 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, rows, n_per_cloud, k, cf, idx, xyz, feat, ldf, out, ldo);
     return (int)hipGetLastError();
 }
 

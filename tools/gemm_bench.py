@@ -7,7 +7,8 @@ import subprocess
 import sys
 
 SHAPES = [(32768, 2048, 256), (524288, 128, 128), (32768, 256, 256), (8192, 480, 256), (32768, 256, 128),
-          (32768, 128, 256), (32768, 134, 256), (32768, 128, 128), (32768, 64, 256), (32768, 256, 64), (8192, 360, 48)]
+          (32768, 128, 256), (32768, 134, 256), (32768, 128, 128), (32768, 64, 256), (32768, 256, 64), (8192, 360, 48),
+          (32768, 144, 256), (32768, 128, 320), (8192, 120, 48), (8192, 240, 48)]
 
 
 def run_one():
