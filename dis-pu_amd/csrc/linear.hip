@@ -306,6 +306,9 @@ static int launch_linear(const LinearArgs& a, int batch, bool transb, hipStream_
     return launch_one<BM, BN, WM, WN, BK, false, true>(a, grid, s);
 }
 
+int linear_skinny_dispatch(int M, int K, int N, const float* X, long ldx, const float* W, long ldw, const float* bias, int act,
+                           float* Y, long ldy, hipStream_t st);   // linear_skinny.hip
+
 static int tile_override() {            // DISPU_LINEAR_TILE=<code>: force one variant (benchmarking only)
     static int v = -2;
     if (v == -2) {
@@ -352,8 +355,12 @@ DISPU_EXPORT int dispu_linear_bn(int batch, int M, int K, int N, const float* X,
     if (batch < 0 || M < 0 || K <= 0 || N <= 0 || !X || !W || !Y || act < 0 || act > 1 || ((scale == nullptr) != (shift == nullptr)))
         return (int)hipErrorInvalidValue;
     if (batch == 0 || M == 0) return 0;
-    LinearArgs a{M, K, N, X, ldx, sx, W, ldw, sw, bias, Y, ldy, sy, R1, ldr1, sr1, R2, ldr2, sr2, act, scale, shift};
     hipStream_t s = (hipStream_t)stream;
+    if (batch == 1 && !transb && !scale && !R1 && !R2 && tile_override() <= 0) {
+        const int rc = linear_skinny_dispatch(M, K, N, X, ldx, W, ldw, bias, act, Y, ldy, s);   // small M x N: latency-bound form
+        if (rc >= 0) return rc;
+    }
+    LinearArgs a{M, K, N, X, ldx, sx, W, ldw, sw, bias, Y, ldy, sy, R1, ldr1, sr1, R2, ldr2, sr2, act, scale, shift};
     const bool tb = transb != 0;
     switch (dispu_linear_tile(batch, M, N)) {
         case 128257: return launch_linear<128, 256, 2, 2, 16>(a, batch, tb, s);

@@ -146,6 +146,31 @@ def test_linear_matches_chain_exactly(dev):
     assert np.array_equal(N(s), OG.matmul_nt(q, kk))
 
 
+def test_linear_skinny_path_matches_chain_exactly(dev):
+    """Small M x N (fewer than 256 tiles of 64 x 64), K <= 384, K % 4 == 0, aligned rows: dispu_linear runs the
+    register-resident v_mfma_f32_16x16x4_f32 kernel (linear_skinny.hip) - same pinned ascending fmaf chain."""
+    from dispu_amd import _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(7)
+    for (M, K, Nn, act, ld, xo) in [(8192, 120, 48, 1, 480, 360), (8192, 240, 48, 1, 480, 240), (8192, 360, 48, 1, 480, 120),
+                                    (1000, 124, 33, 0, 128, 4), (50, 16, 64, 1, 16, 0), (17, 4, 16, 0, 8, 4), (333, 384, 7, 1, 388, 4)]:
+        x = rng.standard_normal((M, ld)).astype(np.float32)
+        w = (rng.standard_normal((K, Nn)) * 0.1).astype(np.float32)
+        b = rng.standard_normal(Nn).astype(np.float32)
+        want = OG.linear(x[:, xo:xo + K], w, b, relu=bool(act))
+        tx, tw, tb = (torch.from_numpy(a).to(dev) for a in (x, w, b))
+        y = torch.zeros((M, Nn + 5), device=dev)
+        _lib.check(L.dispu_linear(1, M, K, Nn, tx.data_ptr() + 4 * xo, ld, 0, tw.data_ptr(), Nn, 0, 0, tb.data_ptr(), act,
+                                  y.data_ptr() + 8, Nn + 5, 0, None, 0, 0, None, 0, 0, _lib.stream_ptr(dev)), "dispu_linear")
+        got = N(y)
+        assert np.array_equal(got[:, 2:Nn + 2], want), (M, K, Nn)
+        assert (got[:, :2] == 0).all() and (got[:, Nn + 2:] == 0).all()
+        # no bias
+        _lib.check(L.dispu_linear(1, M, K, Nn, tx.data_ptr() + 4 * xo, ld, 0, tw.data_ptr(), Nn, 0, 0, None, 0,
+                                  y.data_ptr() + 8, Nn + 5, 0, None, 0, 0, None, 0, 0, _lib.stream_ptr(dev)), "dispu_linear")
+        assert np.array_equal(N(y)[:, 2:Nn + 2], OG.linear(x[:, xo:xo + K], w, None, relu=False)), (M, K, Nn)
+
+
 # 2560 / 4096 points: more than 2 x 1024 waves of the persistent grid -> several point groups per wave (the weight
 # fragment ring and the row prefetch wrap from one group into the next)
 @pytest.mark.parametrize("C,npts", [(24, 512), (48, 512), (48, 777), (24, 2560), (48, 4096)])
