@@ -331,19 +331,37 @@ __global__ __launch_bounds__(64 * KF_NW) void knn_feat_wave_kernel(int n, int m,
 #endif
     KN_T(ts0);
     const bool vec = (c == CP) && ((ldp & 3) == 0) && ((((uintptr_t)sp) & 15) == 0);
-    for (int e = threadIdx.x; e < (CP / 4) * n; e += 64 * KF_NW) {
-        const int p = e / (CP / 4), c4 = e - p * (CP / 4);       // consecutive lanes read one row's consecutive float4s
-        const float* src = sp + (size_t)p * ldp + c4 * 4;
-        float4 v;
-        if (vec) {
-            v = *reinterpret_cast<const float4*>(src);
-        } else {
+    if (vec) {
+        // batches of 8 independent float4 loads per thread, then the 8 LDS stores: one memory round trip per batch
+        // instead of one per element (the rolled loop was load -> wait -> store, 6 round trips for C = 48, n = 256)
+        constexpr int UB = 8;
+        const int total = (CP / 4) * n;
+        for (int e0 = threadIdx.x; e0 < total; e0 += UB * 64 * KF_NW) {
+            float4 v[UB];
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                const int e = min(e0 + u * 64 * KF_NW, total - 1);
+                const int p = e / (CP / 4), c4 = e - p * (CP / 4);
+                v[u] = *reinterpret_cast<const float4*>(sp + (size_t)p * ldp + c4 * 4);
+            }
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                const int e = e0 + u * 64 * KF_NW;
+                const int p = e / (CP / 4), c4 = e - p * (CP / 4);
+                if (e < total) feats[c4 * ns + p] = v[u];
+            }
+        }
+    } else {
+        for (int e = threadIdx.x; e < (CP / 4) * n; e += 64 * KF_NW) {
+            const int p = e / (CP / 4), c4 = e - p * (CP / 4);       // consecutive lanes read one row's consecutive float4s
+            const float* src = sp + (size_t)p * ldp + c4 * 4;
+            float4 v;
             v.x = (c4 * 4 + 0 < c) ? src[0] : 0.f;
             v.y = (c4 * 4 + 1 < c) ? src[1] : 0.f;
             v.z = (c4 * 4 + 2 < c) ? src[2] : 0.f;
             v.w = (c4 * 4 + 3 < c) ? src[3] : 0.f;
+            feats[c4 * ns + p] = v;
         }
-        feats[c4 * ns + p] = v;
     }
     {
         const int q0s = blockIdx.x * qpb;
