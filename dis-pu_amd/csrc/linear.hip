@@ -54,8 +54,15 @@ struct LinearLds {
 // LDS and issue MFMAs; waves WM*WN .. 2*WM*WN-1 only move tiles (global -> registers -> LDS, one tile in flight).
 // One workgroup barrier per slab joins them (127 TFLOP/s on that product).  Each SIMD hosts one wave of each role.
 // EDGE = false: every tile is interior and 16-byte aligned (M % BM == N % BN == K % BK == 0): no predicates at all.
+#ifdef LIN_CLOCK
+__device__ unsigned long long lin_clock_ticks[4];
+#endif
 template <int BM, int BN, int WM, int WN, int BK, bool TRANSB, bool EDGE, int EPI>
 __global__ __launch_bounds__(128 * WM * WN) void linear_mfma_kernel(LinearArgs a) {
+#ifdef LIN_CLOCK
+    const unsigned long long lc0 = __builtin_readcyclecounter();
+    unsigned long long lc_wait = 0;
+#endif
     using L = LinearLds<BM, BN, BK, TRANSB>;
     constexpr int NT = 64 * WM * WN;                  // threads per role
     constexpr int LDA = L::LDA, LDB = L::LDB;
@@ -74,6 +81,9 @@ __global__ __launch_bounds__(128 * WM * WN) void linear_mfma_kernel(LinearArgs a
 
     if (wave >= WM * WN) {
         // ------------------------------------------------------------------------------------ loader waves
+#ifdef DISPU_LOADER_PRIO
+        __builtin_amdgcn_s_setprio(DISPU_LOADER_PRIO);
+#endif
         const int tid = threadIdx.x - NT;
         const float* __restrict__ X = a.X + (size_t)z * a.sx;
         const float* __restrict__ W = a.W + (size_t)z * a.sw;
@@ -135,35 +145,47 @@ __global__ __launch_bounds__(128 * WM * WN) void linear_mfma_kernel(LinearArgs a
             const int kr = idx / (BN / 4), nq = idx % (BN / 4);
             *reinterpret_cast<float4*>(&S[kr * LDB + nq * 4]) = v;
         };
-        auto load_tile = [&](int k0) {
+        // two register sets: the tiles of slabs t+2 and t+3 are both in flight while slab t is computed (a slab lasts
+        // ~2 us, about one loaded-HBM round trip: with a single set the MFMA waves waited ~450 cycles per slab at the
+        // barrier for the loaders, who were waiting for their data)
+        float4 pa1[A_F4], pb1[B_F4];
+        auto load_tile = [&](int k0, float4 (&qa)[A_F4], float4 (&qb)[B_F4]) {
 #pragma unroll
-            for (int it = 0; it < A_F4; ++it) pa[it] = load_rowsk(X, ldx, x_vec, m0, M, k0, it);
+            for (int it = 0; it < A_F4; ++it) qa[it] = load_rowsk(X, ldx, x_vec, m0, M, k0, it);
 #pragma unroll
-            for (int it = 0; it < B_F4; ++it) pb[it] = TRANSB ? load_rowsk(W, ldw, w_vec, n0, N, k0, it) : load_b(k0, it);
+            for (int it = 0; it < B_F4; ++it) qb[it] = TRANSB ? load_rowsk(W, ldw, w_vec, n0, N, k0, it) : load_b(k0, it);
         };
-        auto store_tile = [&](int stage) {
+        auto store_tile = [&](int stage, const float4 (&qa)[A_F4], const float4 (&qb)[B_F4]) {
             float* As = lds + stage * L::STAGE;
             float* Bs = As + BK * LDA;
 #pragma unroll
-            for (int it = 0; it < A_F4; ++it) store_rowsk(As, LDA, pa[it], it);
+            for (int it = 0; it < A_F4; ++it) store_rowsk(As, LDA, qa[it], it);
 #pragma unroll
             for (int it = 0; it < B_F4; ++it) {
-                if constexpr (TRANSB) store_rowsk(Bs, LDB, pb[it], it);
-                else store_b(Bs, pb[it], it);
+                if constexpr (TRANSB) store_rowsk(Bs, LDB, qb[it], it);
+                else store_b(Bs, qb[it], it);
             }
         };
-        load_tile(0);
-        store_tile(0);
-        if (ntile > 1) load_tile(BK);
+        load_tile(0, pa, pb);
+        store_tile(0, pa, pb);
+        if (ntile > 1) load_tile(BK, pa1, pb1);          // odd tiles travel in set 1, even tiles in set 0
+        if (ntile > 2) load_tile(2 * BK, pa, pb);
         __syncthreads();
         // slab t: park tile t+1 in the other stage (its last readers passed the barrier that ended slab t-1) and
-        // request tile t+2, while the MFMA waves work through stage t
-        for (int t = 0; t < ntile; ++t) {
+        // request tile t+3, while the MFMA waves work through stage t
+        for (int t = 0; t < ntile; t += 2) {
             if (t + 1 < ntile) {
-                store_tile((t + 1) & 1);
-                if (t + 2 < ntile) load_tile((t + 2) * BK);
+                store_tile(1, pa1, pb1);
+                if (t + 3 < ntile) load_tile((t + 3) * BK, pa1, pb1);
             }
             __syncthreads();
+            if (t + 1 < ntile) {
+                if (t + 2 < ntile) {
+                    store_tile(0, pa, pb);
+                    if (t + 4 < ntile) load_tile((t + 4) * BK, pa, pb);
+                }
+                __syncthreads();
+            }
         }
         return;
     }
@@ -180,25 +202,49 @@ __global__ __launch_bounds__(128 * WM * WN) void linear_mfma_kernel(LinearArgs a
 
     const int fi = lane & 31, fk = lane >> 5;
     __syncthreads();
+    // Fragment registers are double-buffered by hand: the ds_reads of k-step s+1 are issued BEFORE the MFMAs of step s.
+    // Left to itself the compiler places a step's reads right in front of the MFMAs that need them, behind the previous
+    // step's last MFMA: the wave then sits in s_waitcnt for an LDS round trip (~120 cycles) while the matrix pipe drains
+    // after 64 - eight times per slab (measured: 4860 cycles per 64-MFMA slab instead of 4096).
     for (int t = 0; t < ntile; ++t) {
         const float* As = lds + (t & 1) * L::STAGE;
         const float* Bs = As + BK * LDA;
+        float af[2][TM], bf[2][TN];
 #pragma unroll
-        for (int kk = 0; kk < BK; kk += 2) {
-            float af[TM], bf[TN];
+        for (int i = 0; i < TM; ++i) af[0][i] = As[fk * LDA + wm * (TM * 32) + i * 32 + fi];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) af[i] = As[(kk + fk) * LDA + wm * (TM * 32) + i * 32 + fi];
+        for (int j = 0; j < TN; ++j) bf[0][j] = Bs[fk * LDB + wn * (TN * 32) + j * 32 + fi];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) bf[j] = Bs[(kk + fk) * LDB + wn * (TN * 32) + j * 32 + fi];
+        for (int s2 = 0; s2 < BK / 2; ++s2) {
+            const int cur = s2 & 1, nxt = cur ^ 1;
+            if (s2 + 1 < BK / 2) {
+                const int kk = 2 * (s2 + 1);
+#pragma unroll
+                for (int i = 0; i < TM; ++i) af[nxt][i] = As[(kk + fk) * LDA + wm * (TM * 32) + i * 32 + fi];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bf[nxt][j] = Bs[(kk + fk) * LDB + wn * (TN * 32) + j * 32 + fi];
+            }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][i], bf[cur][j], acc[i][j], 0, 0, 0);
+            // pin: this step's DS reads (the next step's operands) first, then its TM*TN MFMAs
+            __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
         }
+#ifdef LIN_CLOCK
+        const unsigned long long lb0 = __builtin_readcyclecounter();
         __syncthreads();
+        lc_wait += __builtin_readcyclecounter() - lb0;
+#else
+        __syncthreads();
+#endif
     }
 
+#ifdef LIN_CLOCK
+    if (blockIdx.x == 0 && blockIdx.y == 5 && threadIdx.x == 0) { lin_clock_ticks[0] = __builtin_readcyclecounter() - lc0; lin_clock_ticks[1] = ntile; lin_clock_ticks[2] = lc_wait; }
+#endif
     // epilogue: C/D layout of the 32x32 tile: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
     // What the epilogue does is a TEMPLATE choice (EPI), not a per-element test: an earlier version tested
     // bias / scale / act / R1 / R2 inside the 128-element unrolled store loop, which the compiler unswitched into

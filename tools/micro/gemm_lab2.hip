@@ -1,6 +1,7 @@
 // Times the PRODUCTION dispu_linear next to the lab's wave-specialised kernel on identical buffers.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -Idis-pu_amd/csrc tools/micro/gemm_lab2.hip -o tools/micro/gemm_lab2
 #include "../../dis-pu_amd/csrc/linear.hip"
+#include "../../dis-pu_amd/csrc/linear_skinny.hip"
 #include <cstdio>
 #include <vector>
 
@@ -33,6 +34,14 @@ int main() {
         printf("production dispu_linear K %5d: %8.1f us %6.1f TFLOP/s (no bias/act)\n", K, ms * 1e3, 2.0 * M * K * N / ms / 1e9);
         ms = time_it(M, K, N, X, W, B, Y, 1);
         printf("production dispu_linear K %5d: %8.1f us %6.1f TFLOP/s (bias + relu)\n", K, ms * 1e3, 2.0 * M * K * N / ms / 1e9);
+#ifdef LIN_CLOCK
+        {
+            unsigned long long t[4];
+            hipMemcpyFromSymbol(t, HIP_SYMBOL(dispu::lin_clock_ticks), sizeof(t));
+            printf("   main loop of one workgroup: %llu ticks for %llu slabs = %.0f ticks per slab; if the kernel were all main loop the counter ran at %.2f GHz; MFMA wave 0 spent %.0f ticks per slab in the barrier\n",
+                   t[0], t[1], (double)t[0] / t[1], t[0] / (ms * 1e6), (double)t[2] / t[1]);
+        }
+#endif
         hipFree(X); hipFree(W); hipFree(Y); hipFree(B);
     }
     return 0;
