@@ -36,12 +36,19 @@ struct LinearArgs {
     const float* shift;                  // between the bias add and the activation (tf_util.py:176-185 order)
 };
 
-template <int BM, int BN, int BK, bool TRANSB>
+// DMA mode (interior 128 x 256 x 16 tiles, B not transposed): the loader waves issue global_load_lds_dwordx4 - global
+// memory straight into LDS, no data registers, no ds_write - through NST = 4 stages.  A stage then holds
+//   A: [BK/4][BM] float4 = X[row][4 kg .. 4 kg + 3]   (one DMA instruction = 64 rows x 16 bytes, lane-linear in LDS)
+//   B: [BK][BN + 4] floats                            (one DMA instruction = one k row of 256 floats)
+// and an MFMA lane gets its A operands of two k-steps from one ds_read_b128 (component fk / 2 + fk).
+template <int BM, int BN, int BK, bool TRANSB, bool EDGE>
 struct LinearLds {
-    static constexpr int LDA = BM + 1;   // A tile stored k-major [BK][BM+1]: conflict-free b32 frag reads and writes
+    static constexpr bool DMA = !EDGE && !TRANSB && BM == 128 && BN == 256 && BK == 16;
+    static constexpr int NST = DMA ? 4 : 2;
+    static constexpr int LDA = DMA ? BM : BM + 1;   // register path: A tile stored k-major [BK][BM+1]: conflict-free b32 frag reads and writes
     static constexpr int LDB = TRANSB ? BN + 1 : BN + 4;
     static constexpr int STAGE = ((BK * (LDA + LDB) + 3) / 4) * 4;          // floats per stage (16-byte multiple)
-    static constexpr size_t BYTES = (size_t)2 * STAGE * sizeof(float);
+    static constexpr size_t BYTES = (size_t)NST * STAGE * sizeof(float);
 };
 
 // BM x BN block tile, WM x WN MFMA waves + as many LOADER waves, BK k-slab per LDS stage.
@@ -58,12 +65,13 @@ struct LinearLds {
 __device__ unsigned long long lin_clock_ticks[4];
 #endif
 template <int BM, int BN, int WM, int WN, int BK, bool TRANSB, bool EDGE, int EPI>
-__global__ __launch_bounds__(128 * WM * WN) void linear_mfma_kernel(LinearArgs a) {
+__global__ __launch_bounds__(64 * (WM * WN + (LinearLds<BM, BN, BK, TRANSB, EDGE>::DMA ? 4 : WM * WN))) void linear_mfma_kernel(LinearArgs a) {
 #ifdef LIN_CLOCK
     const unsigned long long lc0 = __builtin_readcyclecounter();
     unsigned long long lc_wait = 0;
 #endif
-    using L = LinearLds<BM, BN, BK, TRANSB>;
+    using L = LinearLds<BM, BN, BK, TRANSB, EDGE>;
+    constexpr bool DMA = L::DMA;
     constexpr int NT = 64 * WM * WN;                  // threads per role
     constexpr int LDA = L::LDA, LDB = L::LDB;
     constexpr int TM = BM / (32 * WM), TN = BN / (32 * WN);
@@ -81,6 +89,47 @@ __global__ __launch_bounds__(128 * WM * WN) void linear_mfma_kernel(LinearArgs a
 
     if (wave >= WM * WN) {
         // ------------------------------------------------------------------------------------ loader waves
+        if constexpr (DMA) {
+            // loader wave lw moves, per slab: A k-group lw (2 instructions: rows 0-63, 64-127) and B k-rows 4 lw .. 4 lw + 3.
+            // Slab t+3 is requested while slab t is computed; before the barrier that ends slab t, slab t+1 must have landed:
+            // at most the 12 newest DMA instructions of this wave may still be in flight (s_waitcnt vmcnt(12)).
+            const int lw = __builtin_amdgcn_readfirstlane(wave - WM * WN);
+            const float* __restrict__ X = a.X + (size_t)z * a.sx;
+            const float* __restrict__ W = a.W + (size_t)z * a.sw;
+            const float* pa0 = X + (size_t)(m0 + lane) * a.ldx + 4 * lw;
+            const float* pa1 = X + (size_t)(m0 + 64 + lane) * a.ldx + 4 * lw;
+            const float* pb = W + (size_t)(4 * lw) * a.ldw + n0 + 4 * lane;
+            const long ldw = a.ldw;
+            auto issue = [&](int t) {
+                float* st = lds + (t & 3) * L::STAGE;
+                float* As = st + (lw * BM) * 4;
+                float* Bs = st + BK * LDA + (4 * lw) * LDB;
+                const size_t ko = (size_t)t * BK;
+                __builtin_amdgcn_global_load_lds(pa0 + ko, (__attribute__((address_space(3))) void*)(As), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds(pa1 + ko, (__attribute__((address_space(3))) void*)(As + 64 * 4), 16, 0, 0);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    __builtin_amdgcn_global_load_lds(pb + (ko + j) * ldw, (__attribute__((address_space(3))) void*)(Bs + j * LDB), 16, 0, 0);
+            };
+            // s_waitcnt takes an immediate: wait until at most 6 * newer DMA instructions are outstanding.  Raw s_barrier, not
+            // __syncthreads(): the workgroup fence in front of it would drain every DMA in flight (vmcnt(0)).
+            auto wait_newer = [&](int newer) {
+                if (newer >= 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+                else if (newer == 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            };
+            issue(0);
+            if (ntile > 1) issue(1);
+            if (ntile > 2) issue(2);
+            wait_newer(min(2, ntile - 1));                       // slab 0 has landed
+            asm volatile("s_barrier" ::: "memory");
+            for (int t = 0; t < ntile; ++t) {
+                if (t + 3 < ntile) issue(t + 3);                 // into the stage slab t-1 was read from
+                wait_newer(max(0, min(2, ntile - 2 - t)));       // slab t+1 has landed
+                asm volatile("s_barrier" ::: "memory");
+            }
+            return;
+        }
 #ifdef DISPU_LOADER_PRIO
         __builtin_amdgcn_s_setprio(DISPU_LOADER_PRIO);
 #endif
@@ -206,17 +255,76 @@ __global__ __launch_bounds__(128 * WM * WN) void linear_mfma_kernel(LinearArgs a
     // Left to itself the compiler places a step's reads right in front of the MFMAs that need them, behind the previous
     // step's last MFMA: the wave then sits in s_waitcnt for an LDS round trip (~120 cycles) while the matrix pipe drains
     // after 64 - eight times per slab (measured: 4860 cycles per 64-MFMA slab instead of 4096).
+    if constexpr (DMA) {
+        for (int t = 0; t < ntile; ++t) {
+            const float* st = lds + (t & 3) * L::STAGE;
+            const float4* As4 = reinterpret_cast<const float4*>(st);
+            const float* Bs = st + BK * LDA;
+            // operands of k-step s+1 are requested before the MFMAs of step s (see the register path below).  A: lane
+            // (row, fk) reads the dwords fk and fk + 2 of its row's float4 (one ds_read2_b32): X[row][4 kg + fk] for the
+            // first k-step of the group and X[row][4 kg + 2 + fk] for the second - no select needed.
+            const float* Asf = st + fk;
+            float a2[2][TM][2];
+            float bf[2][TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const float* pr = Asf + (wm * (TM * 32) + i * 32 + fi) * 4;
+                a2[0][i][0] = pr[0]; a2[0][i][1] = pr[2];
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[0][j] = Bs[fk * LDB + wn * (TN * 32) + j * 32 + fi];
+#pragma unroll
+            for (int s2 = 0; s2 < BK / 2; ++s2) {
+                const int kg = s2 >> 1, u = s2 & 1, cur = s2 & 1, nxt = cur ^ 1;
+                if (s2 + 1 < BK / 2) {
+                    const int kk = 2 * (s2 + 1);
+                    if (u == 1) {
+#pragma unroll
+                        for (int i = 0; i < TM; ++i) {
+                            const float* pr = Asf + ((kg + 1) * BM + wm * (TM * 32) + i * 32 + fi) * 4;
+                            a2[(kg + 1) & 1][i][0] = pr[0]; a2[(kg + 1) & 1][i][1] = pr[2];
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) bf[nxt][j] = Bs[(kk + fk) * LDB + wn * (TN * 32) + j * 32 + fi];
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[kg & 1][i][u], bf[cur][j], acc[i][j], 0, 0, 0);
+                if (u == 1) __builtin_amdgcn_sched_group_barrier(0x100, TM + TN / 2, 0);        // ds_read2_b32: one per row tile + one per B pair
+                else __builtin_amdgcn_sched_group_barrier(0x100, TN / 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
+            }
+#ifdef LIN_CLOCK
+            const unsigned long long lb0 = __builtin_readcyclecounter();
+            __syncthreads();
+            lc_wait += __builtin_readcyclecounter() - lb0;
+#else
+            __syncthreads();
+#endif
+        }
+    } else
     for (int t = 0; t < ntile; ++t) {
         const float* As = lds + (t & 1) * L::STAGE;
         const float* Bs = As + BK * LDA;
         float af[2][TM], bf[2][TN];
+#ifdef LIN_NOREAD     // timing experiment only: operands from registers, the LDS is never read (results are wrong)
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[0][i] = af[1][i] = (float)(lane + i + t);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bf[0][j] = bf[1][j] = (float)(lane - j);
+#else
 #pragma unroll
         for (int i = 0; i < TM; ++i) af[0][i] = As[fk * LDA + wm * (TM * 32) + i * 32 + fi];
 #pragma unroll
         for (int j = 0; j < TN; ++j) bf[0][j] = Bs[fk * LDB + wn * (TN * 32) + j * 32 + fi];
+#endif
 #pragma unroll
         for (int s2 = 0; s2 < BK / 2; ++s2) {
             const int cur = s2 & 1, nxt = cur ^ 1;
+#ifndef LIN_NOREAD
             if (s2 + 1 < BK / 2) {
                 const int kk = 2 * (s2 + 1);
 #pragma unroll
@@ -224,14 +332,17 @@ __global__ __launch_bounds__(128 * WM * WN) void linear_mfma_kernel(LinearArgs a
 #pragma unroll
                 for (int j = 0; j < TN; ++j) bf[nxt][j] = Bs[(kk + fk) * LDB + wn * (TN * 32) + j * 32 + fi];
             }
+#endif
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][i], bf[cur][j], acc[i][j], 0, 0, 0);
             // pin: this step's DS reads (the next step's operands) first, then its TM*TN MFMAs
+#ifndef LIN_NOREAD
             __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
+#endif
         }
 #ifdef LIN_CLOCK
         const unsigned long long lb0 = __builtin_readcyclecounter();
@@ -317,7 +428,7 @@ __global__ __launch_bounds__(128 * WM * WN) void linear_mfma_kernel(LinearArgs a
 
 template <int BM, int BN, int WM, int WN, int BK, bool TRANSB, bool EDGE, int EPI>
 static int launch_epi(const LinearArgs& a, dim3 grid, hipStream_t s) {
-    constexpr size_t bytes = LinearLds<BM, BN, BK, TRANSB>::BYTES;
+    constexpr size_t bytes = LinearLds<BM, BN, BK, TRANSB, EDGE>::BYTES;
     auto kern = linear_mfma_kernel<BM, BN, WM, WN, BK, TRANSB, EDGE, EPI>;
     if (bytes > 64 * 1024) {
         static bool done = false;       // opt in to > 64 KiB of dynamic LDS once per instantiation
@@ -327,7 +438,7 @@ static int launch_epi(const LinearArgs& a, dim3 grid, hipStream_t s) {
             done = true;
         }
     }
-    hipLaunchKernelGGL(kern, grid, dim3(128 * WM * WN), bytes, s, a);
+    hipLaunchKernelGGL(kern, grid, dim3(64 * (WM * WN + (LinearLds<BM, BN, BK, TRANSB, EDGE>::DMA ? 4 : WM * WN))), bytes, s, a);
     return (int)hipGetLastError();
 }
 
@@ -410,6 +521,7 @@ DISPU_EXPORT int dispu_linear_bn(int batch, int M, int K, int N, const float* X,
     const bool tb = transb != 0;
     switch (dispu_linear_tile(batch, M, N)) {
         case 128257: return launch_linear<128, 256, 2, 2, 16>(a, batch, tb, s);
+        case 128258: return launch_linear<128, 256, 2, 4, 16>(a, batch, tb, s);     // 8 MFMA waves (64 x 64 each) when the DMA path applies
         case 128256: return launch_linear<128, 256, 2, 2, 32>(a, batch, tb, s);     // benchmarking variants
         case 128129: return launch_linear<128, 128, 2, 2, 16>(a, batch, tb, s);
         case 128128: return launch_linear<128, 128, 2, 2, 32>(a, batch, tb, s);
