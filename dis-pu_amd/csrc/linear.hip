@@ -292,7 +292,11 @@ __global__ __launch_bounds__(64 * (WM * WN + (LinearLds<BM, BN, BK, TRANSB, EDGE
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
+#ifdef LIN_AGPR
+                        mfma_acc(acc[i][j], a2[kg & 1][i][u], bf[cur][j]);
+#else
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[kg & 1][i][u], bf[cur][j], acc[i][j], 0, 0, 0);
+#endif
                 if (u == 1) __builtin_amdgcn_sched_group_barrier(0x100, TM + TN / 2, 0);        // ds_read2_b32: one per row tile + one per B pair
                 else __builtin_amdgcn_sched_group_barrier(0x100, TN / 2, 0);
                 __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
@@ -353,6 +357,9 @@ __global__ __launch_bounds__(64 * (WM * WN + (LinearLds<BM, BN, BK, TRANSB, EDGE
 #endif
     }
 
+#ifdef LIN_AGPR
+    if constexpr (DMA) mfma_acc_settle();
+#endif
 #ifdef LIN_CLOCK
     if (blockIdx.x == 0 && blockIdx.y == 5 && threadIdx.x == 0) { lin_clock_ticks[0] = __builtin_readcyclecounter() - lc0; lin_clock_ticks[1] = ntile; lin_clock_ticks[2] = lc_wait; }
 #endif

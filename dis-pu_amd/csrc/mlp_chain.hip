@@ -40,9 +40,21 @@ constexpr size_t MC_LDS_BYTES = (size_t)(MC_ACT + 2 * MC_WST + MC_HEAD) * sizeof
 
 // one layer on the MFMA waves: acc = act[0:K] . W (slabs g0 .. g0 + K/8 - 1 of the weight stream), then
 // act[0:N] <- relu(acc + bias) (k-major), optionally also to global memory.
+// MC_CLOCK (tools/micro/chain_lab.hip): cycle stamps of one MFMA wave - total and the part spent in the slab barriers.
+// Measured: 2850 cycles per 32-MFMA slab (2048 pipe cycles), 100 - 350 of them in the barrier.  Tried and NOT kept: the weight
+// stream by global_load_lds (3 stages), also with the input tile by DMA ([k/4][row] float4 layout, b128 reads): the barrier wait
+// drops to ~100 cycles but the MFMA waves' own time per slab grows by 250 - 400, a net loss of 2 - 10 %.
+#ifdef MC_CLOCK
+__device__ unsigned long long mc_clock_ticks[4];
+#define MC_WAIT_PARAM , unsigned long long& mc_wait
+#define MC_WAIT_ARG , mc_wait_local
+#else
+#define MC_WAIT_PARAM
+#define MC_WAIT_ARG
+#endif
 template <int K, int N>
 __device__ __forceinline__ void chain_layer(float* act, const float* wst, int g0, const float* __restrict__ bias, float* __restrict__ Yg,
-                                            long ldy, long row0, int wm, int wn, int fi, int fk) {
+                                            long ldy, long row0, int wm, int wn, int fi, int fk MC_WAIT_PARAM) {
     constexpr int TNW = N / 64;                                   // 32-wide column blocks per wave (2 x 2 waves over 128 x N)
     constexpr int LDW = N + 4, BK = mc_bk(N);
     f32x16 acc[2][TNW];
@@ -67,7 +79,13 @@ __device__ __forceinline__ void chain_layer(float* act, const float* wst, int g0
 #pragma unroll
                 for (int j = 0; j < TNW; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
         }
+#ifdef MC_CLOCK
+        const unsigned long long b0_ = __builtin_readcyclecounter();
         __syncthreads();
+        mc_wait += __builtin_readcyclecounter() - b0_;
+#else
+        __syncthreads();
+#endif
     }
     __syncthreads();                                              // every wave has finished reading this layer's input
 #pragma unroll
@@ -193,10 +211,17 @@ __global__ __launch_bounds__(512) void mlp_chain_kernel(ChainArgs a) {
     // ------------------------------------------------------------------------------------------ MFMA waves
     const int wm = wave >> 1, wn = wave & 1;
     const int fi = lane & 31, fk = lane >> 5;
+#ifdef MC_CLOCK
+    unsigned long long mc_wait_local = 0;
+    const unsigned long long mc_t0 = __builtin_readcyclecounter();
+#endif
     __syncthreads();
-    chain_layer<K0, N1>(act, wst, 0, a.b1, a.Y1, a.ldy1, row0, wm, wn, fi, fk);
-    chain_layer<N1, N2>(act, wst, S1, a.b2, nullptr, 0, row0, wm, wn, fi, fk);
-    chain_layer<N2, N3>(act, wst, S1 + S2, a.b3, nullptr, 0, row0, wm, wn, fi, fk);
+    chain_layer<K0, N1>(act, wst, 0, a.b1, a.Y1, a.ldy1, row0, wm, wn, fi, fk MC_WAIT_ARG);
+    chain_layer<N1, N2>(act, wst, S1, a.b2, nullptr, 0, row0, wm, wn, fi, fk MC_WAIT_ARG);
+    chain_layer<N2, N3>(act, wst, S1 + S2, a.b3, nullptr, 0, row0, wm, wn, fi, fk MC_WAIT_ARG);
+#ifdef MC_CLOCK
+    if (blockIdx.x == 7 && threadIdx.x == 0) { mc_clock_ticks[0] = __builtin_readcyclecounter() - mc_t0; mc_clock_ticks[1] = G; mc_clock_ticks[2] = mc_wait_local; }
+#endif
     // head: 64 -> 3 per row, the arithmetic of linear_small_n_kernel (fmaf chain over k, + bias, optional sigmoid offset)
     if (threadIdx.x < MC_BM) {
         const int row = threadIdx.x;
