@@ -320,6 +320,11 @@ __global__ __launch_bounds__(64 * KF_NW) void knn_feat_wave_kernel(int n, int m,
     // the workgroup's query rows, zero padded to CP: read per channel quad as one broadcast ds_read_b128.  (Scalar loads
     // of the query row inside the channel loop exposed an s_load round trip every two quads.)
     float4* qs = reinterpret_cast<float4*>(reinterpret_cast<char*>(sorted) + (R <= 4 ? (size_t)KF_NW * KF_SCRATCH * 8 : (size_t)KF_NW * R * 64 * 8));   // R <= 4: prefilter scratch only   // [qpb][CP/4]
+    constexpr int QLD = CP / 4 + 1;      // query row stride in float4: rows 16 (CP + 4) bytes apart spread the per-query dword reads over the banks
+    // R <= 4: the workgroup's 16 x n distance words (computed on the matrix pipe, read back per query) and the query norms
+    constexpr int NP = 64 * R + 4;
+    uint32_t* dmat = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(qs) + (size_t)16 * QLD * 16);    // [16][NP]
+    float* qn = reinterpret_cast<float*>(dmat + 16 * NP);                                                   // [16]
     const int cloud = blockIdx.y, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const float* __restrict__ sp = points + (size_t)cloud * n * ldp;
     const float* __restrict__ qp = queries + (size_t)cloud * m * ldq;
@@ -374,7 +379,7 @@ __global__ __launch_bounds__(64 * KF_NW) void knn_feat_wave_kernel(int n, int m,
             v.y = (c4 * 4 + 1 < c) ? src[1] : 0.f;
             v.z = (c4 * 4 + 2 < c) ? src[2] : 0.f;
             v.w = (c4 * 4 + 3 < c) ? src[3] : 0.f;
-            qs[e] = v;
+            qs[ql * QLD + c4] = v;
         }
     }
     __syncthreads();
@@ -388,6 +393,18 @@ __global__ __launch_bounds__(64 * KF_NW) void knn_feat_wave_kernel(int n, int m,
         }
         norms[p] = r;
     }
+    if constexpr (R <= 4) {
+        if (threadIdx.x < 16) {                                    // |q|^2, same ascending-channel chain as the candidates' norms
+            float r = 0.f;
+#pragma unroll
+            for (int c4 = 0; c4 < CP / 4; ++c4) {
+                const float4 v = qs[threadIdx.x * QLD + c4];
+                r = __builtin_fmaf(v.x, v.x, r); r = __builtin_fmaf(v.y, v.y, r);
+                r = __builtin_fmaf(v.z, v.z, r); r = __builtin_fmaf(v.w, v.w, r);
+            }
+            qn[threadIdx.x] = r;
+        }
+    }
     __syncthreads();
     float rp[R];
 #pragma unroll
@@ -396,47 +413,69 @@ __global__ __launch_bounds__(64 * KF_NW) void knn_feat_wave_kernel(int n, int m,
     const int q0 = blockIdx.x * qpb, q1 = min(m, q0 + qpb);
     KN_T(ts1);
     if constexpr (R <= 4) {
-        // query pairs (qa, qb = qa + KF_NW): every staged float4 feeds both dot products, both selections run interleaved
-        for (int qv = q0 + wave; qv < q1; qv += 2 * KF_NW) {
+        // Phase 1, all waves: the 16 x n dot products of the workgroup on the matrix pipe.  v_mfma_f32_16x16x4_f32 is bit for
+        // bit the ascending-k fmaf chain (tools/micro/mfma16_exact.hip), i.e. exactly the chain the VALU form of this kernel
+        // ran per (query, candidate): A = the 16 query rows (lane = query, 4 channels per step), B = 16 candidates, one
+        // instruction per channel quad.  Wave w takes candidate tiles w, w + 8; distances (rq - 2 dot) + rp go to LDS as
+        // ordered words [query][candidate].  (As VALU fmaf chains the dots were half of this kernel's time.)
+        {
+            typedef float kf_f32x4 __attribute__((ext_vector_type(4)));
             KN_T(t0);
+            const int i16 = lane & 15, q4 = lane >> 4;
+            const float* qsf = reinterpret_cast<const float*>(qs);
+            const float* ff = reinterpret_cast<const float*>(feats);
+            float aq[CP / 4];
+#pragma unroll
+            for (int c4 = 0; c4 < CP / 4; ++c4) aq[c4] = qsf[(i16 * QLD + c4) * 4 + q4];
+            float rq4[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) rq4[r] = qn[4 * q4 + r];
+            const int ntile = (n + 15) >> 4;
+            // two candidate tiles per pass: their MFMA chains are independent and interleave on the pipe
+            for (int tl = wave; tl < ntile; tl += 2 * KF_NW) {
+                const int tl2 = tl + KF_NW;
+                const bool two = tl2 < ntile;                       // wave-uniform
+                const int cand0 = tl * 16 + i16, cc0 = min(cand0, n - 1);
+                const int cand1 = tl2 * 16 + i16, cc1 = min(cand1, n - 1);
+                kf_f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int c4 = 0; c4 < CP / 4; ++c4) {
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[c4], ff[(c4 * ns + cc0) * 4 + q4], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[c4], ff[(c4 * ns + cc1) * 4 + q4], acc1, 0, 0, 0);
+                }
+                const float rp0 = norms[cc0], rp1 = norms[cc1];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {                       // acc[r] = dot(query 4 q4 + r, candidate cand)
+                    const float t0_ = rq4[r] - 2.0f * acc0[r];
+                    const float d0 = (t0_ + rp0) + 0.0f;
+                    dmat[(4 * q4 + r) * NP + cand0] = (cand0 < n) ? f32_to_ordered(d0) : 0xFFFFFFFFu;
+                    if (two) {
+                        const float t1_ = rq4[r] - 2.0f * acc1[r];
+                        const float d1 = (t1_ + rp1) + 0.0f;
+                        dmat[(4 * q4 + r) * NP + cand1] = (cand1 < n) ? f32_to_ordered(d1) : 0xFFFFFFFFu;
+                    }
+                }
+            }
+            __syncthreads();
+#ifdef KNN_STAMPS
+            { KN_T(t1); k_dot += t1 - t0; }
+#endif
+        }
+        // Phase 2: wave w selects for queries w and w + 8
+        for (int qv = q0 + wave; qv < q1; qv += 2 * KF_NW) {
+            KN_T(t1);
             const int qa = __builtin_amdgcn_readfirstlane(qv);
             const bool has_b = qa + KF_NW < q1;
             const int qb = has_b ? qa + KF_NW : qa;
-            const float4* __restrict__ qra = qs + (qa - q0) * (CP / 4);
-            const float4* __restrict__ qrb = qs + (qb - q0) * (CP / 4);
-            float da[R], db[R];
-#pragma unroll
-            for (int r = 0; r < R; ++r) { da[r] = 0.f; db[r] = 0.f; }
-            float rqa = 0.f, rqb = 0.f;
-#pragma unroll 2
-            for (int c4 = 0; c4 < CP / 4; ++c4) {
-                const float4 a4 = qra[c4], b4 = qrb[c4];
-                rqa = __builtin_fmaf(a4.x, a4.x, rqa); rqa = __builtin_fmaf(a4.y, a4.y, rqa);
-                rqa = __builtin_fmaf(a4.z, a4.z, rqa); rqa = __builtin_fmaf(a4.w, a4.w, rqa);
-                rqb = __builtin_fmaf(b4.x, b4.x, rqb); rqb = __builtin_fmaf(b4.y, b4.y, rqb);
-                rqb = __builtin_fmaf(b4.z, b4.z, rqb); rqb = __builtin_fmaf(b4.w, b4.w, rqb);
-#pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    const int p = lane + 64 * r;
-                    const float4 v = feats[c4 * ns + (p < n ? p : 0)];
-                    da[r] = __builtin_fmaf(a4.x, v.x, da[r]); da[r] = __builtin_fmaf(a4.y, v.y, da[r]);
-                    da[r] = __builtin_fmaf(a4.z, v.z, da[r]); da[r] = __builtin_fmaf(a4.w, v.w, da[r]);
-                    db[r] = __builtin_fmaf(b4.x, v.x, db[r]); db[r] = __builtin_fmaf(b4.y, v.y, db[r]);
-                    db[r] = __builtin_fmaf(b4.z, v.z, db[r]); db[r] = __builtin_fmaf(b4.w, v.w, db[r]);
-                }
-            }
             uint32_t oda[R], odb[R];
             int cp[R];
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 const int p = lane + 64 * r;
-                const float ta = rqa - 2.0f * da[r], tb = rqb - 2.0f * db[r];
-                const float dda = (ta + rp[r]) + 0.0f, ddb = (tb + rp[r]) + 0.0f;
                 cp[r] = p;
-                oda[r] = (p < n) ? f32_to_ordered(dda) : 0xFFFFFFFFu;
-                odb[r] = (p < n) ? f32_to_ordered(ddb) : 0xFFFFFFFFu;
+                oda[r] = (p < n) ? dmat[(qa - q0) * NP + p] : 0xFFFFFFFFu;
+                odb[r] = (p < n) ? dmat[(qb - q0) * NP + p] : 0xFFFFFFFFu;
             }
-            KN_T(t1);
             const size_t oa = ((size_t)cloud * m + qa) * k, ob = ((size_t)cloud * m + qb) * k;
             uint64_t* buf = sorted + (size_t)wave * KF_SCRATCH;
             const auto w2f = [](uint32_t w) { return ordered_to_f32(w); };
@@ -466,14 +505,14 @@ __global__ __launch_bounds__(64 * KF_NW) void knn_feat_wave_kernel(int n, int m,
                 }
             }
 #ifdef KNN_STAMPS
-            { KN_T(t3); k_dot += t1 - t0; k_sort += t2 - t1; k_sel += t3 - t2; k_nq += 2; }
+            { KN_T(t3); k_sort += t2 - t1; k_sel += t3 - t2; k_nq += 2; }
 #endif
         }
     } else {
     for (int qv = q0 + wave; qv < q1; qv += KF_NW) {
         KN_T(t0);
         const int qi = __builtin_amdgcn_readfirstlane(qv);
-        const float4* __restrict__ qrow4 = qs + (qi - q0) * (CP / 4);  // wave-uniform LDS address -> broadcast read
+        const float4* __restrict__ qrow4 = qs + (qi - q0) * QLD;  // wave-uniform LDS address -> broadcast read
         float dot[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) dot[r] = 0.f;
@@ -540,7 +579,7 @@ static int launch_feat_wave(int b, int n, int m, int c, int k, int ldp, int ldq,
                             int* idx, hipStream_t st) {
     const int qpb = 16;         // 2 queries per wave; the cloud's features are re-staged per workgroup (L2-resident)
     dim3 grid((m + qpb - 1) / qpb, b);
-    const size_t lds = (size_t)(CP / 4) * (n + 1) * 16 + (((size_t)n * 4 + 15) & ~15ull) + (R <= 4 ? (size_t)KF_NW * KF_SCRATCH * 8 : (size_t)KF_NW * R * 64 * 8) + (size_t)qpb * CP * 4;
+    const size_t lds = (size_t)(CP / 4) * (n + 1) * 16 + (((size_t)n * 4 + 15) & ~15ull) + (R <= 4 ? (size_t)KF_NW * KF_SCRATCH * 8 : (size_t)KF_NW * R * 64 * 8) + (size_t)qpb * (CP + 4) * 4 + (R <= 4 ? (size_t)16 * (64 * R + 4) * 4 + 64 : (size_t)0);
     static bool attr = false;           // per instantiation: opt in to more than 64 KB of dynamic LDS
     if (!attr) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(knn_feat_wave_kernel<R, CP>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -576,7 +615,7 @@ int knn_feat_wave_dispatch(int b, int n, int m, int c, int k, int ldp, int ldq, 
     if (n > 512 || c > 64 || k > 64) return -1;
     const int cp = (c + 3) & ~3;
     const int r = n <= 64 ? 1 : (n <= 128 ? 2 : (n <= 256 ? 4 : 8));
-    const size_t lds = (size_t)(cp / 4) * (n + 1) * 16 + (((size_t)n * 4 + 15) & ~15ull) + (r <= 4 ? (size_t)0 : (size_t)KF_NW * r * 64 * 8) + (size_t)16 * cp * 4;
+    const size_t lds = (size_t)(cp / 4) * (n + 1) * 16 + (((size_t)n * 4 + 15) & ~15ull) + (r <= 4 ? (size_t)KF_NW * KF_SCRATCH * 8 + (size_t)16 * (64 * r + 4) * 4 + 64 : (size_t)KF_NW * r * 64 * 8) + (size_t)16 * (cp + 4) * 4;
     if (lds > 160 * 1024) return -1;
     if (c <= 4) return feat_wave_r<4>(b, n, m, c, k, ldp, ldq, p, q, dist, idx, st);
     if (c <= 8) return feat_wave_r<8>(b, n, m, c, k, ldp, ldq, p, q, dist, idx, st);
