@@ -45,6 +45,8 @@ SIGNATURES = {
     "dispu_group_center": (_i, [_l, _i, _i, _vp, _vp, _vp]),
     "dispu_pool_nsample": (_i, [_l, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "dispu_idw_weights": (_i, [_l, _vp, _vp, _vp]),
+    "dispu_l2_normalize_rows": (_i, [_l, _i, _vp, _vp, _vp]),
+    "dispu_scale_add": (_i, [_l, _vp, C.c_float, _vp, _vp, _vp]),
     "dispu_edge_feature": (_i, [_l, _i, _i, _i, _vp, _l, _vp, _i, _i, _vp, _l, _vp]),
     "dispu_row_mean_max": (_i, [_i, _i, _vp, _vp, _vp, _vp]),
     "dispu_repulsion": (_i, [_l, _i, _i, _i, C.c_float, _vp, _vp, _vp, _vp]),

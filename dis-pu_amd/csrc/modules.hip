@@ -25,6 +25,7 @@ __global__ void group_center_kernel(long rows, int ns, int c, float* __restrict_
 // Pooling over the nsample axis of X[rows, ns, c] (pointnet_util.py:121-140):
 //   0 max | 1 avg (sum in s order, / ns) | 2 "min" = max(-x) exactly as the reference computes it (it never negates
 //   back) | 3 weighted_avg: w_s = exp(-5*|gxyz_s|) / sum_s exp(-5*|gxyz_s|) | 4 max_and_avg -> [max | avg] (2c)
+//   5 sum in s order (GIN aggregation, gcn_lib/tf_vertex.py:248)
 __global__ void pool_nsample_kernel(long rows, int ns, int c, int mode, const float* __restrict__ X,
                                     const float* __restrict__ gxyz, float* __restrict__ out) {
     const long total = rows * c;
@@ -55,9 +56,27 @@ __global__ void pool_nsample_kernel(long rows, int ns, int c, int mode, const fl
             sum += v;
         }
         if (mode == 0 || mode == 2) out[r * co + l] = mx;
+        else if (mode == 5) out[r * co + l] = sum;
         else if (mode == 1) out[r * co + l] = sum / (float)ns;
         else { out[r * co + l] = mx; out[r * co + c + l] = sum / (float)ns; }
     }
+}
+
+// tf.nn.l2_normalize(x, axis=-1) (GraphSAGE, gcn_lib/tf_vertex.py:133-134): x * rsqrt(max(sum_c x^2, 1e-12)); the sum runs in
+// channel order, the reciprocal square root is 1 / sqrtf (correctly rounded), one lane per row.
+__global__ void l2_normalize_rows_kernel(long rows, int c, const float* __restrict__ X, float* __restrict__ out) {
+    for (long r = (long)blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += (long)gridDim.x * blockDim.x) {
+        const float* x = X + r * c;
+        float ss = 0.f;
+        for (int l = 0; l < c; ++l) ss += x[l] * x[l];
+        const float inv = 1.0f / sqrtf(fmaxf(ss, 1e-12f));
+        for (int l = 0; l < c; ++l) out[r * c + l] = x[l] * inv;
+    }
+}
+
+// out = x * alpha + y, elementwise (GIN: inputs * (1 + epsilon) + aggregated, gcn_lib/tf_vertex.py:205)
+__global__ void scale_add_kernel(long n, const float* __restrict__ x, float alpha, const float* __restrict__ y, float* __restrict__ out) {
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) out[e] = x[e] * alpha + y[e];
 }
 
 // pointnet_fp_module's inverse-distance weights (pointnet_util.py:204-208): d = max(d, 1e-10); w = (1/d) / sum(1/d)
@@ -148,9 +167,23 @@ DISPU_EXPORT int dispu_group_center(long rows, int ns, int c, float* grouped, co
 
 DISPU_EXPORT int dispu_pool_nsample(long rows, int ns, int c, int mode, const float* X, const float* gxyz, float* out,
                                     void* stream) {
-    if (rows < 0 || ns <= 0 || c <= 0 || mode < 0 || mode > 4 || (mode == 3 && !gxyz)) return (int)hipErrorInvalidValue;
+    if (rows < 0 || ns <= 0 || c <= 0 || mode < 0 || mode > 5 || (mode == 3 && !gxyz)) return (int)hipErrorInvalidValue;
     if (rows == 0) return 0;
     hipLaunchKernelGGL(pool_nsample_kernel, dim3(mgrid(rows * c, 256)), dim3(256), 0, (hipStream_t)stream, rows, ns, c, mode, X, gxyz, out);
+    return (int)hipGetLastError();
+}
+
+DISPU_EXPORT int dispu_l2_normalize_rows(long rows, int c, const float* X, float* out, void* stream) {
+    if (rows < 0 || c <= 0) return (int)hipErrorInvalidValue;
+    if (rows == 0) return 0;
+    hipLaunchKernelGGL(l2_normalize_rows_kernel, dim3(mgrid(rows, 256)), dim3(256), 0, (hipStream_t)stream, rows, c, X, out);
+    return (int)hipGetLastError();
+}
+
+DISPU_EXPORT int dispu_scale_add(long n, const float* x, float alpha, const float* y, float* out, void* stream) {
+    if (n < 0) return (int)hipErrorInvalidValue;
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(scale_add_kernel, dim3(mgrid(n, 256)), dim3(256), 0, (hipStream_t)stream, n, x, alpha, y, out);
     return (int)hipGetLastError();
 }
 

@@ -219,8 +219,13 @@ int dispu_mlp_chain(long rows, int K0, int N1, int N2, int N3, const float* X, l
 /* grouped[r,s,:] -= center[r,:]  ("translation normalization", pointnet_util.py:43; loss_utils.py:281). */
 int dispu_group_center(long rows, int ns, int c, float* grouped, const float* center, void* stream);
 /* pooling over nsample of X[rows,ns,c] (pointnet_util.py:121-140): mode 0 max, 1 avg, 2 "min" (= max(-x), as the
- * reference computes it), 3 weighted_avg (needs gxyz[rows,ns,3]), 4 max_and_avg -> [max|avg] (2c outputs). */
+ * reference computes it), 3 weighted_avg (needs gxyz[rows,ns,3]), 4 max_and_avg -> [max|avg] (2c outputs),
+ * 5 sum (GIN aggregation, gcn_lib/tf_vertex.py:248). */
 int dispu_pool_nsample(long rows, int ns, int c, int mode, const float* X, const float* gxyz, float* out, void* stream);
+/* tf.nn.l2_normalize(x, axis=-1) of GraphSAGE (gcn_lib/tf_vertex.py:133-134): out[r,:] = X[r,:] / sqrt(max(sum_c X[r,c]^2, 1e-12)). */
+int dispu_l2_normalize_rows(long rows, int c, const float* X, float* out, void* stream);
+/* out = x * alpha + y elementwise (GIN: inputs * (1 + epsilon) + aggregated, gcn_lib/tf_vertex.py:205). */
+int dispu_scale_add(long n, const float* x, float alpha, const float* y, float* out, void* stream);
 /* pointnet_fp_module inverse-distance weights (pointnet_util.py:204-208): dist[rows,3] -> weight[rows,3]. */
 int dispu_idw_weights(long rows, const float* dist, float* weight, void* stream);
 /* tf_util.get_edge_feature (Common/tf_util.py:654-686): out[(i,s), 0:2c] = [F_i | F_j - F_i]. */

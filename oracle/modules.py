@@ -121,6 +121,38 @@ def edge_conv_layer(P, scope, feat, idx, bn=False, relu=True):
     return conv2d(edge, P, scope, bn=bn, relu=relu).max(2, keepdims=True)
 
 
+def max_relat_conv_layer(P, scope, feat, idx, bn=False, relu=True):
+    """tf_vertex.py:20-79 (MRGCN): conv over [x_i | max_j (x_j - x_i)]."""
+    nbr = OG.gather(feat, idx)
+    rel = (nbr - feat[:, :, None, :]).max(2, keepdims=True)
+    return conv2d(np.concatenate([feat[:, :, None, :], rel], -1), P, scope, bn=bn, relu=relu)
+
+
+def graphsage_conv_layer(P, scope, feat, idx, normalize=True, bn=False, relu=True):
+    """tf_vertex.py:103-180: conv over [x_i | max_j conv_aggr(x_j)], then l2_normalize over channels
+    (x * rsqrt(max(sum x^2, 1e-12)), the sum in channel order)."""
+    h = conv2d(OG.gather(feat, idx), P, scope + "_aggr", bn=bn, relu=relu).max(2, keepdims=True)
+    out = conv2d(np.concatenate([feat[:, :, None, :], h], -1), P, scope, bn=bn, relu=relu)
+    if not normalize:
+        return out
+    ss = np.zeros(out.shape[:-1], np.float32)
+    for c in range(out.shape[-1]):
+        ss = ss + out[..., c] * out[..., c]
+    inv = np.float32(1.0) / np.sqrt(np.maximum(ss, np.float32(1e-12)))
+    return out * inv[..., None]
+
+
+def gin_conv_layer(P, scope, feat, idx, bn=False, relu=True):
+    """tf_vertex.py:182-251: conv over x_i (1 + epsilon) + sum_j x_j (the sum in neighbour order)."""
+    nbr = OG.gather(feat, idx)
+    agg = np.zeros(feat.shape, np.float32)
+    for s in range(nbr.shape[2]):
+        agg = agg + nbr[:, :, s, :]
+    eps = np.float32(np.asarray(P.get(scope + "_epsilon", 0.0)).reshape(-1)[0])
+    comb = feat * (np.float32(1.0) + eps) + agg
+    return conv2d(comb[:, :, None, :], P, scope, bn=bn, relu=relu)
+
+
 def chamfer(pred, gt, radius=1.0, forward_weight=1.0):
     """loss_utils.py:45-64"""
     d1, _, d2, _ = O.nn_distance(gt, pred)

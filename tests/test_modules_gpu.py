@@ -95,6 +95,28 @@ def test_edge_conv_and_knn_graph(dev):
     assert N(got).shape == (3, 200, 1, 64) and np.array_equal(N(got), want)
 
 
+def test_mrgcn_graphsage_gin_layers(dev):
+    """The other three DeepGCN vertex layers the reference defines (gcn_lib/tf_vertex.py:20-79, 103-180, 182-251)."""
+    from dispu_amd import gcn_lib as GL
+    rng = np.random.default_rng(14)
+    f = rng.standard_normal((2, 150, 12)).astype(np.float32)
+    P = make_params(rng, [("g/mr", 24, 32), ("g/sage_aggr", 12, 12), ("g/sage", 24, 40), ("g/gin", 12, 20)], bn=False)
+    P["g/gin_epsilon"] = np.array([0.25], np.float32)
+    idx = OM.knn_graph(f, 9)
+    tidx, tf_ = T(idx.astype(np.int32), dev), T(f, dev).unsqueeze(2)
+    got = GL.max_relat_conv_layer(tf_, tidx, 9, 32, scope="g/mr", params=P)
+    assert N(got).shape == (2, 150, 1, 32) and np.array_equal(N(got), OM.max_relat_conv_layer(P, "g/mr", f, idx))
+    got = GL.graphsage_conv_layer(tf_, tidx, 9, 40, normalize=False, scope="g/sage", params=P)
+    assert np.array_equal(N(got), OM.graphsage_conv_layer(P, "g/sage", f, idx, normalize=False))
+    got = GL.graphsage_conv_layer(tf_, tidx, 9, 40, normalize=True, scope="g/sage", params=P)
+    want = OM.graphsage_conv_layer(P, "g/sage", f, idx, normalize=True)
+    assert np.allclose(N(got), want, rtol=1e-6, atol=1e-7)
+    nrm = np.sqrt((N(got).astype(np.float64) ** 2).sum(-1))
+    assert np.all((np.abs(nrm - 1) < 1e-5) | (nrm == 0))
+    got = GL.gin_conv_layer(tf_, tidx, 9, 20, scope="g/gin", params=P)
+    assert N(got).shape == (2, 150, 1, 20) and np.array_equal(N(got), OM.gin_conv_layer(P, "g/gin", f, idx))
+
+
 def test_losses(dev):
     from dispu_amd import loss_utils as LU
     from dispu_amd import synth
