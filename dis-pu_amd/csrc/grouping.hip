@@ -58,6 +58,64 @@ __global__ __launch_bounds__(QB_BS) void query_ball_kernel(int n, int m, const f
     }
 }
 
+// n <= 1024: a WAVE owns a query.  Lane l keeps candidates 64 r + l (r < R) in registers for all queries of the wave;
+// per 64-candidate block the hits are a ballot mask, a hit's output slot is cnt + (hits in lower lanes), so the first
+// nsample hits are written in index order exactly as the serial scan does, and the wave stops at the block that fills
+// the row.  The lane-per-query kernel above runs b * m / 64 waves that each scan n candidates serially (141 us for the
+// repulsion loss's (8, 1024, 1024, 20)); here all 64 lanes of b * m waves work.
+template <int R, bool FMA>
+__global__ __launch_bounds__(256) void query_ball_wave_kernel(int n, int m, int qpb, const float* __restrict__ radius, int nsample,
+                                                               const float* __restrict__ xyz1, const float* __restrict__ xyz2,
+                                                               int* __restrict__ idx, int* __restrict__ pts_cnt) {
+    const int cloud = blockIdx.y, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const float* __restrict__ p1 = xyz1 + (size_t)cloud * n * 3;
+    const float* __restrict__ p2 = xyz2 + (size_t)cloud * m * 3;
+    const float rad = radius[0];
+    float cx[R], cy[R], cz[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int p = min(64 * r + lane, n - 1);
+        cx[r] = p1[p * 3 + 0]; cy[r] = p1[p * 3 + 1]; cz[r] = p1[p * 3 + 2];
+    }
+    const int q0 = blockIdx.x * qpb, q1 = min(m, q0 + qpb);
+    for (int qv = q0 + wave; qv < q1; qv += 4) {
+        const int j = __builtin_amdgcn_readfirstlane(qv);
+        const float x2 = p2[j * 3 + 0], y2 = p2[j * 3 + 1], z2 = p2[j * 3 + 2];
+        int* __restrict__ row = idx + ((size_t)cloud * m + j) * nsample;
+        int cnt = 0, first = 0;                                    // wave-uniform
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            if (cnt < nsample && 64 * r < n) {
+                const float d2 = sqdist3<FMA>(x2 - cx[r], y2 - cy[r], z2 - cz[r]);
+                const float d = fmaxf(sqrtf(d2), 1e-20f);
+                const bool hit = (d < rad) && (64 * r + lane < n);
+                const unsigned long long mk = __ballot(hit);
+                if (mk) {
+                    if (cnt == 0) first = 64 * r + (int)__builtin_ctzll(mk);
+                    const int pos = cnt + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0u));
+                    if (hit && pos < nsample) row[pos] = 64 * r + lane;
+                    cnt = min(nsample, cnt + (int)__popcll(mk));
+                }
+            }
+        }
+        // first hit replicated into the unused tail; a row without any hit stays untouched
+        if (cnt > 0)
+            for (int l = cnt + lane; l < nsample; l += 64) row[l] = first;
+        if (lane == 0) pts_cnt[(size_t)cloud * m + j] = cnt;
+    }
+}
+
+template <int R>
+static void launch_query_ball_wave(int b, int n, int m, const float* radius, int nsample, const float* xyz1, const float* xyz2,
+                                   int* idx, int* pts_cnt, int arith, hipStream_t st) {
+    const int qpb = ((long)b * m >= 32768) ? 32 : 16;
+    dim3 grid((m + qpb - 1) / qpb, b);
+    if (arith & DISPU_ARITH_CONTRACT)
+        hipLaunchKernelGGL((query_ball_wave_kernel<R, true>), grid, dim3(256), 0, st, n, m, qpb, radius, nsample, xyz1, xyz2, idx, pts_cnt);
+    else
+        hipLaunchKernelGGL((query_ball_wave_kernel<R, false>), grid, dim3(256), 0, st, n, m, qpb, radius, nsample, xyz1, xyz2, idx, pts_cnt);
+}
+
 // Flat gather: element e of out[b,m,ns,c] <- points[cloud, idx[row], e % c].  VEC = floats per lane.
 // Gather rows: out[row, :] = points[cloud(row), idx[row], :].  TX lanes (a power of two) share one output row and
 // stride over its c/VEC vectors; a workgroup covers 256/TX consecutive rows, so every wave writes whole contiguous
@@ -107,6 +165,15 @@ DISPU_EXPORT int dispu_query_ball(int b, int n, int m, const float* radius, int 
                                   const float* xyz2, int* idx, int* pts_cnt, int arith, void* stream) {
     if (b < 0 || n <= 0 || m < 0 || nsample <= 0 || !radius) return (int)hipErrorInvalidValue;
     if (b == 0 || m == 0) return 0;
+    if (n <= 1024) {
+        hipStream_t st = (hipStream_t)stream;
+        if (n <= 64) launch_query_ball_wave<1>(b, n, m, radius, nsample, xyz1, xyz2, idx, pts_cnt, arith, st);
+        else if (n <= 128) launch_query_ball_wave<2>(b, n, m, radius, nsample, xyz1, xyz2, idx, pts_cnt, arith, st);
+        else if (n <= 256) launch_query_ball_wave<4>(b, n, m, radius, nsample, xyz1, xyz2, idx, pts_cnt, arith, st);
+        else if (n <= 512) launch_query_ball_wave<8>(b, n, m, radius, nsample, xyz1, xyz2, idx, pts_cnt, arith, st);
+        else launch_query_ball_wave<16>(b, n, m, radius, nsample, xyz1, xyz2, idx, pts_cnt, arith, st);
+        return (int)hipGetLastError();
+    }
     dim3 grid((m + QB_BS - 1) / QB_BS, b);
     if ((arith & DISPU_ARITH_CONTRACT))
         hipLaunchKernelGGL((query_ball_kernel<true>), grid, dim3(QB_BS), 0, (hipStream_t)stream, n, m, radius, nsample,
