@@ -17,6 +17,7 @@
 //   Epilogue fuses bias, BatchNorm scale/shift, ReLU and two residual adds.
 #include "common.h"
 
+#include <cstdio>
 #include <cstdlib>
 
 namespace dispu {
@@ -520,6 +521,17 @@ DISPU_EXPORT int dispu_linear_bn(int batch, int M, int K, int N, const float* X,
         return (int)hipErrorInvalidValue;
     if (batch == 0 || M == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
+    {
+        static int trace = -1;          // DISPU_LINEAR_TRACE=1: one stderr line per call (which shapes take which path)
+        if (trace < 0) { const char* e = getenv("DISPU_LINEAR_TRACE"); trace = (e && *e == '1') ? 1 : 0; }
+        if (trace) {
+            const int code = dispu_linear_tile(batch, M, N);
+            const int bm = code / 1000, bn = (code % 1000) >= 256 ? 256 : code % 1000, bk = (code % 1000) > 256 || bn == 256 ? 16 : 32;
+            const bool al = ((ldx & 3) == 0) && ((ldw & 3) == 0) && ((sx & 3) == 0) && ((sw & 3) == 0) && ((((uintptr_t)X) & 15) == 0) && ((((uintptr_t)W) & 15) == 0);
+            fprintf(stderr, "dispu_linear batch %d M %d K %d N %d transb %d ldx %ld ldw %ld ldy %ld tile %d interior %d res %d%d bn %d\n", batch, M, K, N, transb, ldx,
+                    ldw, ldy, code, (int)(al && M % bm == 0 && N % bn == 0 && K % bk == 0), R1 != nullptr, R2 != nullptr, scale != nullptr);
+        }
+    }
     if (batch == 1 && !transb && !scale && !R1 && !R2 && tile_override() <= 0) {
         const int rc = linear_skinny_dispatch(M, K, N, X, ldx, W, ldw, bias, act, Y, ldy, s);   // small M x N: latency-bound form
         if (rc >= 0) return rc;
