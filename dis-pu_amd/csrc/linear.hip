@@ -471,8 +471,8 @@ static int launch_linear(const LinearArgs& a, int batch, bool transb, hipStream_
     return launch_one<BM, BN, WM, WN, BK, false, true>(a, grid, s);
 }
 
-int linear_skinny_dispatch(int M, int K, int N, const float* X, long ldx, const float* W, long ldw, const float* bias, int act,
-                           float* Y, long ldy, hipStream_t st);   // linear_skinny.hip
+int linear_skinny_dispatch(int M, int K, int N, const float* X, long ldx, const float* W, long ldw, int transb, const float* bias,
+                           int act, float* Y, long ldy, const float* R1, long ldr1, hipStream_t st);   // linear_skinny.hip
 
 static int tile_override() {            // DISPU_LINEAR_TILE=<code>: force one variant (benchmarking only)
     static int v = -2;
@@ -532,8 +532,8 @@ DISPU_EXPORT int dispu_linear_bn(int batch, int M, int K, int N, const float* X,
                     ldw, ldy, code, (int)(al && M % bm == 0 && N % bn == 0 && K % bk == 0), R1 != nullptr, R2 != nullptr, scale != nullptr);
         }
     }
-    if (batch == 1 && !transb && !scale && !R1 && !R2 && tile_override() <= 0) {
-        const int rc = linear_skinny_dispatch(M, K, N, X, ldx, W, ldw, bias, act, Y, ldy, s);   // small M x N: latency-bound form
+    if (batch == 1 && !scale && !R2 && tile_override() <= 0) {
+        const int rc = linear_skinny_dispatch(M, K, N, X, ldx, W, ldw, transb, bias, act, Y, ldy, R1, ldr1, s);   // latency-bound shapes
         if (rc >= 0) return rc;
     }
     LinearArgs a{M, K, N, X, ldx, sx, W, ldw, sw, bias, Y, ldy, sy, R1, ldr1, sr1, R2, ldr2, sr2, act, scale, shift};

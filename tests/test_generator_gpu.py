@@ -171,6 +171,32 @@ def test_linear_skinny_path_matches_chain_exactly(dev):
         assert np.array_equal(N(y)[:, 2:Nn + 2], OG.linear(x[:, xo:xo + K], w, None, relu=False)), (M, K, Nn)
 
 
+def test_linear_skinny_path_transb_and_residual(dev):
+    """The skinny path also covers the training step's narrow shapes: outputs of <= 32 columns at any M, contractions of
+    <= 32 (K % 4 == 0) with up to 128 columns, W given transposed ([N, K]) and a residual added after the activation."""
+    from dispu_amd import _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(11)
+    for (M, K, Nn, act, tb, res) in [(32768, 96, 24, 1, 0, 0), (32768, 24, 96, 0, 1, 1), (8192, 24, 72, 0, 1, 1), (4100, 16, 3, 0, 1, 1),
+                                     (1000, 32, 100, 1, 1, 0), (999, 28, 128, 0, 0, 1), (5000, 120, 20, 1, 1, 1), (300, 384, 17, 0, 1, 0)]:
+        x = rng.standard_normal((M, K + 4)).astype(np.float32)
+        w = (rng.standard_normal((K, Nn)) * 0.1).astype(np.float32)
+        b = rng.standard_normal(Nn).astype(np.float32)
+        r1 = rng.standard_normal((M, Nn)).astype(np.float32)
+        want = OG.linear(x[:, 4:], w, b, relu=bool(act))
+        if res:
+            want = want + r1
+        wt = np.ascontiguousarray(w.T) if tb else w
+        tx, tw, tb_, tr = (torch.from_numpy(a).to(dev) for a in (x, wt, b, r1))
+        y = torch.zeros((M, Nn + 3), device=dev)
+        _lib.check(L.dispu_linear(1, M, K, Nn, tx.data_ptr() + 16, K + 4, 0, tw.data_ptr(), wt.shape[1], 0, tb, tb_.data_ptr(), act,
+                                  y.data_ptr() + 4, Nn + 3, 0, tr.data_ptr() if res else None, Nn, 0, None, 0, 0,
+                                  _lib.stream_ptr(dev)), "dispu_linear")
+        got = N(y)
+        assert np.array_equal(got[:, 1:Nn + 1], want), (M, K, Nn, tb, res)
+        assert (got[:, :1] == 0).all() and (got[:, Nn + 1:] == 0).all()
+
+
 # 2560 / 4096 points: more than 2 x 1024 waves of the persistent grid -> several point groups per wave (the weight
 # fragment ring and the row prefetch wrap from one group into the next)
 @pytest.mark.parametrize("C,npts", [(24, 512), (48, 512), (48, 777), (24, 2560), (48, 4096)])
