@@ -535,6 +535,17 @@ DISPU_EXPORT int dispu_linear_bn(int batch, int M, int K, int N, const float* X,
     if (batch == 1 && !scale && !R2 && tile_override() <= 0) {
         const int rc = linear_skinny_dispatch(M, K, N, X, ldx, W, ldw, transb, bias, act, Y, ldy, R1, ldr1, s);   // latency-bound shapes
         if (rc >= 0) return rc;
+        // a few columns past a multiple of 128 (N = 134: the PointShuffle conv0 gradient): the tiled kernel would spend a second,
+        // almost empty column of 128-wide edge tiles on them.  Columns are independent: the multiple of 128 goes to the tiled
+        // kernel (interior path when aligned), the tail to the skinny kernel.
+        const int tail = N % 128, n0 = N - tail;
+        if (n0 > 0 && tail > 0 && tail <= 32) {
+            const float* Wt = transb ? W + (size_t)n0 * ldw : W + n0;
+            if (linear_skinny_dispatch(M, K, tail, X, ldx, Wt, ldw, transb, bias ? bias + n0 : nullptr, act, Y + n0, ldy,
+                                       R1 ? R1 + n0 : nullptr, ldr1, s) >= 0)
+                return dispu_linear_bn(batch, M, K, n0, X, ldx, sx, W, ldw, sw, transb, bias, scale, shift, act, Y, ldy, sy, R1, ldr1, sr1,
+                                       R2, ldr2, sr2, stream);
+        }
     }
     LinearArgs a{M, K, N, X, ldx, sx, W, ldw, sw, bias, Y, ldy, sy, R1, ldr1, sr1, R2, ldr2, sr2, act, scale, shift};
     const bool tb = transb != 0;

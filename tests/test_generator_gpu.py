@@ -178,7 +178,8 @@ def test_linear_skinny_path_transb_and_residual(dev):
     L = _lib.lib()
     rng = np.random.default_rng(11)
     for (M, K, Nn, act, tb, res) in [(32768, 96, 24, 1, 0, 0), (32768, 24, 96, 0, 1, 1), (8192, 24, 72, 0, 1, 1), (4100, 16, 3, 0, 1, 1),
-                                     (1000, 32, 100, 1, 1, 0), (999, 28, 128, 0, 0, 1), (5000, 120, 20, 1, 1, 1), (300, 384, 17, 0, 1, 0)]:
+                                     (1000, 32, 100, 1, 1, 0), (999, 28, 128, 0, 0, 1), (5000, 120, 20, 1, 1, 1), (300, 384, 17, 0, 1, 0),
+                                     (2048, 128, 134, 0, 1, 1), (700, 64, 262, 1, 0, 0), (1500, 256, 134, 0, 1, 0)]:   # 128 k + tail: split launches
         x = rng.standard_normal((M, K + 4)).astype(np.float32)
         w = (rng.standard_normal((K, Nn)) * 0.1).astype(np.float32)
         b = rng.standard_normal(Nn).astype(np.float32)
