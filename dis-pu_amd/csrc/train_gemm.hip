@@ -231,6 +231,85 @@ __global__ __launch_bounds__(512) void tn_reduce_kernel(int batch, int K, int N,
     }
 }
 
+// ---- narrow outputs (N <= 64, K <= 256: the edge-conv layers' [96 x 24]-sized weight gradients over 10^4 .. 10^5 rows) --------
+// The tiled kernel above gives such a product ONE 128 x 64 block tile that is < 30 % full and as many workgroups as it has
+// M-splits, each paying a full LDS pipeline for a few KB of output (18 us + the reduction for 16 MB of operands).  Here a
+// WAVE owns one 16 x 16 output tile (k-tile, n-tile) and one chunk of rows, and runs v_mfma_f32_16x16x4_f32 straight from
+// global memory: both operands are row-major with the contraction index as the row, i.e. already in the layout the
+// instruction wants (lane (i, q): X[m + q][16 kt + i] and Z[m + q][16 nt + i]) - no LDS, no transposes.  Loads are buffer
+// loads with the row offset as the instruction's scalar offset (no VALU per load), 16 steps in flight.  One extra "k-tile"
+// whose A operand is 1 in row 0 produces the column sums of Z (the bias gradient) on the same pipe.  Partials go to the
+// scratch layout of tn_reduce_kernel ([chunk][K + 1][N]), which sums them in chunk order: deterministic.
+typedef float tn_f32x4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(1024) void linear_tn_narrow_kernel(int M, int K, int N, int rows_per_chunk, int KT, int NT,
+                                                                 const float* __restrict__ X, long ldx, const float* __restrict__ Z,
+                                                                 long ldz, float* __restrict__ part) {
+    const int lane = threadIdx.x & 63;
+    const int job = blockIdx.y * (blockDim.x >> 6) + (threadIdx.x >> 6);          // (k-tile, n-tile) of this wave
+    if (job >= (KT + 1) * NT) return;
+    const int kt = job / NT, nt = job - kt * NT;
+    const int i = lane & 15, q = lane >> 4;
+    const int chunk = blockIdx.x;
+    const int m0 = chunk * rows_per_chunk;
+    const int steps = min(rows_per_chunk, M - m0) >> 2;                             // M % 4 == 0 (checked by the caller)
+    const bool is_bias = kt == KT;
+    const int kcol = 16 * kt + i, ncol = 16 * nt + i;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(X), 0, (int)((long)M * ldx * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rz = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Z), 0, (int)((long)M * ldz * 4), 0x00020000);
+    const int xoff = (q * (int)ldx + min(kcol, K - 1)) * 4, zoff = (q * (int)ldz + min(ncol, N - 1)) * 4;   // bytes
+    const int xstep = 4 * (int)ldx * 4, zstep = 4 * (int)ldz * 4;                   // four rows per MFMA step
+    const float amask = (!is_bias && kcol < K) ? 1.f : 0.f, bmask = (ncol < N) ? 1.f : 0.f;
+    const float aone = (is_bias && i == 0) ? 1.f : 0.f;
+    tn_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    constexpr int U = 16;
+    int sx = m0 * (int)ldx * 4, sz = m0 * (int)ldz * 4;
+    for (int s0 = 0; s0 < steps; s0 += U) {
+        float av[U], bv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const bool on = s0 + u < steps;                                         // wave-uniform
+            av[u] = (on && !is_bias) ? __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, xoff, sx + u * xstep, 0)) : 0.f;
+            bv[u] = on ? __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rz, zoff, sz + u * zstep, 0)) : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (s0 + u < steps) {
+                // columns past K / N read a clamped (valid) address: zero them (x * 0 with finite x; the bias tile's A is constant)
+                const float a = is_bias ? aone : av[u] * amask;
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv[u] * bmask, acc, 0, 0, 0);
+            }
+        }
+        sx += U * xstep; sz += U * zstep;
+    }
+    // acc[r] = D[k = 16 kt + 4 q + r][n = 16 nt + i]; the bias tile's row 0 = column sums -> row K of the partial
+    float* dst = part + (size_t)chunk * (size_t)(K + 1) * N;
+    if (ncol < N) {
+        if (is_bias) {
+            if (q == 0) dst[(size_t)K * N + ncol] = acc[0];
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int k = 16 * kt + 4 * q + r;
+                if (k < K) dst[(size_t)k * N + ncol] = acc[r];
+            }
+        }
+    }
+}
+
+// chunks of the narrow path (0 = not applicable): ~2048 waves in total, 128 .. 4096 rows per chunk (multiples of 64)
+static int tn_narrow_chunks(int batch, int M, int K, int N, int& rows) {
+    rows = 0;
+    if (batch != 1 || N > 64 || K > 256 || M < 4096 || (M & 3)) return 0;
+    const int jobs = ((K + 15) / 16 + 1) * ((N + 15) / 16);
+    int want = (2048 + jobs - 1) / jobs;
+    rows = (M + want - 1) / want;
+    rows = ((rows + 63) / 64) * 64;
+    if (rows < 128) rows = 128;
+    if (rows > 4096) rows = 4096;
+    return (M + rows - 1) / rows;
+}
+
 static void tn_plan(int batch, int M, int K, int N, int& tk, int& tnn, int& splits, int& rows) {
     tk = (K > 64) ? 2 : 1;
     tnn = (N > 128) ? 4 : (N > 64) ? 2 : 1;
@@ -313,6 +392,9 @@ DISPU_EXPORT long dispu_linear_tn_scratch_floats(int batch, int M, int K, int N)
     if (batch <= 0 || M <= 0 || K <= 0 || N <= 0) return 0;
     int tk, tnn, splits, rows;
     tn_plan(batch, M, K, N, tk, tnn, splits, rows);
+    int nrows;
+    const int nchunks = tn_narrow_chunks(batch, M, K, N, nrows);
+    if (nchunks > splits) splits = nchunks;
     return (long)batch * splits * (K + 1) * N;
 }
 
@@ -327,6 +409,23 @@ DISPU_EXPORT int dispu_linear_tn(int batch, int M, int K, int N, const float* X,
             for (int z = 0; z < batch; ++z)
                 DISPU_TRY(hipMemset2DAsync(out + (size_t)z * so, sizeof(float) * ldo, 0, sizeof(float) * N, K, s));
         return 0;
+    }
+    {
+        int nrows;
+        const int nchunks = tn_narrow_chunks(batch, M, K, N, nrows);
+        if (nchunks > 0 && (long)M * ldx < (1l << 29) && (long)M * ldz < (1l << 29) && scratch != nullptr &&
+            scratch_floats >= (long)nchunks * (K + 1) * N) {
+            const int KT = (K + 15) / 16, NT = (N + 15) / 16, jobs = (KT + 1) * NT;
+            const int wpb = jobs < 16 ? jobs : 16;
+            hipLaunchKernelGGL(linear_tn_narrow_kernel, dim3(nchunks, (jobs + wpb - 1) / wpb), dim3(64 * wpb), 0, s, M, K, N, nrows, KT, NT,
+                               X, ldx, Z, ldz, scratch);
+            DISPU_CHECK_LAUNCH();
+            const size_t rchunks = ((size_t)(K + 1) * N + 63) / 64;
+            hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)(rchunks > 8192 ? 8192 : rchunks)), dim3(512), 0, s, 1, K, N, nchunks, scratch,
+                               out, ldo, so, accumulate, dbias);
+            DISPU_CHECK_LAUNCH();
+            return 0;
+        }
     }
     int tk, tnn, splits, rows;
     tn_plan(batch, M, K, N, tk, tnn, splits, rows);

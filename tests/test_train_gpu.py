@@ -61,7 +61,10 @@ def L():
 # ---------------------------------------------------------------------------------------------- kernels ----
 @pytest.mark.parametrize("batch,M,K,N,ldx,ldz,acc", [(1, 1000, 48, 24, 120, 120, 1), (1, 5000, 134, 128, 134, 128, 1),
                                                       (1, 4096, 2048, 256, 2048, 256, 0), (3, 1024, 1024, 64, 1024, 64, 0),
-                                                      (1, 777, 3, 16, 134, 16, 1), (1, 64, 2, 256, 2, 256, 1), (1, 1, 5, 7, 5, 7, 0)])
+                                                      (1, 777, 3, 16, 134, 16, 1), (1, 64, 2, 256, 2, 256, 1), (1, 1, 5, 7, 5, 7, 0),
+                                                      # narrow outputs (N <= 64, K <= 256, M >= 4096): the wave-per-tile kernel
+                                                      (1, 32768, 96, 24, 168, 120, 1), (1, 8192, 72, 24, 120, 24, 0), (1, 4100, 240, 48, 480, 48, 1),
+                                                      (1, 20000, 3, 16, 134, 16, 1), (1, 4096, 256, 64, 256, 64, 0)])
 def test_linear_tn(dev, L, batch, M, K, N, ldx, ldz, acc):
     rng = np.random.default_rng(M + K)
     X = rng.standard_normal((batch, M, ldx)).astype(np.float32)
