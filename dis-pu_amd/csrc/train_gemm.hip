@@ -204,12 +204,18 @@ __global__ __launch_bounds__(512) void tn_reduce_kernel(int batch, int K, int N,
         if (r < kn1) {
             const float* p = part + z * splits * kn1 + r;
             float v0 = 0.f, v1 = 0.f;
-            int s = grp;
-            for (; s + 8 < splits; s += 16) {
-                v0 += p[(size_t)s * kn1];
-                v1 += p[(size_t)(s + 8) * kn1];
+            // splits grp, grp + 8, grp + 16, ... alternate between two running sums (even / odd position); eight loads are
+            // requested before the first add (as a rolled load-add loop this was a chain of ~16 L2 round trips: 7 us per launch)
+            for (int s = grp; s < splits; s += 64) {
+                float b[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) b[j] = (s + 8 * j < splits) ? p[(size_t)(s + 8 * j) * kn1] : 0.f;
+#pragma unroll
+                for (int j = 0; j < 8; j += 2) {
+                    if (s + 8 * j < splits) v0 += b[j];
+                    if (s + 8 * (j + 1) < splits) v1 += b[j + 1];
+                }
             }
-            if (s < splits) v0 += p[(size_t)s * kn1];
             v = v0 + v1;
         }
         red[grp][lane] = v;
