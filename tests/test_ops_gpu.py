@@ -209,6 +209,19 @@ def test_knn_point_variants(ops, dev, c, k):
     assert np.array_equal(N(i2), oi2) and np.array_equal(N(d2), od)
 
 
+@pytest.mark.parametrize("n,m,c,k", [(17, 5, 24, 9), (64, 64, 48, 17), (65, 37, 24, 9), (100, 100, 12, 17), (200, 33, 48, 20),
+                                     (255, 255, 7, 17), (256, 300, 64, 32), (300, 40, 24, 9), (500, 77, 48, 17), (700, 20, 16, 5)])
+def test_knn_point_2_cloud_sizes(ops, dev, n, m, c, k):
+    """Feature-space k-NN across the kernel variants: n <= 256 (MFMA dot products, candidate tiles of 16, partial last
+    tile), n <= 512 (VALU dots, R = 8) and larger (lane-per-query); queries not a multiple of the 16 per workgroup."""
+    rng = np.random.default_rng(n * 7 + m)
+    a = rng.standard_normal((3, n, c)).astype(np.float32)
+    q = np.concatenate([a[:, : min(m, n) // 2], rng.standard_normal((3, m - min(m, n) // 2, c)).astype(np.float32)], 1)
+    d2, i2 = ops["G"].knn_point_2(k, T(a, dev), T(q, dev))
+    od, oi2 = O.knn_point_2(k, a, q)
+    assert np.array_equal(N(i2), oi2) and np.array_equal(N(d2), od)
+
+
 @pytest.mark.parametrize("arith", [PLAIN, CONTRACT])
 @pytest.mark.parametrize("b,n,m", [(2, 1024, 384), (3, 384, 128), (2, 128, 1), (1, 2, 2), (2, 1500, 2500)])
 def test_three_nn_exact(ops, dev, b, n, m, arith):
