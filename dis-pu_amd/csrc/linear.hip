@@ -131,9 +131,6 @@ __global__ __launch_bounds__(64 * (WM * WN + (LinearLds<BM, BN, BK, TRANSB, EDGE
             }
             return;
         }
-#ifdef DISPU_LOADER_PRIO
-        __builtin_amdgcn_s_setprio(DISPU_LOADER_PRIO);
-#endif
         const int tid = threadIdx.x - NT;
         const float* __restrict__ X = a.X + (size_t)z * a.sx;
         const float* __restrict__ W = a.W + (size_t)z * a.sw;
@@ -293,11 +290,7 @@ __global__ __launch_bounds__(64 * (WM * WN + (LinearLds<BM, BN, BK, TRANSB, EDGE
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-#ifdef LIN_AGPR
-                        mfma_acc(acc[i][j], a2[kg & 1][i][u], bf[cur][j]);
-#else
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[kg & 1][i][u], bf[cur][j], acc[i][j], 0, 0, 0);
-#endif
                 if (u == 1) __builtin_amdgcn_sched_group_barrier(0x100, TM + TN / 2, 0);        // ds_read2_b32: one per row tile + one per B pair
                 else __builtin_amdgcn_sched_group_barrier(0x100, TN / 2, 0);
                 __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
@@ -315,21 +308,13 @@ __global__ __launch_bounds__(64 * (WM * WN + (LinearLds<BM, BN, BK, TRANSB, EDGE
         const float* As = lds + (t & 1) * L::STAGE;
         const float* Bs = As + BK * LDA;
         float af[2][TM], bf[2][TN];
-#ifdef LIN_NOREAD     // timing experiment only: operands from registers, the LDS is never read (results are wrong)
-#pragma unroll
-        for (int i = 0; i < TM; ++i) af[0][i] = af[1][i] = (float)(lane + i + t);
-#pragma unroll
-        for (int j = 0; j < TN; ++j) bf[0][j] = bf[1][j] = (float)(lane - j);
-#else
 #pragma unroll
         for (int i = 0; i < TM; ++i) af[0][i] = As[fk * LDA + wm * (TM * 32) + i * 32 + fi];
 #pragma unroll
         for (int j = 0; j < TN; ++j) bf[0][j] = Bs[fk * LDB + wn * (TN * 32) + j * 32 + fi];
-#endif
 #pragma unroll
         for (int s2 = 0; s2 < BK / 2; ++s2) {
             const int cur = s2 & 1, nxt = cur ^ 1;
-#ifndef LIN_NOREAD
             if (s2 + 1 < BK / 2) {
                 const int kk = 2 * (s2 + 1);
 #pragma unroll
@@ -337,17 +322,14 @@ __global__ __launch_bounds__(64 * (WM * WN + (LinearLds<BM, BN, BK, TRANSB, EDGE
 #pragma unroll
                 for (int j = 0; j < TN; ++j) bf[nxt][j] = Bs[(kk + fk) * LDB + wn * (TN * 32) + j * 32 + fi];
             }
-#endif
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][i], bf[cur][j], acc[i][j], 0, 0, 0);
             // pin: this step's DS reads (the next step's operands) first, then its TM*TN MFMAs
-#ifndef LIN_NOREAD
             __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
-#endif
         }
 #ifdef LIN_CLOCK
         const unsigned long long lb0 = __builtin_readcyclecounter();
@@ -358,9 +340,6 @@ __global__ __launch_bounds__(64 * (WM * WN + (LinearLds<BM, BN, BK, TRANSB, EDGE
 #endif
     }
 
-#ifdef LIN_AGPR
-    if constexpr (DMA) mfma_acc_settle();
-#endif
 #ifdef LIN_CLOCK
     if (blockIdx.x == 0 && blockIdx.y == 5 && threadIdx.x == 0) { lin_clock_ticks[0] = __builtin_readcyclecounter() - lc0; lin_clock_ticks[1] = ntile; lin_clock_ticks[2] = lc_wait; }
 #endif
