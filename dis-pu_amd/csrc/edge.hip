@@ -198,18 +198,42 @@ __global__ __launch_bounds__(LDSF ? 512 : 256) void edge_dense_conv_mfma_kernel(
         // stores from four active lanes cost ~300 cycles of issue each next to the MFMAs: twice the 132-MFMA chain.)
         constexpr int OW = 3 * G + C;                                // 96 / 120 floats per point
         float* stg = stage + wave * (2 * OW);
-        const bool writer = s_nb == 15;
         float* sp = stg + (row >> 4) * OW;
+        float k2 = 0.f, k1 = 0.f, k0 = 0.f;
 #pragma unroll
         for (int r = 0; r < 12; ++r) {
-            const float m2 = edge_row16_max(l2[r] + b2[2 * r + h]);
-            const float m1 = edge_row16_max(l1[r]);
-            const float m0 = edge_row16_max(l0[r]);
-            if (writer) { sp[2 * r + h] = m2; sp[G + 2 * r + h] = m1; sp[2 * G + 2 * r + h] = m0; }
+            float m2 = l2[r] + b2[2 * r + h], m1 = l1[r], m0 = l0[r];
+            // three interleaved row maxima, v_max_f32 with the rotated partner as its DPP operand (row_ror 1, 2, 4, 8): 12
+            // instructions.  The compiler's form of edge_row16_max is v_mov_b32_dpp + v_max_f32 per step (24 + wait states);
+            // here the two other chains' instructions are the wait states each VALU-write -> DPP-read needs.
+            asm("s_nop 1\n\t"
+                "v_max_f32_dpp %0, %0, %0 row_ror:1 row_mask:0xf bank_mask:0xf\n\t"
+                "v_max_f32_dpp %1, %1, %1 row_ror:1 row_mask:0xf bank_mask:0xf\n\t"
+                "v_max_f32_dpp %2, %2, %2 row_ror:1 row_mask:0xf bank_mask:0xf\n\t"
+                "v_max_f32_dpp %0, %0, %0 row_ror:2 row_mask:0xf bank_mask:0xf\n\t"
+                "v_max_f32_dpp %1, %1, %1 row_ror:2 row_mask:0xf bank_mask:0xf\n\t"
+                "v_max_f32_dpp %2, %2, %2 row_ror:2 row_mask:0xf bank_mask:0xf\n\t"
+                "v_max_f32_dpp %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+                "v_max_f32_dpp %1, %1, %1 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+                "v_max_f32_dpp %2, %2, %2 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+                "v_max_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+                "v_max_f32_dpp %1, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+                "v_max_f32_dpp %2, %2, %2 row_ror:8 row_mask:0xf bank_mask:0xf"
+                : "+v"(m2), "+v"(m1), "+v"(m0));
+            // every lane of the row now holds the three maxima of register r: lane r of the row keeps them (one select each)
+            // and the 36 values leave as THREE LDS stores after the loop instead of 36 stores from one active lane per row
+            k2 = (s_nb == r) ? m2 : k2; k1 = (s_nb == r) ? m1 : k1; k0 = (s_nb == r) ? m0 : k0;
         }
-        if (writer) {
+        if (s_nb < 12) { sp[2 * s_nb + h] = k2; sp[G + 2 * s_nb + h] = k1; sp[2 * G + 2 * s_nb + h] = k0; }
+        {   // F_p (the same in all 16 lanes of a row): lane t of the row stores fp[t], lanes t - 16 the rest
+            float fa = 0.f, fb = 0.f;
 #pragma unroll
-            for (int t = 0; t < H; ++t) sp[3 * G + 2 * t + h] = fp[t];
+            for (int t = 0; t < H; ++t) {
+                if (t < 16) fa = (s_nb == t) ? fp[t] : fa;
+                else fb = (s_nb == t - 16) ? fp[t] : fb;
+            }
+            if (s_nb < (H < 16 ? H : 16)) sp[3 * G + 2 * s_nb + h] = fa;
+            if (H > 16 && s_nb < H - 16) sp[3 * G + 2 * (s_nb + 16) + h] = fb;
         }
         // (LDS operations of one wave execute in order: the reads below see the writes above)
         const int p_first = grp * 2;
