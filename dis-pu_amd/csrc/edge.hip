@@ -74,6 +74,9 @@ __global__ __launch_bounds__(LDSF ? 512 : 256) void edge_dense_conv_mfma_kernel(
     constexpr int G = 24, H = C / 2, K0 = 2 * C, K1 = G + C, K2 = 2 * G + C;
     constexpr int S0 = K0 / 2, S1 = K1 / 2, S2 = K2 / 2;
     extern __shared__ __attribute__((aligned(16))) float edge_lds[];
+#ifdef EDGE_STAMPS
+    const unsigned long long e_k0 = __builtin_readcyclecounter();
+#endif
     float* frag = edge_lds;                                      // (S0 + S1 + S2) * 64 weight fragments
     float* stage = frag + (S0 + S1 + S2) * 64;                   // [4 waves][2 points][72 + C] output staging
     float* fl = stage + (LDSF ? 8 : 4) * 2 * (3 * G + C);        // LDSF: [n_per_cloud][C + 4] features of this cloud
@@ -104,6 +107,9 @@ __global__ __launch_bounds__(LDSF ? 512 : 256) void edge_dense_conv_mfma_kernel(
         }
     }
     __syncthreads();
+#ifdef EDGE_STAMPS
+    const unsigned long long e_k1 = __builtin_readcyclecounter();
+#endif
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int row = lane & 31, h = lane >> 5;
@@ -256,7 +262,7 @@ __global__ __launch_bounds__(LDSF ? 512 : 256) void edge_dense_conv_mfma_kernel(
 #ifdef EDGE_STAMPS
     if (blockIdx.x == 3 && blockIdx.y == 0 && lane == 0) {
         unsigned long long* st = reinterpret_cast<unsigned long long*>(Y + (size_t)npoints * ldy) + wave * 6;
-        st[0] = e_conv; st[1] = e_l0; st[2] = e_l1; st[3] = e_l2; st[4] = e_epi; st[5] = e_n;
+        st[0] = e_conv; st[1] = e_l0; st[2] = e_l1; st[3] = e_l2; st[4] = e_epi; st[5] = e_n | ((e_k1 - e_k0) << 16);
     }
 #endif
 }

@@ -27,9 +27,11 @@ int main() {
     hipMemcpy(st, Y + (size_t)np * ldy, sizeof(st), hipMemcpyDeviceToHost);
     printf("edge_dense_conv<48> %.1f us per call\n", ms * 100);
     for (int w = 0; w < 4; ++w) {
+        const unsigned long long pro = st[w * 6 + 5] >> 16;
+        st[w * 6 + 5] &= 0xFFFF;
         const double n_ = (double)st[w * 6 + 5];
-        printf("  wave %d, %llu groups, cycles per group: convert+prefetch %.0f  layer0 (48 MFMA) %.0f  layer1 (36) %.0f  layer2 (48) %.0f  max+store %.0f\n", w,
-               st[w * 6 + 5], st[w * 6] / n_, st[w * 6 + 1] / n_, st[w * 6 + 2] / n_, st[w * 6 + 3] / n_, st[w * 6 + 4] / n_);
+        printf("  wave %d, %llu groups, cycles per group: convert+prefetch %.0f  layer0 (48 MFMA) %.0f  layer1 (36) %.0f  layer2 (48) %.0f  max+store %.0f;  prologue (weight fragments + cloud staging) %llu cycles\n", w,
+               st[w * 6 + 5], st[w * 6] / n_, st[w * 6 + 1] / n_, st[w * 6 + 2] / n_, st[w * 6 + 3] / n_, st[w * 6 + 4] / n_, pro);
     }
     return 0;
 }
