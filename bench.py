@@ -117,6 +117,7 @@ def main():
 
     params = init_params(seed=1234)                           # Xavier-uniform, zero biases (reference init)
     gen = Generator(params=params, device=dev)
+    gen.return_views = True                                   # results stay in the workspace: no copy kernels in the step
     x = torch.from_numpy(synth.patches(PATCHES_PER_GPU, NPOINT, seed=1000 * 2 + rank)).to(dev)   # 1000*config + rank
     gathered = torch.empty((world * PATCHES_PER_GPU, NPOINT * UP, 3), dtype=torch.float32, device=dev) if world > 1 else None
 

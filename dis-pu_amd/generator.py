@@ -52,6 +52,9 @@ class Generator(object):
     ..., see oracle/generator.py:layer_shapes) to arrays: weights [C_in_total, C_out], biases [C_out], plus the
     four BatchNorm vectors of 'refine/PointShuffle/weight_net/wconv0/bn/'."""
 
+    MAX_BATCH = 2048     # patches per launch sequence: keeps every row*stride product below 2^31 and the workspace
+                         # (~17 MB per patch, dominated by F' [B*1024, 2048]) at ~35 GB; larger batches run in chunks
+
     def __init__(self, opts=None, is_training=False, name="Generator", params=None, device=None):
         if is_training:
             raise NotImplementedError("round 1 implements the inference graph (is_training=False)")
@@ -72,6 +75,10 @@ class Generator(object):
         self.fused_residual = bool(int(__import__('os').environ.get('DISPU_FUSED_RES', '1')))
         self.fused_heads = bool(int(__import__('os').environ.get('DISPU_FUSED_HEADS', '1')))   # one launch per head chain
         self.keep_intermediates = False   # fused heads: also write the aggregation output (tests compare it)
+        # forward() computes into a reusable per-(B, N) workspace.  By default the two results are returned as fresh
+        # tensors (like sess.run in the reference); return_views = True hands out the workspace buffers themselves
+        # (no copies -- bench.py / hipGraph capture), which the NEXT call with the same (B, N) overwrites.
+        self.return_views = False
         if params is not None:
             self.load_params(params)
 
@@ -183,6 +190,11 @@ class Generator(object):
         inputs = inputs.contiguous()
         B, N, _ = inputs.shape
         M = N * self.up_ratio
+        if B > self.MAX_BATCH:                                  # patches are independent: run the batch in chunks
+            outs = [self.forward(inputs[lo:lo + self.MAX_BATCH]) for lo in range(0, B, self.MAX_BATCH)]
+            if self.return_views:
+                raise ValueError("return_views needs B <= %d (one workspace)" % self.MAX_BATCH)
+            return torch.cat([o[0] for o in outs]), torch.cat([o[1] for o in outs])
         rn, rm, k = B * N, B * M, K_NEIGH
         ws = self._workspace(B, N)
         L = _lib.lib()
@@ -309,4 +321,6 @@ class Generator(object):
             self._linear(st, ws["f256"], 256, w, b, 1, ws["f64"], 64)
             w, b = self._w(fs + "fc_layer2")
             self._call("fine", L.dispu_linear_small_n, rm, 64, 3, ptr(ws["f64"]), 64, ptr(w), ptr(b), 1, ptr(coarse), 3, ptr(ws["fine"]), 3, st)
-        return coarse, ws["fine"]
+        if self.return_views:
+            return coarse, ws["fine"]
+        return coarse.clone(), ws["fine"].clone()

@@ -13,6 +13,38 @@ def shard_bounds(n_items, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def _all_gather_rows(local, world, group):
+    """[r, ...] (same r on every rank) -> [world * r, ...].  One all_gather_into_tensor (RCCL: a single collective of
+    r * row_bytes per rank); device tensors under gloo (ranks sharing a GPU in tests) hop through host memory."""
+    local = local.contiguous()
+    if local.is_cuda and dist.get_backend(group) == "gloo":
+        host = local.detach().cpu()
+        parts = [torch.empty_like(host) for _ in range(world)]
+        dist.all_gather(parts, host, group=group)
+        return torch.cat(parts, dim=0).to(local.device)
+    out = torch.empty((world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out, local, group=group)
+    return out
+
+
+def shard_sizes(local_rows, n_items, group=None):
+    """Rows held by every rank.  With `n_items` they follow from shard_bounds (no communication); without it the
+    ranks exchange their row counts (one tiny all-gather), so ragged shards never masquerade as equal ones."""
+    world = dist.get_world_size(group)
+    if n_items is not None:
+        sizes = [shard_bounds(n_items, r, world)[1] - shard_bounds(n_items, r, world)[0] for r in range(world)]
+        if sizes[dist.get_rank(group)] != int(local_rows):
+            raise ValueError("this rank holds %d rows but shard_bounds(%d, rank %d, world %d) says %d"
+                             % (local_rows, n_items, dist.get_rank(group), world, sizes[dist.get_rank(group)]))
+        return sizes
+    mine = torch.tensor([int(local_rows)], dtype=torch.int64)
+    if dist.get_backend(group) != "gloo":
+        mine = mine.cuda()
+    parts = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(parts, mine, group=group)
+    return [int(p.item()) for p in parts]
+
+
 def all_gather_clouds(local, n_items=None, out=None, group=None):
     """local [b_local, M, 3] -> [n_items, M, 3] on every rank, in global patch order.
     Equal shards use one all_gather_into_tensor (a single ring/direct collective of b_local*M*12 bytes per
@@ -20,27 +52,25 @@ def all_gather_clouds(local, n_items=None, out=None, group=None):
     if not (dist.is_available() and dist.is_initialized()):
         return local
     world = dist.get_world_size(group)
-    n_items = local.shape[0] * world if n_items is None else int(n_items)
-    sizes = [shard_bounds(n_items, r, world)[1] - shard_bounds(n_items, r, world)[0] for r in range(world)]
+    sizes = shard_sizes(local.shape[0], n_items, group)
     if len(set(sizes)) == 1:
-        if out is None:
-            out = torch.empty((n_items,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-        if local.is_cuda and dist.get_backend(group) == "gloo":
-            # smoke-test configuration only (ranks sharing a GPU): gloo gathers through host memory
-            host = local.detach().cpu().contiguous()
-            parts = [torch.empty_like(host) for _ in range(world)]
-            dist.all_gather(parts, host, group=group)
-            out.copy_(torch.cat(parts, dim=0))
+        if out is not None and not (local.is_cuda and dist.get_backend(group) == "gloo"):
+            dist.all_gather_into_tensor(out, local.contiguous(), group=group)
             return out
-        dist.all_gather_into_tensor(out, local.contiguous(), group=group)
-        return out
+        res = _all_gather_rows(local, world, group)
+        if out is not None:
+            out.copy_(res)
+            return out
+        return res
     mx = max(sizes)
     pad = torch.zeros((mx,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     pad[: local.shape[0]] = local
-    buf = torch.empty((world * mx,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-    dist.all_gather_into_tensor(buf, pad, group=group)
-    parts = [buf[r * mx: r * mx + sizes[r]] for r in range(world)]
-    return torch.cat(parts, dim=0)
+    buf = _all_gather_rows(pad, world, group)
+    res = torch.cat([buf[r * mx: r * mx + sizes[r]] for r in range(world)], dim=0)
+    if out is not None:
+        out.copy_(res)
+        return out
+    return res
 
 
 def upsample_sharded(forward, patches, group=None):

@@ -22,6 +22,7 @@ import numpy as np
 import torch
 
 from . import _lib
+from ._util import f32, req
 from .generator import BN_EPS, DENSE_BLOCKS, GROWTH, K_NEIGH, _Opts, gen_grid
 
 BN_DECAY = 0.95      # DisPU/generator.py:39 bn_decay
@@ -311,6 +312,16 @@ class Trainer(object):
                                             _p(ws["i_pred"]), _p(ws["dgt_unused"]), _p(dpred), st), "nn_distance_grad")
         return value
 
+    def _check_targets(self, gt, radius, B, M):
+        """gt [B, 4N, 3] / radius [B] float32 on the device: the loss workspace (d_gt, i_gt, g_gt, ...) is sized [B, 4N]
+        and the kernels take raw pointers, so anything else must be refused here (DisPU/model.py:47-49 placeholders)."""
+        gt, radius = f32(gt, "gt"), f32(radius, "radius")
+        req(gt.dim() == 3 and tuple(gt.shape) == (B, M, 3),
+            "gt must have shape (%d, %d, 3) for this batch, got %s" % (B, M, tuple(gt.shape)))
+        req(radius.dim() == 1 and radius.shape[0] == B, "radius must have shape (%d,), got %s" % (B, tuple(radius.shape)))
+        req(gt.device == self.device and radius.device == self.device, "gt / radius must live on %s" % self.device)
+        return gt, radius
+
     def loss_backward(self, gt, radius):
         """pu_loss of model.py:75-87 at the current epoch; fills dcoarse / dfine with its gradient."""
         L = _lib.lib()
@@ -318,8 +329,8 @@ class Trainer(object):
         M = N * self.up_ratio
         ws = self._workspace(B, N)
         st = self.st
-        gt = gt.contiguous()
-        inv_r = (1.0 / radius.to(torch.float32)).contiguous()
+        gt, radius = self._check_targets(gt, radius, B, M)
+        inv_r = (1.0 / radius).contiguous()
         wf = weight_fine(self.epoch)
         cd_c = 1000.0 * self._chamfer(ws["coarse"], gt, inv_r, 1000.0, ws["dcoarse"])
         cd_f = 1000.0 * self._chamfer(ws["fine"], gt, inv_r, 1000.0 * wf, ws["dfine"])
@@ -329,7 +340,7 @@ class Trainer(object):
             fine = ws["fine"]
             r07 = torch.full((B,), 0.07, dtype=torch.float32, device=self.device)
             _lib.check(L.dispu_query_ball(B, M, M, _p(r07), 20, _p(fine), _p(fine), _p(ws["ball"]), _p(ws["ball_cnt"]),
-                                          _lib.ARITH_PLAIN, st), "query_ball")
+                                          _lib.ARITH_CONTRACT, st), "query_ball")   # as loss_utils.get_repulsion_loss
             _lib.check(L.dispu_repulsion(B * M, M, 20, 0, 0.001, _p(fine), _p(ws["ball"]), _p(ws["rep"]), st), "repulsion")
             _lib.check(L.dispu_row_mean_max(B, M, _p(ws["rep"]), _p(ws["rowmean"]), _p(ws["rowmax"]), st), "row_mean")
             rep = self.opts.repulsion_w * ws["rowmean"].sum() / (B * 4.0)
@@ -466,6 +477,8 @@ class Trainer(object):
 
     def train_step(self, inputs, gt, radius):
         """one iteration of the loop body of Model.train (model.py:215-232) -> loss terms (device scalars)."""
+        if isinstance(inputs, torch.Tensor) and inputs.dim() == 3:       # refuse bad targets before any launch
+            self._check_targets(gt, radius, inputs.shape[0], inputs.shape[1] * self.up_ratio)
         self.zero_grad()
         self.forward(inputs)
         terms = self.loss_backward(gt, radius)

@@ -48,7 +48,7 @@ def generator_chain(gen, patches, final_ratio=4, step_ratio=4):
     its own output (final_ratio 16 -> two passes: 256 -> 1024 -> 4096 points per patch)."""
     coarse, fine = gen(patches)
     for _ in range(round(math.pow(final_ratio, 1.0 / step_ratio)) - 1):
-        coarse, fine = gen(fine.clone())          # clone: the generator's outputs live in its reusable workspace
+        coarse, fine = gen(fine if not gen.return_views else fine.clone())   # views alias the reusable workspace
     return coarse, fine
 
 

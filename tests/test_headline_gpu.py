@@ -1,0 +1,111 @@
+"""GPU parity at the HEADLINE size: BASELINE configs[1] exactly as bench.py runs it (B = 32 patches of 256 points,
+Xavier weights seed 1234, input seed 1000*2 + rank) -- DisPU/generator.py:31-88 counterpart.
+
+At B = 32 the persistent kernels (ps_local, edge_dense_conv) loop over more than one group per workgroup and the
+GEMMs take their interior 128x256 DMA tiles (rm = 32768), grid shapes the B <= 5 tests never reach.  Checked here:
+  * a spread of the 32 patches against oracle/generator.py (coarse bit-exact, fine <= 1e-5),
+  * batch independence against B = 1 runs (bit-identical),
+  * hipGraph replay == eager launch (bit-identical), the way bench.py times the step,
+  * the same with non-zero biases / a non-trivial BN fold.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import generator as OG
+
+pytestmark = pytest.mark.gpu
+
+BENCH_B, BENCH_N, BENCH_SEED = 32, 256, 1000 * 2 + 0      # bench.py: synth.patches(32, 256, seed=1000*config + rank)
+CHECK = (0, 7, 19, 31)
+
+
+def N(t):
+    return t.detach().cpu().numpy()
+
+
+@pytest.fixture(scope="module")
+def bench_setup(dev):
+    from dispu_amd import synth
+    from dispu_amd.generator import Generator
+    from dispu_amd.params import init_params
+    P = init_params(seed=1234)
+    gen = Generator(params=P, device=dev)
+    x = synth.patches(BENCH_B, BENCH_N, seed=BENCH_SEED)
+    tx = torch.from_numpy(x).to(dev)
+    c, f = gen(tx)
+    torch.cuda.synchronize()
+    return dict(P=P, gen=gen, x=x, tx=tx, c=N(c).copy(), f=N(f).copy())
+
+
+def test_b32_against_oracle(bench_setup):
+    s = bench_setup
+    oc, of = OG.generator_forward(s["P"], s["x"][list(CHECK)])
+    for j, p in enumerate(CHECK):
+        assert np.array_equal(s["c"][p], oc[j]), "coarse of patch %d differs from the oracle (bit-exact expected)" % p
+        err = np.abs(s["f"][p] - of[j]).max()
+        assert err <= 1e-5, "fine of patch %d off by %g" % (p, err)
+    assert np.isfinite(s["f"]).all() and np.isfinite(s["c"]).all()
+
+
+def test_b32_batch_independence(bench_setup):
+    s = bench_setup
+    for p in (3, 19, 30):
+        c1, f1 = s["gen"](s["tx"][p:p + 1])
+        assert np.array_equal(N(c1)[0], s["c"][p]) and np.array_equal(N(f1)[0], s["f"][p]), "patch %d depends on its batch" % p
+
+
+def test_b32_hipgraph_replay_equals_eager(bench_setup, dev):
+    """bench.py's timed region is graph.replay(): the replayed launches must reproduce the eager result bit for bit."""
+    s = bench_setup
+    gen, tx = s["gen"], s["tx"]
+    gen.return_views = True                    # as bench.py: the captured step holds no copy kernels
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        gen(tx)
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        gen(tx)
+    ws = gen._ws[(BENCH_B, BENCH_N)]
+    for _ in range(3):
+        ws["coarse"].zero_()
+        ws["fine"].zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        assert np.array_equal(N(ws["coarse"]), s["c"]) and np.array_equal(N(ws["fine"]), s["f"])
+    gen.return_views = False
+
+
+def test_b32_biases_and_bn(dev):
+    from dispu_amd import synth
+    from dispu_amd.generator import Generator
+    P = OG.init_params(seed=77, bias_scale=0.05, bn_random=True)
+    gen = Generator(params=P, device=dev)
+    x = synth.patches(BENCH_B, BENCH_N, seed=4242)
+    c, f = gen(torch.from_numpy(x).to(dev))
+    c, f = N(c), N(f)
+    sel = [5, 26]
+    oc, of = OG.generator_forward(P, x[sel])
+    for j, p in enumerate(sel):
+        assert np.array_equal(c[p], oc[j])
+        assert np.abs(f[p] - of[j]).max() <= 1e-5
+
+
+def test_b64_and_ragged_batches(dev):
+    """batches that are not a multiple of the persistent kernels' group count, and a larger one (rm = 65536)."""
+    from dispu_amd import synth
+    from dispu_amd.generator import Generator
+    from dispu_amd.params import init_params
+    P = init_params(seed=1234)
+    gen = Generator(params=P, device=dev)
+    x = synth.patches(64, BENCH_N, seed=99)
+    tx = torch.from_numpy(x).to(dev)
+    c64, f64 = gen(tx)
+    c64, f64 = N(c64).copy(), N(f64).copy()
+    for b in (33, 17, 7):
+        c, f = gen(tx[:b])
+        assert np.array_equal(N(c), c64[:b]) and np.array_equal(N(f), f64[:b]), "B=%d differs from the B=64 rows" % b
+    oc, of = OG.generator_forward(P, x[63:64])
+    assert np.array_equal(c64[63], oc[0]) and np.abs(f64[63] - of[0]).max() <= 1e-5

@@ -367,3 +367,32 @@ def test_loss_decreases(dev):
     losses = [float(tr.train_step(xs, gs, rs)["pu_loss"]) for _ in range(10)]
     assert np.isfinite(losses).all()
     assert losses[-1] < 0.7 * losses[0], losses
+
+
+def test_repulsion_term_equals_loss_utils(step, dev):
+    """Trainer's repulsion term and loss_utils.get_repulsion_loss use the same ball-query arithmetic (CONTRACT, the
+    nvcc form of tf_grouping_g.cu:3-36) -> the same value on the same cloud (loss_utils.py:271-298)."""
+    from dispu_amd import loss_utils
+    tr = step["tr"]
+    fine = tr._ws[(2, 256)]["fine"]
+    want = float(loss_utils.get_repulsion_loss(fine.clone()))
+    got = float(step["t"]["repulsion_loss"])
+    assert abs(got - tr.opts.repulsion_w * want) <= 1e-7 * max(1.0, abs(want)), (got, want)
+
+
+def test_train_step_refuses_bad_targets(dev):
+    from dispu_amd import synth
+    from dispu_amd.train import Trainer
+    tr = Trainer(params=OG.init_params(seed=3), device=dev)
+    x, gt = synth.patch_with_gt(2, 256, 1024, seed=9)
+    tx, tg, r = dv(x, dev), dv(gt, dev), torch.ones(2, device=dev)
+    with pytest.raises(ValueError):
+        tr.train_step(tx, torch.cat([tg, tg], dim=1), r)            # more than 4N ground-truth points
+    with pytest.raises(ValueError):
+        tr.train_step(tx, tg[:1], r)                                # batch mismatch
+    with pytest.raises(ValueError):
+        tr.train_step(tx, tg.cpu(), r)                              # host tensor
+    with pytest.raises(TypeError):
+        tr.train_step(tx, tg.double(), r)
+    with pytest.raises(ValueError):
+        tr.train_step(tx, tg, torch.ones(3, device=dev))

@@ -14,6 +14,7 @@ from dispu_amd.params import init_params           # noqa: E402
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 dev = torch.device("cuda:0")
 gen = Generator(params=init_params(1234), device=dev)
+gen.return_views = True
 x = torch.from_numpy(synth.patches(B, 256, seed=2000)).to(dev)
 for _ in range(3):
     gen(x)
