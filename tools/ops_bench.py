@@ -1,27 +1,35 @@
 #!/usr/bin/env python3
-"""Per-op micro-benchmark at the shapes of SURVEY.md 8(d): time (HIP events), algorithmic bytes (inputs once +
-outputs once, the formulas of 8d) -> GB/s and fraction of the 8 TB/s HBM peak.  Most of these ops are latency /
-VALU bound by construction (the table says which); group/gather are the HBM-bound family.
-Run on the GPU box:  python tools/ops_bench.py > gpurun_out/ops_bench.json"""
+"""Per-op micro-benchmark at the shapes of SURVEY.md 8(d).  For every op: time per launch (HIP events on the launch
+stream), ALGORITHMIC bytes (inputs once + outputs once) and lane-operations (the 8d formulas), and the fraction of
+the resource that bounds the op:
+
+  hbm   gather_point / group_point / three_interpolate / match_cost      bytes / time / 8 TB/s
+  valu  FPS / k-NN / ball query / 3-NN / nn_distance                      lane-ops / time / VALU issue peak
+  exp   approx_match                                                      exponentials / time / transcendental peak
+
+VALU issue peak = 256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz = 39.3 T lane-ops/s (one non-packed wave64 VALU
+instruction per 4 cycles per SIMD; the 157.3 TFLOP/s fp32 vector figure counts an FMA as 2 and assumes packed
+issue).  Transcendental peak = a quarter of that (v_exp_f32 is a quarter-rate instruction) = 9.8 T/s.  FPS is also
+bound by the latency of its m-1 dependent rounds: its row carries ns/round next to the VALU fraction.
+
+bench.py imports gpu_ops() / cpu_ops() for the `roofline.ops` and `cpu_baseline.ops` sections of its JSON line.
+Stand-alone:  python tools/ops_bench.py [--cpu] > gpurun_out/ops_bench.json
+"""
 import json
 import os
 import sys
-
-import torch
+import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import dispu_amd.nearest_neighbors as K          # noqa: E402
-import dispu_amd.tf_approxmatch as A             # noqa: E402
-import dispu_amd.tf_grouping as G                # noqa: E402
-import dispu_amd.tf_interpolate as I             # noqa: E402
-import dispu_amd.tf_nndistance as D              # noqa: E402
-import dispu_amd.tf_sampling as S                # noqa: E402
 
 HBM_PEAK = 8.0e12
-dev = torch.device("cuda:0")
+VALU_PEAK = 256 * 4 * 16 * 2.4e9
+EXP_PEAK = VALU_PEAK / 4
+PEAK = {"hbm": (HBM_PEAK, "B/s"), "valu": (VALU_PEAK, "lane-op/s"), "exp": (EXP_PEAK, "exp/s")}
 
 
-def timeit(fn, reps=20, warm=3):
+def _timeit(fn, reps=20, warm=3):
+    import torch
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()
@@ -34,65 +42,144 @@ def timeit(fn, reps=20, warm=3):
     return e0.elapsed_time(e1) * 1e-3 / reps
 
 
-def row(name, shape, seconds, nbytes, bound, note=""):
-    return {"op": name, "shape": shape, "us": round(seconds * 1e6, 2), "algorithmic_MB": round(nbytes / 1e6, 3),
-            "GBps": round(nbytes / seconds / 1e9, 1), "frac_hbm_peak": round(nbytes / seconds / HBM_PEAK, 4), "bound": bound,
-            "note": note}
+def _row(name, shape, seconds, nbytes, bound, work, note=""):
+    """work = the quantity the bounding resource is measured in (bytes for hbm, lane-ops for valu, exps for exp)."""
+    peak, unit = PEAK[bound]
+    return {"op": name, "shape": list(shape), "us": round(seconds * 1e6, 2), "algorithmic_bytes": int(nbytes),
+            "hbm_frac": round(nbytes / seconds / HBM_PEAK, 4), "bound": bound, "work": float(work), "work_unit": unit,
+            "achieved": work / seconds, "peak": peak, "frac": round(work / seconds / peak, 4), "note": note}
 
 
-def main():
+def gpu_ops(dev=None, quick=False):
+    """-> list of rows, one per (op, shape) of SURVEY.md 8(d)."""
+    import torch
+    import dispu_amd.nearest_neighbors as K
+    import dispu_amd.tf_approxmatch as A
+    import dispu_amd.tf_grouping as G
+    import dispu_amd.tf_interpolate as I
+    import dispu_amd.tf_nndistance as D
+    import dispu_amd.tf_sampling as S
+    dev = dev if dev is not None else torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(1234)
+    rand = lambda *s: torch.rand(*s, device=dev, generator=g)
     out = []
-    for (b, n, m) in [(256, 256, 64), (32, 1024, 384), (8, 2048, 24), (8, 24576, 8192)]:
-        x = torch.rand(b, n, 3, device=dev)
-        reps = 3 if n > 8192 else 20
-        t = timeit(lambda: S.farthest_point_sample(m, x), reps=reps, warm=1)
-        out.append(row("farthest_point_sample", [b, n, m], t, b * (12 * n + 4 * m), "latency (m-1 dependent rounds)",
-                       "%.1f ns per round per cloud-block" % (t / max(m - 1, 1) * 1e9)))
+    for (b, n, m) in [(256, 256, 64), (32, 1024, 384), (8, 2048, 24), (1, 24576, 8192), (8, 24576, 8192)]:
+        x = rand(b, n, 3)
+        t = _timeit(lambda: S.farthest_point_sample(m, x), reps=3 if n > 8192 else 20, warm=1)
+        out.append(_row("farthest_point_sample", (b, n, m), t, b * (12 * n + 4 * m), "valu", 10.0 * b * n * (m - 1),
+                        "%.0f ns per dependent round" % (t / max(m - 1, 1) * 1e9)))
     for (b, n, k) in [(32, 1024, 16), (256, 1024, 16), (32, 4096, 16)]:
-        x = torch.rand(b, n, 3, device=dev)
-        t = timeit(lambda: K.knn_query(k, x, x))
-        out.append(row("knn_xyz (self query)", [b, n, k], t, b * (12 * n + 4 * n * k), "VALU / selection latency",
-                       "%.1f M queries/s" % (b * n / t / 1e6)))
+        x = rand(b, n, 3)
+        t = _timeit(lambda: K.knn_query(k, x, x))
+        out.append(_row("knn_xyz (self query)", (b, n, k), t, b * (12 * n + 4 * n * k), "valu", 8.0 * b * n * n,
+                        "%.1f M queries/s" % (b * n / t / 1e6)))
     for c in (24, 48):
-        f = torch.randn(32, 256, c, device=dev)
-        t = timeit(lambda: G.knn_point_2(17, f, f))
-        out.append(row("knn_point_2 (feature kNN)", [32, 256, c, 17], t, 32 * (4 * 256 * c + 4 * 256 * 17), "VALU / selection latency"))
+        f = torch.randn(32, 256, c, device=dev, generator=g)
+        t = _timeit(lambda: G.knn_point_2(17, f, f))
+        out.append(_row("knn_point_2 (feature kNN)", (32, 256, c, 17), t, 32 * (4 * 256 * c + 4 * 256 * 17), "valu",
+                        2.0 * 32 * 256 * 256 * c, "dot products on MFMA, selection on VALU"))
     for (b, n, ns, r) in [(32, 1024, 20, 0.07), (8, 4096, 20, 0.07)]:
-        x = torch.rand(b, n, 3, device=dev)
-        t = timeit(lambda: G.query_ball_point(r, ns, x, x))
-        out.append(row("query_ball_point", [b, n, n, ns], t, b * (24 * n + 4 * n * ns + 4 * n), "VALU / divergence"))
+        x = rand(b, n, 3)
+        t = _timeit(lambda: G.query_ball_point(r, ns, x, x))
+        out.append(_row("query_ball_point", (b, n, n, ns), t, b * (24 * n + 4 * n * ns + 4 * n), "valu", 9.0 * b * n * n,
+                        "upper bound on the scanned prefix (n-bar = n)"))
     for (b, n, m, ns, c) in [(32, 512, 128, 64, 64), (32, 1024, 1024, 16, 128), (64, 1024, 1024, 20, 3), (32, 1024, 384, 64, 256)]:
-        p = torch.randn(b, n, c, device=dev)
-        idx = torch.randint(0, n, (b, m, ns), dtype=torch.int32, device=dev)
-        t = timeit(lambda: G.group_point(p, idx))
-        out.append(row("group_point", [b, n, m, ns, c], t, 4 * b * (n * c + m * ns + m * ns * c), "HBM"))
-    x = torch.rand(32, 16384, 3, device=dev)
-    idx = torch.randint(0, 16384, (32, 8192), dtype=torch.int32, device=dev)
-    t = timeit(lambda: S.gather_point(x, idx))
-    out.append(row("gather_point", [32, 16384, 8192], t, 4 * 32 * (16384 * 3 + 8192 + 8192 * 3), "HBM"))
+        p = torch.randn(b, n, c, device=dev, generator=g)
+        idx = torch.randint(0, n, (b, m, ns), dtype=torch.int32, device=dev, generator=g)
+        t = _timeit(lambda: G.group_point(p, idx))
+        nb = 4 * b * (n * c + m * ns + m * ns * c)
+        out.append(_row("group_point", (b, n, m, ns, c), t, nb, "hbm", nb))
+    x = rand(32, 16384, 3)
+    idx = torch.randint(0, 16384, (32, 8192), dtype=torch.int32, device=dev, generator=g)
+    t = _timeit(lambda: S.gather_point(x, idx))
+    nb = 4 * 32 * (16384 * 3 + 8192 + 8192 * 3)
+    out.append(_row("gather_point", (32, 16384, 8192), t, nb, "hbm", nb))
     for (b, n, m) in [(32, 1024, 256), (32, 1024, 384)]:
-        x1, x2 = torch.rand(b, n, 3, device=dev), torch.rand(b, m, 3, device=dev)
-        t = timeit(lambda: I.three_nn(x1, x2))
-        out.append(row("three_nn", [b, n, m], t, b * (12 * (n + m) + 24 * n), "VALU"))
-    pts = torch.randn(32, 256, 256, device=dev)
-    d, i3 = I.three_nn(torch.rand(32, 1024, 3, device=dev), torch.rand(32, 256, 3, device=dev))
-    w = torch.rand(32, 1024, 3, device=dev)
-    t = timeit(lambda: I.three_interpolate(pts, i3, w))
-    out.append(row("three_interpolate", [32, 256, 256, 1024], t, 32 * (24 * 1024 + 4 * 256 * 256 + 4 * 1024 * 256), "HBM"))
+        x1, x2 = rand(b, n, 3), rand(b, m, 3)
+        t = _timeit(lambda: I.three_nn(x1, x2))
+        out.append(_row("three_nn", (b, n, m), t, b * (12 * (n + m) + 24 * n), "valu", 8.0 * b * n * m))
+    for (b, m, c, n) in [(32, 256, 256, 1024), (32, 1024, 128, 4096)]:
+        pts = torch.randn(b, m, c, device=dev, generator=g)
+        _, i3 = I.three_nn(rand(b, n, 3), rand(b, m, 3))
+        w = rand(b, n, 3)
+        t = _timeit(lambda: I.three_interpolate(pts, i3, w))
+        nb = b * (24 * n + 4 * m * c + 4 * n * c)
+        out.append(_row("three_interpolate", (b, m, c, n), t, nb, "hbm", nb))
     for (b, n) in [(32, 1024), (32, 4096), (1, 8192)]:
-        x1, x2 = torch.rand(b, n, 3, device=dev), torch.rand(b, n, 3, device=dev)
-        t = timeit(lambda: D.nn_distance(x1, x2))
-        out.append(row("nn_distance (both directions)", [b, n, n], t, b * 40 * n, "VALU", "%.1f G pair-evals/s" % (2 * b * n * n / t / 1e9)))
-    for (b, n) in [(4, 1024), (32, 1024), (1, 4096)]:
-        x1, x2 = torch.rand(b, n, 3, device=dev), torch.rand(b, n, 3, device=dev)
-        t = timeit(lambda: A.approx_match(x1, x2), reps=5, warm=1)
-        out.append(row("approx_match", [b, n, n], t, b * (24 * n + 4 * n * n), "transcendental / VALU",
-                       "%.1f G exp/s" % (30 * b * n * n / t / 1e9)))
+        x1, x2 = rand(b, n, 3), rand(b, n, 3)
+        t = _timeit(lambda: D.nn_distance(x1, x2))
+        out.append(_row("nn_distance (both directions)", (b, n, n), t, b * 40 * n, "valu", 16.0 * b * n * n,
+                        "%.1f G pair-evals/s" % (2 * b * n * n / t / 1e9)))
+    for (b, n) in [(4, 1024), (32, 1024), (1, 4096), (32, 4096)][: 3 if quick else 4]:
+        x1, x2 = rand(b, n, 3), rand(b, n, 3)
+        t = _timeit(lambda: A.approx_match(x1, x2), reps=5, warm=1)
+        out.append(_row("approx_match", (b, n, n), t, b * (24 * n + 4 * n * n), "exp", 30.0 * b * n * n,
+                        "%.1f G exp/s (10 levels x 3 passes per pair as the reference evaluates them)" % (30 * b * n * n / t / 1e9)))
         mt = A.approx_match(x1, x2)
-        t = timeit(lambda: A.match_cost(x1, x2, mt), reps=5, warm=1)
-        out.append(row("match_cost", [b, n, n], t, b * (24 * n + 4 * n * n), "HBM-leaning"))
-    print(json.dumps(out, indent=1))
+        t = _timeit(lambda: A.match_cost(x1, x2, mt), reps=5, warm=1)
+        nb = b * (24 * n + 4 * n * n + 4)
+        out.append(_row("match_cost", (b, n, n), t, nb, "hbm", nb))
+    return out
+
+
+def cpu_info():
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    return model, avail
+
+
+def cpu_ops(budget_s=12.0):
+    """The CPU oracle (oracle/dispu_oracle.c, `kind: port`) per op at bounded shapes: once with 1 thread (the reference's CPU
+    ops are single-threaded) and once with every available core (OpenMP over clouds / rows) -- BASELINE.md section 2."""
+    import numpy as np
+    from oracle import oracle as O
+    model, avail = cpu_info()
+    rng = np.random.default_rng(7)
+    R = lambda *s: rng.random(s, dtype=np.float32)
+    x1k, y1k = R(32, 1024, 3), R(32, 1024, 3)
+    idx = rng.integers(0, 1024, (32, 1024, 16)).astype(np.int32)
+    feats = rng.standard_normal((32, 1024, 128)).astype(np.float32)
+    xs, ys = R(4, 1024, 3), R(4, 1024, 3)
+    cases = [
+        ("farthest_point_sample", (32, 1024, 384), lambda: O.farthest_point_sample(384, x1k)),
+        ("knn_xyz (self query)", (32, 1024, 16), lambda: O.knn_batch(x1k, x1k, 16)),
+        ("query_ball_point", (32, 1024, 1024, 20), lambda: O.query_ball_point(0.07, 20, x1k, x1k)),
+        ("group_point", (32, 1024, 1024, 16, 128), lambda: O.group_point(feats, idx)),
+        ("three_nn", (32, 1024, 256), lambda: O.three_nn(x1k, y1k[:, :256])),
+        ("nn_distance (both directions)", (32, 1024, 1024), lambda: O.nn_distance(x1k, y1k)),
+        ("approx_match", (4, 1024, 1024), lambda: O.approx_match(xs, ys)),
+    ]
+    rows, t_start = [], time.perf_counter()
+    for name, shape, fn in cases:
+        r = {"op": name, "shape": list(shape)}
+        for label, c in (("ms_1_thread", 1), ("ms_all_cores", avail)):
+            if time.perf_counter() - t_start > budget_s:
+                r[label] = None
+                continue
+            O.set_threads(c)
+            fn()
+            best = None
+            for _ in range(2):
+                t = time.perf_counter()
+                fn()
+                dt = time.perf_counter() - t
+                best = dt if best is None else min(best, dt)
+            r[label] = round(best * 1e3, 3)
+        rows.append(r)
+    O.set_threads(avail)
+    return {"cpu_model": model, "cores": avail, "kind": "port", "ops": rows}
 
 
 if __name__ == "__main__":
-    main()
+    if "--cpu" in sys.argv:
+        print(json.dumps(cpu_ops(), indent=1))
+    else:
+        print(json.dumps(gpu_ops(), indent=1))
