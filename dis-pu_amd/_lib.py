@@ -36,8 +36,10 @@ SIGNATURES = {
     "dispu_nn_distance_grad": (_i, [_i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "dispu_approx_match_scratch_bytes": (_sz, [_i, _i, _i]),
     "dispu_approx_match": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp]),
-    "dispu_match_cost": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp]),
-    "dispu_match_cost_grad": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
+    "dispu_match_cost_scratch_bytes": (_sz, [_i, _i, _i]),
+    "dispu_match_cost": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
+    "dispu_match_cost_grad_scratch_bytes": (_sz, [_i, _i, _i]),
+    "dispu_match_cost_grad": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "dispu_linear": (_i, [_i, _i, _i, _i, _vp, _l, _l, _vp, _l, _l, _i, _vp, _i, _vp, _l, _l, _vp, _l, _l, _vp, _l, _l, _vp]),
     "dispu_linear_bn": (_i, [_i, _i, _i, _i, _vp, _l, _l, _vp, _l, _l, _i, _vp, _vp, _vp, _i, _vp, _l, _l, _vp, _l, _l, _vp, _l, _l,
                              _vp]),

@@ -2,19 +2,52 @@
 // Replaces approxmatchLauncher / matchcostLauncher / matchcostgradLauncher
 // (tf_ops/approxmatch/tf_approxmatch_g.cu:180-182,226-228,292-295).
 //
-// The reference runs ONE 512-thread block per cloud for all 10 levels x 3 passes.  The three
-// passes of a level depend on each other only through the per-point vectors remainL/R and
-// ratioL/R, so here every pass is its own launch over (point tiles x clouds): all CUs work
-// even at small batch, and each point's sum is still accumulated sequentially in the reference's
-// order (l or k ascending), so results do not depend on the decomposition.
-// Scratch `temp` has the reference's size and role: [b][2*(n+m)] floats =
-// remainL[n] | remainR[m] | ratioL[n] | ratioR[m]   (tf_approxmatch_g.cu:2).
+// The reference runs ONE 512-thread block per cloud through 10 levels x 3 passes; a pass is a row sum (passes 1, 3:
+// per point k of cloud 1 over all l of cloud 2) or a column sum (pass 2) of exp(level * d2) times a per-point weight,
+// and every pass needs ALL results of the previous one.  Here:
+//   * a pass is a 2-D tiling: a workgroup owns 256 points (one lane each) x AM_CH = 128 partners and writes one
+//     partial sum per point, so a single 4096 x 4096 cloud is 512 workgroups instead of 1 (16 in round 1);
+//   * partial sums are combined in ascending chunk order by whoever consumes them (the next pass, while it loads its
+//     partner tile): no atomics, no grid barrier, no extra launch -- the association is fixed and restated by
+//     oracle/dispu_oracle.c:orc_approx_match_chunked(chunk = 128), bit for bit in DISPU_ARITH_PINNED_EXP mode;
+//   * pass 3 of level t and pass 1 of level t+1 are both row sums over the same pairs: one kernel, one d2 per pair;
+//   * `match` is not read-modify-written 10 times: the ten (ratioL, ratioR) vector pairs are kept (40 (n + m) floats
+//     per cloud) and match[l][k] = sum_t exp(level_t d2) ratioL_t[k] ratioR_t[l] is assembled once at the end in the
+//     reference's order (ascending t from 0), written once; pass 3 of the last level only updates remainL, which
+//     nobody reads afterwards, and is not evaluated.
+// 22 launches per call (init, 10 column passes, 1 + 9 row passes, assembly) instead of 31.
 #include "common.h"
 
 namespace dispu {
 
-constexpr int AM_BS = 256;
-constexpr int AM_TILE = 1024;
+constexpr int AM_ROWS = 256;   // points per workgroup, one lane each
+constexpr int AM_CH = 128;     // partners per partial sum -- part of the pinned arithmetic (oracle AM_CHUNK)
+constexpr int AM_LEVELS = 10;
+constexpr int AM_ACH = 64;     // partners per workgroup of the assembly kernel (no sums across partners there)
+
+struct AmLevels { float v[AM_LEVELS]; };
+
+// per-cloud scratch (floats):  remL[10][n] ratL[10][n] remR[10][m] ratR[10][m] p1[nc1][n] p3[nc1][n] p2[nc2][m]
+// remX[t] / ratX[t]: remainL/R entering level t, ratioL/R of level t; p1/p3: partial row sums of passes 1 / 3 per
+// chunk of cloud-2 points; p2: partial column sums of pass 2 per chunk of cloud-1 points.
+struct AmView { float *remL, *ratL, *remR, *ratR, *p1, *p3, *p2; };
+
+__host__ __device__ inline int am_chunks(int x) { return (x + AM_CH - 1) / AM_CH; }
+__host__ __device__ inline size_t am_cloud_floats(int n, int m) {
+    return (size_t)2 * AM_LEVELS * ((size_t)n + m) + (size_t)2 * am_chunks(m) * n + (size_t)am_chunks(n) * m;
+}
+__device__ __forceinline__ AmView am_view(float* temp, int cloud, int n, int m) {
+    AmView v;
+    float* p = temp + (size_t)cloud * am_cloud_floats(n, m);
+    v.remL = p; p += (size_t)AM_LEVELS * n;
+    v.ratL = p; p += (size_t)AM_LEVELS * n;
+    v.remR = p; p += (size_t)AM_LEVELS * m;
+    v.ratR = p; p += (size_t)AM_LEVELS * m;
+    v.p1 = p; p += (size_t)am_chunks(m) * n;
+    v.p3 = p; p += (size_t)am_chunks(m) * n;
+    v.p2 = p;
+    return v;
+}
 
 // PINNED = false: hardware v_exp_f32 like the reference's __expf.  PINNED = true: the same fmaf-chain
 // sequence as oracle/dispu_oracle.c:pinned_exp, bit-identical on CPU and GPU (parity mode).
@@ -38,178 +71,301 @@ __device__ __forceinline__ float am_exp(float x) {
     }
 }
 
-__global__ void am_init_kernel(int n, int m, float multiL, float multiR, float* __restrict__ temp,
-                               float* __restrict__ match) {
-    const int cloud = blockIdx.y;
-    float* t = temp + (size_t)cloud * (n + m) * 2;
-    float* mt = match + (size_t)cloud * n * m;
-    const size_t nm = (size_t)n * m;
-    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < nm; e += (size_t)gridDim.x * blockDim.x) mt[e] = 0.f;
-    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) t[e] = multiL;
-    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < m; e += gridDim.x * blockDim.x) t[n + e] = multiR;
+__global__ void am_init_kernel(int n, int m, float multiL, float multiR, float* __restrict__ temp) {
+    const AmView v = am_view(temp, blockIdx.y, n, m);
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) v.remL[e] = multiL;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < m; e += gridDim.x * blockDim.x) v.remR[e] = multiR;
 }
 
-// PASS 1: ratioL[k] = remainL[k] / (1e-9 + sum_l exp(level*d2)*remainR[l])
-// PASS 2: sumr = (sum_k exp(level*d2)*ratioL[k]) * remainR[l]; ratioR, remainR update
-// PASS 3: w = exp(level*d2)*ratioL[k]*ratioR[l]; match[l*n+k] += w; remainL update
-template <int PASS, bool FMA, bool PINNED>
-__global__ __launch_bounds__(AM_BS) void am_pass_kernel(int n, int m, float level, const float* __restrict__ xyz1,
-                                                         const float* __restrict__ xyz2, float* __restrict__ temp,
-                                                         float* __restrict__ match) {
-    __shared__ float4 tile[AM_TILE];
-    const int cloud = blockIdx.y;
-    float* remainL = temp + (size_t)cloud * (n + m) * 2;
-    float* remainR = remainL + n;
-    float* ratioL = remainR + m;
-    float* ratioR = ratioL + n;
-    const float* __restrict__ p1 = xyz1 + (size_t)cloud * n * 3;
-    const float* __restrict__ p2 = xyz2 + (size_t)cloud * m * 3;
-    float* mt = match + (size_t)cloud * n * m;
-
-    constexpr bool OVER_N = (PASS != 2);           // lanes enumerate cloud 1 (k) in passes 1,3
-    const int nown = OVER_N ? n : m, noth = OVER_N ? m : n;
-    const float* own = OVER_N ? p1 : p2;
-    const float* oth = OVER_N ? p2 : p1;
-    const float* othw = (PASS == 1) ? remainR : (PASS == 2 ? ratioL : ratioR);
-    const int a = blockIdx.x * AM_BS + threadIdx.x;
-    const bool active = a < nown;
-    float xa = 0.f, ya = 0.f, za = 0.f;
-    if (active) { xa = own[a * 3 + 0]; ya = own[a * 3 + 1]; za = own[a * 3 + 2]; }
-    const float rl = (PASS == 3 && active) ? ratioL[a] : 0.f;
-    float sum = (PASS == 1) ? 1e-9f : 0.f;
-    for (int t0 = 0; t0 < noth; t0 += AM_TILE) {
-        const int len = min(AM_TILE, noth - t0);
-        __syncthreads();
-        for (int t = threadIdx.x; t < len; t += AM_BS)
-            tile[t] = make_float4(oth[(t0 + t) * 3 + 0], oth[(t0 + t) * 3 + 1], oth[(t0 + t) * 3 + 2], othw[t0 + t]);
-        __syncthreads();
-        if (!active) continue;
-        for (int t = 0; t < len; ++t) {
-            const float4 q = tile[t];
-            const float d2 = OVER_N ? sqdist3<FMA>(q.x - xa, q.y - ya, q.z - za) : sqdist3<FMA>(xa - q.x, ya - q.y, za - q.z);
-            const float e = am_exp<PINNED>(level * d2);
-            if constexpr (PASS == 3) {
-                const float w = e * rl * q.w;
-                mt[(size_t)(t0 + t) * n + a] += w;
-                sum += w;
-            } else {
-                if constexpr (FMA) sum = __builtin_fmaf(e, q.w, sum);
-                else sum = sum + e * q.w;
-            }
-        }
-    }
-    if (!active) return;
-    if constexpr (PASS == 1) {
-        ratioL[a] = remainL[a] / sum;
-    } else if constexpr (PASS == 2) {
-        const float rr = remainR[a];
-        const float sumr = sum * rr;
-        const float consumption = fminf(rr / (sumr + 1e-9f), 1.0f);
-        ratioR[a] = consumption * rr;
-        remainR[a] = fmaxf(0.0f, rr - sumr);
-    } else {
-        remainL[a] = fmaxf(0.0f, remainL[a] - sum);
-    }
+// pass 2 of level t for one partner l, from the column partials:  (tf_approxmatch_g.cu:100-107)
+//   sumr = (sum_k e ratioL[k]) * remainR[l];  ratioR = min(remainR/(sumr+1e-9), 1) * remainR;  remainR' = max(0, remainR - sumr)
+__device__ __forceinline__ void am_finish_col(const AmView& v, int m, int nc2, int t, int l, float& ratr, float& remn) {
+    const float rr = v.remR[(size_t)t * m + l];
+    float tot = v.p2[l];
+    for (int c = 1; c < nc2; ++c) tot += v.p2[(size_t)c * m + l];
+    const float sumr = tot * rr;
+    const float consumption = fminf(rr / (sumr + 1e-9f), 1.0f);
+    ratr = consumption * rr;
+    remn = fmaxf(0.0f, rr - sumr);
 }
 
-// cost[b] = sum_{k,l} sqrt(d2(k,l)) * match[l*n+k].  One workgroup per cloud; lane t sums
-// k = t, t+BS, ... (outer) x l ascending (inner) exactly like the reference's thread t
-// (tf_approxmatch_g.cu:183-225), then partials are combined wave-first (deterministic order).
-template <bool FMA>
-__global__ __launch_bounds__(1024) void match_cost_kernel(int n, int m, const float* __restrict__ xyz1,
-                                                           const float* __restrict__ xyz2,
-                                                           const float* __restrict__ match, float* __restrict__ cost) {
-    constexpr int BS = 1024;
-    __shared__ float4 tile[AM_TILE];
-    __shared__ float wsum[BS / kWave];
-    const int cloud = blockIdx.x;
+// Row kernel: pass 3 of level t (weights ratioL_t[k] ratioR_t[l]) and pass 1 of level t+1 (weights remainR_{t+1}[l]) over
+// one (256 points of cloud 1) x (AM_CH points of cloud 2) tile.  FIRST: only pass 1 of level 0.
+// ratioR_t / remainR_{t+1} of the partners are finished here from pass 2's partials (every workgroup of a chunk computes the
+// same values; the rb == 0 one stores them for the later kernels).
+template <bool FIRST, bool FMA, bool PINNED>
+__global__ __launch_bounds__(AM_ROWS) void am_row_kernel(int n, int m, int t, float level3, float level1,
+                                                          const float* __restrict__ xyz1, const float* __restrict__ xyz2,
+                                                          float* __restrict__ temp) {
+    __shared__ float4 tile[AM_CH];
+    __shared__ float tilew[AM_CH];
+    const int cloud = blockIdx.z, c = blockIdx.y, rb = blockIdx.x, tid = threadIdx.x;
+    const AmView v = am_view(temp, cloud, n, m);
+    const int nc2 = am_chunks(n);
     const float* __restrict__ p1 = xyz1 + (size_t)cloud * n * 3;
     const float* __restrict__ p2 = xyz2 + (size_t)cloud * m * 3;
-    const float* __restrict__ mt = match + (size_t)cloud * n * m;
-    float sub = 0.f;
-    for (int k0 = 0; k0 < n; k0 += BS) {
-        const int k = k0 + threadIdx.x;
-        const bool active = k < n;
-        float x1 = 0.f, y1 = 0.f, z1 = 0.f;
-        if (active) { x1 = p1[k * 3 + 0]; y1 = p1[k * 3 + 1]; z1 = p1[k * 3 + 2]; }
-        for (int l0 = 0; l0 < m; l0 += AM_TILE) {
-            const int len = min(AM_TILE, m - l0);
-            __syncthreads();
-            for (int t = threadIdx.x; t < len; t += BS)
-                tile[t] = make_float4(p2[(l0 + t) * 3 + 0], p2[(l0 + t) * 3 + 1], p2[(l0 + t) * 3 + 2], 0.f);
-            __syncthreads();
-            if (active) {
-                for (int t = 0; t < len; ++t) {
-                    const float4 q = tile[t];
-                    const float d = sqrtf(sqdist3<FMA>(q.x - x1, q.y - y1, q.z - z1));
-                    const float w = mt[(size_t)(l0 + t) * n + k];
-                    if constexpr (FMA) sub = __builtin_fmaf(d, w, sub);
-                    else sub = sub + d * w;
-                }
-            }
+    const int l0 = c * AM_CH, len = min(AM_CH, m - l0);
+    if (tid < len) {
+        const int l = l0 + tid;
+        float wr = 0.f, w1;
+        if constexpr (FIRST) {
+            w1 = v.remR[l];
+        } else {
+            am_finish_col(v, m, nc2, t, l, wr, w1);
+            if (rb == 0) { v.ratR[(size_t)t * m + l] = wr; v.remR[(size_t)(t + 1) * m + l] = w1; }
         }
+        tile[tid] = make_float4(p2[l * 3 + 0], p2[l * 3 + 1], p2[l * 3 + 2], wr);
+        tilew[tid] = w1;
     }
-    sub = wave_sum_f32(sub);
-    if ((threadIdx.x & (kWave - 1)) == 0) wsum[threadIdx.x / kWave] = sub;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        float s = 0.f;
-        for (int w = 0; w < BS / kWave; ++w) s += wsum[w];
-        cost[cloud] = s;
+    const int k = rb * AM_ROWS + tid;
+    const bool active = k < n;
+    float x1 = 0.f, y1 = 0.f, z1 = 0.f, rl = 0.f;
+    if (active) {
+        x1 = p1[k * 3 + 0]; y1 = p1[k * 3 + 1]; z1 = p1[k * 3 + 2];
+        if constexpr (!FIRST) rl = v.ratL[(size_t)t * n + k];
     }
+    float s3 = 0.f, s1 = 0.f;
+#pragma unroll 4
+    for (int i = 0; i < len; ++i) {
+        const float4 q = tile[i];
+        const float d2 = sqdist3<FMA>(q.x - x1, q.y - y1, q.z - z1);
+        if constexpr (!FIRST) {
+            const float w = am_exp<PINNED>(level3 * d2) * rl * q.w;      // the value `match` receives at this level
+            s3 += w;
+        }
+        const float e1 = am_exp<PINNED>(level1 * d2);
+        if constexpr (FMA) s1 = __builtin_fmaf(e1, tilew[i], s1);
+        else s1 = s1 + e1 * tilew[i];
+    }
+    if (active) {
+        if constexpr (!FIRST) v.p3[(size_t)c * n + k] = s3;
+        v.p1[(size_t)c * n + k] = s1;
+    }
+}
+
+// Column kernel: pass 2 of level t over one (256 points of cloud 2) x (AM_CH points of cloud 1) tile.
+// remainL_t / ratioL_t of the partners are finished here from the row partials (:56-57, :158-159):
+//   remainL_t = max(0, remainL_{t-1} - sum_l w);  ratioL_t = remainL_t / (1e-9 + sum_l e remainR[l])
+template <bool FMA, bool PINNED>
+__global__ __launch_bounds__(AM_ROWS) void am_col_kernel(int n, int m, int t, float level, const float* __restrict__ xyz1,
+                                                          const float* __restrict__ xyz2, float* __restrict__ temp) {
+    __shared__ float4 tile[AM_CH];
+    const int cloud = blockIdx.z, c2 = blockIdx.y, cb = blockIdx.x, tid = threadIdx.x;
+    const AmView v = am_view(temp, cloud, n, m);
+    const int nc1 = am_chunks(m);
+    const float* __restrict__ p1 = xyz1 + (size_t)cloud * n * 3;
+    const float* __restrict__ p2 = xyz2 + (size_t)cloud * m * 3;
+    const int k0 = c2 * AM_CH, len = min(AM_CH, n - k0);
+    if (tid < len) {
+        const int k = k0 + tid;
+        float reml;
+        if (t == 0) {
+            reml = v.remL[k];
+        } else {
+            float tot = v.p3[k];
+            for (int c = 1; c < nc1; ++c) tot += v.p3[(size_t)c * n + k];
+            reml = fmaxf(0.0f, v.remL[(size_t)(t - 1) * n + k] - tot);
+        }
+        float suml = 1e-9f;
+        for (int c = 0; c < nc1; ++c) suml += v.p1[(size_t)c * n + k];
+        const float ratl = reml / suml;
+        if (cb == 0) {
+            if (t > 0) v.remL[(size_t)t * n + k] = reml;
+            v.ratL[(size_t)t * n + k] = ratl;
+        }
+        tile[tid] = make_float4(p1[k * 3 + 0], p1[k * 3 + 1], p1[k * 3 + 2], ratl);
+    }
+    __syncthreads();
+    const int l = cb * AM_ROWS + tid;
+    const bool active = l < m;
+    float x2 = 0.f, y2 = 0.f, z2 = 0.f;
+    if (active) { x2 = p2[l * 3 + 0]; y2 = p2[l * 3 + 1]; z2 = p2[l * 3 + 2]; }
+    float s = 0.f;
+#pragma unroll 4
+    for (int i = 0; i < len; ++i) {
+        const float4 q = tile[i];
+        const float d2 = sqdist3<FMA>(x2 - q.x, y2 - q.y, z2 - q.z);
+        const float e = am_exp<PINNED>(level * d2);
+        if constexpr (FMA) s = __builtin_fmaf(e, q.w, s);
+        else s = s + e * q.w;
+    }
+    if (active) v.p2[(size_t)c2 * m + l] = s;
+}
+
+// match[l][k] = sum_t (exp(level_t d2) ratioL_t[k]) ratioR_t[l], t ascending from 0 (the reference's `match += w` per level
+// on a zeroed buffer, :16,152).  ratioR of the last level is finished here from pass 2's partials.
+struct AmPartner { float x, y, z, pad; float r[AM_LEVELS]; float pad2[2]; };   // 64 bytes
+
+template <bool FMA, bool PINNED>
+__global__ __launch_bounds__(AM_ROWS) void am_assemble_kernel(int n, int m, AmLevels lv, const float* __restrict__ xyz1,
+                                                               const float* __restrict__ xyz2, float* __restrict__ temp,
+                                                               float* __restrict__ match) {
+    __shared__ AmPartner tile[AM_ACH];
+    const int cloud = blockIdx.z, c = blockIdx.y, rb = blockIdx.x, tid = threadIdx.x;
+    const AmView v = am_view(temp, cloud, n, m);
+    const float* __restrict__ p1 = xyz1 + (size_t)cloud * n * 3;
+    const float* __restrict__ p2 = xyz2 + (size_t)cloud * m * 3;
+    const int l0 = c * AM_ACH, len = min(AM_ACH, m - l0);
+    if (tid < len) {
+        const int l = l0 + tid;
+        AmPartner q;
+        q.x = p2[l * 3 + 0]; q.y = p2[l * 3 + 1]; q.z = p2[l * 3 + 2]; q.pad = 0.f; q.pad2[0] = q.pad2[1] = 0.f;
+#pragma unroll
+        for (int t = 0; t < AM_LEVELS - 1; ++t) q.r[t] = v.ratR[(size_t)t * m + l];
+        float remn;
+        am_finish_col(v, m, am_chunks(n), AM_LEVELS - 1, l, q.r[AM_LEVELS - 1], remn);
+        tile[tid] = q;
+    }
+    __syncthreads();
+    const int k = rb * AM_ROWS + tid;
+    if (k >= n) return;
+    const float x1 = p1[k * 3 + 0], y1 = p1[k * 3 + 1], z1 = p1[k * 3 + 2];
+    float rl[AM_LEVELS];
+#pragma unroll
+    for (int t = 0; t < AM_LEVELS; ++t) rl[t] = v.ratL[(size_t)t * n + k];
+    float* __restrict__ mt = match + (size_t)cloud * n * m + (size_t)l0 * n + k;
+    for (int i = 0; i < len; ++i) {
+        const AmPartner& q = tile[i];
+        const float d2 = sqdist3<FMA>(q.x - x1, q.y - y1, q.z - z1);
+        float acc = am_exp<PINNED>(lv.v[0] * d2) * rl[0] * q.r[0];
+#pragma unroll
+        for (int t = 1; t < AM_LEVELS; ++t) acc += am_exp<PINNED>(lv.v[t] * d2) * rl[t] * q.r[t];
+        __builtin_nontemporal_store(acc, mt + (size_t)i * n);
+    }
+}
+
+// ---- match_cost -----------------------------------------------------------------------------------------------------------
+// cost[b] = sum_{k,l} sqrt(d2(k,l)) * match[l*n+k]   (matchcost, tf_approxmatch_g.cu:183-225: one block per cloud).
+// Here `match` is streamed once by (256 k) x (MC_CH l) tiles -- lane = k, so every load is a coalesced 1 KB row
+// segment -- each lane sums its l's sequentially, the workgroup reduces its 256 lane sums in a fixed order (wave butterfly,
+// then waves ascending) to ONE partial, and a second launch adds the partials of a cloud in ascending (row block, chunk)
+// order.  Deterministic; the association differs from the reference's 512-lane tree (tolerance-tested, 1e-5).
+constexpr int MC_CH = 128;      // partners per tile at most; halved until a launch has >= 2048 workgroups (a lane keeps
+                                // 16 loads of 256 B per wave in flight: ~64 KB per CU are needed to cover the HBM latency)
+
+static inline int mc_chunk(int b, int n, int m) {
+    int ch = MC_CH;
+    const long rb = (n + 255) / 256;
+    while (ch > 16 && rb * ((m + ch - 1) / ch) * b < 2048) ch >>= 1;
+    return ch;
+}
+
+template <bool FMA>
+__global__ __launch_bounds__(AM_ROWS) void match_cost_tile_kernel(int n, int m, int ch, const float* __restrict__ xyz1,
+                                                                   const float* __restrict__ xyz2,
+                                                                   const float* __restrict__ match,
+                                                                   float* __restrict__ part) {
+    __shared__ float4 tile[MC_CH];
+    __shared__ float wsum[AM_ROWS / kWave];
+    const int cloud = blockIdx.z, c = blockIdx.y, rb = blockIdx.x, tid = threadIdx.x;
+    const float* __restrict__ p1 = xyz1 + (size_t)cloud * n * 3;
+    const float* __restrict__ p2 = xyz2 + (size_t)cloud * m * 3;
+    const int l0 = c * ch, len = min(ch, m - l0);
+    if (tid < len) tile[tid] = make_float4(p2[(l0 + tid) * 3 + 0], p2[(l0 + tid) * 3 + 1], p2[(l0 + tid) * 3 + 2], 0.f);
+    __syncthreads();
+    const int k = rb * AM_ROWS + tid;
+    float s = 0.f;
+    if (k < n) {
+        const float x1 = p1[k * 3 + 0], y1 = p1[k * 3 + 1], z1 = p1[k * 3 + 2];
+        const float* __restrict__ mt = match + (size_t)cloud * n * m + (size_t)l0 * n + k;
+#pragma unroll 16
+        for (int i = 0; i < len; ++i) {
+            const float4 q = tile[i];
+            const float w = __builtin_nontemporal_load(mt + (size_t)i * n);
+            // v_sqrt_f32 (1 ulp) instead of the correctly rounded sqrtf: the ~20-instruction fix-up sequence made this
+            // HBM-bound stream VALU-bound; the cost is tolerance-checked (1e-5, north star), not bit-compared
+            const float d = __builtin_amdgcn_sqrtf(sqdist3<FMA>(q.x - x1, q.y - y1, q.z - z1));
+            if constexpr (FMA) s = __builtin_fmaf(d, w, s);
+            else s = s + d * w;
+        }
+    }
+    s = wave_sum_f32(s);
+    if ((tid & (kWave - 1)) == 0) wsum[tid / kWave] = s;
+    __syncthreads();
+    if (tid == 0) {
+        float r = wsum[0];
+        for (int w = 1; w < AM_ROWS / kWave; ++w) r += wsum[w];
+        part[((size_t)cloud * gridDim.x + rb) * gridDim.y + c] = r;
+    }
+}
+
+__global__ __launch_bounds__(256) void match_cost_final_kernel(int nparts, const float* __restrict__ part, float* __restrict__ cost) {
+    __shared__ float wsum[256 / kWave];
+    const float* __restrict__ p = part + (size_t)blockIdx.x * nparts;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < nparts; i += 256) s += p[i];
+    s = wave_sum_f32(s);
+    if ((threadIdx.x & (kWave - 1)) == 0) wsum[threadIdx.x / kWave] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) cost[blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
 }
 
 // grad1[b,k,:] = sum_l match[l*n+k] * (p1_k - p2_l) * rsqrt(max(d2,1e-20))   (matchcostgrad1, :270-291)
+// same tiling as the cost: partial sums per (chunk, k), combined in ascending chunk order by match_grad1_combine_kernel.
+template <bool FMA>
+__global__ __launch_bounds__(AM_ROWS) void match_grad1_tile_kernel(int n, int m, int ch, const float* __restrict__ xyz1,
+                                                                    const float* __restrict__ xyz2,
+                                                                    const float* __restrict__ match,
+                                                                    float* __restrict__ part) {
+    __shared__ float4 tile[MC_CH];
+    const int cloud = blockIdx.z, c = blockIdx.y, rb = blockIdx.x, tid = threadIdx.x;
+    const float* __restrict__ p1 = xyz1 + (size_t)cloud * n * 3;
+    const float* __restrict__ p2 = xyz2 + (size_t)cloud * m * 3;
+    const int l0 = c * ch, len = min(ch, m - l0);
+    if (tid < len) tile[tid] = make_float4(p2[(l0 + tid) * 3 + 0], p2[(l0 + tid) * 3 + 1], p2[(l0 + tid) * 3 + 2], 0.f);
+    __syncthreads();
+    const int k = rb * AM_ROWS + tid;
+    if (k >= n) return;
+    const float x1 = p1[k * 3 + 0], y1 = p1[k * 3 + 1], z1 = p1[k * 3 + 2];
+    const float* __restrict__ mt = match + (size_t)cloud * n * m + (size_t)l0 * n + k;
+    float gx = 0.f, gy = 0.f, gz = 0.f;
+#pragma unroll 8
+    for (int i = 0; i < len; ++i) {
+        const float4 q = tile[i];
+        const float ex = x1 - q.x, ey = y1 - q.y, ez = z1 - q.z;
+        const float d = __builtin_nontemporal_load(mt + (size_t)i * n) * rsqrtf(fmaxf(sqdist3<FMA>(ex, ey, ez), 1e-20f));
+        if constexpr (FMA) { gx = __builtin_fmaf(ex, d, gx); gy = __builtin_fmaf(ey, d, gy); gz = __builtin_fmaf(ez, d, gz); }
+        else { gx += ex * d; gy += ey * d; gz += ez * d; }
+    }
+    float* g = part + (((size_t)cloud * gridDim.y + c) * n + k) * 3;
+    g[0] = gx; g[1] = gy; g[2] = gz;
+}
+
+__global__ void match_grad1_combine_kernel(int n, int nc, const float* __restrict__ part, float* __restrict__ grad) {
+    const int cloud = blockIdx.y;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;          // element of [n][3]
+    if (e >= n * 3) return;
+    const float* __restrict__ p = part + (size_t)cloud * nc * n * 3 + e;
+    float s = p[0];
+    for (int c = 1; c < nc; ++c) s += p[(size_t)c * n * 3];
+    grad[(size_t)cloud * n * 3 + e] = s;
+}
+
 // grad2[b,l,:] = sum_k match[l*n+k] * (p2_l - p1_k) * rsqrt(max(d2,1e-20))   (matchcostgrad2, :229-269)
-// WHICH = 1: lane per k, sequential over l (the reference's order).
-// WHICH = 2: one wave per l, lanes stride over k, wave butterfly sum (reference: 256-thread tree).
-template <int WHICH, bool FMA>
-__global__ __launch_bounds__(AM_BS) void match_cost_grad_kernel(int n, int m, const float* __restrict__ xyz1,
-                                                                 const float* __restrict__ xyz2,
-                                                                 const float* __restrict__ match,
-                                                                 float* __restrict__ grad) {
+// one wave per l, lanes stride over k (row l of match is contiguous), wave butterfly sum (reference: 256-thread tree).
+template <bool FMA>
+__global__ __launch_bounds__(256) void match_grad2_kernel(int n, int m, const float* __restrict__ xyz1,
+                                                           const float* __restrict__ xyz2, const float* __restrict__ match,
+                                                           float* __restrict__ grad) {
     const int cloud = blockIdx.y;
     const float* __restrict__ p1 = xyz1 + (size_t)cloud * n * 3;
     const float* __restrict__ p2 = xyz2 + (size_t)cloud * m * 3;
     const float* __restrict__ mt = match + (size_t)cloud * n * m;
-    if constexpr (WHICH == 1) {
-        __shared__ float4 tile[AM_TILE];
-        const int k = blockIdx.x * AM_BS + threadIdx.x;
-        const bool active = k < n;
-        float x1 = 0.f, y1 = 0.f, z1 = 0.f;
-        if (active) { x1 = p1[k * 3 + 0]; y1 = p1[k * 3 + 1]; z1 = p1[k * 3 + 2]; }
-        float gx = 0.f, gy = 0.f, gz = 0.f;
-        for (int l0 = 0; l0 < m; l0 += AM_TILE) {
-            const int len = min(AM_TILE, m - l0);
-            __syncthreads();
-            for (int t = threadIdx.x; t < len; t += AM_BS)
-                tile[t] = make_float4(p2[(l0 + t) * 3 + 0], p2[(l0 + t) * 3 + 1], p2[(l0 + t) * 3 + 2], 0.f);
-            __syncthreads();
-            if (!active) continue;
-            for (int t = 0; t < len; ++t) {
-                const float4 q = tile[t];
-                const float ex = x1 - q.x, ey = y1 - q.y, ez = z1 - q.z;
-                const float d = mt[(size_t)(l0 + t) * n + k] * rsqrtf(fmaxf(sqdist3<FMA>(ex, ey, ez), 1e-20f));
-                if constexpr (FMA) { gx = __builtin_fmaf(ex, d, gx); gy = __builtin_fmaf(ey, d, gy); gz = __builtin_fmaf(ez, d, gz); }
-                else { gx += ex * d; gy += ey * d; gz += ez * d; }
-            }
-        }
-        if (active) { float* g = grad + ((size_t)cloud * n + k) * 3; g[0] = gx; g[1] = gy; g[2] = gz; }
-    } else {
-        const int lane = threadIdx.x & (kWave - 1);
-        const int l = blockIdx.x * (AM_BS / kWave) + threadIdx.x / kWave;
-        if (l >= m) return;  // wave-uniform
-        const float x2 = p2[l * 3 + 0], y2 = p2[l * 3 + 1], z2 = p2[l * 3 + 2];
-        float gx = 0.f, gy = 0.f, gz = 0.f;
-        for (int k = lane; k < n; k += kWave) {
-            const float ex = x2 - p1[k * 3 + 0], ey = y2 - p1[k * 3 + 1], ez = z2 - p1[k * 3 + 2];
-            const float d = mt[(size_t)l * n + k] * rsqrtf(fmaxf(sqdist3<FMA>(ex, ey, ez), 1e-20f));
-            if constexpr (FMA) { gx = __builtin_fmaf(ex, d, gx); gy = __builtin_fmaf(ey, d, gy); gz = __builtin_fmaf(ez, d, gz); }
-            else { gx += ex * d; gy += ey * d; gz += ez * d; }
-        }
-        gx = wave_sum_f32(gx); gy = wave_sum_f32(gy); gz = wave_sum_f32(gz);
-        if (lane == 0) { float* g = grad + ((size_t)cloud * m + l) * 3; g[0] = gx; g[1] = gy; g[2] = gz; }
+    const int lane = threadIdx.x & (kWave - 1);
+    const int l = blockIdx.x * (256 / kWave) + threadIdx.x / kWave;
+    if (l >= m) return;  // wave-uniform
+    const float x2 = p2[l * 3 + 0], y2 = p2[l * 3 + 1], z2 = p2[l * 3 + 2];
+    float gx = 0.f, gy = 0.f, gz = 0.f;
+#pragma unroll 4
+    for (int k = lane; k < n; k += kWave) {
+        const float ex = x2 - p1[k * 3 + 0], ey = y2 - p1[k * 3 + 1], ez = z2 - p1[k * 3 + 2];
+        const float d = __builtin_nontemporal_load(mt + (size_t)l * n + k) * rsqrtf(fmaxf(sqdist3<FMA>(ex, ey, ez), 1e-20f));
+        if constexpr (FMA) { gx = __builtin_fmaf(ex, d, gx); gy = __builtin_fmaf(ey, d, gy); gz = __builtin_fmaf(ez, d, gz); }
+        else { gx += ex * d; gy += ey * d; gz += ez * d; }
     }
+    gx = wave_sum_f32(gx); gy = wave_sum_f32(gy); gz = wave_sum_f32(gz);
+    if (lane == 0) { float* g = grad + ((size_t)cloud * m + l) * 3; g[0] = gx; g[1] = gy; g[2] = gz; }
 }
 
 template <bool FMA, bool PINNED>
@@ -217,18 +373,27 @@ static int run_approx_match(int b, int n, int m, const float* xyz1, const float*
                             hipStream_t s) {
     const float multiL = (n >= m) ? 1.0f : (float)(m / n);
     const float multiR = (n >= m) ? (float)(n / m) : 1.0f;
-    hipLaunchKernelGGL(am_init_kernel, dim3(64, b), dim3(256), 0, s, n, m, multiL, multiR, temp, match);
-    dim3 gn((n + AM_BS - 1) / AM_BS, b), gm((m + AM_BS - 1) / AM_BS, b);
-    for (int j = 7; j >= -2; --j) {
+    AmLevels lv;
+    for (int t = 0; t < AM_LEVELS; ++t) {
+        const int j = 7 - t;
         float level = 0.0f;
         if (j != -2) {
             level = -1.0f;
-            for (int t = 0; t < (j < 0 ? -j : j); ++t) level = (j < 0) ? level * 0.25f : level * 4.0f;  // -(4^j), exact
+            for (int q = 0; q < (j < 0 ? -j : j); ++q) level = (j < 0) ? level * 0.25f : level * 4.0f;  // -(4^j), exact
         }
-        hipLaunchKernelGGL((am_pass_kernel<1, FMA, PINNED>), gn, dim3(AM_BS), 0, s, n, m, level, xyz1, xyz2, temp, match);
-        hipLaunchKernelGGL((am_pass_kernel<2, FMA, PINNED>), gm, dim3(AM_BS), 0, s, n, m, level, xyz1, xyz2, temp, match);
-        hipLaunchKernelGGL((am_pass_kernel<3, FMA, PINNED>), gn, dim3(AM_BS), 0, s, n, m, level, xyz1, xyz2, temp, match);
+        lv.v[t] = level;
     }
+    const dim3 blk(AM_ROWS);
+    const dim3 grow((n + AM_ROWS - 1) / AM_ROWS, am_chunks(m), b), gcol((m + AM_ROWS - 1) / AM_ROWS, am_chunks(n), b);
+    hipLaunchKernelGGL(am_init_kernel, dim3(8, b), dim3(256), 0, s, n, m, multiL, multiR, temp);
+    hipLaunchKernelGGL((am_row_kernel<true, FMA, PINNED>), grow, blk, 0, s, n, m, 0, 0.f, lv.v[0], xyz1, xyz2, temp);
+    for (int t = 0; t < AM_LEVELS; ++t) {
+        hipLaunchKernelGGL((am_col_kernel<FMA, PINNED>), gcol, blk, 0, s, n, m, t, lv.v[t], xyz1, xyz2, temp);
+        if (t + 1 < AM_LEVELS)
+            hipLaunchKernelGGL((am_row_kernel<false, FMA, PINNED>), grow, blk, 0, s, n, m, t, lv.v[t], lv.v[t + 1], xyz1, xyz2, temp);
+    }
+    const dim3 gasm((n + AM_ROWS - 1) / AM_ROWS, (m + AM_ACH - 1) / AM_ACH, b);
+    hipLaunchKernelGGL((am_assemble_kernel<FMA, PINNED>), gasm, blk, 0, s, n, m, lv, xyz1, xyz2, temp, match);
     return (int)hipGetLastError();
 }
 
@@ -237,13 +402,15 @@ static int run_approx_match(int b, int n, int m, const float* xyz1, const float*
 using namespace dispu;
 
 DISPU_EXPORT size_t dispu_approx_match_scratch_bytes(int b, int n, int m) {
-    return sizeof(float) * (size_t)b * ((size_t)n + m) * 2;
+    if (b <= 0 || n <= 0 || m <= 0) return 0;
+    return sizeof(float) * (size_t)b * am_cloud_floats(n, m);
 }
 
 DISPU_EXPORT int dispu_approx_match(int b, int n, int m, const float* xyz1, const float* xyz2, float* match,
                                     float* temp, int arith, void* stream) {
     if (b < 0 || n <= 0 || m <= 0 || !temp) return (int)hipErrorInvalidValue;
     if (b == 0) return 0;
+    if (b > 65535 || (size_t)n * 3 > 0x7fffffffull || (size_t)m * 3 > 0x7fffffffull) return (int)hipErrorInvalidValue;
     hipStream_t s = (hipStream_t)stream;
     const bool fma = (arith & DISPU_ARITH_CONTRACT) != 0, pin = (arith & DISPU_ARITH_PINNED_EXP) != 0;
     if (fma && pin) return run_approx_match<true, true>(b, n, m, xyz1, xyz2, match, temp, s);
@@ -252,29 +419,51 @@ DISPU_EXPORT int dispu_approx_match(int b, int n, int m, const float* xyz1, cons
     return run_approx_match<false, false>(b, n, m, xyz1, xyz2, match, temp, s);
 }
 
+DISPU_EXPORT size_t dispu_match_cost_scratch_bytes(int b, int n, int m) {
+    if (b <= 0 || n <= 0 || m <= 0) return 0;
+    const int ch = mc_chunk(b, n, m);
+    const size_t rb = (n + AM_ROWS - 1) / AM_ROWS, nc = (m + ch - 1) / ch;
+    return sizeof(float) * (size_t)b * rb * nc;
+}
+
 DISPU_EXPORT int dispu_match_cost(int b, int n, int m, const float* xyz1, const float* xyz2, const float* match,
-                                  float* cost, int arith, void* stream) {
-    if (b < 0 || n <= 0 || m <= 0) return (int)hipErrorInvalidValue;
+                                  float* cost, float* scratch, int arith, void* stream) {
+    if (b < 0 || n <= 0 || m <= 0 || !scratch) return (int)hipErrorInvalidValue;
     if (b == 0) return 0;
+    if (b > 65535) return (int)hipErrorInvalidValue;
+    hipStream_t s = (hipStream_t)stream;
+    const int ch = mc_chunk(b, n, m);
+    const dim3 grid((n + AM_ROWS - 1) / AM_ROWS, (m + ch - 1) / ch, b);
     if ((arith & DISPU_ARITH_CONTRACT))
-        hipLaunchKernelGGL((match_cost_kernel<true>), dim3(b), dim3(1024), 0, (hipStream_t)stream, n, m, xyz1, xyz2, match, cost);
+        hipLaunchKernelGGL((match_cost_tile_kernel<true>), grid, dim3(AM_ROWS), 0, s, n, m, ch, xyz1, xyz2, match, scratch);
     else
-        hipLaunchKernelGGL((match_cost_kernel<false>), dim3(b), dim3(1024), 0, (hipStream_t)stream, n, m, xyz1, xyz2, match, cost);
+        hipLaunchKernelGGL((match_cost_tile_kernel<false>), grid, dim3(AM_ROWS), 0, s, n, m, ch, xyz1, xyz2, match, scratch);
+    hipLaunchKernelGGL(match_cost_final_kernel, dim3(b), dim3(256), 0, s, (int)(grid.x * grid.y), scratch, cost);
     return (int)hipGetLastError();
 }
 
+DISPU_EXPORT size_t dispu_match_cost_grad_scratch_bytes(int b, int n, int m) {
+    if (b <= 0 || n <= 0 || m <= 0) return 0;
+    const int ch = mc_chunk(b, n, m);
+    return sizeof(float) * (size_t)b * ((m + ch - 1) / ch) * (size_t)n * 3;
+}
+
 DISPU_EXPORT int dispu_match_cost_grad(int b, int n, int m, const float* xyz1, const float* xyz2, const float* match,
-                                       float* grad1, float* grad2, int arith, void* stream) {
-    if (b < 0 || n <= 0 || m <= 0) return (int)hipErrorInvalidValue;
+                                       float* grad1, float* grad2, float* scratch, int arith, void* stream) {
+    if (b < 0 || n <= 0 || m <= 0 || !scratch) return (int)hipErrorInvalidValue;
     if (b == 0) return 0;
+    if (b > 65535) return (int)hipErrorInvalidValue;
     hipStream_t s = (hipStream_t)stream;
-    dim3 g1((n + AM_BS - 1) / AM_BS, b), g2((m + AM_BS / kWave - 1) / (AM_BS / kWave), b);
+    const int ch = mc_chunk(b, n, m);
+    const int nc = (m + ch - 1) / ch;
+    const dim3 g1((n + AM_ROWS - 1) / AM_ROWS, nc, b), g2((m + 3) / 4, b), gc((n * 3 + 255) / 256, b);
     if ((arith & DISPU_ARITH_CONTRACT)) {
-        hipLaunchKernelGGL((match_cost_grad_kernel<1, true>), g1, dim3(AM_BS), 0, s, n, m, xyz1, xyz2, match, grad1);
-        hipLaunchKernelGGL((match_cost_grad_kernel<2, true>), g2, dim3(AM_BS), 0, s, n, m, xyz1, xyz2, match, grad2);
+        hipLaunchKernelGGL((match_grad1_tile_kernel<true>), g1, dim3(AM_ROWS), 0, s, n, m, ch, xyz1, xyz2, match, scratch);
+        hipLaunchKernelGGL((match_grad2_kernel<true>), g2, dim3(256), 0, s, n, m, xyz1, xyz2, match, grad2);
     } else {
-        hipLaunchKernelGGL((match_cost_grad_kernel<1, false>), g1, dim3(AM_BS), 0, s, n, m, xyz1, xyz2, match, grad1);
-        hipLaunchKernelGGL((match_cost_grad_kernel<2, false>), g2, dim3(AM_BS), 0, s, n, m, xyz1, xyz2, match, grad2);
+        hipLaunchKernelGGL((match_grad1_tile_kernel<false>), g1, dim3(AM_ROWS), 0, s, n, m, ch, xyz1, xyz2, match, scratch);
+        hipLaunchKernelGGL((match_grad2_kernel<false>), g2, dim3(256), 0, s, n, m, xyz1, xyz2, match, grad2);
     }
+    hipLaunchKernelGGL(match_grad1_combine_kernel, gc, dim3(256), 0, s, n, nc, scratch, grad1);
     return (int)hipGetLastError();
 }

@@ -117,6 +117,20 @@ __device__ __forceinline__ void mfma_acc_settle() {   // >= 18 wait states betwe
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
 }
 
+// 16-byte non-temporal store (global_store_dwordx4 ... nt): streamed outputs that are not re-read by the kernel
+typedef float dispu_f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store_nt4(float* dst, float4 v) {
+    __builtin_nontemporal_store(dispu_f32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<dispu_f32x4*>(dst));
+}
+
+// Workgroup ids are dealt round-robin to the 8 XCDs (each with its own L2).  xcd_block() turns the hardware id into a
+// logical block index such that every XCD works on ONE contiguous range of logical blocks: blocks that gather from
+// the same cloud then share an L2 instead of pulling the cloud's rows into all eight.
+__device__ __forceinline__ unsigned xcd_block(unsigned bid, unsigned grid) {
+    const unsigned per = grid >> 3;
+    return (grid & 7u) ? bid : (bid & 7u) * per + (bid >> 3);
+}
+
 __device__ __forceinline__ float wave_sum_f32(float v) {
     // butterfly; order fixed (xor 32,16,8,4,2,1) so the result is deterministic
 #pragma unroll

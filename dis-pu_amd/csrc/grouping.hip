@@ -116,25 +116,84 @@ static void launch_query_ball_wave(int b, int n, int m, const float* radius, int
         hipLaunchKernelGGL((query_ball_wave_kernel<R, false>), grid, dim3(256), 0, st, n, m, qpb, radius, nsample, xyz1, xyz2, idx, pts_cnt);
 }
 
-// Flat gather: element e of out[b,m,ns,c] <- points[cloud, idx[row], e % c].  VEC = floats per lane.
-// Gather rows: out[row, :] = points[cloud(row), idx[row], :].  TX lanes (a power of two) share one output row and
-// stride over its c/VEC vectors; a workgroup covers 256/TX consecutive rows, so every wave writes whole contiguous
-// rows (coalesced) and the index / cloud arithmetic is done once per row in 32-bit (no per-element 64-bit division).
-template <int VEC>
-__global__ __launch_bounds__(256) void group_point_kernel(int n, int c, int rows_per_cloud, long rows, int tx_log2,
-                                                          const float* __restrict__ points, const int* __restrict__ idx,
-                                                          float* __restrict__ out) {
-    const int TX = 1 << tx_log2;
-    const int tx = threadIdx.x & (TX - 1);
-    const int rpb = 256 >> tx_log2;                         // rows per workgroup pass
+// Gather rows: out[row, :] = points[cloud(row), idx[row], :]  -- a pure copy, HBM-bound (the one family where
+// >= 60 % of the HBM peak is the right target).  TX lanes (a power of two) form a row SLOT and stride over the row's
+// c/VEC vectors; a workgroup has 256/TX slots and every slot copies R rows per launch: the R index loads are issued
+// together, then R x (c / VEC / TX) independent 16-byte loads per lane are in flight before the first store (round 1 had
+// ONE load in flight per lane behind a dependent index load: 46 % of HBM at c = 256).  At a fixed r the slots cover
+// consecutive rows, so every store instruction of a wave writes one contiguous segment; stores are non-temporal (the
+// output is written once and never re-read here) so they do not evict the gathered rows from L2, and workgroup ids are
+// re-mapped so each XCD copies one contiguous range of rows (= the same few clouds share one L2).
+template <int VEC, int R>
+__global__ __launch_bounds__(256) void group_rows_kernel(int n, int c, unsigned rows_per_cloud, unsigned rows, int tx_log2,
+                                                         const float* __restrict__ points, const int* __restrict__ idx,
+                                                         float* __restrict__ out) {
+    const unsigned TX = 1u << tx_log2, tx = threadIdx.x & (TX - 1), slot = threadIdx.x >> tx_log2, slots = 256u >> tx_log2;
+    const unsigned base = xcd_block(blockIdx.x, gridDim.x) * (slots * R) + slot;
     const int cv = c / VEC;
-    for (long row = (long)blockIdx.x * rpb + (threadIdx.x >> tx_log2); row < rows; row += (long)gridDim.x * rpb) {
-        const long cloud = row / rows_per_cloud;
-        const float* __restrict__ src = points + (cloud * n + idx[row]) * c;
-        float* __restrict__ dst = out + row * c;
-        for (int l = tx; l < cv; l += TX) {
-            if constexpr (VEC == 4) reinterpret_cast<float4*>(dst)[l] = reinterpret_cast<const float4*>(src)[l];
-            else dst[l] = src[l];
+    const float* src[R];
+    bool ok[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const unsigned row = base + r * slots;
+        ok[r] = row < rows;
+        const unsigned rr = ok[r] ? row : 0u;
+        src[r] = points + ((size_t)(rr / rows_per_cloud) * n + idx[rr]) * c;
+    }
+    for (int l = tx; l < cv; l += TX) {
+        if constexpr (VEC == 4) {
+            float4 v[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) v[r] = reinterpret_cast<const float4*>(src[r])[l];
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                if (ok[r]) store_nt4(out + (size_t)(base + r * slots) * c + 4 * l, v[r]);
+        } else {
+            float v[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) v[r] = src[r][l];
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                if (ok[r]) __builtin_nontemporal_store(v[r], out + (size_t)(base + r * slots) * c + l);
+        }
+    }
+}
+
+// c == 3 (xyz rows: gather_point, and group_point on coordinates): a lane owns R rows -- index load, one 12-byte load
+// each -- and the 256 x 3 floats of a pass leave through LDS as 192 coalesced float4 stores instead of 768 scattered
+// 4-byte ones.
+template <int R>
+__global__ __launch_bounds__(256) void gather_xyz_kernel(int n, unsigned rows_per_cloud, unsigned rows, const float* __restrict__ inp,
+                                                         const int* __restrict__ idx, float* __restrict__ out) {
+    __shared__ float stage[R][768];
+    const unsigned base = xcd_block(blockIdx.x, gridDim.x) * (256u * R);
+    float vx[R], vy[R], vz[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const unsigned row = base + r * 256 + threadIdx.x;
+        const unsigned rr = row < rows ? row : 0u;
+        const float* s = inp + ((size_t)(rr / rows_per_cloud) * n + idx[rr]) * 3;
+        vx[r] = s[0]; vy[r] = s[1]; vz[r] = s[2];
+    }
+    const bool full = base + 256u * R <= rows && ((uintptr_t)out % 16 == 0);
+    if (full) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            stage[r][threadIdx.x * 3 + 0] = vx[r]; stage[r][threadIdx.x * 3 + 1] = vy[r]; stage[r][threadIdx.x * 3 + 2] = vz[r];
+        }
+        __syncthreads();
+        if (threadIdx.x < 192) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const float4 v = reinterpret_cast<const float4*>(stage[r])[threadIdx.x];
+                store_nt4(out + (size_t)(base + r * 256) * 3 + 4 * threadIdx.x, v);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const unsigned row = base + r * 256 + threadIdx.x;
+            if (row < rows) { float* d = out + (size_t)row * 3; d[0] = vx[r]; d[1] = vy[r]; d[2] = vz[r]; }
         }
     }
 }
@@ -184,25 +243,38 @@ DISPU_EXPORT int dispu_query_ball(int b, int n, int m, const float* radius, int 
     return (int)hipGetLastError();
 }
 
-DISPU_EXPORT int dispu_group_point(int b, int n, int c, int m, int nsample, const float* points, const int* idx,
-                                   float* out, void* stream) {
-    if (b < 0 || n <= 0 || c <= 0 || m < 0 || nsample < 0) return (int)hipErrorInvalidValue;
-    const size_t rows = (size_t)b * m * nsample;
+namespace dispu {
+// rows x c gather shared by dispu_group_point and dispu_gather_point (csrc/sampling.hip)
+int launch_gather_rows(size_t rows, int n, int c, size_t rows_per_cloud, const float* points, const int* idx, float* out,
+                       hipStream_t st) {
     if (rows == 0) return 0;
+    if (rows >= 0x7fffffffull || rows_per_cloud >= 0x7fffffffull) return (int)hipErrorInvalidValue;   // 32-bit row arithmetic
+    const unsigned rws = (unsigned)rows, rpc = (unsigned)rows_per_cloud;
+    if (c == 3) {
+        constexpr int R = 4;
+        const unsigned g = (rws + 256 * R - 1) / (256 * R);
+        hipLaunchKernelGGL((gather_xyz_kernel<R>), dim3(g), dim3(256), 0, st, n, rpc, rws, points, idx, out);
+        return (int)hipGetLastError();
+    }
     const bool vec4 = (c % 4 == 0) && (((uintptr_t)points | (uintptr_t)out) % 16 == 0);
     const int cv = vec4 ? c / 4 : c;
     int tx_log2 = 0;
     while ((1 << tx_log2) < cv && tx_log2 < 6) ++tx_log2;           // lanes per row: next power of two >= cv, at most 64
-    const size_t rpb = (size_t)256 >> tx_log2;
-    size_t g = (rows + rpb - 1) / rpb;
-    if (g > 65536) g = 65536;
+    const unsigned slots = 256u >> tx_log2;
+    constexpr int R = 8;
+    const unsigned g = (rws + slots * R - 1) / (slots * R);
     if (vec4)
-        hipLaunchKernelGGL((group_point_kernel<4>), dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, n, c, m * nsample,
-                           (long)rows, tx_log2, points, idx, out);
+        hipLaunchKernelGGL((group_rows_kernel<4, R>), dim3(g), dim3(256), 0, st, n, c, rpc, rws, tx_log2, points, idx, out);
     else
-        hipLaunchKernelGGL((group_point_kernel<1>), dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, n, c, m * nsample,
-                           (long)rows, tx_log2, points, idx, out);
+        hipLaunchKernelGGL((group_rows_kernel<1, R>), dim3(g), dim3(256), 0, st, n, c, rpc, rws, tx_log2, points, idx, out);
     return (int)hipGetLastError();
+}
+}  // namespace dispu
+
+DISPU_EXPORT int dispu_group_point(int b, int n, int c, int m, int nsample, const float* points, const int* idx,
+                                   float* out, void* stream) {
+    if (b < 0 || n <= 0 || c <= 0 || m < 0 || nsample < 0) return (int)hipErrorInvalidValue;
+    return launch_gather_rows((size_t)b * m * nsample, n, c, (size_t)m * nsample, points, idx, out, (hipStream_t)stream);
 }
 
 DISPU_EXPORT int dispu_group_point_grad(int b, int n, int c, int m, int nsample, const float* grad_out, const int* idx,

@@ -48,19 +48,60 @@ __global__ __launch_bounds__(NN3_BS) void three_nn_kernel(int n, int m, const fl
     }
 }
 
-// out[b,j,l] = (p[i1,l]*w1 + p[i2,l]*w2) + p[i3,l]*w3   (left to right, every op rounded)
-__global__ void three_interpolate_kernel(int m, int c, int n, size_t total, const float* __restrict__ points,
-                                         const int* __restrict__ idx, const float* __restrict__ weight,
-                                         float* __restrict__ out) {
-    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
-        const size_t row = e / c;
-        const int l = (int)(e - row * c);
-        const size_t cloud = row / n;
-        const int* id = idx + row * 3;
-        const float* w = weight + row * 3;
-        const float* base = points + cloud * m * c + l;
-        const float s = base[(size_t)id[0] * c] * w[0] + base[(size_t)id[1] * c] * w[1];
-        out[e] = s + base[(size_t)id[2] * c] * w[2];
+// out[b,j,l] = (p[i1,l]*w1 + p[i2,l]*w2) + p[i3,l]*w3   (left to right, every op rounded: threeinterpolate_cpu,
+// tf_interpolate.cpp:106-127).  HBM-bound.  Same slot scheme as group_rows_kernel (csrc/grouping.hip): TX lanes
+// own an output row and stride over its c/VEC vectors, R rows per slot, so 3 R independent gathers per lane are in flight;
+// the row's three indices and weights are loaded once per slot lane instead of once per element; non-temporal float4
+// stores; XCD-contiguous row ranges.
+template <int VEC, int R>
+__global__ __launch_bounds__(256) void three_interpolate_rows_kernel(int m, int c, unsigned n, unsigned rows, int tx_log2,
+                                                                     const float* __restrict__ points, const int* __restrict__ idx,
+                                                                     const float* __restrict__ weight, float* __restrict__ out) {
+    const unsigned TX = 1u << tx_log2, tx = threadIdx.x & (TX - 1), slot = threadIdx.x >> tx_log2, slots = 256u >> tx_log2;
+    const unsigned base = xcd_block(blockIdx.x, gridDim.x) * (slots * R) + slot;
+    const int cv = c / VEC;
+    const float *s0[R], *s1[R], *s2[R];
+    float w0[R], w1[R], w2[R];
+    bool ok[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const unsigned row = base + r * slots;
+        ok[r] = row < rows;
+        const unsigned rr = ok[r] ? row : 0u;
+        const int* id = idx + (size_t)rr * 3;
+        const float* w = weight + (size_t)rr * 3;
+        const float* cloud = points + (size_t)(rr / n) * m * c;
+        s0[r] = cloud + (size_t)id[0] * c; s1[r] = cloud + (size_t)id[1] * c; s2[r] = cloud + (size_t)id[2] * c;
+        w0[r] = w[0]; w1[r] = w[1]; w2[r] = w[2];
+    }
+    for (int l = tx; l < cv; l += TX) {
+        if constexpr (VEC == 4) {
+            float4 a[R], b[R], d[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                a[r] = reinterpret_cast<const float4*>(s0[r])[l];
+                b[r] = reinterpret_cast<const float4*>(s1[r])[l];
+                d[r] = reinterpret_cast<const float4*>(s2[r])[l];
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                float4 o;
+                o.x = (a[r].x * w0[r] + b[r].x * w1[r]) + d[r].x * w2[r];
+                o.y = (a[r].y * w0[r] + b[r].y * w1[r]) + d[r].y * w2[r];
+                o.z = (a[r].z * w0[r] + b[r].z * w1[r]) + d[r].z * w2[r];
+                o.w = (a[r].w * w0[r] + b[r].w * w1[r]) + d[r].w * w2[r];
+                if (ok[r]) store_nt4(out + (size_t)(base + r * slots) * c + 4 * l, o);
+            }
+        } else {
+            float a[R], b[R], d[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) { a[r] = s0[r][l]; b[r] = s1[r][l]; d[r] = s2[r][l]; }
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const float o = (a[r] * w0[r] + b[r] * w1[r]) + d[r] * w2[r];
+                if (ok[r]) __builtin_nontemporal_store(o, out + (size_t)(base + r * slots) * c + l);
+            }
+        }
     }
 }
 
@@ -107,10 +148,22 @@ DISPU_EXPORT int dispu_three_nn(int b, int n, int m, const float* xyz1, const fl
 DISPU_EXPORT int dispu_three_interpolate(int b, int m, int c, int n, const float* points, const int* idx,
                                          const float* weight, float* out, void* stream) {
     if (b < 0 || n < 0 || m <= 0 || c <= 0) return (int)hipErrorInvalidValue;
-    const size_t total = (size_t)b * n * c;
-    if (total == 0) return 0;
-    hipLaunchKernelGGL(three_interpolate_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, m, c, n,
-                       total, points, idx, weight, out);
+    const size_t rows = (size_t)b * n;
+    if (rows == 0) return 0;
+    if (rows >= 0x7fffffffull) return (int)hipErrorInvalidValue;            // 32-bit row arithmetic
+    const bool vec4 = (c % 4 == 0) && (((uintptr_t)points | (uintptr_t)out) % 16 == 0);
+    const int cv = vec4 ? c / 4 : c;
+    int tx_log2 = 0;
+    while ((1 << tx_log2) < cv && tx_log2 < 6) ++tx_log2;
+    const unsigned slots = 256u >> tx_log2;
+    constexpr int R = 4;
+    const unsigned g = ((unsigned)rows + slots * R - 1) / (slots * R);
+    if (vec4)
+        hipLaunchKernelGGL((three_interpolate_rows_kernel<4, R>), dim3(g), dim3(256), 0, (hipStream_t)stream, m, c, (unsigned)n,
+                           (unsigned)rows, tx_log2, points, idx, weight, out);
+    else
+        hipLaunchKernelGGL((three_interpolate_rows_kernel<1, R>), dim3(g), dim3(256), 0, (hipStream_t)stream, m, c, (unsigned)n,
+                           (unsigned)rows, tx_log2, points, idx, weight, out);
     return (int)hipGetLastError();
 }
 

@@ -151,17 +151,10 @@ static int launch_fps_reg(int b, int n, int m, const float* xyz, int* out, int a
     return (int)hipGetLastError();
 }
 
-// out[i,j,:] = inp[i, idx[i,j], :]   (c == 3, like the reference kernel tf_sampling_g.cu:172-181)
-__global__ void gather_point_kernel(int n, int m, size_t total, const float* __restrict__ inp,
-                                    const int* __restrict__ idx, float* __restrict__ out) {
-    for (size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x; r < total; r += (size_t)gridDim.x * blockDim.x) {
-        const size_t cloud = r / m;
-        const float* src = inp + (cloud * n + idx[r]) * 3;
-        const float a = src[0], b = src[1], c = src[2];
-        float* dst = out + r * 3;
-        dst[0] = a; dst[1] = b; dst[2] = c;
-    }
-}
+// out[i,j,:] = inp[i, idx[i,j], :]   (c == 3, like the reference kernel tf_sampling_g.cu:172-181): gather_xyz_kernel of
+// csrc/grouping.hip (12-byte loads per lane, LDS-staged float4 stores).
+int launch_gather_rows(size_t rows, int n, int c, size_t rows_per_cloud, const float* points, const int* idx, float* out,
+                       hipStream_t st);
 
 // inp_g[i, idx[i,j], :] += out_g[i,j,:]  on a zero-filled buffer (tf_sampling_g.cu:183-192, tf_sampling.cpp:174)
 __global__ void gather_point_grad_kernel(int n, int m, size_t total, const float* __restrict__ out_g,
@@ -216,11 +209,7 @@ static inline int grid_for(size_t total, int bs) {
 
 DISPU_EXPORT int dispu_gather_point(int b, int n, int m, const float* inp, const int* idx, float* out, void* stream) {
     if (b < 0 || n <= 0 || m < 0) return (int)hipErrorInvalidValue;
-    const size_t total = (size_t)b * m;
-    if (total == 0) return 0;
-    hipLaunchKernelGGL(gather_point_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, n, m, total,
-                       inp, idx, out);
-    return (int)hipGetLastError();
+    return launch_gather_rows((size_t)b * m, n, 3, (size_t)m, inp, idx, out, (hipStream_t)stream);
 }
 
 DISPU_EXPORT int dispu_gather_point_grad(int b, int n, int m, const float* out_g, const int* idx, float* inp_g,

@@ -32,8 +32,10 @@ def match_cost_grad(xyz1, xyz2, match, arith=_lib.ARITH_CONTRACT):
     req(tuple(match.shape) == (b, m, n), "MatchCost expects (batch_size,#query,#dataset) match shape")
     g1 = torch.empty((b, n, 3), dtype=torch.float32, device=xyz1.device)
     g2 = torch.empty((b, m, 3), dtype=torch.float32, device=xyz1.device)
-    _lib.check(_lib.lib().dispu_match_cost_grad(b, n, m, _lib.ptr(xyz1), _lib.ptr(xyz2), _lib.ptr(match), _lib.ptr(g1),
-                                                _lib.ptr(g2), int(arith), _lib.stream_ptr(xyz1.device)), "dispu_match_cost_grad")
+    L = _lib.lib()
+    scratch = torch.empty((max(L.dispu_match_cost_grad_scratch_bytes(b, n, m) // 4, 1),), dtype=torch.float32, device=xyz1.device)
+    _lib.check(L.dispu_match_cost_grad(b, n, m, _lib.ptr(xyz1), _lib.ptr(xyz2), _lib.ptr(match), _lib.ptr(g1), _lib.ptr(g2),
+                                       _lib.ptr(scratch), int(arith), _lib.stream_ptr(xyz1.device)), "dispu_match_cost_grad")
     return g1, g2
 
 
@@ -43,8 +45,10 @@ class _MatchCost(torch.autograd.Function):
         b, n, _ = xyz1.shape
         m = xyz2.shape[1]
         cost = torch.empty((b,), dtype=torch.float32, device=xyz1.device)
-        _lib.check(_lib.lib().dispu_match_cost(b, n, m, _lib.ptr(xyz1), _lib.ptr(xyz2), _lib.ptr(match), _lib.ptr(cost),
-                                               int(arith), _lib.stream_ptr(xyz1.device)), "dispu_match_cost")
+        L = _lib.lib()
+        scratch = torch.empty((max(L.dispu_match_cost_scratch_bytes(b, n, m) // 4, 1),), dtype=torch.float32, device=xyz1.device)
+        _lib.check(L.dispu_match_cost(b, n, m, _lib.ptr(xyz1), _lib.ptr(xyz2), _lib.ptr(match), _lib.ptr(cost), _lib.ptr(scratch),
+                                      int(arith), _lib.stream_ptr(xyz1.device)), "dispu_match_cost")
         ctx.save_for_backward(xyz1, xyz2, match)
         ctx.arith = arith
         return cost

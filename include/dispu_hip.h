@@ -129,16 +129,22 @@ int dispu_nn_distance_grad(int b, int n, const float* xyz1, int m, const float* 
 /* ---- tf_ops/approxmatch --------------------------------------------------------------------- */
 
 /* approxmatchLauncher(b,n,m,xyz1,xyz2,match,temp)   tf_ops/approxmatch/tf_approxmatch.cpp:141,164-170;
- * kernel tf_approxmatch_g.cu:1-182.  match [b,m,n]; temp [b, 2*(n+m)] floats. */
+ * kernel tf_approxmatch_g.cu:1-182.  match [b,m,n].  `temp`: dispu_approx_match_scratch_bytes(b,n,m) bytes (the reference's
+ * temp is [b, 2*(n+m)] floats; here it also holds the per-level ratio vectors and the per-chunk partial sums of the 2-D
+ * tiled passes).  Sums are associated in chunks of 128 partners (csrc/approxmatch.hip; oracle chunk = 128). */
 size_t dispu_approx_match_scratch_bytes(int b, int n, int m);
 int dispu_approx_match(int b, int n, int m, const float* xyz1, const float* xyz2, float* match, float* temp, int arith,
                        void* stream);
-/* matchcostLauncher(b,n,m,xyz1,xyz2,match,out)   tf_approxmatch.cpp:142; kernel tf_approxmatch_g.cu:183-228. */
+/* matchcostLauncher(b,n,m,xyz1,xyz2,match,out)   tf_approxmatch.cpp:142; kernel tf_approxmatch_g.cu:183-228.
+ * `scratch`: dispu_match_cost_scratch_bytes(b,n,m) bytes (one partial per (256 x 128) tile of `match`). */
+size_t dispu_match_cost_scratch_bytes(int b, int n, int m);
 int dispu_match_cost(int b, int n, int m, const float* xyz1, const float* xyz2, const float* match, float* cost,
-                     int arith, void* stream);
-/* matchcostgradLauncher(b,n,m,xyz1,xyz2,match,grad1,grad2)   tf_approxmatch.cpp:143; kernels :229-295. */
+                     float* scratch, int arith, void* stream);
+/* matchcostgradLauncher(b,n,m,xyz1,xyz2,match,grad1,grad2)   tf_approxmatch.cpp:143; kernels :229-295.
+ * `scratch`: dispu_match_cost_grad_scratch_bytes(b,n,m) bytes (grad1 partials per chunk of 128 cloud-2 points). */
+size_t dispu_match_cost_grad_scratch_bytes(int b, int n, int m);
 int dispu_match_cost_grad(int b, int n, int m, const float* xyz1, const float* xyz2, const float* match, float* grad1,
-                          float* grad2, int arith, void* stream);
+                          float* grad2, float* scratch, int arith, void* stream);
 
 /* ---- per-point MLP stacks (Common/tf_util.py conv1d/conv2d 1x1, Common/ops.py blocks) --------------
  * The reference builds these from TensorFlow core ops (conv2d -> bias_add -> relu, matmul, softmax,

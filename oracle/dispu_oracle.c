@@ -445,10 +445,18 @@ ORC_API void orc_nn_distance_grad(int b, int n, int m, const float *xyz1, const 
  * bit-reproducible pinned_exp above (pinned = 1; bit-exact against the HIP library in the same mode).  d2 here is the
  * (x2-x1) form; the products level*d2 and exp*weight are plain multiplies, the running sums
  * are fused (suml += w with w a product -> fma) only in contract mode. */
-ORC_API void orc_approx_match(int b, int n, int m, const float *xyz1, const float *xyz2, float *match,
-                              int contract, int pinned) {
+/* `chunk` selects the association of the three running sums.  chunk <= 0: one sequential chain per point, the
+ * reference kernel's order (a thread adds its m or n terms one after the other).  chunk = C > 0: the chain is cut into
+ * consecutive pieces of C partners, each piece summed sequentially from 0, and the pieces are added in ascending
+ * order (to 1e-9f for pass 1, to the first piece for passes 2 and 3).  This is the order of the MI355X kernels
+ * (csrc/approxmatch.hip: one workgroup per (256 points) x (C partners) tile, AM_CH = 128), which lets one cloud
+ * fill the chip; it differs from the sequential chain by reassociation only (tests bound the difference). */
+ORC_API void orc_approx_match_chunked(int b, int n, int m, const float *xyz1, const float *xyz2, float *match,
+                                      int contract, int pinned, int chunk) {
     const float multiL = (n >= m) ? 1.0f : (float)(m / n);
     const float multiR = (n >= m) ? (float)(n / m) : 1.0f;
+    const int seq = chunk <= 0;                 /* sequential: pass 1's chain starts at 1e-9f, as the reference's does */
+    if (seq) chunk = (n > m ? n : m);
 #pragma omp parallel for schedule(dynamic)
     for (int i = 0; i < b; ++i) {
         const float *p1 = xyz1 + (size_t)i * n * 3;
@@ -465,20 +473,30 @@ ORC_API void orc_approx_match(int b, int n, int m, const float *xyz1, const floa
             for (int k = 0; k < n; ++k) {
                 const float x1 = p1[k * 3], y1 = p1[k * 3 + 1], z1 = p1[k * 3 + 2];
                 float suml = 1e-9f;
-                for (int l = 0; l < m; ++l) {
-                    const float d2 = sqdist3(p2[l * 3] - x1, p2[l * 3 + 1] - y1, p2[l * 3 + 2] - z1, contract);
-                    const float e = ORC_EXP(level * d2);
-                    suml = contract ? fmaf(e, remainR[l], suml) : suml + e * remainR[l];
+                for (int l0 = 0; l0 < m; l0 += chunk) {
+                    const int lend = l0 + chunk < m ? l0 + chunk : m;
+                    float s = seq ? 1e-9f : 0.0f;
+                    for (int l = l0; l < lend; ++l) {
+                        const float d2 = sqdist3(p2[l * 3] - x1, p2[l * 3 + 1] - y1, p2[l * 3 + 2] - z1, contract);
+                        const float e = ORC_EXP(level * d2);
+                        s = contract ? fmaf(e, remainR[l], s) : s + e * remainR[l];
+                    }
+                    suml = seq ? s : suml + s;
                 }
                 ratioL[k] = remainL[k] / suml;
             }
             for (int l = 0; l < m; ++l) {
                 const float x2 = p2[l * 3], y2 = p2[l * 3 + 1], z2 = p2[l * 3 + 2];
                 float sumr = 0.0f;
-                for (int k = 0; k < n; ++k) {
-                    const float d2 = sqdist3(x2 - p1[k * 3], y2 - p1[k * 3 + 1], z2 - p1[k * 3 + 2], contract);
-                    const float e = ORC_EXP(level * d2);
-                    sumr = contract ? fmaf(e, ratioL[k], sumr) : sumr + e * ratioL[k];
+                for (int k0 = 0; k0 < n; k0 += chunk) {
+                    const int kend = k0 + chunk < n ? k0 + chunk : n;
+                    float s = 0.0f;
+                    for (int k = k0; k < kend; ++k) {
+                        const float d2 = sqdist3(x2 - p1[k * 3], y2 - p1[k * 3 + 1], z2 - p1[k * 3 + 2], contract);
+                        const float e = ORC_EXP(level * d2);
+                        s = contract ? fmaf(e, ratioL[k], s) : s + e * ratioL[k];
+                    }
+                    sumr = (k0 == 0) ? s : sumr + s;
                 }
                 sumr *= remainR[l];
                 const float consumption = fminf(remainR[l] / (sumr + 1e-9f), 1.0f);
@@ -489,17 +507,27 @@ ORC_API void orc_approx_match(int b, int n, int m, const float *xyz1, const floa
                 const float x1 = p1[k * 3], y1 = p1[k * 3 + 1], z1 = p1[k * 3 + 2];
                 const float rl = ratioL[k];
                 float suml = 0.0f;
-                for (int l = 0; l < m; ++l) {
-                    const float d2 = sqdist3(p2[l * 3] - x1, p2[l * 3 + 1] - y1, p2[l * 3 + 2] - z1, contract);
-                    const float w = ORC_EXP(level * d2) * rl * ratioR[l];
-                    mt[(size_t)l * n + k] += w;
-                    suml += w;
+                for (int l0 = 0; l0 < m; l0 += chunk) {
+                    const int lend = l0 + chunk < m ? l0 + chunk : m;
+                    float s = 0.0f;
+                    for (int l = l0; l < lend; ++l) {
+                        const float d2 = sqdist3(p2[l * 3] - x1, p2[l * 3 + 1] - y1, p2[l * 3 + 2] - z1, contract);
+                        const float w = ORC_EXP(level * d2) * rl * ratioR[l];
+                        mt[(size_t)l * n + k] += w;
+                        s += w;
+                    }
+                    suml = (l0 == 0) ? s : suml + s;
                 }
                 remainL[k] = fmaxf(0.0f, remainL[k] - suml);
             }
         }
         free(remainL); free(ratioL); free(remainR); free(ratioR);
     }
+}
+
+ORC_API void orc_approx_match(int b, int n, int m, const float *xyz1, const float *xyz2, float *match,
+                              int contract, int pinned) {
+    orc_approx_match_chunked(b, n, m, xyz1, xyz2, match, contract, pinned, 0);     /* the reference's sequential order */
 }
 
 /* A12  match_cost.  matchcost tf_approxmatch_g.cu:183-225: thread t (of BS = 512, :227) sums

@@ -202,12 +202,17 @@ def nn_distance_grad(xyz1, xyz2, grad_dist1, idx1, grad_dist2, idx2):
 
 
 # ---- A11/A12 approxmatch (tf_ops/approxmatch/tf_approxmatch.py:13-51) ----------------------------
-def approx_match(xyz1, xyz2, contract=1, pinned_exp=False):
+AM_CHUNK = 128      # csrc/approxmatch.hip AM_CH: partners per partial sum of the MI355X kernels
+
+
+def approx_match(xyz1, xyz2, contract=1, pinned_exp=False, chunk=0):
+    """chunk = 0: the reference kernel's sequential summation order; chunk = AM_CHUNK: the MI355X kernels' order
+    (partial sums over consecutive pieces of `chunk` partners, added in ascending order)."""
     xyz1, xyz2 = _f(xyz1), _f(xyz2)
     b, n, _ = xyz1.shape
     m = xyz2.shape[1]
     match = np.empty((b, m, n), np.float32)
-    lib().orc_approx_match(b, n, m, _p(xyz1), _p(xyz2), _p(match), int(contract), int(bool(pinned_exp)))
+    lib().orc_approx_match_chunked(b, n, m, _p(xyz1), _p(xyz2), _p(match), int(contract), int(bool(pinned_exp)), int(chunk))
     return match
 
 

@@ -257,14 +257,20 @@ def test_nn_distance_grad_and_autograd(ops, dev):
     assert np.allclose(N(t1.grad), want[0], atol=1e-5) and np.allclose(N(t2.grad), want[1], atol=1e-5)
 
 
-@pytest.mark.parametrize("b,n,m", [(2, 256, 256), (1, 1024, 1024), (2, 100, 300), (2, 300, 100), (1, 1100, 1030)])
+@pytest.mark.parametrize("b,n,m", [(2, 256, 256), (1, 1024, 1024), (2, 100, 300), (2, 300, 100), (1, 1100, 1030), (3, 1, 5), (2, 129, 127),
+                                   (1, 2048, 512)])
 def test_approx_match_and_cost(ops, dev, b, n, m):
-    x1, x2 = synth_patches(b, n, seed=n), synth_patches(b, m, seed=m + 1)
-    # parity mode: pinned exp on both sides -> the whole auction is bit-reproducible
+    if min(n, m) < 8:                 # the patch synthesiser normalises by the max radius: undefined for a single point
+        rng = np.random.default_rng(n * 1000 + m)
+        x1, x2 = rng.random((b, n, 3), dtype=np.float32), rng.random((b, m, 3), dtype=np.float32)
+    else:
+        x1, x2 = synth_patches(b, n, seed=n), synth_patches(b, m, seed=m + 1)
+    # parity mode: pinned exp on both sides and the kernels' summation order (partial sums per 128 partners, added in
+    # ascending order: oracle chunk = AM_CHUNK) -> the whole auction is bit-reproducible
     mp = ops["A"].approx_match(T(x1, dev), T(x2, dev), arith=CONTRACT | PINNED_EXP)
-    assert np.array_equal(N(mp), O.approx_match(x1, x2, contract=1, pinned_exp=True))
+    assert np.array_equal(N(mp), O.approx_match(x1, x2, contract=1, pinned_exp=True, chunk=O.AM_CHUNK))
     mp0 = ops["A"].approx_match(T(x1, dev), T(x2, dev), arith=PLAIN | PINNED_EXP)
-    assert np.array_equal(N(mp0), O.approx_match(x1, x2, contract=0, pinned_exp=True))
+    assert np.array_equal(N(mp0), O.approx_match(x1, x2, contract=0, pinned_exp=True, chunk=O.AM_CHUNK))
     # production mode: hardware exp (like the reference's __expf) vs libm expf in the oracle
     match = ops["A"].approx_match(T(x1, dev), T(x2, dev))
     mo = O.approx_match(x1, x2)

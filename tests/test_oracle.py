@@ -153,3 +153,22 @@ def test_edge_shapes():
     assert O.knn_batch(x, x, 2)[0].tolist() == [[0, 1], [1, 0]]
     assert O.farthest_point_sample(1, x).tolist() == [[0]]
     assert O.farthest_point_sample(4, x).tolist() == [[0, 1, 0, 0]]   # exhausted cloud: all temp 0 -> index 0
+
+
+def test_approxmatch_chunked_order_is_a_reassociation():
+    """The MI355X kernels add the auction's row / column sums in pieces of 128 partners (oracle chunk = AM_CHUNK) instead of
+    one sequential chain (tf_approxmatch_g.cu:37-55: the reference's order, chunk = 0).  Same algorithm, different
+    association: the plan still has unit row / column sums and the EMD agrees to 1e-5 (north-star tolerance)."""
+    rng = np.random.default_rng(3)
+    for (b, n, m) in [(2, 256, 256), (1, 700, 1000)]:
+        x1, x2 = rng.random((b, n, 3), dtype=np.float32), rng.random((b, m, 3), dtype=np.float32)
+        seq = O.approx_match(x1, x2)
+        chk = O.approx_match(x1, x2, chunk=O.AM_CHUNK)
+        assert not np.array_equal(seq, chk)                               # it IS a different association
+        if n == m:
+            assert np.abs(chk.sum(1) - 1).max() < 1e-5 and np.abs(chk.sum(2) - 1).max() < 1e-5
+        assert np.allclose(O.match_cost(x1, x2, chk), O.match_cost(x1, x2, seq), rtol=1e-5)
+    # a single chunk (n, m <= 128) differs from the sequential chain only in where pass 1's 1e-9 is added
+    x1, x2 = rng.random((1, 100, 3), dtype=np.float32), rng.random((1, 90, 3), dtype=np.float32)
+    a, s = O.approx_match(x1, x2, chunk=O.AM_CHUNK), O.approx_match(x1, x2)
+    assert np.abs(a - s).max() < 1e-3 and np.allclose(O.match_cost(x1, x2, a), O.match_cost(x1, x2, s), rtol=1e-5)
