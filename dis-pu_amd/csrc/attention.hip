@@ -24,11 +24,22 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int FA_D = 64, FA_TK = 32, FA_LDK = FA_D + 1;
 constexpr int FA_STAGE = FA_TK * FA_LDK + FA_TK * FA_D;     // floats: K tile [32][65] + V tile [32][64]
 
+// BP = true: the cell's output projection (conv_back_project, ops.py:341-343: 64 -> 256, bias, ReLU) runs as the epilogue:
+//   Y^T[o][q] = relu(b[o] + sum_d W[d][o] O^T[d][q])
+// again in the transposed orientation, so the normalised O^T accumulators are the B operand AS THEY ARE (step (c, r) pairs
+// the d rows the two half-waves hold in register r) and W [64][256] (64 KB, copied to LDS by the loader waves while the first
+// K|V tile is in flight) is the A operand, one conflict-free ds_read_b32 per MFMA.  The [rows, 64] attention output never
+// reaches HBM and the separate 64 -> 256 GEMM launch (28 % of the MFMA peak, 21 % of HBM: bound by neither) disappears.
+// d is contracted in the order 0,4,1,5,... (not ascending): like the softmax itself this branch is tolerance-checked.
+constexpr int FA_BPN = 256;
+
+template <bool BP>
 __global__ __launch_bounds__(512) void flash_attention_kernel(int m, int nk, const float* __restrict__ Q, long ldq,
                                                                const float* __restrict__ K, long ldk,
                                                                const float* __restrict__ V, long ldv, float scale,
-                                                               float* __restrict__ O, long ldo) {
-    __shared__ __attribute__((aligned(16))) float lds[2 * FA_STAGE];
+                                                               float* __restrict__ O, long ldo,
+                                                               const float* __restrict__ Wbp, const float* __restrict__ bbp) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];       // [2 * FA_STAGE] (+ W [64][256] when BP)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int cloud = blockIdx.y;
     const float* __restrict__ kb = K + (size_t)cloud * nk * ldk;
@@ -62,6 +73,17 @@ __global__ __launch_bounds__(512) void flash_attention_kernel(int m, int nk, con
             }
         };
         load_tile(0);
+        if constexpr (BP) {                                  // W [64][256] -> LDS behind the first tile's loads: 16 float4 per thread
+            float* Wl = lds + 2 * FA_STAGE;
+#pragma unroll
+            for (int h = 0; h < 4; ++h) {
+                float4 w[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) w[u] = *reinterpret_cast<const float4*>(Wbp + (size_t)(tid + (h * 4 + u) * 256) * 4);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) *reinterpret_cast<float4*>(Wl + (size_t)(tid + (h * 4 + u) * 256) * 4) = w[u];
+            }
+        }
         store_tile(0);
         if (ntile > 1) load_tile(FA_TK);
         __syncthreads();
@@ -134,12 +156,48 @@ __global__ __launch_bounds__(512) void flash_attention_kernel(int m, int nk, con
     }
     const float ltot = lsum + __shfl_xor(lsum, 32, 64);
     const float inv = 1.0f / ltot;
-    if (qok) {
-        float* __restrict__ op = O + ((size_t)cloud * m + qrow) * ldo;
+    float* __restrict__ op = O + ((size_t)cloud * m + (qok ? qrow : 0)) * ldo;
+    if constexpr (!BP) {
+        if (qok) {
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) op[c * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh] = oacc[c][r] * inv;
+        }
+    } else {
+        const float* Wl = lds + 2 * FA_STAGE;
 #pragma unroll
         for (int c = 0; c < 2; ++c)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) op[c * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh] = oacc[c][r] * inv;
+            for (int r = 0; r < 16; ++r) oacc[c][r] = oacc[c][r] * inv;
+#pragma unroll 1
+        for (int ot = 0; ot < FA_BPN / 32; ot += 2) {
+            f32x16 y0, y1;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { y0[r] = 0.f; y1[r] = 0.f; }
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int d = c * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                    y0 = __builtin_amdgcn_mfma_f32_32x32x2f32(Wl[d * FA_BPN + ot * 32 + li], oacc[c][r], y0, 0, 0, 0);
+                    y1 = __builtin_amdgcn_mfma_f32_32x32x2f32(Wl[d * FA_BPN + ot * 32 + 32 + li], oacc[c][r], y1, 0, 0, 0);
+                }
+            if (qok) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int o0 = ot * 32 + 8 * g + 4 * kh;
+                    const float4 b0 = *reinterpret_cast<const float4*>(bbp + o0), b1 = *reinterpret_cast<const float4*>(bbp + o0 + 32);
+                    float4 v0, v1;
+                    v0.x = fmaxf(y0[4 * g + 0] + b0.x, 0.f); v0.y = fmaxf(y0[4 * g + 1] + b0.y, 0.f);
+                    v0.z = fmaxf(y0[4 * g + 2] + b0.z, 0.f); v0.w = fmaxf(y0[4 * g + 3] + b0.w, 0.f);
+                    v1.x = fmaxf(y1[4 * g + 0] + b1.x, 0.f); v1.y = fmaxf(y1[4 * g + 1] + b1.y, 0.f);
+                    v1.z = fmaxf(y1[4 * g + 2] + b1.z, 0.f); v1.w = fmaxf(y1[4 * g + 3] + b1.w, 0.f);
+                    *reinterpret_cast<float4*>(op + o0) = v0;
+                    *reinterpret_cast<float4*>(op + o0 + 32) = v1;
+                }
+            }
+        }
     }
 }
 
@@ -156,7 +214,30 @@ DISPU_EXPORT int dispu_attention(int b, int m, int nk, int d, const float* Q, lo
         ((((uintptr_t)Q) | ((uintptr_t)K) | ((uintptr_t)V)) & 15))
         return (int)hipErrorInvalidValue;
     if (b == 0) return 0;
-    hipLaunchKernelGGL(flash_attention_kernel, dim3((m + 127) / 128, b), dim3(512), 0, (hipStream_t)stream, m, nk, Q, ldq, K, ldk,
-                       V, ldv, scale, O, ldo);
+    hipLaunchKernelGGL((flash_attention_kernel<false>), dim3((m + 127) / 128, b), dim3(512), 2 * FA_STAGE * sizeof(float),
+                       (hipStream_t)stream, m, nk, Q, ldq, K, ldk, V, ldv, scale, O, ldo, (const float*)nullptr, (const float*)nullptr);
+    return (int)hipGetLastError();
+}
+
+// Y[b, m, 256] = relu(softmax(scale * Q.K^T) . V . W + bias): the non-local cell with its output projection
+// (PointNonLocalCell, Common/ops.py:326-343) in one launch.  W [64, 256] row-major, bias [256]; same shape rules as
+// dispu_attention, ldy % 4 == 0, Y / W / bias 16-byte aligned.
+DISPU_EXPORT int dispu_attention_project(int b, int m, int nk, int d, const float* Q, long ldq, const float* K, long ldk,
+                                         const float* V, long ldv, float scale, const float* W, const float* bias, int n_out,
+                                         float* Y, long ldy, void* stream) {
+    if (b < 0 || m <= 0 || nk <= 0 || d != 64 || n_out != FA_BPN || (nk % 32) != 0 || (ldq & 3) || (ldk & 3) || (ldv & 3) ||
+        (ldy & 3) || !W || !bias ||
+        ((((uintptr_t)Q) | ((uintptr_t)K) | ((uintptr_t)V) | ((uintptr_t)W) | ((uintptr_t)bias) | ((uintptr_t)Y)) & 15))
+        return (int)hipErrorInvalidValue;
+    if (b == 0) return 0;
+    constexpr size_t bytes = (size_t)(2 * FA_STAGE + FA_D * FA_BPN) * sizeof(float);
+    static bool attr = false;
+    if (!attr) {
+        DISPU_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(flash_attention_kernel<true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+        attr = true;
+    }
+    hipLaunchKernelGGL((flash_attention_kernel<true>), dim3((m + 127) / 128, b), dim3(512), bytes, (hipStream_t)stream, m, nk, Q, ldq,
+                       K, ldk, V, ldv, scale, Y, ldy, W, bias);
     return (int)hipGetLastError();
 }

@@ -72,6 +72,7 @@ class Generator(object):
         self.profile = None          # set to [] to collect (name, start_event, end_event) per launch
         self.fused_local = True      # PointShuffle2 local cell in one kernel (False: the 4-kernel chain, for A/B tests)
         self.fused_attention = True  # non-local cell attention on chip (False: GEMM -> softmax -> GEMM through HBM)
+        self.fused_project = True    # conv_back_project as the attention kernel's epilogue (False: separate GEMM)
         self.fused_residual = bool(int(__import__('os').environ.get('DISPU_FUSED_RES', '1')))
         self.fused_heads = bool(int(__import__('os').environ.get('DISPU_FUSED_HEADS', '1')))   # one launch per head chain
         self.keep_intermediates = False   # fused heads: also write the aggregation output (tests compare it)
@@ -257,7 +258,14 @@ class Generator(object):
         self._call("knn_xyz", L.dispu_knn_xyz, B, M, M, k, ptr(coarse), ptr(coarse), ptr(ws["psidx"]), None, _lib.ARITH_PLAIN, st)
         # PointNonLocalCell (ops.py:302-346)
         self._linear(st, up128, 128, self.w_up3, self.b_up3, 0, ws["up3"], 320)      # K|V, Q and conv0's feature part at once
-        if self.fused_attention and M % 32 == 0:
+        w_bp, b_bp = self._w(ps + "PointShuffle/conv_back_project")
+        projected = False
+        if self.fused_attention and M % 32 == 0 and self.fused_project:
+            # softmax(Q.K^T / 8).V.W_bp on chip: neither the [B, M, M] logits nor the [B*M, 64] attention output reach HBM
+            self._call("attention_project", L.dispu_attention_project, B, M, M, 64, ptr(ws["q"]), 320, ptr(ws["kv"]), 320,
+                       off(ws["kv"], 64), 320, 0.125, ptr(w_bp), ptr(b_bp), 256, ptr(ws["nl"]), 256, st)
+            projected = True
+        elif self.fused_attention and M % 32 == 0:
             # softmax(Q.K^T / 8).V on chip (flash style): the [B, M, M] logits never exist in HBM
             self._call("attention", L.dispu_attention, B, M, M, 64, ptr(ws["q"]), 320, ptr(ws["kv"]), 320, off(ws["kv"], 64), 320,
                        0.125, ptr(ws["att"]), 64, st)
@@ -271,8 +279,8 @@ class Generator(object):
             self._call("softmax", L.dispu_softmax_rows, rm, M, 0.125, ptr(s), M, st)
             self._linear(st, s, M, ws["kv"], None, 0, ws["att"], 64, M=M, ldx=M, ldw=320, ldy=64, batch=B, sx=M * M,
                          sw=M * 320, sy=M * 64, woff=64)
-        w, b = self._w(ps + "PointShuffle/conv_back_project")
-        self._linear(st, ws["att"], 64, w, b, 1, ws["nl"], 256)
+        if not projected:
+            self._linear(st, ws["att"], 64, w_bp, b_bp, 1, ws["nl"], 256)
         # skip connection
         self._call("skip_max", L.dispu_ps_skip_max, rm, M, k, 128, ptr(ws["psidx"]), ptr(coarse), ptr(up128), 128, ptr(ws["skipin"]), 144, st)
         _, b = self._w(ps + "skip")

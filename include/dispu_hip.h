@@ -208,6 +208,12 @@ int dispu_ps_local(long npoints, int n_per_cloud, int k, int c, const int* idx, 
  * written to HBM.  d must be 64, nk % 32 == 0, rows 16-byte aligned (else hipErrorInvalidValue: use the 3-kernel path). */
 int dispu_attention(int b, int m, int nk, int d, const float* Q, long ldq, const float* K, long ldk, const float* V,
                     long ldv, float scale, float* O, long ldo, void* stream);
+/* The same cell including its output projection conv_back_project (ops.py:341-343: 64 -> n_out = 256 channels, bias,
+ * ReLU) as the kernel's epilogue: Y[b*m, 256] = relu(softmax(scale Q K^T) V W + bias); the [b*m, 64] attention output is
+ * never written.  W [64, 256] row-major, bias [256]. */
+int dispu_attention_project(int b, int m, int nk, int d, const float* Q, long ldq, const float* K, long ldk, const float* V,
+                            long ldv, float scale, const float* W, const float* bias, int n_out, float* Y, long ldy,
+                            void* stream);
 /* S <- softmax(S * mul) per row, in place (tf.nn.softmax of PointNonLocalCell, ops.py:338). */
 int dispu_softmax_rows(long rows, int n, float mul, float* S, long lds, void* stream);
 

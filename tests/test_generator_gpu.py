@@ -265,3 +265,50 @@ def test_odd_batch_sizes_match_oracle(dev, B):
     c, f = Generator(params=P, device=dev)(torch.from_numpy(x).to(dev))
     assert np.array_equal(N(c), coarse)
     assert np.abs(N(f) - fine).max() <= 1e-5
+
+
+@pytest.mark.parametrize("b,m", [(2, 1024), (3, 160), (1, 4096)])
+def test_fused_attention_project(dev, b, m):
+    """dispu_attention_project = relu(softmax(QK^T/8) V W + bias) (PointNonLocalCell incl. conv_back_project, ops.py:326-343)
+    vs float64, and vs dispu_attention followed by dispu_linear (the unfused pair)."""
+    from dispu_amd import _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(m + 1)
+    q = rng.standard_normal((b, m, 64)).astype(np.float32)
+    kv = rng.standard_normal((b, m, 128)).astype(np.float32)
+    w = (rng.standard_normal((64, 256)) * 0.2).astype(np.float32)
+    bias = (rng.standard_normal(256) * 0.1).astype(np.float32)
+    q[0, 7] *= 5.0
+    tq, tkv, tw, tb = (torch.from_numpy(a).to(dev) for a in (q, kv, w, bias))
+    y = torch.zeros((b, m, 256), device=dev)
+    st = _lib.stream_ptr(dev)
+    _lib.check(L.dispu_attention_project(b, m, m, 64, tq.data_ptr(), 64, tkv.data_ptr(), 128, tkv.data_ptr() + 256, 128, 0.125,
+                                         tw.data_ptr(), tb.data_ptr(), 256, y.data_ptr(), 256, st), "dispu_attention_project")
+    s = np.einsum("bqd,bkd->bqk", q.astype(np.float64), kv[..., :64].astype(np.float64)) / 8.0
+    s -= s.max(-1, keepdims=True)
+    p = np.exp(s)
+    att = np.einsum("bqk,bkd->bqd", p / p.sum(-1, keepdims=True), kv[..., 64:].astype(np.float64))
+    want = np.maximum(att @ w.astype(np.float64) + bias, 0.0)
+    assert np.abs(N(y) - want).max() <= 2e-5 * max(1.0, np.abs(want).max())
+    o = torch.zeros((b, m, 64), device=dev)
+    _lib.check(L.dispu_attention(b, m, m, 64, tq.data_ptr(), 64, tkv.data_ptr(), 128, tkv.data_ptr() + 256, 128, 0.125,
+                                 o.data_ptr(), 64, st), "dispu_attention")
+    y2 = torch.zeros((b * m, 256), device=dev)
+    _lib.check(L.dispu_linear(1, b * m, 64, 256, o.data_ptr(), 64, 0, tw.data_ptr(), 256, 0, 0, tb.data_ptr(), 1, y2.data_ptr(), 256, 0,
+                              None, 0, 0, None, 0, 0, st), "dispu_linear")
+    assert np.abs(N(y).reshape(-1, 256) - N(y2)).max() <= 1e-5 * max(1.0, np.abs(want).max())
+
+
+def test_projection_epilogue_equals_separate_gemm_in_generator(dev):
+    from dispu_amd import synth
+    from dispu_amd.generator import Generator
+    P = OG.init_params(seed=5, bias_scale=0.05)
+    x = torch.from_numpy(synth.patches(2, 256, seed=13)).to(dev)
+    res = []
+    for fused in (True, False):
+        gen = Generator(params=P, device=dev)
+        gen.fused_project = fused
+        c, f = gen(x)
+        res.append((N(gen._ws[(2, 256)]["nl"]).copy(), N(f).copy()))
+    assert np.abs(res[0][0] - res[1][0]).max() <= 1e-5 * max(1.0, np.abs(res[1][0]).max())
+    assert np.abs(res[0][1] - res[1][1]).max() <= 1e-6
