@@ -87,9 +87,16 @@ __global__ void denormalize_patches_kernel(long total, int m, const float* __res
 
 using namespace dispu;
 
+namespace dispu {
+int knn_general_launch(int mode, int b, int n, int m, int c, int k, long ldp, long ldq, const float* points, const float* queries,
+                       float* dist, int* idx, int neg, hipStream_t st);
+}
+
 DISPU_EXPORT int dispu_knn_patch(int b, int n, int m, int k, const float* cloud, const float* queries, int* idx, void* stream) {
-    if (b < 0 || n <= 0 || m < 0 || k <= 0 || k > n || n > 8192) return (int)hipErrorInvalidValue;
+    if (b < 0 || n <= 0 || m < 0 || k <= 0 || k > n) return (int)hipErrorInvalidValue;
     if (b == 0 || m == 0) return 0;
+    // clouds whose 64-bit keys do not fit one workgroup's LDS: radix-select kernel (same distances, same tie rule), k <= 4096
+    if (n > 8192) return dispu::knn_general_launch(0, b, n, m, 3, k, 3, 3, cloud, queries, nullptr, idx, 0, (hipStream_t)stream);
     int npad = 1;
     while (npad < n) npad <<= 1;
     if (npad < 2) npad = 2;

@@ -219,15 +219,21 @@ int knn_xyz_wave_dispatch(int b, int n, int m, int k, const float* s, const floa
 int knn_feat_wave_dispatch(int b, int n, int m, int c, int k, int ldp, int ldq, const float* p, const float* q, float* dist,
                            int* idx, hipStream_t st);
 
+// general path (knn_general.hip): any k <= 4096, c <= 4096, any n; mode 0/1 xyz plain/contract, 2 knn_point, 3 knn_point_2
+int knn_general_launch(int mode, int b, int n, int m, int c, int k, long ldp, long ldq, const float* points, const float* queries,
+                       float* dist, int* idx, int neg, hipStream_t st);
+
 }  // namespace dispu
 
 using namespace dispu;
 
 DISPU_EXPORT int dispu_knn_xyz(int b, int n, int m, int k, const float* support, const float* query, int* idx,
                                float* dist, int arith, void* stream) {
-    if (b < 0 || n <= 0 || m < 0 || k <= 0 || k > n || k > 32 || !idx) return (int)hipErrorInvalidValue;
+    if (b < 0 || n <= 0 || m < 0 || k <= 0 || k > n || !idx) return (int)hipErrorInvalidValue;
     if (b == 0 || m == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
+    if (k > 32)                                      // nanoflann takes any K (knn_.cxx:104-135): general selection kernel
+        return knn_general_launch((arith & DISPU_ARITH_CONTRACT) ? 1 : 0, b, n, m, 3, k, 3, 3, support, query, dist, idx, 0, st);
     if (!(arith & DISPU_KNN_LANE_PER_QUERY)) {       // fast path: wave-per-query (knn_wave.hip), n <= 1024
         const int rc = knn_xyz_wave_dispatch(b, n, m, k, support, query, idx, dist, arith, st);
         if (rc >= 0) return rc;
@@ -241,8 +247,9 @@ DISPU_EXPORT int dispu_knn_xyz(int b, int n, int m, int k, const float* support,
 
 DISPU_EXPORT int dispu_knn_feat(int b, int n, int m, int c, int k, const float* points, const float* queries,
                                 float* dist, int* idx, void* stream) {
-    if (b < 0 || n <= 0 || m < 0 || c <= 0 || k <= 0 || k > n || k > 32 || !idx) return (int)hipErrorInvalidValue;
+    if (b < 0 || n <= 0 || m < 0 || c <= 0 || k <= 0 || k > n || !idx) return (int)hipErrorInvalidValue;
     if (b == 0 || m == 0) return 0;
+    if (k > 32 || c > 128) return knn_general_launch(3, b, n, m, c, k, c, c, points, queries, dist, idx, 0, (hipStream_t)stream);
     const int rc = knn_feat_wave_dispatch(b, n, m, c, k, c, c, points, queries, dist, idx, (hipStream_t)stream);
     if (rc >= 0) return rc;
     return launch_feat<true, false>(b, n, m, c, k, c, c, points, queries, dist, idx, (hipStream_t)stream);
@@ -252,8 +259,9 @@ DISPU_EXPORT int dispu_knn_feat(int b, int n, int m, int c, int k, const float* 
 // activation buffer (the generator keeps its dense-block features inside one [rows, 480] buffer).
 DISPU_EXPORT int dispu_knn_feat_strided(int b, int n, int m, int c, int k, const float* points, int ldp,
                                         const float* queries, int ldq, float* dist, int* idx, void* stream) {
-    if (b < 0 || n <= 0 || m < 0 || c <= 0 || k <= 0 || k > n || k > 32 || !idx || ldp < c || ldq < c) return (int)hipErrorInvalidValue;
+    if (b < 0 || n <= 0 || m < 0 || c <= 0 || k <= 0 || k > n || !idx || ldp < c || ldq < c) return (int)hipErrorInvalidValue;
     if (b == 0 || m == 0) return 0;
+    if (k > 32 || c > 128) return knn_general_launch(3, b, n, m, c, k, ldp, ldq, points, queries, dist, idx, 0, (hipStream_t)stream);
     const int rc = knn_feat_wave_dispatch(b, n, m, c, k, ldp, ldq, points, queries, dist, idx, (hipStream_t)stream);
     if (rc >= 0) return rc;
     return launch_feat<true, false>(b, n, m, c, k, ldp, ldq, points, queries, dist, idx, (hipStream_t)stream);
@@ -261,7 +269,8 @@ DISPU_EXPORT int dispu_knn_feat_strided(int b, int n, int m, int c, int k, const
 
 DISPU_EXPORT int dispu_knn_point(int b, int n, int m, int c, int k, const float* xyz1, const float* xyz2, float* val,
                                  int* idx, void* stream) {
-    if (b < 0 || n <= 0 || m < 0 || c <= 0 || k <= 0 || k > n || k > 32 || !idx) return (int)hipErrorInvalidValue;
+    if (b < 0 || n <= 0 || m < 0 || c <= 0 || k <= 0 || k > n || !idx) return (int)hipErrorInvalidValue;
     if (b == 0 || m == 0) return 0;
+    if (k > 32 || c > 128) return knn_general_launch(2, b, n, m, c, k, c, c, xyz1, xyz2, val, idx, 1, (hipStream_t)stream);
     return launch_feat<false, true>(b, n, m, c, k, c, c, xyz1, xyz2, val, idx, (hipStream_t)stream);
 }

@@ -17,7 +17,7 @@ def knn_batch(pts, queries, K, omp=False, return_dist=False, arith=_lib.ARITH_PL
         and pts.shape[0] == queries.shape[0], "knn_batch expects pts (B,N1,3) and queries (B,N2,3)")
     b, n, _ = pts.shape
     m = queries.shape[1]
-    req(0 < int(K) <= n and int(K) <= 32, "knn_batch supports 1 <= K <= min(N1, 32)")
+    req(0 < int(K) <= n and int(K) <= 4096, "knn_batch supports 1 <= K <= min(N1, 4096)")
     idx = torch.empty((b, m, int(K)), dtype=torch.int32, device=pts.device)
     dist = torch.empty((b, m, int(K)), dtype=torch.float32, device=pts.device) if return_dist else None
     _lib.check(_lib.lib().dispu_knn_xyz(b, n, m, int(K), _lib.ptr(pts), _lib.ptr(queries), _lib.ptr(idx), _lib.ptr(dist),
@@ -32,7 +32,7 @@ def knn_query(k, support_pts, query_pts):
     pts, queries = f32(support_pts, "support_pts"), f32(query_pts, "query_pts")
     b, n, _ = pts.shape
     m = queries.shape[1]
-    req(0 < int(k) <= n and int(k) <= 32, "knn_query supports 1 <= k <= min(N1, 32)")
+    req(0 < int(k) <= n and int(k) <= 4096, "knn_query supports 1 <= k <= min(N1, 4096)")
     idx = torch.empty((b, m, int(k)), dtype=torch.int32, device=pts.device)
     _lib.check(_lib.lib().dispu_knn_xyz(b, n, m, int(k), _lib.ptr(pts), _lib.ptr(queries), _lib.ptr(idx), _lib.ptr(None),
                                         _lib.ARITH_PLAIN, _lib.stream_ptr(pts.device)), "dispu_knn_xyz")

@@ -79,13 +79,14 @@ int dispu_group_point_grad(int b, int n, int c, int m, int nsample, const float*
                            float* grad_points, void* stream);
 
 /* tf_grouping.knn_point(k, xyz1[b,n,c], xyz2[b,m,c]) -> (val = -d2 [b,m,k], idx [b,m,k])
- * tf_ops/grouping/tf_grouping.py:116-141 (pure TF: broadcast-subtract, reduce_sum, top_k).  k <= 32, c <= 128. */
+ * tf_ops/grouping/tf_grouping.py:116-141 (pure TF: broadcast-subtract, reduce_sum, top_k).  Any k <= n, c up to 4096 (k <= 32 and c <= 128: register-resident
+ * kernels; beyond: the radix-select kernel of csrc/knn_general.hip, k <= 4096). */
 int dispu_knn_point(int b, int n, int m, int c, int k, const float* xyz1, const float* xyz2, float* val, int* idx,
                     void* stream);
 
 /* tf_grouping.knn_point_2(k, points[b,n,c], queries[b,m,c]) -> (dist [b,m,k] = +D, idx [b,m,k])
  * tf_grouping.py:61-66,95-114 (D = rA - 2 A.B^T + rB; top_k(-D)).  The (batch,point) pair tensor of
- * the reference is assembled by the Python shim.  dist may be NULL.  k <= 32, c <= 128. */
+ * the reference is assembled by the Python shim.  dist may be NULL.  Limits as dispu_knn_point. */
 int dispu_knn_feat(int b, int n, int m, int c, int k, const float* points, const float* queries, float* dist,
                    int* idx, void* stream);
 
@@ -98,7 +99,7 @@ int dispu_knn_feat_strided(int b, int n, int m, int c, int k, const float* point
 /* cpp_knn_batch_omp(batch_data,batch_size,npts,dim=3,queries,nqueries,K,indices)
  * libs/nearest_neighbors/knn_.cxx:104-135 (nanoflann KD-tree on the host, int64 output).  Device-side
  * exact brute force; idx int32 [b,m,k] ascending distance, ties -> lower index; dist (squared, may be
- * NULL).  k <= 32 and k <= n. */
+ * NULL).  k <= n, k <= 4096 (k > 32: csrc/knn_general.hip). */
 int dispu_knn_xyz(int b, int n, int m, int k, const float* support, const float* query, int* idx, float* dist,
                   int arith, void* stream);
 
@@ -324,7 +325,7 @@ int dispu_augment(int b, int n, const float* in, const float* noise, const float
 
 /* ---- whole-cloud inference glue (DisPU/model.py:306-381, Common/pc_util.py:83-92,147-161; host numpy/sklearn in
  * the reference, one patch at a time) -------------------------------------------------------------------------- */
-/* extract_knn_patch: for each of m queries the k nearest of the cloud's n points (k up to n, n <= 8192), ascending
+/* extract_knn_patch: for each of m queries the k nearest of the cloud's n points (k up to n; n > 8192: the radix-select kernel, k <= 4096), ascending
  * squared distance (plain arithmetic), ties -> lower index.  idx [b, m, k]. */
 int dispu_knn_patch(int b, int n, int m, int k, const float* cloud, const float* queries, int* idx, void* stream);
 /* normalize_point_cloud per patch: out = (in - mean) / max|in - mean|; centroid [b,3], furthest [b]. */

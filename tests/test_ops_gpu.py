@@ -393,3 +393,43 @@ def test_knn_xyz_prefilter_degenerate_clouds(ops, dev, n, ndup, k):
     i, d = ops["K"].knn_batch(T(c, dev), T(c, dev), 16, return_dist=True)
     oi, od = O.knn_batch(c, c, 16, return_dist=True)
     assert np.array_equal(N(i), oi) and np.array_equal(N(d), od)
+
+
+# ---- shapes beyond the register-resident fast paths: general radix-select kernel (csrc/knn_general.hip) ---------------
+@pytest.mark.parametrize("b,n,m,k", [(2, 1024, 200, 64), (1, 3000, 77, 33), (2, 500, 500, 500), (1, 24576, 40, 256), (1, 5000, 9, 1000)])
+def test_knn_xyz_large_k(ops, dev, b, n, m, k):
+    """nanoflann takes any K (libs/nearest_neighbors/knn_.cxx:104-135)."""
+    s = synth_patches(b, n, seed=n + k)
+    q = s[:, :m]
+    for arith, contract in ((PLAIN, 0), (CONTRACT, 1)):
+        idx, dist = ops["K"].knn_batch(T(s, dev), T(q, dev), k, return_dist=True, arith=arith)
+        oi, od = O.knn_batch(s, q, k, contract=contract, return_dist=True)
+        assert np.array_equal(N(idx), oi) and np.array_equal(N(dist), od)
+
+
+def test_knn_general_path_agrees_with_fast_path(ops, dev):
+    """k = 33 takes the general kernel, k = 32 the register-resident one: the first 32 columns must be identical; duplicate
+    points make the threshold a tie (index-ordered quota of the radix select)."""
+    s = synth_patches(2, 700, seed=3)
+    s[:, 100:160] = s[:, 5:6]                                    # 61 copies of one point
+    ts = T(s, dev)
+    i33, d33 = ops["K"].knn_batch(ts, ts, 33, return_dist=True)
+    i32, d32 = ops["K"].knn_batch(ts, ts, 32, return_dist=True)
+    assert np.array_equal(N(i33)[..., :32], N(i32)) and np.array_equal(N(d33)[..., :32], N(d32))
+    oi, od = O.knn_batch(s, s, 33, return_dist=True)
+    assert np.array_equal(N(i33), oi) and np.array_equal(N(d33), od)
+
+
+@pytest.mark.parametrize("n,m,c,k", [(300, 50, 256, 17), (256, 64, 200, 40), (1024, 33, 24, 48), (90, 90, 131, 90), (400, 10, 3, 100)])
+def test_knn_point_large_k_and_c(ops, dev, n, m, c, k):
+    """knn_point / knn_point_2 are tf.nn.top_k over a full distance matrix: any k, any channel count
+    (tf_ops/grouping/tf_grouping.py:95-141)."""
+    rng = np.random.default_rng(n + 13 * c + k)
+    a = rng.standard_normal((2, n, c)).astype(np.float32)
+    q = np.concatenate([a[:, : m // 2], rng.standard_normal((2, m - m // 2, c)).astype(np.float32)], 1)
+    val, idx = ops["G"].knn_point(k, T(a, dev), T(q, dev))
+    ov, oi = O.knn_point(k, a, q)
+    assert np.array_equal(N(idx), oi) and np.array_equal(N(val), ov)
+    d2, i2 = ops["G"].knn_point_2(k, T(a, dev), T(q, dev))
+    od, oi2 = O.knn_point_2(k, a, q)
+    assert np.array_equal(N(i2), oi2) and np.array_equal(N(d2), od)

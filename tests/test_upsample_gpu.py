@@ -19,7 +19,7 @@ def N(t):
 def test_knn_patch_large_k(dev):
     from dispu_amd import upsample as U
     rng = np.random.default_rng(0)
-    for (n, m, k) in [(2048, 24, 256), (1000, 7, 256), (300, 5, 300), (8192, 3, 256)]:
+    for (n, m, k) in [(2048, 24, 256), (1000, 7, 256), (300, 5, 300), (8192, 3, 256), (24576, 12, 256), (10000, 4, 1024)]:   # n > 8192: radix-select kernel
         pc = rng.random((1, n, 3)).astype(np.float32)
         pc[0, 10] = pc[0, 3]                                   # duplicate -> tie resolved by index
         q = pc[:, :m].copy()
