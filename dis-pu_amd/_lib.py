@@ -69,6 +69,9 @@ SIGNATURES = {
     "dispu_attention": (_i, [_i, _i, _i, _i, _vp, _l, _vp, _l, _vp, _l, C.c_float, _vp, _l, _vp]),
     "dispu_attention_project": (_i, [_i, _i, _i, _i, _vp, _l, _vp, _l, _vp, _l, C.c_float, _vp, _vp, _i, _vp, _l, _vp]),
     "dispu_softmax_rows": (_i, [_l, _i, C.c_float, _vp, _l, _vp]),
+    "dispu_linear_bf16": (_i, [_i, _i, _i, _i, _vp, _l, _l, _vp, _l, _l, _i, _vp, _i, _vp, _l, _l, _vp, _l, _l, _vp, _l, _l, _vp]),
+    "dispu_linear_tn_bf16_scratch_floats": (_l, [_i, _i, _i, _i]),
+    "dispu_linear_tn_bf16": (_i, [_i, _i, _i, _i, _vp, _l, _l, _vp, _l, _l, _vp, _l, _l, _i, _vp, _vp, _l, _vp]),
     "dispu_linear_tn_scratch_floats": (_l, [_i, _i, _i, _i]),
     "dispu_linear_tn": (_i, [_i, _i, _i, _i, _vp, _l, _l, _vp, _l, _l, _vp, _l, _l, _i, _vp, _vp, _l, _vp]),
     "dispu_act_bias_grad_scratch_floats": (_l, [_l, _i]),

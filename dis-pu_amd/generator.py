@@ -56,8 +56,6 @@ class Generator(object):
                          # (~17 MB per patch, dominated by F' [B*1024, 2048]) at ~35 GB; larger batches run in chunks
 
     def __init__(self, opts=None, is_training=False, name="Generator", params=None, device=None):
-        if is_training:
-            raise NotImplementedError("round 1 implements the inference graph (is_training=False)")
         self.opts = opts if opts is not None else _Opts()
         self.is_training = is_training
         self.name = name
@@ -80,12 +78,25 @@ class Generator(object):
         # tensors (like sess.run in the reference); return_views = True hands out the workspace buffers themselves
         # (no copies -- bench.py / hipGraph capture), which the NEXT call with the same (B, N) overwrites.
         self.return_views = False
+        self._trainer = None
         if params is not None:
             self.load_params(params)
 
     # ------------------------------------------------------------------------------------------ weights ----
     def load_params(self, params):
         dev = self.device
+        if self.is_training:
+            # training graph (DisPU/generator.py:22-31 with is_training=True; DisPU/model.py:68): BatchNorm on batch
+            # statistics with moving averages updated (decay 0.95), every activation kept for the backward pass.  The
+            # forward is Trainer.forward (train.py); `trainer` exposes loss / backward / Adam on the same variables.
+            from .train import Trainer, TrainOpts
+            topts = TrainOpts()
+            for k in dir(self.opts):
+                if not k.startswith("_"):
+                    setattr(topts, k, getattr(self.opts, k))
+            self._trainer = Trainer(opts=topts, params=params, device=dev)
+            self.P = self._trainer.P
+            return
         self.P = {k: torch.from_numpy(np.ascontiguousarray(v, np.float32)).to(dev) for k, v in params.items()}
         bn = "refine/PointShuffle/weight_net/wconv0/bn/"
         g, b = params[bn + "gamma"].astype(np.float64), params[bn + "beta"].astype(np.float64)
@@ -182,9 +193,17 @@ class Generator(object):
     def __call__(self, inputs):
         return self.forward(inputs)
 
+    @property
+    def trainer(self):
+        """the Trainer behind a Generator(is_training=True): loss_backward / backward / adam / train_step (train.py)."""
+        return self._trainer
+
     def forward(self, inputs):
         if not self.P:
             raise RuntimeError("Generator has no parameters: call load_params() first")
+        if self.is_training:
+            coarse, fine = self._trainer.forward(inputs)
+            return (coarse, fine) if self.return_views else (coarse.clone(), fine.clone())
         if not (isinstance(inputs, torch.Tensor) and inputs.is_cuda and inputs.dtype == torch.float32 and inputs.dim() == 3
                 and inputs.shape[2] == 3):
             raise ValueError("Generator expects a float32 [B,N,3] tensor on a ROCm device")

@@ -1,7 +1,8 @@
 """PointNet++ set-abstraction / feature-propagation modules -- the reference's Common/pointnet_util.py:22-222 with
 torch tensors, composed from the hot-path ops (FPS, gather, ball query / k-NN, group, 3-NN, interpolate) and the
 fused 1x1-conv GEMM.  Same function names, argument order and return values; variables are passed through
-`params` (see tf_util.py) instead of TF variable scopes.  Inference mode.
+`params` (see tf_util.py) instead of TF variable scopes.  is_training=True runs BatchNorm on batch statistics and updates
+the moving statistics in `params` (forward only: the hand-written backward exists for the generator, train.py).
 
 torch is used here only to allocate / concatenate / reshape device buffers; every arithmetic step is a HIP kernel
 of libdispu_hip.so."""
@@ -73,10 +74,10 @@ def pointnet_sa_module(xyz, points, npoint, radius, nsample, mlp, mlp2, group_al
     else:
         new_xyz, new_points, idx, grouped_xyz = sample_and_group(npoint, radius, nsample, xyz, points, tnet_spec, knn, use_xyz)
     for i, co in enumerate(mlp):
-        new_points = tf_util.conv2d(new_points, co, (1, 1), scope + "/conv%d" % i, params, bn=bn, is_training=is_training)
+        new_points = tf_util.conv2d(new_points, co, (1, 1), scope + "/conv%d" % i, params, bn=bn, is_training=is_training, bn_decay=bn_decay)
     new_points = _pool(new_points, pooling, grouped_xyz)
     for i, co in enumerate(mlp2 or []):
-        new_points = tf_util.conv2d(new_points, co, (1, 1), scope + "/conv_post_%d" % i, params, bn=bn, is_training=is_training)
+        new_points = tf_util.conv2d(new_points, co, (1, 1), scope + "/conv_post_%d" % i, params, bn=bn, is_training=is_training, bn_decay=bn_decay)
     return new_xyz, new_points.squeeze(2), idx
 
 
@@ -96,7 +97,7 @@ def pointnet_sa_module_msg(xyz, points, npoint, radius_list, nsample_list, mlp_l
             grouped_points = grouped_xyz
         for j, co in enumerate(mlp_list[i]):
             grouped_points = tf_util.conv2d(grouped_points, co, (1, 1), scope + "/conv%d_%d" % (i, j), params, bn=bn,
-                                            is_training=is_training)
+                                            is_training=is_training, bn_decay=bn_decay)
         outs.append(_pool(grouped_points, "max").squeeze(2))
     return new_xyz, torch.cat(outs, dim=-1)
 
@@ -111,5 +112,5 @@ def pointnet_fp_module(xyz1, xyz2, points1, points2, mlp, is_training, bn_decay,
     new_points1 = torch.cat([interpolated, points1], dim=2) if points1 is not None else interpolated
     new_points1 = new_points1.unsqueeze(2)
     for i, co in enumerate(mlp):
-        new_points1 = tf_util.conv2d(new_points1, co, (1, 1), scope + "/conv_%d" % i, params, bn=bn, is_training=is_training)
+        new_points1 = tf_util.conv2d(new_points1, co, (1, 1), scope + "/conv_%d" % i, params, bn=bn, is_training=is_training, bn_decay=bn_decay)
     return new_points1.squeeze(2)

@@ -63,7 +63,15 @@ class Trainer(object):
 
     `params`: the same name -> array mapping Generator.load_params takes (oracle/generator.py:layer_shapes names)."""
 
-    def __init__(self, opts=None, params=None, device=None, process_group=None):
+    def __init__(self, opts=None, params=None, device=None, process_group=None, dtype="f32"):
+        """dtype "f32": the reference's arithmetic (every product on the fp32 matrix pipe, bit-equal to an fmaf chain).
+        dtype "bf16" (BASELINE configs[4]): mixed precision -- master weights, activations and gradients stay fp32 in HBM,
+        the dense products (forward, dX, dW) round their operands to bf16 and run on v_mfma_f32_32x32x16_bf16 with fp32
+        accumulation (csrc/linear_bf16.hip); the 3-wide coordinate heads, the loss, BatchNorm, softmax and Adam stay fp32."""
+        if dtype not in ("f32", "bf16"):
+            raise ValueError("dtype must be 'f32' or 'bf16'")
+        self.dtype = dtype
+        self.bf16 = dtype == "bf16"
         self.opts = opts if opts is not None else TrainOpts()
         self.device = torch.device(device if device is not None else "cuda:0")
         self.up_ratio = int(self.opts.up_ratio)
@@ -154,17 +162,29 @@ class Trainer(object):
         return self._scratch
 
     # ----------------------------------------------------------------------------------------------- helpers ----
+    def _dl(self, batch, M, K, N, *rest):
+        """dispu_linear, or its bf16-product twin when the trainer runs mixed precision (narrow 3-wide layers stay fp32)."""
+        L = _lib.lib()
+        fn = L.dispu_linear_bf16 if (self.bf16 and K > 4 and N > 4) else L.dispu_linear
+        return fn(batch, M, K, N, *rest)
+
     def _lin(self, X, xoff, K, wname, act, Y, yoff, N, M=None, bias=True, W=None, woff=0):
         """Y[:, yoff:yoff+N] = act(X[:, xoff:xoff+K] . W + b)"""
         L = _lib.lib()
         M = X.shape[0] if M is None else M
         W = self.P[wname + "/weights"] if W is None else W
         b = self.P[wname + "/biases"] if bias else None
-        _lib.check(L.dispu_linear(1, M, K, N, _p(X, xoff), X.stride(0), 0, _p(W, woff), W.stride(0), 0, 0, _p(b), act,
+        _lib.check(self._dl(1, M, K, N, _p(X, xoff), X.stride(0), 0, _p(W, woff), W.stride(0), 0, 0, _p(b), act,
                                   _p(Y, yoff), Y.stride(0), 0, None, 0, 0, None, 0, 0, self.st), "dispu_linear")
 
     def _tn(self, batch, M, K, N, X, xoff, ldx, sx, Zt, zoff, ldz, sz, out, ooff, ldo, so, accumulate, dbias=None):
         L = _lib.lib()
+        if self.bf16 and K > 4 and N > 4:
+            need = L.dispu_linear_tn_bf16_scratch_floats(batch, M, K, N)
+            sc = self._scratch_floats(need)
+            _lib.check(L.dispu_linear_tn_bf16(batch, M, K, N, _p(X, xoff), ldx, sx, _p(Zt, zoff), ldz, sz, _p(out, ooff), ldo, so,
+                                              accumulate, _p(dbias), _p(sc), sc.numel(), self.st), "dispu_linear_tn_bf16")
+            return
         need = L.dispu_linear_tn_scratch_floats(batch, M, K, N)
         sc = self._scratch_floats(need)
         _lib.check(L.dispu_linear_tn(batch, M, K, N, _p(X, xoff), ldx, sx, _p(Zt, zoff), ldz, sz, _p(out, ooff), ldo, so,
@@ -192,7 +212,7 @@ class Trainer(object):
             self._act_bias_grad(M, N, dY, dyoff, Y, yoff, act, dY, dyoff, None)          # relu_grad, in place
         self._tn(1, M, K, N, X, xoff, X.stride(0), 0, dY, dyoff, dY.stride(0), 0, dW, woff, dW.stride(0), 0, 1, dbias=db)
         if dX is not None:
-            _lib.check(L.dispu_linear(1, M, N, K, _p(dY, dyoff), dY.stride(0), 0, _p(W, woff), W.stride(0), 0, 1, None, 0,
+            _lib.check(self._dl(1, M, N, K, _p(dY, dyoff), dY.stride(0), 0, _p(W, woff), W.stride(0), 0, 1, None, 0,
                                       _p(dX, dxoff), dX.stride(0), 0, _p(dX, dxoff) if acc_dx else None,
                                       dX.stride(0) if acc_dx else 0, 0, None, 0, 0, self.st), "dispu_linear(dX)")
 
@@ -261,10 +281,10 @@ class Trainer(object):
         self._lin(up128, 0, 128, ps + "PointShuffle/conv_kv", 0, ws["kv"], 0, 128)
         self._lin(up128, 0, 128, ps + "PointShuffle/conv_query", 0, ws["q"], 0, 64)
         S = ws["S"]
-        _lib.check(L.dispu_linear(B, M, 64, M, _p(ws["q"]), 64, M * 64, _p(ws["kv"]), 128, M * 128, 1, None, 0, _p(S), M, M * M,
+        _lib.check(self._dl(B, M, 64, M, _p(ws["q"]), 64, M * 64, _p(ws["kv"]), 128, M * 128, 1, None, 0, _p(S), M, M * M,
                                   None, 0, 0, None, 0, 0, st), "scores")
         _lib.check(L.dispu_softmax_rows(rm, M, 0.125, _p(S), M, st), "softmax")
-        _lib.check(L.dispu_linear(B, M, M, 64, _p(S), M, M * M, _p(ws["kv"], 64), 128, M * 128, 0, None, 0, _p(ws["att"]), 64,
+        _lib.check(self._dl(B, M, M, 64, _p(S), M, M * M, _p(ws["kv"], 64), 128, M * 128, 0, None, 0, _p(ws["att"]), 64,
                                   M * 64, None, 0, 0, None, 0, 0, st), "att.V")
         self._lin(ws["att"], 0, 64, ps + "PointShuffle/conv_back_project", 1, ws["nl"], 0, 256)
         # skip
@@ -396,13 +416,13 @@ class Trainer(object):
                       premasked=True)
         S, dS, kv, dkv, q = ws["S"], ws["dS"], ws["kv"], ws["dkv"], ws["q"]
         # dP = dO . V^T
-        _lib.check(L.dispu_linear(B, M, 64, M, _p(ws["datt"]), 64, M * 64, _p(kv, 64), 128, M * 128, 1, None, 0, _p(dS), M, M * M,
+        _lib.check(self._dl(B, M, 64, M, _p(ws["datt"]), 64, M * 64, _p(kv, 64), 128, M * 128, 1, None, 0, _p(dS), M, M * M,
                                   None, 0, 0, None, 0, 0, st), "dP")
         # dV = P^T . dO  -> dkv[:, 64:128]
         self._tn(B, M, M, 64, S, 0, M, M * M, ws["datt"], 0, 64, M * 64, dkv, 64, 128, M * 128, 0)
         _lib.check(L.dispu_softmax_rows_grad(rm, M, 0.125, _p(S), M, _p(dS), M, st), "softmax_grad")
         # dQ = dS . K
-        _lib.check(L.dispu_linear(B, M, M, 64, _p(dS), M, M * M, _p(kv), 128, M * 128, 0, None, 0, _p(ws["dq"]), 64, M * 64,
+        _lib.check(self._dl(B, M, M, 64, _p(dS), M, M * M, _p(kv), 128, M * 128, 0, None, 0, _p(ws["dq"]), 64, M * 64,
                                   None, 0, 0, None, 0, 0, st), "dQ")
         # dK = dS^T . Q -> dkv[:, 0:64]
         self._tn(B, M, M, 64, dS, 0, M, M * M, q, 0, 64, M * 64, dkv, 0, 128, M * 128, 0)

@@ -256,6 +256,17 @@ int dispu_repulsion(long rows, int n_per_cloud, int ns, int use_l1, float h, con
  * points are those gradients written out; each cites the forward op it differentiates.  Convention: for a layer
  * Y = act(X.W + b):  dZ = dY * act'(Y) (dispu_act_bias_grad, which also yields db = colsum dZ),
  * dW = X^T.dZ (dispu_linear_tn),  dX = dZ.W^T (dispu_linear with transb = 1, R1 = dX to accumulate). */
+/* Mixed-precision variants for the training step (BASELINE configs[4] names bf16; the reference itself is fp32-only, so this
+ * is an opt-in extension, Trainer(dtype="bf16")): same contracts as dispu_linear / dispu_linear_tn, fp32 tensors in memory,
+ * operands rounded to bf16 (RNE) on the way into LDS, v_mfma_f32_32x32x16_bf16 products, fp32 accumulation and epilogue.
+ * dispu_linear_tn_bf16's dbias (optional, batch == 1) is an fp32 column sum of the UN-rounded Z, taken inside the kernel. */
+int dispu_linear_bf16(int batch, int M, int K, int N, const float* X, long ldx, long sx, const float* W, long ldw, long sw,
+                      int transb, const float* bias, int act, float* Y, long ldy, long sy, const float* R1, long ldr1, long sr1,
+                      const float* R2, long ldr2, long sr2, void* stream);
+long dispu_linear_tn_bf16_scratch_floats(int batch, int M, int K, int N);
+int dispu_linear_tn_bf16(int batch, int M, int K, int N, const float* X, long ldx, long sx, const float* Z, long ldz, long sz,
+                         float* out, long ldo, long so, int accumulate, float* dbias, float* scratch, long scratch_floats,
+                         void* stream);
 /* floats of scratch dispu_linear_tn needs for (batch, M, K, N). */
 long dispu_linear_tn_scratch_floats(int batch, int M, int K, int N);
 /* out[z][k][n] (+)= sum_m X[z][m][k] * Z[z][m][n]   (conv2d_backprop_filter of a 1x1 conv; the TN products of the

@@ -1,0 +1,154 @@
+"""Mixed-precision training step (BASELINE configs[4] names bf16; the reference is fp32-only, DisPU/model.py:215-232 /
+Common/tf_util.py:52-185, so this is an extension with its OWN tolerance, stated here):
+
+  * the bf16-product GEMMs (csrc/linear_bf16.hip: NN forward, NT input gradient, TN weight gradient) are EXACT up to
+    fp32 accumulation against a float64 product of the bf16-rounded operands (<= 2e-6 of sum |a||b|) -- that pins operand
+    layouts, masking, split reduction and epilogues;
+  * against the fp32 operands the product error is the bf16 rounding of the operands, <= 2^-8 relative per factor;
+  * a whole Trainer(dtype="bf16") step: loss terms within 2 % of the fp32 step, flat gradient cosine >= 0.97 (index
+    decisions -- feature k-NN, arg-min of the Chamfer terms -- may flip at near-ties, which moves a few rows by O(1)),
+    and ten Adam steps decrease the loss like the fp32 run.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import generator as OG
+
+pytestmark = pytest.mark.gpu
+
+
+def N_(t):
+    return t.detach().cpu().numpy()
+
+
+def bf16_round(a):
+    return torch.from_numpy(np.ascontiguousarray(a, np.float32)).bfloat16().float().numpy().astype(np.float64)
+
+
+def dv(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(dev)
+
+
+@pytest.mark.parametrize("M,K,N,transb,act,res", [(1000, 134, 48, 0, 1, 0), (256, 32, 128, 0, 0, 2), (4096, 2048, 256, 0, 1, 2), (513, 72, 24, 1, 0, 1),
+                                                   (8192, 256, 480, 1, 0, 1), (130, 5, 7, 0, 1, 0), (64, 480, 256, 0, 0, 0)])
+def test_linear_bf16_vs_float64_of_rounded_operands(dev, M, K, N, transb, act, res):
+    from dispu_amd import _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(M + K + N)
+    x = rng.standard_normal((M, K)).astype(np.float32)
+    w = (rng.standard_normal((N, K) if transb else (K, N)) * 0.1).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32) * 0.1
+    r1, r2 = rng.standard_normal((M, N)).astype(np.float32), rng.standard_normal((M, N)).astype(np.float32)
+    tx, tw, tb, t1, t2 = (dv(a, dev) for a in (x, w, bias, r1, r2))
+    y = torch.full((M, N), 7.0, device=dev)
+    p = lambda t: _lib.C.c_void_p(t.data_ptr()) if t is not None else None
+    _lib.check(L.dispu_linear_bf16(1, M, K, N, p(tx), K, 0, p(tw), K if transb else N, 0, transb, p(tb), act, p(y), N, 0,
+                                   p(t1) if res >= 1 else None, N, 0, p(t2) if res >= 2 else None, N, 0, _lib.stream_ptr(dev)), "dispu_linear_bf16")
+    xr, wr = bf16_round(x), bf16_round(w)
+    z = xr @ (wr.T if transb else wr) + bias
+    if act:
+        z = np.maximum(z, 0)
+    if res >= 1:
+        z = z + r1
+    if res >= 2:
+        z = z + r2
+    bound = 2e-6 * (np.abs(xr) @ np.abs(wr.T if transb else wr)) + 1e-6 * (1 + np.abs(z))
+    assert (np.abs(N_(y) - z) <= bound).all(), float(np.abs(N_(y) - z).max())
+    # and against the un-rounded operands: the bf16 rounding of both factors
+    zf = x.astype(np.float64) @ (w.astype(np.float64).T if transb else w.astype(np.float64))
+    zb = xr @ (wr.T if transb else wr)
+    assert np.abs(zb - zf).max() <= 2.0 ** -7 * (np.abs(x).astype(np.float64) @ np.abs(w.astype(np.float64).T if transb else w.astype(np.float64))).max()
+
+
+def test_linear_bf16_batched_and_strided(dev):
+    """the attention products of the training forward: batched, operands are column slices (ld > width)."""
+    from dispu_amd import _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(1)
+    b, m = 3, 160
+    q = rng.standard_normal((b * m, 64)).astype(np.float32)
+    kv = rng.standard_normal((b * m, 128)).astype(np.float32)
+    tq, tkv = dv(q, dev), dv(kv, dev)
+    s = torch.zeros((b, m, m), device=dev)
+    _lib.check(L.dispu_linear_bf16(b, m, 64, m, tq.data_ptr(), 64, m * 64, tkv.data_ptr(), 128, m * 128, 1, None, 0, s.data_ptr(), m, m * m,
+                                   None, 0, 0, None, 0, 0, _lib.stream_ptr(dev)), "scores")
+    want = np.einsum("bqd,bkd->bqk", bf16_round(q).reshape(b, m, 64), bf16_round(kv[:, :64]).reshape(b, m, 64))
+    assert np.abs(N_(s) - want).max() <= 1e-4
+    o = torch.zeros((b * m, 64), device=dev)
+    _lib.check(L.dispu_linear_bf16(b, m, m, 64, s.data_ptr(), m, m * m, tkv.data_ptr() + 256, 128, m * 128, 0, None, 0, o.data_ptr(), 64, m * 64,
+                                   None, 0, 0, None, 0, 0, _lib.stream_ptr(dev)), "att.V")
+    want2 = np.einsum("bqk,bkd->bqd", bf16_round(N_(s)), bf16_round(kv[:, 64:]).reshape(b, m, 64))
+    assert np.abs(N_(o).reshape(b, m, 64) - want2).max() <= 2e-3 * np.abs(want2).max()
+
+
+@pytest.mark.parametrize("M,K,N,acc", [(4096, 96, 24, 1), (131072, 120, 24, 1), (32768, 256, 128, 0), (1000, 134, 256, 1), (70000, 2048, 256, 1), (100, 7, 9, 0)])
+def test_linear_tn_bf16(dev, M, K, N, acc):
+    from dispu_amd import _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(M + K)
+    x = rng.standard_normal((M, K)).astype(np.float32)
+    z = (rng.standard_normal((M, N)) * 0.1).astype(np.float32)
+    o0 = rng.standard_normal((K, N)).astype(np.float32)
+    tx, tz, to = dv(x, dev), dv(z, dev), dv(o0, dev)
+    need = L.dispu_linear_tn_bf16_scratch_floats(1, M, K, N)
+    sc = torch.empty(max(need, 1), device=dev)
+    db0 = rng.standard_normal(N).astype(np.float32)
+    tdb = dv(db0, dev)
+    _lib.check(L.dispu_linear_tn_bf16(1, M, K, N, tx.data_ptr(), K, 0, tz.data_ptr(), N, 0, to.data_ptr(), N, 0, acc, tdb.data_ptr(), sc.data_ptr(),
+                                      sc.numel(), _lib.stream_ptr(dev)), "dispu_linear_tn_bf16")
+    wdb = z.astype(np.float64).sum(0) + (db0 if acc else 0)                  # bias gradient: fp32 sums of the un-rounded Z
+    assert np.abs(N_(tdb) - wdb).max() <= 2e-6 * np.abs(z).astype(np.float64).sum(0).max() + 1e-6
+    xr, zr = bf16_round(x), bf16_round(z)
+    want = xr.T @ zr + (o0 if acc else 0)
+    bound = 4e-6 * (np.abs(xr).T @ np.abs(zr)) + 1e-6 * (1 + np.abs(want))
+    assert (np.abs(N_(to) - want) <= bound).all(), float(np.abs(N_(to) - want).max())
+
+
+@pytest.fixture(scope="module")
+def steps(dev):
+    from dispu_amd import synth
+    from dispu_amd.train import Trainer
+    P = OG.init_params(seed=1234, bias_scale=0.05, bn_random=True)
+    x, gt = synth.patch_with_gt(4, 256, 1024, seed=7)
+    tx, tg, r = dv(x, dev), dv(gt, dev), torch.ones(4, device=dev)
+    out = {}
+    for dt in ("f32", "bf16"):
+        tr = Trainer(params=P, device=dev, dtype=dt)
+        tr.zero_grad()
+        c, f = tr.forward(tx)
+        terms = tr.loss_backward(tg, r)
+        tr.backward()
+        torch.cuda.synchronize()
+        out[dt] = dict(tr=tr, c=N_(c).copy(), f=N_(f).copy(), terms={k: float(v) for k, v in terms.items()}, g=N_(tr.flat_g).astype(np.float64))
+    out["data"] = (tx, tg, r, P)
+    return out
+
+
+def test_bf16_step_forward_and_loss(steps):
+    a, b = steps["f32"], steps["bf16"]
+    assert np.isfinite(b["f"]).all()
+    # coordinates: bf16 products perturb the features by ~2^-8 relative; the clouds stay within 2e-2 of the fp32 ones
+    assert np.abs(b["c"] - a["c"]).max() <= 2e-2 and np.abs(b["f"] - a["f"]).max() <= 3e-2
+    assert np.median(np.abs(b["f"] - a["f"])) <= 2e-3
+    for k in ("dis_coarse_cd", "dis_fine_cd", "pu_loss"):
+        assert abs(b["terms"][k] - a["terms"][k]) <= 2e-2 * abs(a["terms"][k]), (k, a["terms"][k], b["terms"][k])
+
+
+def test_bf16_step_gradient_direction(steps):
+    ga, gb = steps["f32"]["g"], steps["bf16"]["g"]
+    cos = float(ga @ gb / (np.linalg.norm(ga) * np.linalg.norm(gb)))
+    rel = float(np.linalg.norm(ga - gb) / np.linalg.norm(ga))
+    print("bf16 vs fp32 gradient: cosine %.4f, relative L2 %.3f" % (cos, rel))
+    assert cos >= 0.97, cos
+
+
+def test_bf16_training_decreases_the_loss(steps, dev):
+    from dispu_amd.train import Trainer
+    tx, tg, r, P = steps["data"]
+    hist = {}
+    for dt in ("f32", "bf16"):
+        tr = Trainer(params=P, device=dev, dtype=dt)
+        hist[dt] = [float(tr.train_step(tx, tg, r)["pu_loss"]) for _ in range(10)]
+    assert hist["bf16"][-1] < 0.9 * hist["bf16"][0], hist["bf16"]
+    assert abs(hist["bf16"][-1] - hist["f32"][-1]) <= 0.15 * hist["f32"][-1], (hist["f32"][-1], hist["bf16"][-1])

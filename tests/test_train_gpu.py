@@ -396,3 +396,42 @@ def test_train_step_refuses_bad_targets(dev):
         tr.train_step(tx, tg.double(), r)
     with pytest.raises(ValueError):
         tr.train_step(tx, tg, torch.ones(3, device=dev))
+
+
+def test_generator_is_training_routes_to_training_forward(step, dev):
+    """Generator(opts, is_training=True)(inputs) (DisPU/generator.py:22-31, DisPU/model.py:68) = the training-mode forward:
+    BatchNorm on batch statistics, moving averages updated; same values as Trainer.forward on the same variables."""
+    from dispu_amd.generator import Generator
+    gen = Generator(is_training=True, params=step["P"], device=dev)
+    c, f = gen(dv(step["x"], dev))
+    close(N_(c), step["ref"]["coarse"], 1e-5, "coarse")
+    close(N_(f), step["ref"]["fine"], 1e-5, "fine")
+    close(N_(gen.trainer.moving_mean), step["ref"]["bn"]["moving_mean"], 1e-5, "moving_mean")
+    # and it differs from the inference graph exactly by the BatchNorm statistics
+    ci, fi = Generator(is_training=False, params=step["P"], device=dev)(dv(step["x"], dev))
+    assert np.array_equal(N_(ci), N_(c)) or np.abs(N_(ci) - N_(c)).max() < 1e-5      # coarse does not depend on BN
+    assert np.abs(N_(fi) - N_(f)).max() > 0
+
+
+def test_conv2d_training_mode_batch_norm(dev):
+    """tf_util.conv2d(bn=True, is_training=True): contrib batch_norm on batch statistics + moving-average update
+    (Common/tf_util.py:512-531, decay bn_decay)."""
+    from dispu_amd import tf_util
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((2, 50, 8, 12)).astype(np.float32)
+    P = {"s/weights": (rng.standard_normal((12, 20)) * 0.3).astype(np.float32), "s/biases": rng.standard_normal(20).astype(np.float32) * 0.1,
+         "s/bn/gamma": (1 + 0.1 * rng.standard_normal(20)).astype(np.float32), "s/bn/beta": (0.1 * rng.standard_normal(20)).astype(np.float32),
+         "s/bn/moving_mean": np.zeros(20, np.float32), "s/bn/moving_variance": np.ones(20, np.float32)}
+    y = N_(tf_util.conv2d(dv(x, dev), 20, (1, 1), "s", P, bn=True, is_training=True, bn_decay=0.9))
+    z = x.reshape(-1, 12).astype(np.float64) @ P["s/weights"].astype(np.float64) + P["s/biases"]
+    mu, var = z.mean(0), z.var(0)
+    want = np.maximum((z - mu) / np.sqrt(var + 1e-3) * P["s/bn/gamma"] + P["s/bn/beta"], 0).reshape(2, 50, 8, 20)
+    assert np.abs(y - want).max() <= 2e-5
+    n = z.shape[0]
+    assert np.abs(N_(P["s/bn/moving_mean"]) - 0.1 * mu).max() <= 1e-5
+    assert np.abs(N_(P["s/bn/moving_variance"]) - (0.9 + 0.1 * var * n / (n - 1))).max() <= 1e-5   # fused BN: unbiased variance in the average
+    # inference afterwards folds the UPDATED moving statistics
+    y2 = N_(tf_util.conv2d(dv(x, dev), 20, (1, 1), "s", P, bn=True, is_training=False))
+    mm, mv = N_(P["s/bn/moving_mean"]).astype(np.float64), N_(P["s/bn/moving_variance"]).astype(np.float64)
+    want2 = np.maximum((z - mm) / np.sqrt(mv + 1e-3) * P["s/bn/gamma"] + P["s/bn/beta"], 0).reshape(2, 50, 8, 20)
+    assert np.abs(y2 - want2).max() <= 2e-5

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Training-step benchmark (BASELINE configs[4] shape: full train step, data-parallel over the ranks, RCCL gradient
-all-reduce; fp32 here -- the reference is fp32-only).  Not the driver's headline bench (that is bench.py, configs[1]).
+all-reduce; --dtype f32 (the reference's arithmetic) or bf16 (mixed precision, an extension: the reference is fp32-only)).  Not the driver's headline bench (that is bench.py, configs[1]).
 
     python tools/train_bench.py --batch 8 --steps 20                 # one GPU, 8 patches (config 5's per-GPU share)
     python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 tools/train_bench.py --batch 8
@@ -25,6 +25,8 @@ def main():
     ap.add_argument("--batch", type=int, default=8, help="patches per GPU")
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--dtype", choices=("f32", "bf16"), default="f32",
+                    help="f32: the reference's arithmetic; bf16: bf16 products / fp32 accumulation and storage (csrc/linear_bf16.hip)")
     args = ap.parse_args()
     from dispu_amd import synth
     from dispu_amd.train import Trainer
@@ -39,7 +41,7 @@ def main():
     # weights: Xavier-uniform, seed 1234 (identical on every rank) -- generated without the oracle package
     from dispu_amd.params import init_params
     P = init_params(1234)
-    tr = Trainer(params=P, device=dev)
+    tr = Trainer(params=P, device=dev, dtype=args.dtype)
     x, gt = synth.patch_with_gt(args.batch, 256, 1024, seed=5000 + rank)
     x, gt = torch.from_numpy(x).to(dev), torch.from_numpy(gt).to(dev)
     radius = torch.ones(args.batch, device=dev)
@@ -81,7 +83,8 @@ def main():
         phases = dict(zip(("forward_ms", "loss_ms", "backward_ms", "allreduce_adam_ms"), (acc / 5).round(3).tolist()))
         print(json.dumps({"metric": "training patches/sec (256->1024 generator, full step)", "value": world * args.batch * args.steps / dt,
                           "unit": "patches/s", "n_gpus": world, "patches_per_gpu": args.batch, "steps": args.steps,
-                          "ms_per_step": dt / args.steps * 1e3, "dtype": "f32", "pu_loss": float(terms["pu_loss"]), **phases}))
+                          "ms_per_step": dt / args.steps * 1e3,
+                          "dtype": "f32" if args.dtype == "f32" else "bf16 products, f32 accumulate / storage", "pu_loss": float(terms["pu_loss"]), **phases}))
     if world > 1:
         dist.destroy_process_group()
 
