@@ -123,6 +123,34 @@ def test_fps_index_exact(ops, dev, b, n, m, arith):
     assert np.array_equal(got, O.farthest_point_sample(m, x, contract=arith))
 
 
+@pytest.mark.parametrize("b,n,m,kind", [(1, 24576, 8192, "surface"), (2, 24576, 700, "cube"), (2, 12000, 3000, "surface"), (3, 5000, 1200, "cube"),
+                                        (1, 8193, 64, "cube"), (2, 6000, 600, "dups"), (1, 4097, 4097, "grid")])
+def test_fps_large_clouds_index_exact(ops, dev, b, n, m, kind):
+    """Large clouds at the whole-cloud test path's shape (1, 24576, 8192) (DisPU/model.py:375) and around the register-kernel
+    boundaries: the sampled indices equal the oracle's exactly, including tie decisions (duplicated points, grids) --
+    tf_sampling_g.cu:105-170."""
+    rng = np.random.default_rng(n + m)
+    if kind == "surface":                                  # points on a sphere-like 2-manifold, like merged patches
+        g = rng.standard_normal((b, n, 3))
+        x = (g / np.linalg.norm(g, axis=2, keepdims=True) * (1 + 0.02 * rng.standard_normal((b, n, 1)))).astype(np.float32)
+    elif kind == "cube":
+        x = rng.random((b, n, 3)).astype(np.float32)
+    elif kind == "dups":
+        x = np.repeat(rng.random((b, n // 4, 3)).astype(np.float32), 4, axis=1)
+        x = x[:, rng.permutation(x.shape[1])]
+    else:
+        side = int(np.ceil(n ** (1 / 3)))
+        gx = np.stack(np.meshgrid(np.arange(side), np.arange(side), np.arange(side), indexing="ij"), -1).reshape(-1, 3)[:n]
+        x = np.broadcast_to(gx.astype(np.float32)[None], (b, n, 3)).copy()
+    n = x.shape[1]
+    for arith in (CONTRACT, PLAIN):
+        got = N(ops["S"].farthest_point_sample(m, T(x, dev), arith=arith))
+        want = O.farthest_point_sample(m, x, contract=arith)
+        assert np.array_equal(got, want), (kind, arith, int(np.argmax((got != want).any(0))))
+        if m > 2000:
+            break                                          # one flavour is enough at the big shapes (the oracle takes seconds)
+
+
 def test_fps_ties_and_duplicates(ops, dev):
     """Adversarial: grids (many exact ties), duplicated points, more samples than distinct points."""
     gx = np.stack(np.meshgrid(np.arange(10), np.arange(10), np.arange(7), indexing="ij"), -1).reshape(1, -1, 3).astype(np.float32)
