@@ -324,10 +324,27 @@ def load_generator_params(prefix, scope="generator"):
     return OrderedDict((k, P[k]) for k in want)
 
 
-def save_generator_params(prefix, params, scope="generator", step=None):
-    """the inverse: write the weights under the reference's variable names and 4-D / 3-D kernel shapes, plus the
-    `checkpoint` state file, so `tf.train.Saver().restore` of the reference graph can read them."""
+def save_generator_params(prefix, params, scope="generator", step=None, epoch=None, global_step=0, adam_slots=False):
+    """the inverse of load_generator_params: write the generator's variables under the reference's names and 4-D / 3-D kernel
+    shapes, plus the graph's two non-generator globals `epoch` (float32 scalar) and `global_step` (int32 scalar)
+    (DisPU/model.py:42-45) and the `checkpoint` state file.
+
+    File name: the reference saves as `<log_dir>/model-<epoch>` (model.py:226) and parses the number after the dash
+    (Common/model_utils.py:138), so `step` is appended to `prefix` when given and a prefix without a `-<number>` tail is
+    refused.  Returns the prefix written.
+
+    What can restore it: this module's reader, and a tf.train.Saver over the reference's TEST graph (model.py:350-353: the
+    generator variables and the two globals are all it holds).  The TRAIN graph's Saver also wants the Adam slots
+    (`<var>/Adam`, `<var>/Adam_1`, `beta1_power`, `beta2_power`); `adam_slots=True` writes them as a fresh optimizer state
+    (zeros, beta powers 0.9 / 0.999).  No checkpoint written by real TensorFlow is available here: the format is pinned by
+    known-answer bytes and round trips only (tests/test_checkpoint.py), "parity unpinned" at the TF boundary."""
     from .params import layer_shapes
+    if step is not None:
+        prefix = "%s-%d" % (prefix, int(step))
+    base = os.path.basename(prefix)
+    m = re.search(r"-(\d+)$", base)
+    if not m:
+        raise ValueError("checkpoint prefix %r needs a -<step> tail (pass step=...): pre_load_checkpoint parses it" % base)
     shapes = dict(layer_shapes())
     out = {}
     for k, v in params.items():
@@ -335,8 +352,16 @@ def save_generator_params(prefix, params, scope="generator", step=None):
         if k.endswith("/weights"):
             a = a.reshape(shapes[k[:-len("/weights")]])
         out[scope + "/" + k] = a
+        if adam_slots and k.endswith(("/weights", "/biases", "/gamma", "/beta")):
+            out[scope + "/" + k + "/Adam"] = np.zeros_like(a)
+            out[scope + "/" + k + "/Adam_1"] = np.zeros_like(a)
+    if adam_slots:
+        out["beta1_power"] = np.array(0.9, np.float32)
+        out["beta2_power"] = np.array(0.999, np.float32)
+    out["epoch"] = np.array(float(int(m.group(1)) if epoch is None else epoch), np.float32)
+    out["global_step"] = np.array(int(global_step), np.int32)
     write_bundle(prefix, out)
     d = os.path.dirname(os.path.abspath(prefix))
-    base = os.path.basename(prefix)
     with open(os.path.join(d, "checkpoint"), "w") as f:
         f.write('model_checkpoint_path: "%s"\nall_model_checkpoint_paths: "%s"\n' % (base, base))
+    return prefix

@@ -269,7 +269,7 @@ __global__ __launch_bounds__(AM_ROWS) void match_cost_tile_kernel(int n, int m, 
     if (k < n) {
         const float x1 = p1[k * 3 + 0], y1 = p1[k * 3 + 1], z1 = p1[k * 3 + 2];
         const float* __restrict__ mt = match + (size_t)cloud * n * m + (size_t)l0 * n + k;
-#pragma unroll 16
+#pragma unroll 8
         for (int i = 0; i < len; ++i) {
             const float4 q = tile[i];
             const float w = __builtin_nontemporal_load(mt + (size_t)i * n);

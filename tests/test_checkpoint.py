@@ -68,6 +68,25 @@ def test_generator_checkpoint_round_trip(tmp_path):
     assert list(Q) == list(P)
     assert all(np.array_equal(Q[k], P[k]) for k in P)
     assert CK.pre_load_checkpoint(str(tmp_path / "nope")) == (0, None)
+    # the graph's non-generator globals travel too (DisPU/model.py:42-45), with the reference's dtypes
+    raw = CK.read_bundle(prefix)
+    assert raw["epoch"].dtype == np.float32 and raw["epoch"].shape == () and float(raw["epoch"]) == 40.0
+    assert raw["global_step"].dtype == np.int32 and int(raw["global_step"]) == 0
+
+
+def test_checkpoint_prefix_rules_and_adam_slots(tmp_path):
+    P = PP.init_params(7)
+    with pytest.raises(ValueError):
+        CK.save_generator_params(str(tmp_path / "model"), P)          # pre_load_checkpoint could not parse this name
+    written = CK.save_generator_params(str(tmp_path / "model"), P, step=12, global_step=345, adam_slots=True)
+    assert written.endswith("model-12") and CK.pre_load_checkpoint(str(tmp_path)) == (12, written)
+    raw = CK.read_bundle(written)
+    assert int(raw["global_step"]) == 345 and float(raw["epoch"]) == 12.0
+    assert abs(float(raw["beta1_power"]) - 0.9) < 1e-7 and abs(float(raw["beta2_power"]) - 0.999) < 1e-7
+    w = "generator/refine/PointShuffle/after_conv/weights"
+    assert raw[w + "/Adam"].shape == raw[w].shape == (1, 128, 16, 256) and not raw[w + "/Adam_1"].any()
+    Q = CK.load_generator_params(written)                             # slots and globals are skipped on the way back
+    assert list(Q) == list(P) and all(np.array_equal(Q[k], P[k]) for k in P)
 
 
 def test_optimizer_slots_are_ignored_and_missing_variables_reported(tmp_path):
