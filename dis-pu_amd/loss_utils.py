@@ -1,8 +1,8 @@
 """Losses of the reference's training graph (Common/loss_utils.py: chamfer :45-64, hausdorff_loss :67-84,
 earth_mover :170-176, get_repulsion_loss :271-298) on the hot-path ops.  Same names / arguments / return values
 (scalar tensors).  chamfer and earth_mover are differentiable w.r.t. the point sets through the registered
-gradients of nn_distance / match_cost; hausdorff (logged only in the reference, DisPU/model.py:76,79) and the
-repulsion term are forward-only in round 1."""
+gradients of nn_distance / match_cost, hausdorff through them and the max reductions (the reference only logs it,
+DisPU/model.py:76,79); the repulsion term here is forward-only (its gradient kernel is used by train.py)."""
 import torch
 
 from . import _lib
@@ -33,6 +33,23 @@ class _RowMean(torch.autograd.Function):
         return (g / ctx.n).unsqueeze(1).expand(-1, ctx.n).contiguous()
 
 
+class _RowMax(torch.autograd.Function):
+    """max over axis 1 with the HIP reduction forward; the gradient goes to the maximal entries, split evenly among ties
+    (tf.reduce_max's rule)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        mx = _row_mean_max(x)[1]
+        ctx.save_for_backward(x, mx)
+        return mx
+
+    @staticmethod
+    def backward(ctx, g):
+        x, mx = ctx.saved_tensors
+        hit = (x == mx.unsqueeze(1)).to(x.dtype)
+        return hit * (g / hit.sum(1)).unsqueeze(1)
+
+
 def chamfer(pred, gt, radius=1.0, forward_weight=1.0, threshold=None, return_hd=False):
     """loss_utils.py:45-64: mean_b[(fw * mean(dist gt->pred) + mean(dist pred->gt)) / radius]."""
     if threshold is not None:
@@ -46,8 +63,8 @@ def hausdorff_loss(pred, gt, radius=1.0, forward_weight=1.0, threshold=None):
     """loss_utils.py:67-84: max_b[(fw * max(dist gt->pred) + max(dist pred->gt)) / radius]."""
     if threshold is not None:
         raise NotImplementedError("threshold is never set by the reference's training graph")
-    dists_forward, _, dists_backward, _ = nn_distance(gt.detach(), pred.detach())
-    hd = forward_weight * _row_mean_max(dists_forward)[1] + _row_mean_max(dists_backward)[1]
+    dists_forward, _, dists_backward, _ = nn_distance(gt, pred)
+    hd = forward_weight * _RowMax.apply(dists_forward) + _RowMax.apply(dists_backward)
     return (hd / radius).max()
 
 

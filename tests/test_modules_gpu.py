@@ -140,3 +140,25 @@ def test_losses(dev):
     tp.grad = None
     emd.backward()
     assert np.isfinite(N(tp.grad)).all() and np.abs(N(tp.grad)).max() > 0
+
+
+def test_hausdorff_loss_gradient(dev):
+    """hausdorff_loss (Common/loss_utils.py:67-84) is logged, not trained on, in the reference; its gradient here flows through
+    nn_distance's registered gradient and the two max reductions.  Checked against finite differences of the oracle loss at the
+    coordinates that carry it (the points realising the maxima) and zero elsewhere."""
+    from dispu_amd import loss_utils as LU
+    from dispu_amd import synth
+    pred, gt = synth.patch_with_gt(2, 300, 280, seed=9)
+    tp, tg = T(pred, dev).requires_grad_(True), T(gt, dev)
+    hd = LU.hausdorff_loss(tp, tg)
+    hd.backward()
+    g = N(tp.grad)
+    assert abs(float(hd) - OM.hausdorff_loss(pred, gt)) <= 1e-6
+    nz = np.argwhere(np.abs(g).sum(-1) > 0)
+    assert 1 <= len(nz) <= 4                                # at most the two arg-max points of the winning cloud (+ their matches)
+    eps = 1e-3
+    for (b, i) in nz:
+        for c in range(3):
+            e = np.zeros_like(pred); e[b, i, c] = eps
+            num = (OM.hausdorff_loss(pred + e, gt) - OM.hausdorff_loss(pred - e, gt)) / (2 * eps)
+            assert abs(num - g[b, i, c]) < 5e-3 * max(1.0, abs(num))

@@ -53,6 +53,48 @@ def test_config4_16x_with_cd_and_emd(dev):
     assert abs(emd - OM.earth_mover(N(tf), gt)) <= 1e-5 * OM.earth_mover(N(tf), gt)
 
 
+def test_config4_at_full_batch_properties(dev):
+    """BASELINE configs[3] at the size of SURVEY 8(d): B = 32 patches, 256 -> 1024 -> 4096, CD + EMD against 4096-point ground
+    truths.  The oracle's approx_match needs seconds per 4096^2 cloud, so the full batch is checked through size-independent
+    properties, and two of the 32 clouds against the oracle:
+      * the second generator pass is batch independent (row 5 of the B = 32 run == a B = 1 run on the same input), bit for bit;
+      * match: non-negative, every row and column sums to 1 (n == m);  EMD(x, x) is ~0 against EMD(x, y);
+      * Chamfer of the batch == the mean of per-cloud Chamfer values computed alone (nn_distance is per cloud);
+      * clouds 3 and 30: match_cost / chamfer against the oracle on the same GPU clouds (1e-5)."""
+    from dispu_amd import loss_utils as LU
+    from dispu_amd import synth
+    from dispu_amd import tf_approxmatch as A
+    from dispu_amd import upsample as U
+    from dispu_amd.generator import Generator
+    from dispu_amd.params import init_params
+    from oracle import modules as OM
+    B = 32
+    x, gt = synth.patch_with_gt(B, 256, 4096, seed=1000 * 3)
+    gen = Generator(params=init_params(seed=1234), device=dev)
+    tx, tg = torch.from_numpy(x).to(dev), torch.from_numpy(gt).to(dev)
+    _, fine = U.generator_chain(gen, tx, final_ratio=16)
+    assert tuple(fine.shape) == (B, 4096, 3) and torch.isfinite(fine).all()
+    _, f1 = gen(tx)
+    _, f5 = gen(f1[5:6].clone())
+    assert torch.equal(f5[0], fine[5])
+    match = A.approx_match(fine, tg)
+    assert float(match.min()) >= 0.0
+    assert float((match.sum(1) - 1).abs().max()) <= 2e-5 and float((match.sum(2) - 1).abs().max()) <= 2e-5
+    cost = A.match_cost(fine, tg, match)
+    self_cost = A.match_cost(fine, fine, A.approx_match(fine, fine))
+    assert float((self_cost / cost).max()) < 0.05
+    emd = float(LU.earth_mover(fine, tg))
+    assert abs(emd - float((cost / 4096.0).mean())) <= 1e-6 * emd
+    cd = float(LU.chamfer(fine, tg))
+    alone = np.mean([float(LU.chamfer(fine[i:i + 1], tg[i:i + 1])) for i in range(B)])
+    assert abs(cd - alone) <= 1e-6 * max(1.0, abs(alone))
+    for i in (3, 30):
+        fi, gi = N(fine[i:i + 1]), gt[i:i + 1]
+        assert abs(float(LU.chamfer(fine[i:i + 1], tg[i:i + 1])) - OM.chamfer(fi, gi)) <= 1e-5 * max(1.0, OM.chamfer(fi, gi))
+        co = O.match_cost(fi, gi, N(match[i:i + 1]))                       # the oracle's cost of the GPU plan
+        assert abs(float(cost[i]) - float(co[0])) <= 1e-5 * float(co[0])
+
+
 def test_upsample_cloud_stage_parity(dev):
     from dispu_amd import synth
     from dispu_amd import upsample as U
