@@ -170,7 +170,7 @@ def main():
     def step_eager():
         _, fine = gen(x)
         if world > 1:
-            parallel.all_gather_clouds(fine, out=gathered)
+            parallel.all_gather_clouds(fine, n_items=world * PATCHES_PER_GPU, out=gathered)
         return fine
 
     step_eager()
@@ -199,7 +199,7 @@ def main():
         if graph is not None:
             graph.replay()
             if world > 1:
-                parallel.all_gather_clouds(fine_buf, out=gathered)
+                parallel.all_gather_clouds(fine_buf, n_items=world * PATCHES_PER_GPU, out=gathered)
         else:
             step_eager()
 
@@ -281,7 +281,7 @@ def main():
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": "BASELINE configs[%d]: %d patches x %d points per GPU, generator forward 256->1024 (4x), "
                                       "fp32%s" % (1 if world == 1 else 2, PATCHES_PER_GPU, NPOINT,
-                                                  "" if world == 1 else ", + RCCL all-gather of the upsampled clouds"),
+                                                  "" if world == 1 else ", + %s all-gather of the upsampled clouds" % ("RCCL" if backend == "nccl" else backend)),
                           "patches_per_gpu": PATCHES_PER_GPU, "global_patches": world * PATCHES_PER_GPU,
                           "points_out_per_step": pts, "launch": launch, "weights": "xavier-uniform seed 1234, zero bias",
                           "parallelism": "patch-sharded x%d" % world},

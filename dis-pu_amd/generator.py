@@ -71,6 +71,7 @@ class Generator(object):
         self.fused_local = True      # PointShuffle2 local cell in one kernel (False: the 4-kernel chain, for A/B tests)
         self.fused_attention = True  # non-local cell attention on chip (False: GEMM -> softmax -> GEMM through HBM)
         self.fused_project = True    # conv_back_project as the attention kernel's epilogue (False: separate GEMM)
+        self.split_up3 = bool(int(__import__('os').environ.get('DISPU_SPLIT_UP3', '1')))
         self.fused_residual = bool(int(__import__('os').environ.get('DISPU_FUSED_RES', '1')))
         self.fused_heads = bool(int(__import__('os').environ.get('DISPU_FUSED_HEADS', '1')))   # one launch per head chain
         self.keep_intermediates = False   # fused heads: also write the aggregation output (tests compare it)
@@ -276,7 +277,13 @@ class Generator(object):
         up128 = ws["up128"]
         self._call("knn_xyz", L.dispu_knn_xyz, B, M, M, k, ptr(coarse), ptr(coarse), ptr(ws["psidx"]), None, _lib.ARITH_PLAIN, st)
         # PointNonLocalCell (ops.py:302-346)
-        self._linear(st, up128, 128, self.w_up3, self.b_up3, 0, ws["up3"], 320)      # K|V, Q and conv0's feature part at once
+        if self.split_up3:
+            # N = 320 as 256 + 64 columns: each launch reads up128 ONCE (128 x 256 / 128 x 64 tiles); one launch with 128 x 64
+            # tiles re-read it five times (128 MB of counter traffic against 59 MB algorithmic in round 1)
+            self._linear(st, up128, 128, self.w_up3, self.b_up3, 0, ws["up3"], 256)
+            self._linear(st, up128, 128, self.w_up3, self.b_up3[256:], 0, ws["up3"], 64, woff=256, yoff=256)
+        else:
+            self._linear(st, up128, 128, self.w_up3, self.b_up3, 0, ws["up3"], 320)  # K|V, Q and conv0's feature part at once
         w_bp, b_bp = self._w(ps + "PointShuffle/conv_back_project")
         projected = False
         if self.fused_attention and M % 32 == 0 and self.fused_project:
