@@ -203,6 +203,11 @@ __global__ __launch_bounds__(PL_NT) void ps_local_kernel(long npoints, int n_per
 // operand of the contraction in the lane that holds it: the [128 x 128] pair tensor never leaves the registers.
 // k ascends through (point, s) and the foreign point contributes exact zeros, so every output is the same
 // s-ascending fmaf chain as above -> bit-identical output.
+template <int CTRL>
+__device__ __forceinline__ float pl_quad(float v) {      // v from the lane given by the quad permutation CTRL
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+
 constexpr int PW_WRES = PL_K * PL_LDB;                               // resident W1 [128 k][132]
 constexpr int PW_ASTG = PL_BK * PL_LDA;                              // one A slab, k-major [32][129]
 constexpr int PW_FLOATS = PW_WRES + 2 * PW_ASTG + 2 * 2048 + 2 * 1024 + 512;
@@ -434,17 +439,30 @@ __global__ __launch_bounds__(512) void ps_local_ws_kernel(long npoints, int n_pe
                     o[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bvv, o[j], 0, 0, 0);
                 }
             }
+            // F' leaves as float4: the four lanes of a quad hold t = 4a .. 4a + 3 of four CONSECUTIVE channels (registers
+            // 4 g4 .. 4 g4 + 3); a 4 x 4 transpose inside the quad (two DPP quad_perm exchanges) gives every lane one channel
+            // with four consecutive t = one 16-byte store.  16 stores per lane and (i, j) pair became 4: the MFMA waves issue
+            // 16 vector-memory instructions per group instead of 64.
             const int pi = g * 8 + pblk + q;
-            if (pi < np) {
-                float* dst = out + (size_t)pi * 2048 + tt;
+            const int tq = tt & 3, t0 = tt & ~3;
+            float* dst = out + (size_t)(pi < np ? pi : 0) * 2048 + t0;
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int c = wn * 64 + j * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
-                        dst[c * 16] = o[j][r];
-                    }
-            }
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const float a0 = o[j][4 * g4 + 0], a1 = o[j][4 * g4 + 1], a2 = o[j][4 * g4 + 2], a3 = o[j][4 * g4 + 3];
+                    // exchange across lane bit 0 (quad_perm [1,0,3,2])
+                    const bool odd = tq & 1;
+                    const float s0 = pl_quad<0xB1>(odd ? a0 : a1), s2 = pl_quad<0xB1>(odd ? a2 : a3);
+                    const float b0 = odd ? s0 : a0, b1 = odd ? a1 : s0, b2 = odd ? s2 : a2, b3 = odd ? a3 : s2;
+                    // exchange across lane bit 1 (quad_perm [2,3,0,1])
+                    const bool hi = tq & 2;
+                    const float u0 = pl_quad<0x4E>(hi ? b0 : b2), u1 = pl_quad<0x4E>(hi ? b1 : b3);
+                    float4 v;
+                    v.x = hi ? u0 : b0; v.y = hi ? u1 : b1; v.z = hi ? b2 : u0; v.w = hi ? b3 : u1;
+                    const int c = wn * 64 + j * 32 + 8 * g4 + 4 * fk + tq;
+                    if (pi < np) *reinterpret_cast<float4*>(dst + c * 16) = v;
+                }
         }
 #ifdef PL_STAMPS
         { PL_T(p2s); c_con += p2s - p0s; }
