@@ -8,16 +8,35 @@ namespace dispu {
 
 constexpr int NN3_BS = 256;
 constexpr int NN3_TILE = 1024;
+constexpr int NN3_Q = 64;             // queries per workgroup; its 4 waves scan one quarter of every candidate tile each
 
+// sorted insert of (d, k) into the ascending triple, branch-free: strict '<' keeps the earlier (lower) index on ties,
+// exactly like the if / else-if chain of threenn_cpu (tf_interpolate.cpp:77-93) when candidates arrive in ascending index
+__device__ __forceinline__ void nn3_insert(float d, int k, float& b1, float& b2, float& b3, int& i1, int& i2, int& i3) {
+    const bool c1 = d < b1, c2 = d < b2, c3 = d < b3;
+    i3 = c2 ? i2 : (c3 ? k : i3);
+    i2 = c1 ? i1 : (c2 ? k : i2);
+    i1 = c1 ? k : i1;
+    b3 = c2 ? b2 : (c3 ? d : b3);
+    b2 = c1 ? b1 : (c2 ? d : b2);
+    b1 = c1 ? d : b1;
+}
+
+// Round 2: 64 queries per workgroup, the four waves split the candidates (4x the waves: (32, 1024, 256) had 512 waves on
+// 1024 SIMDs) and the divergent three-way insertion became 12 selects.  Every wave keeps a sorted triple of its candidates;
+// the four triples are merged by (distance, index) order, which is what one sequential scan with strict '<' produces.
 template <bool FMA>
 __global__ __launch_bounds__(NN3_BS) void three_nn_kernel(int n, int m, const float* __restrict__ xyz1,
                                                            const float* __restrict__ xyz2, float* __restrict__ dist,
                                                            int* __restrict__ idx) {
     __shared__ float4 tile[NN3_TILE];
+    __shared__ float pd[4][3][NN3_Q];
+    __shared__ int pi[4][3][NN3_Q];
     const int cloud = blockIdx.y;
     const float* __restrict__ p1 = xyz1 + (size_t)cloud * n * 3;
     const float* __restrict__ p2 = xyz2 + (size_t)cloud * m * 3;
-    const int j = blockIdx.x * NN3_BS + threadIdx.x;
+    const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const int j = blockIdx.x * NN3_Q + lane;
     const bool active = j < n;
     float x1 = 0.f, y1 = 0.f, z1 = 0.f;
     if (active) { x1 = p1[j * 3 + 0]; y1 = p1[j * 3 + 1]; z1 = p1[j * 3 + 2]; }
@@ -31,16 +50,34 @@ __global__ __launch_bounds__(NN3_BS) void three_nn_kernel(int n, int m, const fl
         for (int t = threadIdx.x; t < len; t += NN3_BS)
             tile[t] = make_float4(p2[(k0 + t) * 3 + 0], p2[(k0 + t) * 3 + 1], p2[(k0 + t) * 3 + 2], 0.f);
         __syncthreads();
-        for (int t = 0; t < len; ++t) {
+        const int q4 = (len + 3) >> 2;
+        const int t0 = part * q4, t1 = min(len, t0 + q4);
+#pragma unroll 4
+        for (int t = t0; t < t1; ++t) {
             const float4 q = tile[t];
-            const float d = sqdist3<FMA>(q.x - x1, q.y - y1, q.z - z1);
-            const int k = k0 + t;
-            if (d < b1) { b3 = b2; i3 = i2; b2 = b1; i2 = i1; b1 = d; i1 = k; }
-            else if (d < b2) { b3 = b2; i3 = i2; b2 = d; i2 = k; }
-            else if (d < b3) { b3 = d; i3 = k; }
+            nn3_insert(sqdist3<FMA>(q.x - x1, q.y - y1, q.z - z1), k0 + t, b1, b2, b3, i1, i2, i3);
         }
     }
-    if (active) {
+    pd[part][0][lane] = b1; pd[part][1][lane] = b2; pd[part][2][lane] = b3;
+    pi[part][0][lane] = i1; pi[part][1][lane] = i2; pi[part][2][lane] = i3;
+    __syncthreads();
+    if (part == 0 && active) {
+        // merge: insert the other waves' entries in (distance, index) order.  An entry that never received a candidate is
+        // (+inf, 0): it can only tie with other +inf entries, whose index the reference leaves at 0 as well.
+#pragma unroll
+        for (int p = 1; p < 4; ++p)
+#pragma unroll
+            for (int e = 0; e < 3; ++e) {
+                const float d = pd[p][e][lane];
+                const int k = pi[p][e][lane];
+                const bool c1 = d < b1 || (d == b1 && k < i1), c2 = d < b2 || (d == b2 && k < i2), c3 = d < b3 || (d == b3 && k < i3);
+                i3 = c2 ? i2 : (c3 ? k : i3);
+                i2 = c1 ? i1 : (c2 ? k : i2);
+                i1 = c1 ? k : i1;
+                b3 = c2 ? b2 : (c3 ? d : b3);
+                b2 = c1 ? b1 : (c2 ? d : b2);
+                b1 = c1 ? d : b1;
+            }
         float* dd = dist + ((size_t)cloud * n + j) * 3;
         int* ii = idx + ((size_t)cloud * n + j) * 3;
         dd[0] = b1; dd[1] = b2; dd[2] = b3;
@@ -137,7 +174,7 @@ DISPU_EXPORT int dispu_three_nn(int b, int n, int m, const float* xyz1, const fl
                                 int arith, void* stream) {
     if (b < 0 || n < 0 || m <= 0) return (int)hipErrorInvalidValue;
     if (b == 0 || n == 0) return 0;
-    dim3 grid((n + NN3_BS - 1) / NN3_BS, b);
+    dim3 grid((n + NN3_Q - 1) / NN3_Q, b);
     if ((arith & DISPU_ARITH_CONTRACT))
         hipLaunchKernelGGL((three_nn_kernel<true>), grid, dim3(NN3_BS), 0, (hipStream_t)stream, n, m, xyz1, xyz2, dist, idx);
     else

@@ -3,7 +3,7 @@
 // (tf_ops/nn_distance/tf_nndistance_g.cu:128-131,152-157) behind dispu_nn_distance(_grad).
 //
 // One launch covers BOTH directions (blockIdx.z) instead of the reference's two serial launches
-// of a fixed 32x16 grid: a workgroup owns 256 points of the "from" cloud, the "to" cloud streams
+// of a fixed 32x16 grid: a workgroup owns 64 points of the "from" cloud, the "to" cloud streams
 // through LDS as float4 so each candidate costs one broadcast ds_read_b128 + 9 VALU ops.
 // Tie rule: strict '<' in ascending index order == lowest index wins (tf_nndistance_g.cu:29,119).
 #include "common.h"
@@ -12,43 +12,67 @@ namespace dispu {
 
 constexpr int NND_BS = 256;
 constexpr int NND_TILE = 2048;
+constexpr int NND_Q = 64;            // queries per workgroup; its 4 waves scan one quarter of every candidate tile each
 
+// Round 2: a workgroup owns 64 points of the "from" cloud and its FOUR waves split the candidates (wave p scans quarter p
+// of every LDS tile), so (32, 1024, 1024) is 4096 waves instead of 1024 (one per SIMD, LDS-latency bound: 40 us).  A wave
+// keeps the reference's rule inside its candidates (strict '<' in ascending index order); the four partial results are
+// combined by (distance, index) order, which is the lowest index among the global minima - the same answer as one
+// sequential scan (tf_nndistance_g.cu:29,119), including its `k == 0` rule: wave 0 starts from candidate 0
+// unconditionally, the others from (+inf, INT_MAX).
 template <bool FMA>
 __global__ __launch_bounds__(NND_BS) void nn_distance_kernel(int n, int m, const float* __restrict__ xyz1,
                                                               const float* __restrict__ xyz2,
                                                               float* __restrict__ dist1, int* __restrict__ idx1,
                                                               float* __restrict__ dist2, int* __restrict__ idx2) {
     __shared__ float4 tile[NND_TILE];
+    __shared__ float pd[4][NND_Q];
+    __shared__ int pi[4][NND_Q];
     const int cloud = blockIdx.y;
     const bool fwd = blockIdx.z == 0;
     const int nf = fwd ? n : m, nt = fwd ? m : n;
-    if (blockIdx.x * NND_BS >= nf) return;  // block-uniform
+    if (blockIdx.x * NND_Q >= nf) return;  // block-uniform
     const float* __restrict__ from = (fwd ? xyz1 : xyz2) + (size_t)cloud * nf * 3;
     const float* __restrict__ to = (fwd ? xyz2 : xyz1) + (size_t)cloud * nt * 3;
     float* __restrict__ od = (fwd ? dist1 : dist2) + (size_t)cloud * nf;
     int* __restrict__ oi = (fwd ? idx1 : idx2) + (size_t)cloud * nf;
-    const int j = blockIdx.x * NND_BS + threadIdx.x;
+    const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const int j = blockIdx.x * NND_Q + lane;
     const bool active = j < nf;
     float x1 = 0.f, y1 = 0.f, z1 = 0.f;
     if (active) { x1 = from[j * 3 + 0]; y1 = from[j * 3 + 1]; z1 = from[j * 3 + 2]; }
     // `if (k == 0 || d < best)` of the reference (tf_nndistance_g.cu:29): candidate 0 is taken unconditionally
     // (matters only for inf / NaN distances); it is revisited in the loop where d < d is false.
-    float best = sqdist3<FMA>(to[0] - x1, to[1] - y1, to[2] - z1);
-    int besti = 0;
+    float best = (part == 0) ? sqdist3<FMA>(to[0] - x1, to[1] - y1, to[2] - z1) : __builtin_inff();
+    int besti = (part == 0) ? 0 : 0x7fffffff;
     for (int k0 = 0; k0 < nt; k0 += NND_TILE) {
         const int len = min(NND_TILE, nt - k0);
         __syncthreads();
         for (int t = threadIdx.x; t < len; t += NND_BS)
             tile[t] = make_float4(to[(k0 + t) * 3 + 0], to[(k0 + t) * 3 + 1], to[(k0 + t) * 3 + 2], 0.f);
         __syncthreads();
-#pragma unroll 4
-        for (int t = 0; t < len; ++t) {
+        const int q4 = (len + 3) >> 2;
+        const int t0 = part * q4, t1 = min(len, t0 + q4);
+#pragma unroll 8
+        for (int t = t0; t < t1; ++t) {
             const float4 q = tile[t];
             const float d = sqdist3<FMA>(q.x - x1, q.y - y1, q.z - z1);
             if (d < best) { best = d; besti = k0 + t; }
         }
     }
-    if (active) { od[j] = best; oi[j] = besti; }
+    pd[part][lane] = best;
+    pi[part][lane] = besti;
+    __syncthreads();
+    if (part == 0 && active) {
+#pragma unroll
+        for (int p = 1; p < 4; ++p) {
+            const float d = pd[p][lane];
+            const int i = pi[p][lane];
+            if (d < best || (d == best && i < besti)) { best = d; besti = i; }
+        }
+        od[j] = best;
+        oi[j] = besti;
+    }
 }
 
 // g = 2*grad_dist[j]; grad_from[j] += g*(p1-p2); grad_to[idx[j]] -= g*(p1-p2)   (tf_nndistance_g.cu:132-151)
@@ -86,7 +110,7 @@ DISPU_EXPORT int dispu_nn_distance(int b, int n, const float* xyz1, int m, const
     if (b < 0 || n <= 0 || m <= 0) return (int)hipErrorInvalidValue;
     if (b == 0) return 0;
     const int mx = n > m ? n : m;
-    dim3 grid((mx + NND_BS - 1) / NND_BS, b, 2);
+    dim3 grid((mx + NND_Q - 1) / NND_Q, b, 2);
     if ((arith & DISPU_ARITH_CONTRACT))
         hipLaunchKernelGGL((nn_distance_kernel<true>), grid, dim3(NND_BS), 0, (hipStream_t)stream, n, m, xyz1, xyz2, dist1,
                            idx1, dist2, idx2);
