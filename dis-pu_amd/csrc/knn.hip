@@ -219,6 +219,10 @@ int knn_xyz_wave_dispatch(int b, int n, int m, int k, const float* s, const floa
 int knn_feat_wave_dispatch(int b, int n, int m, int c, int k, int ldp, int ldq, const float* p, const float* q, float* dist,
                            int* idx, hipStream_t st);
 
+// 1024 < n <= 8192, k <= 32 (knn_wave.hip): per-chunk wave kernel + merge; needs caller scratch
+size_t knn_xyz_chunked_scratch(int b, int n, int m, int k);
+int knn_xyz_chunked_dispatch(int b, int n, int m, int k, const float* s, const float* q, int* idx, float* dist, void* scratch,
+                             size_t scratch_bytes, int arith, hipStream_t st);
 // general path (knn_general.hip): any k <= 4096, c <= 4096, any n; mode 0/1 xyz plain/contract, 2 knn_point, 3 knn_point_2
 int knn_general_launch(int mode, int b, int n, int m, int c, int k, long ldp, long ldq, const float* points, const float* queries,
                        float* dist, int* idx, int neg, hipStream_t st);
@@ -243,6 +247,24 @@ DISPU_EXPORT int dispu_knn_xyz(int b, int n, int m, int k, const float* support,
     if (k <= 16) return launch_xyz<16>(b, n, m, k, support, query, idx, dist, arith, st);
     if (k <= 20) return launch_xyz<20>(b, n, m, k, support, query, idx, dist, arith, st);
     return launch_xyz<32>(b, n, m, k, support, query, idx, dist, arith, st);
+}
+
+// dispu_knn_xyz with caller scratch (dispu_knn_xyz_scratch_bytes, 0 for shapes that need none): clouds of 1025 .. 8192 points
+// then take the chunked wave path instead of the lane-per-query kernel.  Same results.
+DISPU_EXPORT size_t dispu_knn_xyz_scratch_bytes(int b, int n, int m, int k) {
+    if (b <= 0 || n <= 0 || m <= 0 || k <= 0) return 0;
+    return knn_xyz_chunked_scratch(b, n, m, k);
+}
+
+DISPU_EXPORT int dispu_knn_xyz_ws(int b, int n, int m, int k, const float* support, const float* query, int* idx, float* dist,
+                                  void* scratch, size_t scratch_bytes, int arith, void* stream) {
+    if (b < 0 || n <= 0 || m < 0 || k <= 0 || k > n || !idx) return (int)hipErrorInvalidValue;
+    if (b == 0 || m == 0) return 0;
+    if (!(arith & DISPU_KNN_LANE_PER_QUERY)) {
+        const int rc = knn_xyz_chunked_dispatch(b, n, m, k, support, query, idx, dist, scratch, scratch_bytes, arith, (hipStream_t)stream);
+        if (rc >= 0) return rc;
+    }
+    return dispu_knn_xyz(b, n, m, k, support, query, idx, dist, arith, stream);
 }
 
 DISPU_EXPORT int dispu_knn_feat(int b, int n, int m, int c, int k, const float* points, const float* queries,

@@ -228,11 +228,11 @@ __device__ __forceinline__ void select_k2(const uint64_t (&ka)[R], const uint64_
 
 template <int R, bool FMA>
 __global__ __launch_bounds__(256, 4) void knn_xyz_wave_kernel(int n, int m, int k, int qpb, const float* __restrict__ support,
-                                                            const float* __restrict__ query, int* __restrict__ idx,
+                                                            long sstride, const float* __restrict__ query, int* __restrict__ idx,
                                                             float* __restrict__ dist) {
     __shared__ uint64_t sorted[4][R * 64 + 4];
     const int cloud = blockIdx.y, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const float* __restrict__ s = support + (size_t)cloud * n * 3;
+    const float* __restrict__ s = support + (size_t)cloud * sstride;      // sstride = 3 n, or 3 n_total when `support` is a chunk of a larger cloud
     const float* __restrict__ q = query + (size_t)cloud * m * 3;
     // lane l holds candidate 64 r + ((l + ROT r) & 63) of every 64-block r.  ROT = 17 for the prefiltered path: clouds
     // whose near neighbours sit a multiple of 64 apart in memory (the generator's coarse clouds: the 4 children of a
@@ -563,14 +563,15 @@ __global__ __launch_bounds__(64 * KF_NW) void knn_feat_wave_kernel(int n, int m,
 
 template <int R>
 static int launch_xyz_wave(int b, int n, int m, int k, const float* s, const float* q, int* idx, float* dist, int arith,
-                           hipStream_t st) {
+                           hipStream_t st, long sstride = 0) {
+    if (sstride == 0) sstride = 3l * n;
     // queries per workgroup: a wave's queries are a serial chain, so keep it short while the total stays >= ~4 waves/SIMD
     const int qpb = ((long)b * m >= 32768) ? 32 : 16;
     dim3 grid((m + qpb - 1) / qpb, b);
     if (arith & DISPU_ARITH_CONTRACT)
-        hipLaunchKernelGGL((knn_xyz_wave_kernel<R, true>), grid, dim3(256), 0, st, n, m, k, qpb, s, q, idx, dist);
+        hipLaunchKernelGGL((knn_xyz_wave_kernel<R, true>), grid, dim3(256), 0, st, n, m, k, qpb, s, sstride, q, idx, dist);
     else
-        hipLaunchKernelGGL((knn_xyz_wave_kernel<R, false>), grid, dim3(256), 0, st, n, m, k, qpb, s, q, idx, dist);
+        hipLaunchKernelGGL((knn_xyz_wave_kernel<R, false>), grid, dim3(256), 0, st, n, m, k, qpb, s, sstride, q, idx, dist);
     return (int)hipGetLastError();
 }
 
@@ -599,6 +600,70 @@ int knn_xyz_wave_dispatch(int b, int n, int m, int k, const float* s, const floa
     if (n <= 256) return launch_xyz_wave<4>(b, n, m, k, s, q, idx, dist, arith, st);
     if (n <= 512) return launch_xyz_wave<8>(b, n, m, k, s, q, idx, dist, arith, st);
     return launch_xyz_wave<16>(b, n, m, k, s, q, idx, dist, arith, st);
+}
+
+// ---- 1024 < n <= 8192: the cloud is cut into nc balanced chunks of <= 1024 candidates, the wave kernel above finds every
+// chunk's k nearest (exact, ties -> lower index) into caller scratch, and knn_xyz_merge_kernel merges the nc sorted lists by
+// (distance, global index).  Any global k-nearest neighbour is among its chunk's k nearest, so the result equals one scan
+// over the whole cloud.  The lane-per-query kernel of knn.hip needs 0.9 ms at (32, 4096, 4096, 16) - the second generator
+// pass of 16x upsampling, BASELINE configs[3] - because some lane of a wave accepts nearly every candidate and the 16-slot
+// sorted insert then runs for all 64.
+constexpr int KX_MAXCHUNKS = 8;
+
+__global__ __launch_bounds__(256) void knn_xyz_merge_kernel(long nq, int k, int nc, int cs, const int* __restrict__ cidx,
+                                                            const float* __restrict__ cdist, int* __restrict__ idx,
+                                                            float* __restrict__ dist) {
+    const long q = (long)blockIdx.x * 256 + threadIdx.x;
+    if (q >= nq) return;
+    int h[KX_MAXCHUNKS];
+    float hd[KX_MAXCHUNKS];
+#pragma unroll
+    for (int c = 0; c < KX_MAXCHUNKS; ++c) { h[c] = 0; hd[c] = (c < nc) ? cdist[((size_t)c * nq + q) * k] : __builtin_inff(); }
+    for (int t = 0; t < k; ++t) {
+        int bc = 0;
+        float bd = hd[0];
+#pragma unroll
+        for (int c = 1; c < KX_MAXCHUNKS; ++c)
+            if (hd[c] < bd) { bd = hd[c]; bc = c; }          // equal heads: the lower chunk holds the lower global index
+        int bi = 0;
+#pragma unroll
+        for (int c = 0; c < KX_MAXCHUNKS; ++c)
+            if (c == bc) {
+                bi = cidx[((size_t)c * nq + q) * k + h[c]] + c * cs;
+                ++h[c];
+                hd[c] = (h[c] < k) ? cdist[((size_t)c * nq + q) * k + h[c]] : __builtin_inff();
+            }
+        idx[q * k + t] = bi;
+        if (dist) dist[q * k + t] = bd;
+    }
+}
+
+size_t knn_xyz_chunked_scratch(int b, int n, int m, int k) {
+    if (n <= 1024 || n > 1024 * KX_MAXCHUNKS || k > 32) return 0;
+    const int nc = (n + 1023) / 1024;
+    return (size_t)nc * b * m * k * 8;
+}
+
+// -1: shape outside this path / scratch too small
+int knn_xyz_chunked_dispatch(int b, int n, int m, int k, const float* s, const float* q, int* idx, float* dist, void* scratch,
+                             size_t scratch_bytes, int arith, hipStream_t st) {
+    const size_t need = knn_xyz_chunked_scratch(b, n, m, k);
+    if (need == 0 || !scratch || scratch_bytes < need) return -1;
+    const int nc = (n + 1023) / 1024, cs = (n + nc - 1) / nc;
+    if (n - (nc - 1) * cs < k) return -1;
+    const size_t nq = (size_t)b * m;
+    int* cidx = reinterpret_cast<int*>(scratch);
+    float* cdist = reinterpret_cast<float*>(cidx + (size_t)nc * nq * k);
+    for (int c = 0; c < nc; ++c) {
+        const int len = (c + 1 < nc) ? cs : n - c * cs;
+        const float* sc = s + (size_t)c * cs * 3;
+        int rc;
+        if (len <= 512) rc = launch_xyz_wave<8>(b, len, m, k, sc, q, cidx + (size_t)c * nq * k, cdist + (size_t)c * nq * k, arith, st, 3l * n);
+        else rc = launch_xyz_wave<16>(b, len, m, k, sc, q, cidx + (size_t)c * nq * k, cdist + (size_t)c * nq * k, arith, st, 3l * n);
+        if (rc != 0) return rc;
+    }
+    hipLaunchKernelGGL(knn_xyz_merge_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, (long)nq, k, nc, cs, cidx, cdist, idx, dist);
+    return (int)hipGetLastError();
 }
 
 template <int CP>

@@ -275,7 +275,11 @@ class Generator(object):
         # ---- PointShuffle2 (ops.py:1012-1087)
         ps = "refine/PointShuffle/"
         up128 = ws["up128"]
-        self._call("knn_xyz", L.dispu_knn_xyz, B, M, M, k, ptr(coarse), ptr(coarse), ptr(ws["psidx"]), None, _lib.ARITH_PLAIN, st)
+        nb = L.dispu_knn_xyz_scratch_bytes(B, M, M, k)             # > 0 for M > 1024 (second pass of 16x upsampling): chunked search
+        if nb and ws.get("knn_scratch") is None:
+            ws["knn_scratch"] = torch.empty((nb,), dtype=torch.uint8, device=self.device)
+        self._call("knn_xyz", L.dispu_knn_xyz_ws, B, M, M, k, ptr(coarse), ptr(coarse), ptr(ws["psidx"]), None,
+                   ptr(ws["knn_scratch"]) if nb else None, nb, _lib.ARITH_PLAIN, st)
         # PointNonLocalCell (ops.py:302-346)
         if self.split_up3:
             # N = 320 as 256 + 64 columns: each launch reads up128 ONCE (128 x 256 / 128 x 64 tiles); one launch with 128 x 64

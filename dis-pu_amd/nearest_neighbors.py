@@ -7,6 +7,15 @@ from . import _lib
 from ._util import f32, req
 
 
+def _knn_xyz(b, n, m, k, pts, queries, idx, dist, arith):
+    """dispu_knn_xyz_ws with the scratch the chunked path asks for (clouds of 1025 .. 8192 points; 0 bytes otherwise)."""
+    L = _lib.lib()
+    nbytes = L.dispu_knn_xyz_scratch_bytes(b, n, m, k)
+    scratch = torch.empty((nbytes,), dtype=torch.uint8, device=pts.device) if nbytes else None
+    _lib.check(L.dispu_knn_xyz_ws(b, n, m, k, _lib.ptr(pts), _lib.ptr(queries), _lib.ptr(idx), _lib.ptr(dist), _lib.ptr(scratch), nbytes,
+                                  arith, _lib.stream_ptr(pts.device)), "dispu_knn_xyz")
+
+
 def knn_batch(pts, queries, K, omp=False, return_dist=False, arith=_lib.ARITH_PLAIN):
     """(pts[B,N1,3] f32, queries[B,N2,3] f32, K) -> int64 [B,N2,K]  (ascending distance; self first when the
     query is a support point).  `omp` is accepted for signature parity (the reference switches between a
@@ -20,8 +29,7 @@ def knn_batch(pts, queries, K, omp=False, return_dist=False, arith=_lib.ARITH_PL
     req(0 < int(K) <= n and int(K) <= 4096, "knn_batch supports 1 <= K <= min(N1, 4096)")
     idx = torch.empty((b, m, int(K)), dtype=torch.int32, device=pts.device)
     dist = torch.empty((b, m, int(K)), dtype=torch.float32, device=pts.device) if return_dist else None
-    _lib.check(_lib.lib().dispu_knn_xyz(b, n, m, int(K), _lib.ptr(pts), _lib.ptr(queries), _lib.ptr(idx), _lib.ptr(dist),
-                                        int(arith), _lib.stream_ptr(pts.device)), "dispu_knn_xyz")
+    _knn_xyz(b, n, m, int(K), pts, queries, idx, dist, int(arith))
     if return_dist:
         return idx.to(torch.int64), dist
     return idx.to(torch.int64)
@@ -34,6 +42,5 @@ def knn_query(k, support_pts, query_pts):
     m = queries.shape[1]
     req(0 < int(k) <= n and int(k) <= 4096, "knn_query supports 1 <= k <= min(N1, 4096)")
     idx = torch.empty((b, m, int(k)), dtype=torch.int32, device=pts.device)
-    _lib.check(_lib.lib().dispu_knn_xyz(b, n, m, int(k), _lib.ptr(pts), _lib.ptr(queries), _lib.ptr(idx), _lib.ptr(None),
-                                        _lib.ARITH_PLAIN, _lib.stream_ptr(pts.device)), "dispu_knn_xyz")
+    _knn_xyz(b, n, m, int(k), pts, queries, idx, None, _lib.ARITH_PLAIN)
     return idx

@@ -102,6 +102,12 @@ int dispu_knn_feat_strided(int b, int n, int m, int c, int k, const float* point
  * NULL).  k <= n, k <= 4096 (k > 32: csrc/knn_general.hip). */
 int dispu_knn_xyz(int b, int n, int m, int k, const float* support, const float* query, int* idx, float* dist,
                   int arith, void* stream);
+/* The same search with caller scratch (dispu_knn_xyz_scratch_bytes(b,n,m,k) bytes; 0 = this shape needs none): clouds of
+ * 1025 .. 8192 points and k <= 32 are cut into chunks of <= 1024 candidates, searched by the wave-per-query kernel and merged
+ * (2x faster than the lane-per-query kernel at (32, 4096, 4096, 16), the second pass of 16x upsampling).  Same results. */
+size_t dispu_knn_xyz_scratch_bytes(int b, int n, int m, int k);
+int dispu_knn_xyz_ws(int b, int n, int m, int k, const float* support, const float* query, int* idx, float* dist, void* scratch,
+                     size_t scratch_bytes, int arith, void* stream);
 
 /* ---- tf_ops/interpolation (CPU-only ops in the reference) ------------------------------------- */
 

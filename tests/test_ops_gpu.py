@@ -461,3 +461,22 @@ def test_knn_point_large_k_and_c(ops, dev, n, m, c, k):
     d2, i2 = ops["G"].knn_point_2(k, T(a, dev), T(q, dev))
     od, oi2 = O.knn_point_2(k, a, q)
     assert np.array_equal(N(i2), oi2) and np.array_equal(N(d2), od)
+
+
+@pytest.mark.parametrize("b,n,m,k", [(2, 4096, 700, 16), (1, 3000, 500, 8), (1, 1025, 64, 32), (2, 8192, 100, 16), (1, 5000, 5000, 17), (3, 2048, 2048, 1)])
+def test_knn_xyz_chunked_path(ops, dev, b, n, m, k):
+    """Clouds of 1025 .. 8192 points (the second generator pass of 16x upsampling queries 4096-point clouds): per-chunk
+    wave kernel + merge (csrc/knn_wave.hip) == one scan over the whole cloud == the lane-per-query kernel, incl. duplicates."""
+    s = synth_patches(b, n, seed=n + k)
+    s[:, 1500 % n] = s[:, 7]                                   # equal distances in different chunks -> the lower index first
+    s[:, n - 1] = s[:, 7]
+    q = s[:, :m]
+    ts, tq = T(s, dev), T(q, dev)
+    oi, od = O.knn_batch(s, q, k, return_dist=True)
+    i, d = ops["K"].knn_batch(ts, tq, k, return_dist=True)
+    assert np.array_equal(N(i), oi) and np.array_equal(N(d), od)
+    i2, d2 = ops["K"].knn_batch(ts, tq, k, return_dist=True, arith=PLAIN | 4)       # DISPU_KNN_LANE_PER_QUERY
+    assert np.array_equal(N(i2), oi) and np.array_equal(N(d2), od)
+    oi1, od1 = O.knn_batch(s, q, k, contract=1, return_dist=True)
+    i3, d3 = ops["K"].knn_batch(ts, tq, k, return_dist=True, arith=CONTRACT)
+    assert np.array_equal(N(i3), oi1) and np.array_equal(N(d3), od1)
