@@ -10,6 +10,8 @@
 // loop as soon as all of its lanes are full (cnt == nsample).
 #include "common.h"
 
+#include <cstdlib>
+
 namespace dispu {
 
 constexpr int QB_BS = 256;
@@ -98,6 +100,66 @@ __global__ __launch_bounds__(256) void query_ball_wave_kernel(int n, int m, int 
                 }
             }
         }
+        // first hit replicated into the unused tail; a row without any hit stays untouched
+        if (cnt > 0)
+            for (int l = cnt + lane; l < nsample; l += 64) row[l] = first;
+        if (lane == 0) pts_cnt[(size_t)cloud * m + j] = cnt;
+    }
+}
+
+// n > 1024: the same wave-per-query scan over CHUNKS of 1024 candidates.  The chunk's candidates sit in registers for all
+// queries of the workgroup; a query's progress (hits so far, first hit) waits in LDS between chunks, and a wave skips a
+// query whose row is already full - the scan is in index order, so the rows fill exactly as in the serial loop.  The
+// lane-per-query kernel ran (8, 4096, 4096, 20) in 564 us (5 % of the VALU rate: b * m / 64 = 512 waves, serial 4096-long
+// scans with divergent stores).
+template <bool FMA>
+__global__ __launch_bounds__(256) void query_ball_wave_chunked_kernel(int n, int m, int qpb, const float* __restrict__ radius, int nsample,
+                                                                       const float* __restrict__ xyz1, const float* __restrict__ xyz2,
+                                                                       int* __restrict__ idx, int* __restrict__ pts_cnt) {
+    constexpr int R = 16;
+    __shared__ int s_cnt[64], s_first[64];                       // qpb <= 64 queries per workgroup
+    const int cloud = blockIdx.y, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const float* __restrict__ p1 = xyz1 + (size_t)cloud * n * 3;
+    const float* __restrict__ p2 = xyz2 + (size_t)cloud * m * 3;
+    const float rad = radius[0];
+    const int q0 = blockIdx.x * qpb, q1 = min(m, q0 + qpb);
+    if (threadIdx.x < 64) { s_cnt[threadIdx.x] = 0; s_first[threadIdx.x] = 0; }
+    __syncthreads();
+    for (int c0 = 0; c0 < n; c0 += 64 * R) {
+        float cx[R], cy[R], cz[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int p = min(c0 + 64 * r + lane, n - 1);
+            cx[r] = p1[p * 3 + 0]; cy[r] = p1[p * 3 + 1]; cz[r] = p1[p * 3 + 2];
+        }
+        for (int qv = q0 + wave; qv < q1; qv += 4) {            // a query always belongs to the same wave: no barrier needed
+            const int j = __builtin_amdgcn_readfirstlane(qv);
+            int cnt = s_cnt[j - q0], first = s_first[j - q0];   // wave-uniform
+            if (cnt >= nsample) continue;
+            const float x2 = p2[j * 3 + 0], y2 = p2[j * 3 + 1], z2 = p2[j * 3 + 2];
+            int* __restrict__ row = idx + ((size_t)cloud * m + j) * nsample;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                if (cnt < nsample && c0 + 64 * r < n) {
+                    const float d2 = sqdist3<FMA>(x2 - cx[r], y2 - cy[r], z2 - cz[r]);
+                    const float d = fmaxf(sqrtf(d2), 1e-20f);
+                    const bool hit = (d < rad) && (c0 + 64 * r + lane < n);
+                    const unsigned long long mk = __ballot(hit);
+                    if (mk) {
+                        if (cnt == 0) first = c0 + 64 * r + (int)__builtin_ctzll(mk);
+                        const int pos = cnt + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0u));
+                        if (hit && pos < nsample) row[pos] = c0 + 64 * r + lane;
+                        cnt = min(nsample, cnt + (int)__popcll(mk));
+                    }
+                }
+            }
+            if (lane == 0) { s_cnt[j - q0] = cnt; s_first[j - q0] = first; }
+        }
+    }
+    for (int qv = q0 + wave; qv < q1; qv += 4) {
+        const int j = __builtin_amdgcn_readfirstlane(qv);
+        const int cnt = s_cnt[j - q0], first = s_first[j - q0];
+        int* __restrict__ row = idx + ((size_t)cloud * m + j) * nsample;
         // first hit replicated into the unused tail; a row without any hit stays untouched
         if (cnt > 0)
             for (int l = cnt + lane; l < nsample; l += 64) row[l] = first;
@@ -231,6 +293,17 @@ DISPU_EXPORT int dispu_query_ball(int b, int n, int m, const float* radius, int 
         else if (n <= 256) launch_query_ball_wave<4>(b, n, m, radius, nsample, xyz1, xyz2, idx, pts_cnt, arith, st);
         else if (n <= 512) launch_query_ball_wave<8>(b, n, m, radius, nsample, xyz1, xyz2, idx, pts_cnt, arith, st);
         else launch_query_ball_wave<16>(b, n, m, radius, nsample, xyz1, xyz2, idx, pts_cnt, arith, st);
+        return (int)hipGetLastError();
+    }
+    if (!getenv("DISPU_QB_LANE")) {                 // wave-per-query over 1024-candidate chunks (DISPU_QB_LANE=1: the lane-per-query twin)
+        const int qpb = ((long)b * m >= 32768) ? 32 : 16;
+        dim3 g((m + qpb - 1) / qpb, b);
+        if ((arith & DISPU_ARITH_CONTRACT))
+            hipLaunchKernelGGL((query_ball_wave_chunked_kernel<true>), g, dim3(256), 0, (hipStream_t)stream, n, m, qpb, radius, nsample, xyz1,
+                               xyz2, idx, pts_cnt);
+        else
+            hipLaunchKernelGGL((query_ball_wave_chunked_kernel<false>), g, dim3(256), 0, (hipStream_t)stream, n, m, qpb, radius, nsample, xyz1,
+                               xyz2, idx, pts_cnt);
         return (int)hipGetLastError();
     }
     dim3 grid((m + QB_BS - 1) / QB_BS, b);

@@ -180,7 +180,8 @@ def test_gather_point_and_grad(ops, dev):
 @pytest.mark.parametrize("arith", [PLAIN, CONTRACT])
 @pytest.mark.parametrize("b,n,m,r,ns", [(2, 1024, 1024, 0.07, 20), (3, 1500, 300, 0.2, 32), (1, 5, 7, 0.5, 4), (2, 2500, 64, 0.1, 64),
                                         (2, 65, 65, 0.3, 70), (3, 128, 77, 0.25, 8), (2, 300, 300, 0.2, 33), (1, 512, 100, 0.5, 64),
-                                        (2, 1000, 1023, 0.15, 96), (8, 1024, 1024, 0.07, 20)])
+                                        (2, 1000, 1023, 0.15, 96), (8, 1024, 1024, 0.07, 20), (2, 4096, 4096, 0.07, 20), (1, 8200, 500, 0.05, 40),
+                                        (2, 1025, 1025, 2.0, 200), (1, 3000, 100, 1e-4, 8)])
 def test_query_ball_index_exact(ops, dev, b, n, m, r, ns, arith):
     x = synth_patches(b, n, seed=n)
     q = x[:, :m] if m <= n else np.concatenate([x, x[:, : m - n]], 1)
