@@ -408,8 +408,9 @@ DISPU_EXPORT size_t dispu_approx_match_scratch_bytes(int b, int n, int m) {
 
 DISPU_EXPORT int dispu_approx_match(int b, int n, int m, const float* xyz1, const float* xyz2, float* match,
                                     float* temp, int arith, void* stream) {
-    if (b < 0 || n <= 0 || m <= 0 || !temp) return (int)hipErrorInvalidValue;
+    if (b < 0 || n <= 0 || m <= 0) return (int)hipErrorInvalidValue;
     if (b == 0) return 0;
+    if (!temp) return (int)hipErrorInvalidValue;
     if (b > 65535 || (size_t)n * 3 > 0x7fffffffull || (size_t)m * 3 > 0x7fffffffull) return (int)hipErrorInvalidValue;
     hipStream_t s = (hipStream_t)stream;
     const bool fma = (arith & DISPU_ARITH_CONTRACT) != 0, pin = (arith & DISPU_ARITH_PINNED_EXP) != 0;
@@ -428,8 +429,9 @@ DISPU_EXPORT size_t dispu_match_cost_scratch_bytes(int b, int n, int m) {
 
 DISPU_EXPORT int dispu_match_cost(int b, int n, int m, const float* xyz1, const float* xyz2, const float* match,
                                   float* cost, float* scratch, int arith, void* stream) {
-    if (b < 0 || n <= 0 || m <= 0 || !scratch) return (int)hipErrorInvalidValue;
+    if (b < 0 || n <= 0 || m <= 0) return (int)hipErrorInvalidValue;
     if (b == 0) return 0;
+    if (!scratch) return (int)hipErrorInvalidValue;
     if (b > 65535) return (int)hipErrorInvalidValue;
     hipStream_t s = (hipStream_t)stream;
     const int ch = mc_chunk(b, n, m);
@@ -450,8 +452,9 @@ DISPU_EXPORT size_t dispu_match_cost_grad_scratch_bytes(int b, int n, int m) {
 
 DISPU_EXPORT int dispu_match_cost_grad(int b, int n, int m, const float* xyz1, const float* xyz2, const float* match,
                                        float* grad1, float* grad2, float* scratch, int arith, void* stream) {
-    if (b < 0 || n <= 0 || m <= 0 || !scratch) return (int)hipErrorInvalidValue;
+    if (b < 0 || n <= 0 || m <= 0) return (int)hipErrorInvalidValue;
     if (b == 0) return 0;
+    if (!scratch) return (int)hipErrorInvalidValue;
     if (b > 65535) return (int)hipErrorInvalidValue;
     hipStream_t s = (hipStream_t)stream;
     const int ch = mc_chunk(b, n, m);

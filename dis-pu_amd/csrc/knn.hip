@@ -233,8 +233,9 @@ using namespace dispu;
 
 DISPU_EXPORT int dispu_knn_xyz(int b, int n, int m, int k, const float* support, const float* query, int* idx,
                                float* dist, int arith, void* stream) {
-    if (b < 0 || n <= 0 || m < 0 || k <= 0 || k > n || !idx) return (int)hipErrorInvalidValue;
+    if (b < 0 || n <= 0 || m < 0 || k <= 0 || k > n) return (int)hipErrorInvalidValue;
     if (b == 0 || m == 0) return 0;
+    if (!idx) return (int)hipErrorInvalidValue;
     hipStream_t st = (hipStream_t)stream;
     if (k > 32)                                      // nanoflann takes any K (knn_.cxx:104-135): general selection kernel
         return knn_general_launch((arith & DISPU_ARITH_CONTRACT) ? 1 : 0, b, n, m, 3, k, 3, 3, support, query, dist, idx, 0, st);
@@ -258,8 +259,9 @@ DISPU_EXPORT size_t dispu_knn_xyz_scratch_bytes(int b, int n, int m, int k) {
 
 DISPU_EXPORT int dispu_knn_xyz_ws(int b, int n, int m, int k, const float* support, const float* query, int* idx, float* dist,
                                   void* scratch, size_t scratch_bytes, int arith, void* stream) {
-    if (b < 0 || n <= 0 || m < 0 || k <= 0 || k > n || !idx) return (int)hipErrorInvalidValue;
+    if (b < 0 || n <= 0 || m < 0 || k <= 0 || k > n) return (int)hipErrorInvalidValue;
     if (b == 0 || m == 0) return 0;
+    if (!idx) return (int)hipErrorInvalidValue;
     if (!(arith & DISPU_KNN_LANE_PER_QUERY)) {
         const int rc = knn_xyz_chunked_dispatch(b, n, m, k, support, query, idx, dist, scratch, scratch_bytes, arith, (hipStream_t)stream);
         if (rc >= 0) return rc;
@@ -269,8 +271,9 @@ DISPU_EXPORT int dispu_knn_xyz_ws(int b, int n, int m, int k, const float* suppo
 
 DISPU_EXPORT int dispu_knn_feat(int b, int n, int m, int c, int k, const float* points, const float* queries,
                                 float* dist, int* idx, void* stream) {
-    if (b < 0 || n <= 0 || m < 0 || c <= 0 || k <= 0 || k > n || !idx) return (int)hipErrorInvalidValue;
+    if (b < 0 || n <= 0 || m < 0 || c <= 0 || k <= 0 || k > n) return (int)hipErrorInvalidValue;
     if (b == 0 || m == 0) return 0;
+    if (!idx) return (int)hipErrorInvalidValue;
     if (k > 32 || c > 128) return knn_general_launch(3, b, n, m, c, k, c, c, points, queries, dist, idx, 0, (hipStream_t)stream);
     const int rc = knn_feat_wave_dispatch(b, n, m, c, k, c, c, points, queries, dist, idx, (hipStream_t)stream);
     if (rc >= 0) return rc;
@@ -281,8 +284,9 @@ DISPU_EXPORT int dispu_knn_feat(int b, int n, int m, int c, int k, const float* 
 // activation buffer (the generator keeps its dense-block features inside one [rows, 480] buffer).
 DISPU_EXPORT int dispu_knn_feat_strided(int b, int n, int m, int c, int k, const float* points, int ldp,
                                         const float* queries, int ldq, float* dist, int* idx, void* stream) {
-    if (b < 0 || n <= 0 || m < 0 || c <= 0 || k <= 0 || k > n || !idx || ldp < c || ldq < c) return (int)hipErrorInvalidValue;
+    if (b < 0 || n <= 0 || m < 0 || c <= 0 || k <= 0 || k > n || ldp < c || ldq < c) return (int)hipErrorInvalidValue;
     if (b == 0 || m == 0) return 0;
+    if (!idx) return (int)hipErrorInvalidValue;
     if (k > 32 || c > 128) return knn_general_launch(3, b, n, m, c, k, ldp, ldq, points, queries, dist, idx, 0, (hipStream_t)stream);
     const int rc = knn_feat_wave_dispatch(b, n, m, c, k, ldp, ldq, points, queries, dist, idx, (hipStream_t)stream);
     if (rc >= 0) return rc;
@@ -291,8 +295,9 @@ DISPU_EXPORT int dispu_knn_feat_strided(int b, int n, int m, int c, int k, const
 
 DISPU_EXPORT int dispu_knn_point(int b, int n, int m, int c, int k, const float* xyz1, const float* xyz2, float* val,
                                  int* idx, void* stream) {
-    if (b < 0 || n <= 0 || m < 0 || c <= 0 || k <= 0 || k > n || !idx) return (int)hipErrorInvalidValue;
+    if (b < 0 || n <= 0 || m < 0 || c <= 0 || k <= 0 || k > n) return (int)hipErrorInvalidValue;
     if (b == 0 || m == 0) return 0;
+    if (!idx) return (int)hipErrorInvalidValue;
     if (k > 32 || c > 128) return knn_general_launch(2, b, n, m, c, k, c, c, xyz1, xyz2, val, idx, 1, (hipStream_t)stream);
     return launch_feat<false, true>(b, n, m, c, k, c, c, xyz1, xyz2, val, idx, (hipStream_t)stream);
 }

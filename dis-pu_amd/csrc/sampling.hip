@@ -179,8 +179,9 @@ DISPU_EXPORT size_t dispu_fps_scratch_bytes(int b, int n, int m) {
 }
 
 DISPU_EXPORT int dispu_fps(int b, int n, int m, const float* inp, float* temp, int* out, int arith, void* stream) {
-    if (b < 0 || n <= 0 || m <= 0 || !inp || !out) return (int)hipErrorInvalidValue;
-    if (b == 0) return 0;
+    if (b < 0 || n <= 0 || m <= 0) return (int)hipErrorInvalidValue;
+    if (b == 0) return 0;                              // empty tensors carry null pointers
+    if (!inp || !out) return (int)hipErrorInvalidValue;
     hipStream_t s = (hipStream_t)stream;
     if (n <= 64) return launch_fps_reg<64, 1>(b, n, m, inp, out, arith, s);
     if (n <= 128) return launch_fps_reg<64, 2>(b, n, m, inp, out, arith, s);

@@ -481,3 +481,47 @@ def test_knn_xyz_chunked_path(ops, dev, b, n, m, k):
     oi1, od1 = O.knn_batch(s, q, k, contract=1, return_dist=True)
     i3, d3 = ops["K"].knn_batch(ts, tq, k, return_dist=True, arith=CONTRACT)
     assert np.array_equal(N(i3), oi1) and np.array_equal(N(d3), od1)
+
+
+def test_empty_and_ragged_inputs(ops, dev):
+    """Edge cases the reference's shape checks admit: empty batches / query sets, single points, k == n, row counts that are not
+    a multiple of any tile (the reference tests none of these explicitly; its kernels loop `for (i = blockIdx.x; i < b; ...)`
+    and simply do nothing for b == 0)."""
+    S, G, I, D, A, K = (ops[k] for k in "SGIDAK")
+    z3 = lambda *s: torch.zeros(s, device=dev)
+    # empty batch
+    assert tuple(S.farthest_point_sample(4, z3(0, 10, 3)).shape) == (0, 4)
+    assert tuple(S.gather_point(z3(0, 10, 3), torch.zeros((0, 5), dtype=torch.int32, device=dev)).shape) == (0, 5, 3)
+    assert tuple(G.group_point(z3(0, 10, 8), torch.zeros((0, 5, 4), dtype=torch.int32, device=dev)).shape) == (0, 5, 4, 8)
+    assert tuple(D.nn_distance(z3(0, 10, 3), z3(0, 7, 3))[0].shape) == (0, 10)
+    assert tuple(A.approx_match(z3(0, 10, 3), z3(0, 7, 3)).shape) == (0, 7, 10)
+    assert tuple(A.match_cost(z3(0, 10, 3), z3(0, 7, 3), z3(0, 7, 10)).shape) == (0,)
+    assert tuple(K.knn_batch(z3(0, 10, 3), z3(0, 4, 3), 3).shape) == (0, 4, 3)
+    # empty query / sample sets
+    x = torch.rand(2, 33, 3, device=dev)
+    assert tuple(G.query_ball_point(0.5, 4, x, z3(2, 0, 3))[0].shape) == (2, 0, 4)
+    assert tuple(G.group_point(x, torch.zeros((2, 0, 4), dtype=torch.int32, device=dev)).shape) == (2, 0, 4, 3)
+    assert tuple(K.knn_batch(x, z3(2, 0, 3), 5).shape) == (2, 0, 5)
+    # single point, k == n, odd sizes through every row-slot kernel
+    one = torch.rand(3, 1, 3, device=dev)
+    assert N(S.farthest_point_sample(1, one)).tolist() == [[0], [0], [0]]
+    assert N(K.knn_batch(one, one, 1)).reshape(-1).tolist() == [0, 0, 0]
+    xn = np.random.default_rng(2).random((2, 37, 3)).astype(np.float32)
+    assert np.array_equal(N(K.knn_batch(T(xn, dev), T(xn, dev), 37)), O.knn_batch(xn, xn, 37))
+    rng = np.random.default_rng(4)
+    for c in (1, 2, 3, 5, 12, 130, 260):
+        pts = rng.standard_normal((3, 19, c)).astype(np.float32)
+        idx = rng.integers(0, 19, (3, 7, 5)).astype(np.int32)
+        assert np.array_equal(N(G.group_point(T(pts, dev), T(idx, dev))), O.group_point(pts, idx))
+        i3 = rng.integers(0, 19, (3, 11, 3)).astype(np.int32)
+        w3 = rng.random((3, 11, 3)).astype(np.float32)
+        assert np.array_equal(N(I.three_interpolate(T(pts, dev), T(i3, dev), T(w3, dev))), O.three_interpolate(pts, i3, w3))
+    idx1 = rng.integers(0, 37, (2, 1031)).astype(np.int32)              # gather_xyz: a ragged last pass (1031 = 1024 + 7)
+    assert np.array_equal(N(S.gather_point(T(xn, dev), T(idx1, dev))), O.gather_point(xn, idx1))
+    y = rng.random((2, 5, 3)).astype(np.float32)
+    d1, i1, d2, i2 = D.nn_distance(T(xn, dev), T(y, dev))
+    o = O.nn_distance(xn, y)
+    assert np.array_equal(N(d1), o[0]) and np.array_equal(N(i1), o[1]) and np.array_equal(N(d2), o[2]) and np.array_equal(N(i2), o[3])
+    dd, ii = I.three_nn(T(xn, dev), T(y[:, :2], dev))                     # fewer than three candidates: +inf / index 0 fill
+    od, oi = O.three_nn(xn, y[:, :2])
+    assert np.array_equal(N(ii), oi) and np.array_equal(N(dd), od)
