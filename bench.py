@@ -128,6 +128,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--eager", action="store_true", help="do not capture the forward in a hipGraph")
+    ap.add_argument("--split-bf16", action="store_true",
+                    help="EXPLORATORY, not the headline: after_conv's products as 3-way split-bf16 MFMAs (fp32-accurate, fp32 accumulate)")
     ap.add_argument("--no-ops", action="store_true", help="skip the per-op roofline table (roofline.ops, cpu_baseline.ops)")
     args = ap.parse_args()
 
@@ -162,6 +164,7 @@ def main():
     params = init_params(seed=1234)                           # Xavier-uniform, zero biases (reference init)
     gen = Generator(params=params, device=dev)
     gen.return_views = True                                   # results stay in the workspace: no copy kernels in the step
+    gen.split_bf16 = bool(args.split_bf16)
     x = torch.from_numpy(synth.patches(PATCHES_PER_GPU, NPOINT, seed=1000 * 2 + rank)).to(dev)   # 1000*config + rank
     gathered = torch.empty((world * PATCHES_PER_GPU, NPOINT * UP, 3), dtype=torch.float32, device=dev) if world > 1 else None
 
@@ -278,7 +281,9 @@ def main():
         pts = world * PATCHES_PER_GPU * NPOINT * UP
         out = {"metric": "upsampled points/sec (256->1024, 4x)", "value": pts * args.steps / dt, "unit": "points/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "f32" if not args.split_bf16 else "f32 storage; after_conv products 3-way split-bf16 (24-bit), fp32 accumulate [exploratory]",
+               "data": "synthetic",
                "config": {"workload": "BASELINE configs[%d]: %d patches x %d points per GPU, generator forward 256->1024 (4x), "
                                       "fp32%s" % (1 if world == 1 else 2, PATCHES_PER_GPU, NPOINT,
                                                   "" if world == 1 else ", + %s all-gather of the upsampled clouds" % ("RCCL" if backend == "nccl" else backend)),

@@ -71,6 +71,10 @@ class Generator(object):
         self.fused_local = True      # PointShuffle2 local cell in one kernel (False: the 4-kernel chain, for A/B tests)
         self.fused_attention = True  # non-local cell attention on chip (False: GEMM -> softmax -> GEMM through HBM)
         self.fused_project = True    # conv_back_project as the attention kernel's epilogue (False: separate GEMM)
+        # EXPLORATORY: after_conv's products as 3-way split-bf16 MFMAs (fp32-accurate, not the fmaf chain; the branch is
+        # tolerance-checked).  Off by default; bench.py --split-bf16 reports it beside the strict-fp32 line.
+        self.split_bf16 = False
+        self._planes = {}
         self.split_up3 = bool(int(__import__('os').environ.get('DISPU_SPLIT_UP3', '1')))
         self.fused_residual = bool(int(__import__('os').environ.get('DISPU_FUSED_RES', '1')))
         self.fused_heads = bool(int(__import__('os').environ.get('DISPU_FUSED_HEADS', '1')))   # one launch per head chain
@@ -99,6 +103,7 @@ class Generator(object):
             self.P = self._trainer.P
             return
         self.P = {k: torch.from_numpy(np.ascontiguousarray(v, np.float32)).to(dev) for k, v in params.items()}
+        self._planes = {}
         bn = "refine/PointShuffle/weight_net/wconv0/bn/"
         g, b = params[bn + "gamma"].astype(np.float64), params[bn + "beta"].astype(np.float64)
         mu, var = params[bn + "moving_mean"].astype(np.float64), params[bn + "moving_variance"].astype(np.float64)
@@ -334,7 +339,15 @@ class Generator(object):
                        ptr(self.bn_scale), ptr(self.bn_shift), ptr(wv), st)
             self._call("point_matmul", L.dispu_ps_point_matmul, rm, k, 128, 16, ptr(x2), 128, ptr(wv), ptr(ws["fp"]), 2048, st)
         w, b = self._w(ps + "after_conv")
-        if self.fused_residual:
+        if self.split_bf16 and rm % 128 == 0:
+            pl = self._planes.get("after_conv")
+            if pl is None:
+                pl = torch.empty((3 * 2048 * 256,), dtype=torch.bfloat16, device=self.device)
+                _lib.check(L.dispu_bf16x3_split_weights(2048, 256, ptr(w), 256, ptr(pl), st), "dispu_bf16x3_split_weights")
+                self._planes["after_conv"] = pl
+            self._call("linear_bf16x3[%dx2048x256]" % rm, L.dispu_linear_bf16x3, rm, 2048, 256, ptr(ws["fp"]), 2048, ptr(pl), ptr(b), 1,
+                       ptr(ws["aft"]), 256, ptr(ws["skip"]), 256, ptr(ws["nl"]), 256, st)
+        elif self.fused_residual:
             self._linear(st, ws["fp"], 2048, w, b, 1, ws["aft"], 256, R1=ws["skip"], R2=ws["nl"])
         else:
             # same arithmetic order ((act(.) + skip) + nl) in a separate streaming kernel

@@ -273,6 +273,14 @@ long dispu_linear_tn_bf16_scratch_floats(int batch, int M, int K, int N);
 int dispu_linear_tn_bf16(int batch, int M, int K, int N, const float* X, long ldx, long sx, const float* Z, long ldz, long sz,
                          float* out, long ldo, long so, int accumulate, float* dbias, float* scratch, long scratch_floats,
                          void* stream);
+/* EXPLORATORY, opt-in (Generator.split_bf16 / bench.py --split-bf16; never the default): fp32-accurate products on the bf16
+ * matrix pipe.  Operands are split into three bf16 terms each (24 mantissa bits), the six partial products of order <= 2 are
+ * exact bf16 MFMAs accumulated in fp32.  Not the ascending-k fmaf chain of dispu_linear: offered only for the generator's
+ * tolerance-checked refinement branch.  dispu_bf16x3_split_weights writes W's planes once ([3][N][K] bf16, 6 K N bytes);
+ * dispu_linear_bf16x3: Y = R2 + R1 + act(X . W + bias), M % 128 == N % 128 == K % 32 == 0. */
+int dispu_bf16x3_split_weights(int K, int N, const float* W, long ldw, void* planes, void* stream);
+int dispu_linear_bf16x3(int M, int K, int N, const float* X, long ldx, const void* planes, const float* bias, int act, float* Y,
+                        long ldy, const float* R1, long ldr1, const float* R2, long ldr2, void* stream);
 /* floats of scratch dispu_linear_tn needs for (batch, M, K, N). */
 long dispu_linear_tn_scratch_floats(int batch, int M, int K, int N);
 /* out[z][k][n] (+)= sum_m X[z][m][k] * Z[z][m][n]   (conv2d_backprop_filter of a 1x1 conv; the TN products of the

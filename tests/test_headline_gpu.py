@@ -109,3 +109,47 @@ def test_b64_and_ragged_batches(dev):
         assert np.array_equal(N(c), c64[:b]) and np.array_equal(N(f), f64[:b]), "B=%d differs from the B=64 rows" % b
     oc, of = OG.generator_forward(P, x[63:64])
     assert np.array_equal(c64[63], oc[0]) and np.abs(f64[63] - of[0]).max() <= 1e-5
+
+
+def test_split_bf16_gemm_is_fp32_accurate(dev):
+    """dispu_linear_bf16x3 (exploratory): three-term bf16 splitting of both operands, six exact partial products per k accumulated
+    in fp32 -> as accurate as an fp32 GEMM (compared with float64), though not the same rounding as dispu_linear's fmaf chain."""
+    from dispu_amd import _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(0)
+    M, K, Nn = 512, 2048, 256
+    x = np.maximum(rng.standard_normal((M, K)), 0).astype(np.float32) * rng.random((M, 1)).astype(np.float32)
+    w = (rng.standard_normal((K, Nn)) * 0.03).astype(np.float32)
+    b = rng.standard_normal(Nn).astype(np.float32) * 0.1
+    r1, r2 = rng.standard_normal((M, Nn)).astype(np.float32), rng.standard_normal((M, Nn)).astype(np.float32)
+    tx, tw, tb, t1, t2 = (torch.from_numpy(a).to(dev) for a in (x, w, b, r1, r2))
+    planes = torch.empty(3 * K * Nn, dtype=torch.bfloat16, device=dev)
+    st = _lib.stream_ptr(dev)
+    _lib.check(L.dispu_bf16x3_split_weights(K, Nn, tw.data_ptr(), Nn, planes.data_ptr(), st), "split")
+    rec = planes.view(3, Nn, K).float().sum(0).t()                                 # the three planes add back up to W ...
+    assert float((rec - tw).abs().max()) <= 2.0 ** -22 * float(tw.abs().max())    # ... to 24 bits
+    y = torch.zeros((M, Nn), device=dev)
+    _lib.check(L.dispu_linear_bf16x3(M, K, Nn, tx.data_ptr(), K, planes.data_ptr(), tb.data_ptr(), 1, y.data_ptr(), Nn, t1.data_ptr(), Nn,
+                                     t2.data_ptr(), Nn, st), "dispu_linear_bf16x3")
+    y32 = torch.zeros((M, Nn), device=dev)
+    _lib.check(L.dispu_linear(1, M, K, Nn, tx.data_ptr(), K, 0, tw.data_ptr(), Nn, 0, 0, tb.data_ptr(), 1, y32.data_ptr(), Nn, 0,
+                              t1.data_ptr(), Nn, 0, t2.data_ptr(), Nn, 0, st), "dispu_linear")
+    want = np.maximum(x.astype(np.float64) @ w.astype(np.float64) + b, 0) + r1 + r2
+    scale = (np.abs(x).astype(np.float64) @ np.abs(w).astype(np.float64)).max()
+    e3, e32 = np.abs(N(y) - want).max() / scale, np.abs(N(y32) - want).max() / scale
+    print("max error / sum|a||b|: split-bf16 %.2e, fp32 MFMA %.2e" % (e3, e32))
+    assert e3 <= 4e-7 and e3 <= 4 * e32 + 1e-7
+
+
+def test_generator_split_bf16_mode_within_tolerance(bench_setup, dev):
+    """Generator.split_bf16 (exploratory): after_conv through the split-bf16 GEMM.  coarse (decided before the refinement branch)
+    stays bit-exact, fine stays within the 1e-5 tolerance against the oracle and within 2e-6 of the strict-fp32 run."""
+    from dispu_amd.generator import Generator
+    s = bench_setup
+    gen = Generator(params=s["P"], device=dev)
+    gen.split_bf16 = True
+    c, f = gen(s["tx"])
+    assert np.array_equal(N(c), s["c"])
+    assert np.abs(N(f) - s["f"]).max() <= 2e-6
+    oc, of = OG.generator_forward(s["P"], s["x"][[11]])
+    assert np.abs(N(f)[11] - of[0]).max() <= 1e-5
