@@ -13,7 +13,7 @@
 // contiguous), so the B tiles are plain 16-byte copies into LDS; the activations are split on the fly while they are staged.
 // 128 x 128 x 32 tiles, 4 waves (2 x 2), two LDS stages of 6 planes (120 KB), register-prefetched.
 //
-// MEASURED (MI355X, round 2): as accurate as the fp32 MFMA GEMM (max error 1.7e-7 of sum |a||b| against 1.9e-7), but 317 us for
+// MEASURED (MI355X, round 2): as accurate as the fp32 MFMA GEMM (max error 1.7e-7 of sum |a||b| against 1.9e-7), but 317 - 390 us for
 // the after_conv shape against 277 us for the wave-specialised fp32 kernel - a NEGATIVE result for this simple pipeline: with
 // the matrix work cut to 6/16 the loop is bound by operand bytes and the on-the-fly split, see the comment in the kernel.  Kept
 // as an opt-in, tested path; not used by default anywhere.
