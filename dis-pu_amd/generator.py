@@ -217,9 +217,9 @@ class Generator(object):
         B, N, _ = inputs.shape
         M = N * self.up_ratio
         if B > self.MAX_BATCH:                                  # patches are independent: run the batch in chunks
-            outs = [self.forward(inputs[lo:lo + self.MAX_BATCH]) for lo in range(0, B, self.MAX_BATCH)]
             if self.return_views:
                 raise ValueError("return_views needs B <= %d (one workspace)" % self.MAX_BATCH)
+            outs = [self.forward(inputs[lo:lo + self.MAX_BATCH]) for lo in range(0, B, self.MAX_BATCH)]
             return torch.cat([o[0] for o in outs]), torch.cat([o[1] for o in outs])
         rn, rm, k = B * N, B * M, K_NEIGH
         ws = self._workspace(B, N)
