@@ -153,3 +153,20 @@ def test_generator_split_bf16_mode_within_tolerance(bench_setup, dev):
     assert np.abs(N(f) - s["f"]).max() <= 2e-6
     oc, of = OG.generator_forward(s["P"], s["x"][[11]])
     assert np.abs(N(f)[11] - of[0]).max() <= 1e-5
+
+
+def test_oversize_batches_run_in_chunks(dev):
+    """Batches above Generator.MAX_BATCH (2048: keeps row * stride products below 2^31) are processed in chunks; patches are
+    independent, so the result is the unchunked one.  Exercised here with a tiny limit."""
+    from dispu_amd import synth
+    from dispu_amd.generator import Generator
+    from dispu_amd.params import init_params
+    gen = Generator(params=init_params(seed=1234), device=dev)
+    x = torch.from_numpy(synth.patches(7, BENCH_N, seed=5)).to(dev)
+    c7, f7 = gen(x)
+    gen.MAX_BATCH = 3
+    c, f = gen(x)
+    assert torch.equal(c, c7) and torch.equal(f, f7)
+    gen.return_views = True
+    with pytest.raises(ValueError):
+        gen(x)
