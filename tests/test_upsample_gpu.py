@@ -123,3 +123,18 @@ def test_upsample_cloud_stage_parity(dev):
     # end to end against the independent oracle run: same point set up to float noise unless a near-tie flipped
     d1, _, d2, _ = O.nn_distance(out[None], want[None], contract=0)
     assert np.median(d1) < 1e-9 and np.median(d2) < 1e-9
+
+
+def test_upsample_clouds_batch_equals_single(dev):
+    """upsample_clouds: C clouds through ONE launch sequence (FPS over C clouds at once, C * 24 patches in one generator batch)
+    == C calls of upsample_cloud, bit for bit (DisPU/model.py:343-381 per cloud)."""
+    from dispu_amd import upsample as U
+    from dispu_amd.generator import Generator
+    rng = np.random.default_rng(8)
+    g = rng.standard_normal((3, 1024, 3))
+    pcs = (g / np.linalg.norm(g, axis=2, keepdims=True) * rng.uniform(0.5, 1.5, (3, 1, 3)) + rng.uniform(-2, 2, (3, 1, 3))).astype(np.float32)
+    gen = Generator(params=OG.init_params(seed=3), device=dev)
+    both = N(U.upsample_clouds(gen, pcs))
+    assert both.shape == (3, 4096, 3)
+    for c in range(3):
+        assert np.array_equal(both[c], U.upsample_cloud(gen, pcs[c]))
