@@ -29,6 +29,8 @@ SIGNATURES = {
     "dispu_knn_feat": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "dispu_knn_feat_strided": (_i, [_i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp]),
     "dispu_knn_xyz": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp]),
+    "dispu_knn_feat_scratch_bytes": (_sz, [_i, _i, _i, _i, _i]),
+    "dispu_knn_feat_strided_ws": (_i, [_i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _sz, _vp]),
     "dispu_knn_xyz_scratch_bytes": (_sz, [_i, _i, _i, _i]),
     "dispu_knn_xyz_ws": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _i, _vp]),
     "dispu_three_nn": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp]),

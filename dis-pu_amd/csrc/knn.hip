@@ -217,7 +217,10 @@ static int launch_feat(int b, int n, int m, int c, int k, int ldp, int ldq, cons
 int knn_xyz_wave_dispatch(int b, int n, int m, int k, const float* s, const float* q, int* idx, float* dist, int arith,
                           hipStream_t st);
 int knn_feat_wave_dispatch(int b, int n, int m, int c, int k, int ldp, int ldq, const float* p, const float* q, float* dist,
-                           int* idx, hipStream_t st);
+                           int* idx, hipStream_t st, long pstride = 0);
+size_t knn_feat_chunked_scratch(int b, int n, int m, int c, int k);
+int knn_feat_chunked_dispatch(int b, int n, int m, int c, int k, int ldp, int ldq, const float* p, const float* q, float* dist, int* idx,
+                              void* scratch, size_t scratch_bytes, hipStream_t st);
 
 // 1024 < n <= 8192, k <= 32 (knn_wave.hip): per-chunk wave kernel + merge; needs caller scratch
 size_t knn_xyz_chunked_scratch(int b, int n, int m, int k);
@@ -291,6 +294,23 @@ DISPU_EXPORT int dispu_knn_feat_strided(int b, int n, int m, int c, int k, const
     const int rc = knn_feat_wave_dispatch(b, n, m, c, k, ldp, ldq, points, queries, dist, idx, (hipStream_t)stream);
     if (rc >= 0) return rc;
     return launch_feat<true, false>(b, n, m, c, k, ldp, ldq, points, queries, dist, idx, (hipStream_t)stream);
+}
+
+// dispu_knn_feat_strided with caller scratch (dispu_knn_feat_scratch_bytes; 0 = none needed): clouds of 513 .. 4096 points take
+// the chunked wave path.  Same results.
+DISPU_EXPORT size_t dispu_knn_feat_scratch_bytes(int b, int n, int m, int c, int k) {
+    if (b <= 0 || n <= 0 || m <= 0 || c <= 0 || k <= 0) return 0;
+    return knn_feat_chunked_scratch(b, n, m, c, k);
+}
+
+DISPU_EXPORT int dispu_knn_feat_strided_ws(int b, int n, int m, int c, int k, const float* points, int ldp, const float* queries, int ldq,
+                                           float* dist, int* idx, void* scratch, size_t scratch_bytes, void* stream) {
+    if (b < 0 || n <= 0 || m < 0 || c <= 0 || k <= 0 || k > n || ldp < c || ldq < c) return (int)hipErrorInvalidValue;
+    if (b == 0 || m == 0) return 0;
+    if (!idx) return (int)hipErrorInvalidValue;
+    const int rc = knn_feat_chunked_dispatch(b, n, m, c, k, ldp, ldq, points, queries, dist, idx, scratch, scratch_bytes, (hipStream_t)stream);
+    if (rc >= 0) return rc;
+    return dispu_knn_feat_strided(b, n, m, c, k, points, ldp, queries, ldq, dist, idx, stream);
 }
 
 DISPU_EXPORT int dispu_knn_point(int b, int n, int m, int c, int k, const float* xyz1, const float* xyz2, float* val,

@@ -241,7 +241,11 @@ class Generator(object):
                 w, b = self._w(fe + "layer%d_prep" % d)
                 self._linear(st, feat, 480 - col, w, b, 1, ws["prep"], 48, xoff=col)
                 F, ldf, foff, C = ws["prep"], 48, 0, 48
-            self._call("knn_feat", L.dispu_knn_feat_strided, B, N, N, C, k + 1, off(F, foff), ldf, off(F, foff), ldf, None, ptr(ws["kidx"]), st)
+            nbf = L.dispu_knn_feat_scratch_bytes(B, N, N, C, k + 1)   # > 0 for 512 < N <= 4096 (second pass of 16x): chunked search
+            if nbf and (ws.get("knnf_scratch") is None or ws["knnf_scratch"].numel() < nbf):
+                ws["knnf_scratch"] = torch.empty((nbf,), dtype=torch.uint8, device=self.device)
+            self._call("knn_feat", L.dispu_knn_feat_strided_ws, B, N, N, C, k + 1, off(F, foff), ldf, off(F, foff), ldf, None, ptr(ws["kidx"]),
+                       ptr(ws["knnf_scratch"]) if nbf else None, nbf, st)
             w0, b0 = self._w(fe + "layer%d/l0" % d)
             w1, b1 = self._w(fe + "layer%d/l1" % d)
             w2, b2 = self._w(fe + "layer%d/l2" % d)

@@ -105,7 +105,10 @@ def knn_point_2(k, points, queries, sort=True, unique=True):
     req(0 < int(k) <= n, "input must have at least k columns")
     dist = torch.empty((b, m, int(k)), dtype=torch.float32, device=points.device)
     idx = torch.empty((b, m, int(k)), dtype=torch.int32, device=points.device)
-    _lib.check(_lib.lib().dispu_knn_feat(b, n, m, c, int(k), _lib.ptr(points), _lib.ptr(queries), _lib.ptr(dist),
-                                         _lib.ptr(idx), _lib.stream_ptr(points.device)), "dispu_knn_feat")
+    L = _lib.lib()
+    nbytes = L.dispu_knn_feat_scratch_bytes(b, n, m, c, int(k))          # clouds of 513 .. 4096 points: chunked wave search
+    scratch = torch.empty((nbytes,), dtype=torch.uint8, device=points.device) if nbytes else None
+    _lib.check(L.dispu_knn_feat_strided_ws(b, n, m, c, int(k), _lib.ptr(points), c, _lib.ptr(queries), c, _lib.ptr(dist), _lib.ptr(idx),
+                                           _lib.ptr(scratch), nbytes, _lib.stream_ptr(points.device)), "dispu_knn_feat")
     bidx = torch.arange(b, dtype=torch.int32, device=points.device).view(b, 1, 1).expand(b, m, int(k))
     return dist, torch.stack([bidx, idx], dim=3)

@@ -525,3 +525,17 @@ def test_empty_and_ragged_inputs(ops, dev):
     dd, ii = I.three_nn(T(xn, dev), T(y[:, :2], dev))                     # fewer than three candidates: +inf / index 0 fill
     od, oi = O.three_nn(xn, y[:, :2])
     assert np.array_equal(N(ii), oi) and np.array_equal(N(dd), od)
+
+
+@pytest.mark.parametrize("n,m,c,k", [(513, 100, 24, 17), (1024, 1024, 48, 17), (2000, 300, 48, 9), (4096, 64, 24, 32), (1024, 50, 64, 17)])
+def test_knn_point_2_chunked_path(ops, dev, n, m, c, k):
+    """Feature-space k-NN on clouds of 513 .. 4096 points (the dense blocks of the second 16x pass work on 1024-point patches):
+    per-chunk wave kernel + merge == tf.nn.top_k over the full distance matrix (tf_grouping.py:95-114), duplicates included."""
+    rng = np.random.default_rng(n + c)
+    a = rng.standard_normal((2, n, c)).astype(np.float32)
+    a[:, 600 % n] = a[:, 3]
+    a[:, n - 1] = a[:, 3]                                   # equal distances in different chunks: lower index first
+    q = np.concatenate([a[:, : m // 2], rng.standard_normal((2, m - m // 2, c)).astype(np.float32)], 1)
+    d2, i2 = ops["G"].knn_point_2(k, T(a, dev), T(q, dev))
+    od, oi2 = O.knn_point_2(k, a, q)
+    assert np.array_equal(N(i2), oi2) and np.array_equal(N(d2), od)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-launch time of one generator forward (HIP events on the launch stream, eager), every launch listed.
-    python tools/step_breakdown.py [B]"""
+    python tools/step_breakdown.py [B] [points per patch]"""
 import os
 import sys
 
@@ -12,10 +12,11 @@ from dispu_amd.generator import Generator          # noqa: E402
 from dispu_amd.params import init_params           # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+NPT = int(sys.argv[2]) if len(sys.argv) > 2 else 256      # points per patch (1024: the second pass of 16x upsampling)
 dev = torch.device("cuda:0")
 gen = Generator(params=init_params(1234), device=dev)
 gen.return_views = True
-x = torch.from_numpy(synth.patches(B, 256, seed=2000)).to(dev)
+x = torch.from_numpy(synth.patches(B, NPT, seed=2000)).to(dev)
 for _ in range(3):
     gen(x)
 torch.cuda.synchronize()
