@@ -609,7 +609,7 @@ int knn_xyz_wave_dispatch(int b, int n, int m, int k, const float* s, const floa
 // over the whole cloud.  The lane-per-query kernel of knn.hip needs 0.9 ms at (32, 4096, 4096, 16) - the second generator
 // pass of 16x upsampling, BASELINE configs[3] - because some lane of a wave accepts nearly every candidate and the 16-slot
 // sorted insert then runs for all 64.
-constexpr int KX_MAXCHUNKS = 8;
+constexpr int KX_MAXCHUNKS = 16;
 
 __global__ __launch_bounds__(256) void knn_xyz_merge_kernel(long nq, int k, int nc, int cs, const int* __restrict__ cidx,
                                                             const float* __restrict__ cdist, int* __restrict__ idx,
@@ -640,7 +640,7 @@ __global__ __launch_bounds__(256) void knn_xyz_merge_kernel(long nq, int k, int 
 }
 
 size_t knn_xyz_chunked_scratch(int b, int n, int m, int k) {
-    if (n <= 1024 || n > 1024 * KX_MAXCHUNKS || k > 32) return 0;
+    if (n <= 1024 || n > 1024 * 8 || k > 32) return 0;
     const int nc = (n + 1023) / 1024;
     return (size_t)nc * b * m * k * 8;
 }
@@ -693,11 +693,14 @@ int knn_feat_wave_dispatch(int b, int n, int m, int c, int k, int ldp, int ldq, 
 }
 
 // ---- feature space, 512 < n <= 4096 (the second pass of 16x upsampling runs the dense blocks on 1024-point patches): balanced
-// chunks of <= 512 candidates through the wave kernel above, merged like the xyz lists.  The lane-per-query kernel needed
+// chunks of <= 256 candidates through the wave kernel above (its R <= 4 form: dot products on the matrix pipe, 49 KB of staged
+// features per workgroup; 512-candidate chunks re-stage 98 KB for every 16 queries and were slower: 303 vs 466 us unchunked),
+// merged like the xyz lists.  The lane-per-query kernel needed
 // 470 us per call at (32, 1024, 1024, 48, 17) - a quarter of that pass.
+constexpr int KF_CHUNK = 256;
 size_t knn_feat_chunked_scratch(int b, int n, int m, int c, int k) {
-    if (n <= 512 || n > 512 * KX_MAXCHUNKS || c > 64 || k > 32) return 0;
-    const int nc = (n + 511) / 512;
+    if (n <= 512 || n > KF_CHUNK * KX_MAXCHUNKS || c > 64 || k > 32) return 0;
+    const int nc = (n + KF_CHUNK - 1) / KF_CHUNK;
     return (size_t)nc * b * m * k * 8;
 }
 
@@ -705,7 +708,7 @@ int knn_feat_chunked_dispatch(int b, int n, int m, int c, int k, int ldp, int ld
                               void* scratch, size_t scratch_bytes, hipStream_t st) {
     const size_t need = knn_feat_chunked_scratch(b, n, m, c, k);
     if (need == 0 || !scratch || scratch_bytes < need) return -1;
-    const int nc = (n + 511) / 512, cs = (n + nc - 1) / nc;
+    const int nc = (n + KF_CHUNK - 1) / KF_CHUNK, cs = (n + nc - 1) / nc;
     if (n - (nc - 1) * cs < k) return -1;
     const size_t nq = (size_t)b * m;
     int* cidx = reinterpret_cast<int*>(scratch);
