@@ -12,4 +12,4 @@ from . import _lib  # noqa: F401  (does not load the .so until first use)
 
 __all__ = ["tf_sampling", "tf_grouping", "tf_interpolate", "tf_nndistance", "tf_approxmatch",
            "nearest_neighbors"]
-__version__ = "0.1.0"
+__version__ = "0.2.0"

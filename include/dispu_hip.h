@@ -43,7 +43,7 @@ extern "C" {
  * used for n <= 1024 (identical results; A/B tests and profiling). */
 #define DISPU_KNN_LANE_PER_QUERY 4
 
-/* Library / ABI version (1 = round 1). */
+/* Library / ABI version (1 = round 1; 2 = round 2: scratch arguments of dispu_match_cost(_grad), the *_ws k-NN entries, dispu_attention_project, the bf16 GEMMs). */
 int dispu_version(void);
 /* hipGetErrorString for the codes returned below. */
 const char* dispu_error_string(int code);
