@@ -203,15 +203,25 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(long rows, int c, int row
 
 // stats[0:c] = mean, [c:2c] = biased variance, [2c:3c] = 1/sqrt(var + eps); moving statistics updated in place
 // (decay * moving + (1 - decay) * batch; the variance fed to the moving average is Bessel-corrected, fused BN).
-__global__ void bn_finalize_kernel(long rows, int c, int nparts, const double* __restrict__ part, float eps, float decay,
+// one WAVE per channel (blockIdx.x = channel): lanes add the partials s = lane, lane + 64, ... in double, a fixed butterfly
+// combines them.  (One THREAD per channel walked all 1024 partials serially: 34 us for 16 channels.)
+__device__ __forceinline__ double bn_wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__global__ __launch_bounds__(64) void bn_finalize_kernel(long rows, int c, int nparts, const double* __restrict__ part, float eps, float decay,
                                    float* __restrict__ stats, float* __restrict__ moving_mean, float* __restrict__ moving_var) {
-    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
-    if (ch >= c) return;
+    const int ch = blockIdx.x;
     double a = 0.0, b = 0.0;
-    for (int s = 0; s < nparts; ++s) {
+    for (int s = threadIdx.x; s < nparts; s += 64) {
         a += part[((size_t)s * 2 + 0) * c + ch];
         b += part[((size_t)s * 2 + 1) * c + ch];
     }
+    a = bn_wave_sum(a);
+    b = bn_wave_sum(b);
+    if (threadIdx.x != 0) return;
     const double mean = a / (double)rows;
     double var = b / (double)rows - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -273,15 +283,17 @@ __global__ __launch_bounds__(256) void bn_grad_stats_kernel(long rows, int c, in
 }
 
 // sums[0:c] = sum dz, sums[c:2c] = sum dz*xhat;  dbeta += sum dz, dgamma += sum dz*xhat
-__global__ void bn_grad_finalize_kernel(int c, int nparts, const double* __restrict__ part, float* __restrict__ sums,
+__global__ __launch_bounds__(64) void bn_grad_finalize_kernel(int c, int nparts, const double* __restrict__ part, float* __restrict__ sums,
                                         float* __restrict__ dgamma, float* __restrict__ dbeta) {
-    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
-    if (ch >= c) return;
+    const int ch = blockIdx.x;
     double a = 0.0, b = 0.0;
-    for (int s = 0; s < nparts; ++s) {
+    for (int s = threadIdx.x; s < nparts; s += 64) {
         a += part[((size_t)s * 2 + 0) * c + ch];
         b += part[((size_t)s * 2 + 1) * c + ch];
     }
+    a = bn_wave_sum(a);
+    b = bn_wave_sum(b);
+    if (threadIdx.x != 0) return;
     sums[ch] = (float)a;
     sums[c + ch] = (float)b;
     if (dbeta) dbeta[ch] += (float)a;
@@ -489,7 +501,7 @@ DISPU_EXPORT int dispu_bn_train(long rows, int c, const float* X, long ldx, cons
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(bn_stats_kernel, dim3(nb), dim3(256), 0, s, rows, c, rpb, X, ldx, (double*)scratch);
     DISPU_CHECK_LAUNCH();
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(64), 0, s, rows, c, nb, (const double*)scratch, eps, decay, stats,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(c), dim3(64), 0, s, rows, c, nb, (const double*)scratch, eps, decay, stats,
                        moving_mean, moving_var);
     DISPU_CHECK_LAUNCH();
     hipLaunchKernelGGL(bn_apply_kernel, dim3(tgrid((size_t)rows * c, 256)), dim3(256), 0, s, rows, c, X, ldx, stats, gamma, beta,
@@ -508,7 +520,7 @@ DISPU_EXPORT int dispu_bn_train_grad(long rows, int c, const float* X, long ldx,
     hipLaunchKernelGGL(bn_grad_stats_kernel, dim3(nb), dim3(256), 0, s, rows, c, rpb, X, ldx, Y, ldy, dY, lddy, stats, act,
                        (double*)scratch);
     DISPU_CHECK_LAUNCH();
-    hipLaunchKernelGGL(bn_grad_finalize_kernel, dim3(1), dim3(64), 0, s, c, nb, (const double*)scratch, sums, dgamma, dbeta);
+    hipLaunchKernelGGL(bn_grad_finalize_kernel, dim3(c), dim3(64), 0, s, c, nb, (const double*)scratch, sums, dgamma, dbeta);
     DISPU_CHECK_LAUNCH();
     hipLaunchKernelGGL(bn_grad_apply_kernel, dim3(tgrid((size_t)rows * c, 256)), dim3(256), 0, s, rows, c, X, ldx, Y, ldy, dY,
                        lddy, stats, gamma, sums, act, dX, lddx);
