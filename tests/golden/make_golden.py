@@ -118,5 +118,21 @@ def main():
          am_cost=O.match_cost(a1, a2, m_orc, contract=1))
 
 
+def chunked_approxmatch_pin():
+    """Round 2: the MI355X EMD kernels associate the auction's sums in chunks of 128 partners (oracle chunk = AM_CHUNK).  This
+    freezes that restatement (pinned exp -> bit-reproducible on any IEEE machine) so a later edit of either side is caught.
+    Oracle-generated (the CUDA kernel cannot run here); the sequential order stays pinned by ref_approxmatch.npz."""
+    a1 = synth.patches(2, 300, seed=31)
+    a2 = synth.patches(2, 260, seed=32)
+    m = O.approx_match(a1, a2, contract=1, pinned_exp=True, chunk=O.AM_CHUNK)
+    save("oracle_approxmatch_chunk128.npz", xyz1=a1, xyz2=a2, chunk=np.int32(O.AM_CHUNK), match_pinned=m,
+         cost=O.match_cost(a1, a2, m, contract=1))
+
+
 if __name__ == "__main__":
-    main()
+    import sys
+    if len(sys.argv) > 1 and sys.argv[1] == "chunked":
+        chunked_approxmatch_pin()
+    else:
+        main()
+        chunked_approxmatch_pin()

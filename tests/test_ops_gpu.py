@@ -83,6 +83,14 @@ def test_knn_vs_nanoflann_golden(ops, dev, golden_dir):
     assert np.array_equal(N(ops["K"].knn_query(k, s, q)), z["idx_query"])
 
 
+def test_approxmatch_chunked_golden(ops, dev, golden_dir):
+    """the frozen chunk-of-128 association (tests/golden/oracle_approxmatch_chunk128.npz): bit-exact in pinned-exp mode."""
+    z = g(golden_dir, "oracle_approxmatch_chunk128.npz")
+    m = ops["A"].approx_match(T(z["xyz1"], dev), T(z["xyz2"], dev), arith=CONTRACT | PINNED_EXP)
+    assert np.array_equal(N(m), z["match_pinned"])
+    assert np.allclose(N(ops["A"].match_cost(T(z["xyz1"], dev), T(z["xyz2"], dev), m)), z["cost"], rtol=1e-5)
+
+
 def test_approxmatch_vs_golden(ops, dev, golden_dir):
     z = g(golden_dir, "ref_approxmatch.npz")
     x1, x2 = T(z["xyz1"], dev), T(z["xyz2"], dev)

@@ -172,3 +172,11 @@ def test_approxmatch_chunked_order_is_a_reassociation():
     x1, x2 = rng.random((1, 100, 3), dtype=np.float32), rng.random((1, 90, 3), dtype=np.float32)
     a, s = O.approx_match(x1, x2, chunk=O.AM_CHUNK), O.approx_match(x1, x2)
     assert np.abs(a - s).max() < 1e-3 and np.allclose(O.match_cost(x1, x2, a), O.match_cost(x1, x2, s), rtol=1e-5)
+
+
+def test_approxmatch_chunked_golden(golden_dir):
+    """oracle_approxmatch_chunk128.npz freezes the chunk-of-128 association of the MI355X EMD kernels (pinned exp: bit-reproducible)."""
+    z = g(golden_dir, "oracle_approxmatch_chunk128.npz")
+    m = O.approx_match(z["xyz1"], z["xyz2"], contract=1, pinned_exp=True, chunk=int(z["chunk"]))
+    assert np.array_equal(m, z["match_pinned"])
+    assert np.allclose(O.match_cost(z["xyz1"], z["xyz2"], m, contract=1), z["cost"], rtol=1e-6)
