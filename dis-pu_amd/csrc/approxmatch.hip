@@ -71,6 +71,16 @@ __device__ __forceinline__ float am_exp(float x) {
     }
 }
 
+// exp(level * d2) of the auction.  Hardware mode: the reference's __expf(level * d2) is exp2((level * d2) * log2e); every level
+// is 0 or -(4^j), a power of two, so level * d2 is exact and (level * d2) * log2e == d2 * (level * log2e) BIT FOR BIT - the
+// host folds level * log2e (also exact) and the kernels save one multiply per exponential.
+constexpr float AM_LOG2E = 0x1.715476p+0f;       // the float the native exp uses
+template <bool PINNED>
+__device__ __forceinline__ float am_exp_level(float d2, float level) {
+    if constexpr (PINNED) return am_exp<true>(level * d2);
+    else return __builtin_amdgcn_exp2f(d2 * (level * AM_LOG2E));   // level * AM_LOG2E is loop-invariant (hoisted)
+}
+
 __global__ void am_init_kernel(int n, int m, float multiL, float multiR, float* __restrict__ temp) {
     const AmView v = am_view(temp, blockIdx.y, n, m);
     for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) v.remL[e] = multiL;
@@ -131,10 +141,10 @@ __global__ __launch_bounds__(AM_ROWS) void am_row_kernel(int n, int m, int t, fl
         const float4 q = tile[i];
         const float d2 = sqdist3<FMA>(q.x - x1, q.y - y1, q.z - z1);
         if constexpr (!FIRST) {
-            const float w = am_exp<PINNED>(level3 * d2) * rl * q.w;      // the value `match` receives at this level
+            const float w = am_exp_level<PINNED>(d2, level3) * rl * q.w;      // the value `match` receives at this level
             s3 += w;
         }
-        const float e1 = am_exp<PINNED>(level1 * d2);
+        const float e1 = am_exp_level<PINNED>(d2, level1);
         if constexpr (FMA) s1 = __builtin_fmaf(e1, tilew[i], s1);
         else s1 = s1 + e1 * tilew[i];
     }
@@ -186,7 +196,7 @@ __global__ __launch_bounds__(AM_ROWS) void am_col_kernel(int n, int m, int t, fl
     for (int i = 0; i < len; ++i) {
         const float4 q = tile[i];
         const float d2 = sqdist3<FMA>(x2 - q.x, y2 - q.y, z2 - q.z);
-        const float e = am_exp<PINNED>(level * d2);
+        const float e = am_exp_level<PINNED>(d2, level);
         if constexpr (FMA) s = __builtin_fmaf(e, q.w, s);
         else s = s + e * q.w;
     }
@@ -228,9 +238,9 @@ __global__ __launch_bounds__(AM_ROWS) void am_assemble_kernel(int n, int m, AmLe
     for (int i = 0; i < len; ++i) {
         const AmPartner& q = tile[i];
         const float d2 = sqdist3<FMA>(q.x - x1, q.y - y1, q.z - z1);
-        float acc = am_exp<PINNED>(lv.v[0] * d2) * rl[0] * q.r[0];
+        float acc = am_exp_level<PINNED>(d2, lv.v[0]) * rl[0] * q.r[0];
 #pragma unroll
-        for (int t = 1; t < AM_LEVELS; ++t) acc += am_exp<PINNED>(lv.v[t] * d2) * rl[t] * q.r[t];
+        for (int t = 1; t < AM_LEVELS; ++t) acc += am_exp_level<PINNED>(d2, lv.v[t]) * rl[t] * q.r[t];
         __builtin_nontemporal_store(acc, mt + (size_t)i * n);
     }
 }
