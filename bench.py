@@ -18,6 +18,7 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL between processes needs it on this driver (before torch loads HIP)
 
 PATCHES_PER_GPU = 32
 NPOINT = 256
