@@ -276,7 +276,11 @@ def main():
         if world == 1 and not args.no_ops:
             sys.path.insert(0, os.path.join(ROOT, "tools"))
             import ops_bench
-            roof["ops"] = ops_bench.gpu_ops(dev, quick=True)
+            try:
+                roof["ops"] = ops_bench.gpu_ops(dev, quick=True)
+            except Exception as e:                             # noqa: BLE001 -- the headline line must survive a failing side table
+                roof["ops"] = None
+                roof["ops_error"] = "%s: %s" % (type(e).__name__, e)
             roof["ops_peaks"] = {"hbm_B_per_s": ops_bench.HBM_PEAK, "valu_lane_ops_per_s": ops_bench.VALU_PEAK,
                                  "exp_per_s": ops_bench.EXP_PEAK}
         pts = world * PATCHES_PER_GPU * NPOINT * UP
@@ -293,7 +297,10 @@ def main():
                           "parallelism": "patch-sharded x%d" % world},
                "roofline": roof}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(params, with_ops=not args.no_ops)
+            try:
+                out["cpu_baseline"] = cpu_baseline(params, with_ops=not args.no_ops)
+            except Exception as e:                             # noqa: BLE001
+                out["cpu_baseline"] = {"value": None, "unit": "points/s", "cores": 0, "kind": "port", "sample": "failed: %s: %s" % (type(e).__name__, e)}
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
