@@ -169,13 +169,22 @@ __global__ void gather_point_grad_kernel(int n, int m, size_t total, const float
     }
 }
 
+// csrc/fps_wave.hip: exact sampling with wave-level skipping for 8192 < n <= 24576 (scratch = the sorted permutation)
+bool fps_wave_wants_scratch(int n, int m);
+int fps_wave_dispatch(int b, int n, int m, const float* xyz, void* temp, int* out, int arith, hipStream_t s);
+
+static bool fps_dense_only() {
+    static const bool v = [] { const char* e = getenv("DISPU_FPS_DENSE"); return e && e[0] == '1'; }();
+    return v;
+}
+
 }  // namespace dispu
 
 using namespace dispu;
 
 DISPU_EXPORT size_t dispu_fps_scratch_bytes(int b, int n, int m) {
-    (void)m;
-    return n > 24576 ? (size_t)b * n * sizeof(float) : 0;
+    if (n > 24576 || (fps_wave_wants_scratch(n, m) && !fps_dense_only())) return (size_t)b * n * sizeof(float);
+    return 0;
 }
 
 DISPU_EXPORT int dispu_fps(int b, int n, int m, const float* inp, float* temp, int* out, int arith, void* stream) {
@@ -190,6 +199,10 @@ DISPU_EXPORT int dispu_fps(int b, int n, int m, const float* inp, float* temp, i
     if (n <= 1024) return launch_fps_reg<256, 4>(b, n, m, inp, out, arith, s);
     if (n <= 2048) return launch_fps_reg<256, 8>(b, n, m, inp, out, arith, s);
     if (n <= 4096) return launch_fps_reg<1024, 4>(b, n, m, inp, out, arith, s);
+    if (!fps_dense_only()) {                           // without scratch the dense kernels below still answer
+        const int r = fps_wave_dispatch(b, n, m, inp, temp, out, arith, s);
+        if (r >= 0) return r;
+    }
     if (n <= 8192) return launch_fps_reg<1024, 8>(b, n, m, inp, out, arith, s);
     if (n <= 16384) return launch_fps_reg<1024, 16>(b, n, m, inp, out, arith, s);
     if (n <= 24576) return launch_fps_reg<1024, 24>(b, n, m, inp, out, arith, s);

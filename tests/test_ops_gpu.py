@@ -132,7 +132,11 @@ def test_fps_index_exact(ops, dev, b, n, m, arith):
 
 
 @pytest.mark.parametrize("b,n,m,kind", [(1, 24576, 8192, "surface"), (2, 24576, 700, "cube"), (2, 12000, 3000, "surface"), (3, 5000, 1200, "cube"),
-                                        (1, 8193, 64, "cube"), (2, 6000, 600, "dups"), (1, 4097, 4097, "grid")])
+                                        (1, 8193, 64, "cube"), (2, 6000, 600, "dups"), (1, 4097, 4097, "grid"),
+                                        # the wave-skipping kernel (csrc/fps_wave.hip: 4096 < n <= 24576, m >= 64): ties inside a
+                                        # lane, inside a wave and across waves; ragged last wave; both register layouts
+                                        (1, 16385, 300, "dups"), (1, 10000, 800, "grid"), (2, 24576, 1500, "dups"), (1, 20000, 900, "grid"),
+                                        (3, 9001, 257, "surface"), (1, 16384, 2048, "cube")])
 def test_fps_large_clouds_index_exact(ops, dev, b, n, m, kind):
     """Large clouds at the whole-cloud test path's shape (1, 24576, 8192) (DisPU/model.py:375) and around the register-kernel
     boundaries: the sampled indices equal the oracle's exactly, including tie decisions (duplicated points, grids) --
