@@ -15,7 +15,10 @@ Execution differences from the reference (not results):
   * duplicate_up's 482-wide conv is evaluated per source point (as in inference) and differentiated in that form.
 Training-mode forward values equal the inference path's except for BatchNorm (batch statistics here).
 """
+import contextlib
+import ctypes
 import math
+import os
 from collections import OrderedDict
 
 import numpy as np
@@ -81,8 +84,17 @@ class Trainer(object):
         self.epoch = 0
         self.global_step = 0
         self._ws = {}
-        self._scratch = None
+        self._scratch = {}                    # per stream: scratch of the split reductions / column sums
         self._bn_scratch = None
+        # weight-gradient products (dW = X^T dZ) are off the backward chain: only Adam reads them.  They run on a second
+        # HIP stream next to the dX products that ARE the chain (both read dZ; at 8 patches neither fills 256 CUs alone).
+        self.overlap_dw = os.environ.get("DISPU_TRAIN_OVERLAP", "1") != "0"
+        self._aux = []
+        self._cur = "main"
+        self._side = None
+        self._fork_ev = None
+        self._join_ev = None
+        self._side_busy = False
         self.P = None
         if params is not None:
             self.load_params(params)
@@ -148,18 +160,72 @@ class Trainer(object):
             nl=E(rm, 256), dnl=E(rm, 256), sum=E(rm, 256), dsum=E(rm, 256), agg=E(rm, 256), dagg=E(rm, 256),
             f256=E(rm, 256), df256=E(rm, 256), f64=E(rm, 64), df64=E(rm, 64), z=E(rm, 3), dz=E(rm, 3), fine=E(B, M, 3), dfine=E(B, M, 3),
             # loss
-            d_gt=E(B, M), i_gt=E(B, M, dtype=i32), d_pred=E(B, M), i_pred=E(B, M, dtype=i32), g_gt=E(B, M), g_pred=E(B, M),
-            dgt_unused=E(B, M, 3), ball=E(B, M, 20, dtype=i32), ball_cnt=E(B, M, dtype=i32), rep=E(B, M), rowmean=E(B), rowmax=E(B),
+            cd=[dict(d_gt=E(B, M), i_gt=E(B, M, dtype=i32), d_pred=E(B, M), i_pred=E(B, M, dtype=i32), g_gt=E(B, M), g_pred=E(B, M),
+                     dgt_unused=E(B, M, 3), rowmean=E(B), rowmax=E(B)) for _ in range(2)],      # one set per Chamfer term
+            ball=E(B, M, 20, dtype=i32), ball_cnt=E(B, M, dtype=i32), rep=E(B, M), rowmean=E(B), rowmax=E(B),
             zeros=Z(1))
         # grid code of duplicate_up: row (cloud*up + r)*N + i carries grid[r]
         ws["gcode"].view(B, self.up_ratio, N, 2).copy_(self.grid.view(1, self.up_ratio, 1, 2).expand(B, self.up_ratio, N, 2))
         self._ws[key] = ws
         return ws
 
-    def _scratch_floats(self, n):
-        if self._scratch is None or self._scratch.numel() < n:
-            self._scratch = torch.empty(max(int(n), 1 << 20), dtype=torch.float32, device=self.device)
-        return self._scratch
+    def _scratch_floats(self, n, side=False):
+        """scratch of the launches queued on ONE stream (they run in order, so they can share it): the dW stream's, or the
+        current stream's (main or a branch)."""
+        key = "dw" if side else self._cur
+        cur = self._scratch.get(key)
+        if cur is None or cur.numel() < n:
+            if cur is not None:
+                torch.cuda.synchronize(self.device)          # a launch on that stream may still be using the old buffer
+            cur = self._scratch[key] = torch.empty(max(int(n), 1 << 20), dtype=torch.float32, device=self.device)
+        return cur
+
+    # ---- second stream for the weight-gradient products
+    def _fork(self):
+        """-> stream pointer for a dW product that may start once everything queued on the main stream so far is done."""
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.device)
+            self._fork_ev = torch.cuda.Event()
+            self._join_ev = torch.cuda.Event()
+        main = torch.cuda.current_stream(self.device)
+        self._fork_ev.record(main)
+        self._side.wait_event(self._fork_ev)
+        self._side_busy = True
+        return ctypes.c_void_p(self._side.cuda_stream)
+
+    def _join(self):
+        """the current stream waits for every dW product queued so far (before a buffer they read is overwritten, before Adam)."""
+        if self._side_busy:
+            self._join_ev.record(self._side)
+            torch.cuda.current_stream(self.device).wait_event(self._join_ev)
+            self._side_busy = False
+
+    @contextlib.contextmanager
+    def _branch(self, i):
+        """Launches inside run on auxiliary stream i, after everything queued on the current stream so far; `_merge(i)` makes
+        the current stream wait for them.  At 8 patches per GPU a chain of 10 us kernels leaves most of the 256 CUs idle:
+        independent sub-graphs (non-local cell | skip + local cell; the two Chamfer terms) run side by side."""
+        if not self.overlap_dw:
+            yield
+            return
+        while len(self._aux) <= i:
+            self._aux.append((torch.cuda.Stream(device=self.device), torch.cuda.Event(), torch.cuda.Event()))
+        aux, ev_fork, _ = self._aux[i]
+        ev_fork.record(torch.cuda.current_stream(self.device))
+        aux.wait_event(ev_fork)
+        old_st, old_cur = self.st, self._cur
+        with torch.cuda.stream(aux):
+            self.st, self._cur = ctypes.c_void_p(aux.cuda_stream), "aux%d" % i
+            try:
+                yield
+            finally:
+                self.st, self._cur = old_st, old_cur
+
+    def _merge(self, i):
+        if self.overlap_dw and i < len(self._aux):
+            aux, _, ev_done = self._aux[i]
+            ev_done.record(aux)
+            torch.cuda.current_stream(self.device).wait_event(ev_done)
 
     # ----------------------------------------------------------------------------------------------- helpers ----
     def _dl(self, batch, M, K, N, *rest):
@@ -177,18 +243,17 @@ class Trainer(object):
         _lib.check(self._dl(1, M, K, N, _p(X, xoff), X.stride(0), 0, _p(W, woff), W.stride(0), 0, 0, _p(b), act,
                                   _p(Y, yoff), Y.stride(0), 0, None, 0, 0, None, 0, 0, self.st), "dispu_linear")
 
-    def _tn(self, batch, M, K, N, X, xoff, ldx, sx, Zt, zoff, ldz, sz, out, ooff, ldo, so, accumulate, dbias=None):
+    def _tn(self, batch, M, K, N, X, xoff, ldx, sx, Zt, zoff, ldz, sz, out, ooff, ldo, so, accumulate, dbias=None, side=False):
+        """out (+)= X^T . Zt.  side=True: on the second stream (the caller guarantees nothing overwrites X / Zt before _join)."""
         L = _lib.lib()
-        if self.bf16 and K > 4 and N > 4:
-            need = L.dispu_linear_tn_bf16_scratch_floats(batch, M, K, N)
-            sc = self._scratch_floats(need)
-            _lib.check(L.dispu_linear_tn_bf16(batch, M, K, N, _p(X, xoff), ldx, sx, _p(Zt, zoff), ldz, sz, _p(out, ooff), ldo, so,
-                                              accumulate, _p(dbias), _p(sc), sc.numel(), self.st), "dispu_linear_tn_bf16")
-            return
-        need = L.dispu_linear_tn_scratch_floats(batch, M, K, N)
-        sc = self._scratch_floats(need)
-        _lib.check(L.dispu_linear_tn(batch, M, K, N, _p(X, xoff), ldx, sx, _p(Zt, zoff), ldz, sz, _p(out, ooff), ldo, so,
-                                     accumulate, _p(dbias), _p(sc), sc.numel(), self.st), "dispu_linear_tn")
+        side = side and self.overlap_dw
+        bf = self.bf16 and K > 4 and N > 4
+        need = (L.dispu_linear_tn_bf16_scratch_floats if bf else L.dispu_linear_tn_scratch_floats)(batch, M, K, N)
+        sc = self._scratch_floats(need, side)
+        st = self._fork() if side else self.st
+        fn = L.dispu_linear_tn_bf16 if bf else L.dispu_linear_tn
+        _lib.check(fn(batch, M, K, N, _p(X, xoff), ldx, sx, _p(Zt, zoff), ldz, sz, _p(out, ooff), ldo, so, accumulate, _p(dbias), _p(sc),
+                      sc.numel(), st), "dispu_linear_tn_bf16" if bf else "dispu_linear_tn")
 
     def _act_bias_grad(self, M, N, dY, dyoff, Y, yoff, act, dZ, dzoff, dbias):
         L = _lib.lib()
@@ -210,7 +275,7 @@ class Trainer(object):
         db = self.G[wname + "/biases"] if bias else None
         if act and not premasked:
             self._act_bias_grad(M, N, dY, dyoff, Y, yoff, act, dY, dyoff, None)          # relu_grad, in place
-        self._tn(1, M, K, N, X, xoff, X.stride(0), 0, dY, dyoff, dY.stride(0), 0, dW, woff, dW.stride(0), 0, 1, dbias=db)
+        self._tn(1, M, K, N, X, xoff, X.stride(0), 0, dY, dyoff, dY.stride(0), 0, dW, woff, dW.stride(0), 0, 1, dbias=db, side=True)
         if dX is not None:
             _lib.check(self._dl(1, M, N, K, _p(dY, dyoff), dY.stride(0), 0, _p(W, woff), W.stride(0), 0, 1, None, 0,
                                       _p(dX, dxoff), dX.stride(0), 0, _p(dX, dxoff) if acc_dx else None,
@@ -228,14 +293,14 @@ class Trainer(object):
         rn, rm = B * N, B * M
         ws = self._workspace(B, N)
         L = _lib.lib()
-        self.st = st = _lib.stream_ptr(x.device)
+        self.st = _lib.stream_ptr(x.device)
         self._shape = (B, N)
         self._x = x
         P = self.P
         feat = ws["feat"]
         fe = "generator/feature_extraction_coarse/"
         _lib.check(L.dispu_linear_small_k(rn, 3, 24, _p(x), 3, _p(P[fe + "layer0/weights"]), _p(P[fe + "layer0/biases"]), 0,
-                                          _p(feat, 456), 480, st), "layer0")
+                                          _p(feat, 456), 480, self.st), "layer0")
         col = 456
         self._blocks = []
         for d in range(1, DENSE_BLOCKS + 1):
@@ -246,8 +311,8 @@ class Trainer(object):
                 F, foff, C = ws["prep"][d], 0, 48
             ldf = F.stride(0)
             kidx, Eb = ws["kidx"][d], ws["edge"][d]
-            _lib.check(L.dispu_knn_feat_strided(B, N, N, C, k + 1, _p(F, foff), ldf, _p(F, foff), ldf, None, _p(kidx), st), "knn_feat")
-            _lib.check(L.dispu_edge_feature(rn, N, k, C, _p(F, foff), ldf, _p(kidx), k + 1, 1, _p(Eb, 72), Eb.stride(0), st), "edge_feature")
+            _lib.check(L.dispu_knn_feat_strided(B, N, N, C, k + 1, _p(F, foff), ldf, _p(F, foff), ldf, None, _p(kidx), self.st), "knn_feat")
+            _lib.check(L.dispu_edge_feature(rn, N, k, C, _p(F, foff), ldf, _p(kidx), k + 1, 1, _p(Eb, 72), Eb.stride(0), self.st), "edge_feature")
             sc = fe + "layer%d" % d
             self._lin(Eb, 72, 2 * C, sc + "/l0", 1, Eb, 48, 24)
             self._lin(Eb, 48, 24 + C, sc + "/l1", 1, Eb, 24, 24)
@@ -255,7 +320,7 @@ class Trainer(object):
             width = 3 * GROWTH + C
             in_col = col
             col -= width
-            _lib.check(L.dispu_max_k(rn, k, width, _p(Eb), Eb.stride(0), _p(feat, col), 480, st), "max_k")
+            _lib.check(L.dispu_max_k(rn, k, width, _p(Eb), Eb.stride(0), _p(feat, col), 480, self.st), "max_k")
             self._blocks.append((d, C, col, in_col, width))
         assert col == 0
 
@@ -263,8 +328,23 @@ class Trainer(object):
         w1 = P["generator/upshuffle_0/conv1/weights"]
         self._lin(feat, 0, 480, None, 0, ws["h256"], 0, 256, bias=False, W=w1)
         _lib.check(L.dispu_dup_grid(B, N, 256, self.up_ratio, _p(ws["h256"]), 256, _p(w1, 480 * 256),
-                                    _p(P["generator/upshuffle_0/conv1/biases"]), _p(self.grid), _p(ws["up256"]), 256, st), "dup_grid")
+                                    _p(P["generator/upshuffle_0/conv1/biases"]), _p(self.grid), _p(ws["up256"]), 256, self.st), "dup_grid")
         self._lin(ws["up256"], 0, 256, "generator/upshuffle_0/conv2", 1, ws["up128"], 0, 128)
+        # non-local cell with materialised attention (kept for the backward).  It reads up128 only: a branch next to the coarse
+        # regressor, the grouping, the skip and the local cell; merged before add3
+        ps = "refine/PointShuffle/"
+        up128 = ws["up128"]
+        S = ws["S"]
+        with self._branch(0):
+            self._lin(up128, 0, 128, ps + "PointShuffle/conv_kv", 0, ws["kv"], 0, 128)
+            self._lin(up128, 0, 128, ps + "PointShuffle/conv_query", 0, ws["q"], 0, 64)
+            S = ws["S"]
+            _lib.check(self._dl(B, M, 64, M, _p(ws["q"]), 64, M * 64, _p(ws["kv"]), 128, M * 128, 1, None, 0, _p(S), M, M * M,
+                                      None, 0, 0, None, 0, 0, self.st), "scores")
+            _lib.check(L.dispu_softmax_rows(rm, M, 0.125, _p(S), M, self.st), "softmax")
+            _lib.check(self._dl(B, M, M, 64, _p(S), M, M * M, _p(ws["kv"], 64), 128, M * 128, 0, None, 0, _p(ws["att"]), 64,
+                                      M * 64, None, 0, 0, None, 0, 0, self.st), "att.V")
+            self._lin(ws["att"], 0, 64, ps + "PointShuffle/conv_back_project", 1, ws["nl"], 0, 256)
         cs = "generator/coarse_coordinate_regressor/"
         self._lin(ws["up128"], 0, 128, cs + "fc_layer0", 1, ws["c256"], 0, 256)
         self._lin(ws["c256"], 0, 256, cs + "fc_layer1", 1, ws["c64"], 0, 64)
@@ -274,22 +354,13 @@ class Trainer(object):
         # PointShuffle2
         ps = "refine/PointShuffle/"
         up128 = ws["up128"]
-        _lib.check(L.dispu_knn_xyz(B, M, M, k, _p(coarse), _p(coarse), _p(ws["psidx"]), None, _lib.ARITH_PLAIN, st), "knn_xyz")
+        _lib.check(L.dispu_knn_xyz(B, M, M, k, _p(coarse), _p(coarse), _p(ws["psidx"]), None, _lib.ARITH_PLAIN, self.st), "knn_xyz")
         gf = ws["gf"]
-        _lib.check(L.dispu_ps_group(rm, M, k, 128, _p(ws["psidx"]), _p(coarse), _p(up128), 128, _p(gf), 134, st), "ps_group")
-        # non-local cell with materialised attention (kept for the backward)
-        self._lin(up128, 0, 128, ps + "PointShuffle/conv_kv", 0, ws["kv"], 0, 128)
-        self._lin(up128, 0, 128, ps + "PointShuffle/conv_query", 0, ws["q"], 0, 64)
-        S = ws["S"]
-        _lib.check(self._dl(B, M, 64, M, _p(ws["q"]), 64, M * 64, _p(ws["kv"]), 128, M * 128, 1, None, 0, _p(S), M, M * M,
-                                  None, 0, 0, None, 0, 0, st), "scores")
-        _lib.check(L.dispu_softmax_rows(rm, M, 0.125, _p(S), M, st), "softmax")
-        _lib.check(self._dl(B, M, M, 64, _p(S), M, M * M, _p(ws["kv"], 64), 128, M * 128, 0, None, 0, _p(ws["att"]), 64,
-                                  M * 64, None, 0, 0, None, 0, 0, st), "att.V")
-        self._lin(ws["att"], 0, 64, ps + "PointShuffle/conv_back_project", 1, ws["nl"], 0, 256)
-        # skip
-        _lib.check(L.dispu_max_k(rm, k, 134, _p(gf), 134, _p(ws["gmax"]), 134, st), "max_k")
-        self._lin(ws["gmax"], 0, 134, ps + "skip", 1, ws["skip"], 0, 256)
+        _lib.check(L.dispu_ps_group(rm, M, k, 128, _p(ws["psidx"]), _p(coarse), _p(up128), 128, _p(gf), 134, self.st), "ps_group")
+        # skip (a second branch next to the local cell)
+        with self._branch(1):
+            _lib.check(L.dispu_max_k(rm, k, 134, _p(gf), 134, _p(ws["gmax"]), 134, self.st), "max_k")
+            self._lin(ws["gmax"], 0, 134, ps + "skip", 1, ws["skip"], 0, 256)
         # local cell
         self._lin(gf, 0, 134, ps + "conv0", 1, ws["h0"], 0, 128)
         self._lin(ws["h0"], 0, 128, ps + "conv1", 1, ws["h1"], 0, 128)
@@ -299,37 +370,38 @@ class Trainer(object):
             self._bn_scratch = torch.empty((nb + 7) // 8, dtype=torch.float64, device=self.device)
         _lib.check(L.dispu_bn_train(rm * k, 16, _p(ws["wl"]), 16, _p(P[BN + "gamma"]), _p(P[BN + "beta"]), BN_EPS, BN_DECAY, 1,
                                     _p(ws["wv"]), 16, _p(ws["bn_stats"]), _p(self.moving_mean), _p(self.moving_var),
-                                    _p(self._bn_scratch), self._bn_scratch.numel() * 8, st), "bn_train")
-        _lib.check(L.dispu_ps_point_matmul(rm, k, 128, 16, _p(ws["h1"]), 128, _p(ws["wv"]), _p(ws["hp"]), 2048, st), "point_matmul")
+                                    _p(self._bn_scratch), self._bn_scratch.numel() * 8, self.st), "bn_train")
+        _lib.check(L.dispu_ps_point_matmul(rm, k, 128, 16, _p(ws["h1"]), 128, _p(ws["wv"]), _p(ws["hp"]), 2048, self.st), "point_matmul")
         self._lin(ws["hp"], 0, 2048, ps + "after_conv", 1, ws["aft"], 0, 256)
-        _lib.check(L.dispu_add3(rm * 256, _p(ws["aft"]), _p(ws["skip"]), _p(ws["nl"]), _p(ws["sum"]), st), "add3")
+        self._merge(0)
+        self._merge(1)
+        _lib.check(L.dispu_add3(rm * 256, _p(ws["aft"]), _p(ws["skip"]), _p(ws["nl"]), _p(ws["sum"]), self.st), "add3")
         self._lin(ws["sum"], 0, 256, ps + "aggregation", 1, ws["agg"], 0, 256)
         # fine regressor
         fs = "refine/fine_coordinate_regressor/"
         self._lin(ws["agg"], 0, 256, fs + "fc_layer0", 1, ws["f256"], 0, 256)
         self._lin(ws["f256"], 0, 256, fs + "fc_layer1", 1, ws["f64"], 0, 64)
         self._lin(ws["f64"], 0, 64, fs + "fc_layer2", 0, ws["z"], 0, 3)
-        _lib.check(L.dispu_sigmoid_offset(rm * 3, _p(ws["z"]), _p(coarse), _p(ws["fine"]), st), "sigmoid_offset")
+        _lib.check(L.dispu_sigmoid_offset(rm * 3, _p(ws["z"]), _p(coarse), _p(ws["fine"]), self.st), "sigmoid_offset")
         return ws["coarse"], ws["fine"]
 
     # -------------------------------------------------------------------------------------------------- loss ----
-    def _chamfer(self, pred, gt, inv_r, coef, dpred):
+    def _chamfer(self, pred, gt, inv_r, coef, dpred, slot):
         """1000-scaled-by-caller Chamfer value and d(coef * CD)/d pred written into dpred (loss_utils.py:45-64 with
         nn_distance(gt, pred), gradient tf_nndistance.py:31-37)."""
         L = _lib.lib()
-        ws = self._workspace(*self._shape)
+        ws = self._workspace(*self._shape)["cd"][slot]
         B, n_gt, n_pred = gt.shape[0], gt.shape[1], pred.shape[1]
-        st = self.st
         _lib.check(L.dispu_nn_distance(B, n_gt, _p(gt), n_pred, _p(pred), _p(ws["d_gt"]), _p(ws["i_gt"]), _p(ws["d_pred"]),
-                                       _p(ws["i_pred"]), _lib.ARITH_CONTRACT, st), "nn_distance")
-        _lib.check(L.dispu_row_mean_max(B, n_gt, _p(ws["d_gt"]), _p(ws["rowmean"]), _p(ws["rowmax"]), st), "row_mean")
+                                       _p(ws["i_pred"]), _lib.ARITH_CONTRACT, self.st), "nn_distance")
+        _lib.check(L.dispu_row_mean_max(B, n_gt, _p(ws["d_gt"]), _p(ws["rowmean"]), _p(ws["rowmax"]), self.st), "row_mean")
         fwd = ws["rowmean"].clone()
-        _lib.check(L.dispu_row_mean_max(B, n_pred, _p(ws["d_pred"]), _p(ws["rowmean"]), _p(ws["rowmax"]), st), "row_mean")
+        _lib.check(L.dispu_row_mean_max(B, n_pred, _p(ws["d_pred"]), _p(ws["rowmean"]), _p(ws["rowmax"]), self.st), "row_mean")
         value = ((fwd + ws["rowmean"]) * inv_r).sum() / B
-        _lib.check(L.dispu_fill_rows(B, n_gt, _p(inv_r), coef / (n_gt * B), _p(ws["g_gt"]), st), "fill_rows")
-        _lib.check(L.dispu_fill_rows(B, n_pred, _p(inv_r), coef / (n_pred * B), _p(ws["g_pred"]), st), "fill_rows")
+        _lib.check(L.dispu_fill_rows(B, n_gt, _p(inv_r), coef / (n_gt * B), _p(ws["g_gt"]), self.st), "fill_rows")
+        _lib.check(L.dispu_fill_rows(B, n_pred, _p(inv_r), coef / (n_pred * B), _p(ws["g_pred"]), self.st), "fill_rows")
         _lib.check(L.dispu_nn_distance_grad(B, n_gt, _p(gt), n_pred, _p(pred), _p(ws["g_gt"]), _p(ws["i_gt"]), _p(ws["g_pred"]),
-                                            _p(ws["i_pred"]), _p(ws["dgt_unused"]), _p(dpred), st), "nn_distance_grad")
+                                            _p(ws["i_pred"]), _p(ws["dgt_unused"]), _p(dpred), self.st), "nn_distance_grad")
         return value
 
     def _check_targets(self, gt, radius, B, M):
@@ -348,24 +420,27 @@ class Trainer(object):
         B, N = self._shape
         M = N * self.up_ratio
         ws = self._workspace(B, N)
-        st = self.st
         gt, radius = self._check_targets(gt, radius, B, M)
         inv_r = (1.0 / radius).contiguous()
         wf = weight_fine(self.epoch)
-        cd_c = 1000.0 * self._chamfer(ws["coarse"], gt, inv_r, 1000.0, ws["dcoarse"])
-        cd_f = 1000.0 * self._chamfer(ws["fine"], gt, inv_r, 1000.0 * wf, ws["dfine"])
+        with self._branch(0):                                   # the coarse term next to the fine term and the repulsion term
+            cd_c = 1000.0 * self._chamfer(ws["coarse"], gt, inv_r, 1000.0, ws["dcoarse"], 0)
+        cd_f = 1000.0 * self._chamfer(ws["fine"], gt, inv_r, 1000.0 * wf, ws["dfine"], 1)
         terms = {"dis_coarse_cd": cd_c, "dis_fine_cd": cd_f, "weight_fine": wf}
         rep = torch.zeros((), dtype=torch.float32, device=self.device)
         if self.opts.use_repulse:
             fine = ws["fine"]
             r07 = torch.full((B,), 0.07, dtype=torch.float32, device=self.device)
             _lib.check(L.dispu_query_ball(B, M, M, _p(r07), 20, _p(fine), _p(fine), _p(ws["ball"]), _p(ws["ball_cnt"]),
-                                          _lib.ARITH_CONTRACT, st), "query_ball")   # as loss_utils.get_repulsion_loss
-            _lib.check(L.dispu_repulsion(B * M, M, 20, 0, 0.001, _p(fine), _p(ws["ball"]), _p(ws["rep"]), st), "repulsion")
-            _lib.check(L.dispu_row_mean_max(B, M, _p(ws["rep"]), _p(ws["rowmean"]), _p(ws["rowmax"]), st), "row_mean")
+                                          _lib.ARITH_CONTRACT, self.st), "query_ball")   # as loss_utils.get_repulsion_loss
+            _lib.check(L.dispu_repulsion(B * M, M, 20, 0, 0.001, _p(fine), _p(ws["ball"]), _p(ws["rep"]), self.st), "repulsion")
+            _lib.check(L.dispu_row_mean_max(B, M, _p(ws["rep"]), _p(ws["rowmean"]), _p(ws["rowmax"]), self.st), "row_mean")
             rep = self.opts.repulsion_w * ws["rowmean"].sum() / (B * 4.0)
             _lib.check(L.dispu_repulsion_grad(B * M, M, 20, 0.001, self.opts.repulsion_w / (B * M * 4.0), _p(fine), _p(ws["ball"]),
-                                              _p(ws["dfine"]), st), "repulsion_grad")
+                                              _p(ws["dfine"]), self.st), "repulsion_grad")
+        self._merge(0)
+        if self.overlap_dw:
+            cd_c.record_stream(torch.cuda.current_stream(self.device))    # allocated on the branch stream, read from here on
         terms["repulsion_loss"] = rep
         terms["pu_loss"] = cd_c + wf * cd_f + rep
         return terms
@@ -378,7 +453,6 @@ class Trainer(object):
         M, k = N * self.up_ratio, K_NEIGH
         rn, rm = B * N, B * M
         ws = self._workspace(B, N)
-        st = self.st
         P, G = self.P, self.G
         coarse = ws["coarse"].view(rm, 3)
         dcoarse, dfine = ws["dcoarse"].view(rm, 3), ws["dfine"].view(rm, 3)
@@ -386,7 +460,7 @@ class Trainer(object):
         fs = "refine/fine_coordinate_regressor/"
 
         # fine = coarse + sigmoid(z) - 0.5
-        _lib.check(L.dispu_sigmoid_offset_grad(rm * 3, _p(ws["z"]), _p(dfine), _p(ws["dz"]), _p(dcoarse), st), "sigmoid_grad")
+        _lib.check(L.dispu_sigmoid_offset_grad(rm * 3, _p(ws["z"]), _p(dfine), _p(ws["dz"]), _p(dcoarse), self.st), "sigmoid_grad")
         self._lin_bwd(ws["f64"], 0, 64, fs + "fc_layer2", 0, ws["z"], 0, 3, ws["dz"], 0, ws["df64"])
         self._lin_bwd(ws["f256"], 0, 256, fs + "fc_layer1", 1, ws["f64"], 0, 64, ws["df64"], 0, ws["df256"])
         self._lin_bwd(ws["agg"], 0, 256, fs + "fc_layer0", 1, ws["f256"], 0, 256, ws["df256"], 0, ws["dagg"])
@@ -396,41 +470,47 @@ class Trainer(object):
         self._act_bias_grad(rm, 256, ws["dsum"], 0, ws["skip"], 0, 1, ws["dskip"], 0, None)
         self._act_bias_grad(rm, 256, ws["dsum"], 0, ws["nl"], 0, 1, ws["dnl"], 0, None)
 
+        # non-local cell: reads dnl, writes datt / dS / dkv / dq / dup128 -- nothing the local cell or the skip branch touches, so
+        # it runs as a branch next to them; merged before ps_group_grad accumulates into dup128
+        with self._branch(0):
+            self._lin_bwd(ws["att"], 0, 64, ps + "PointShuffle/conv_back_project", 1, ws["nl"], 0, 256, ws["dnl"], 0, ws["datt"],
+                          premasked=True)
+            S, dS, kv, dkv, q = ws["S"], ws["dS"], ws["kv"], ws["dkv"], ws["q"]
+            # dP = dO . V^T
+            _lib.check(self._dl(B, M, 64, M, _p(ws["datt"]), 64, M * 64, _p(kv, 64), 128, M * 128, 1, None, 0, _p(dS), M, M * M,
+                                      None, 0, 0, None, 0, 0, self.st), "dP")
+            # dV = P^T . dO  -> dkv[:, 64:128]
+            self._tn(B, M, M, 64, S, 0, M, M * M, ws["datt"], 0, 64, M * 64, dkv, 64, 128, M * 128, 0)
+            _lib.check(L.dispu_softmax_rows_grad(rm, M, 0.125, _p(S), M, _p(dS), M, self.st), "softmax_grad")
+            # dQ = dS . K
+            _lib.check(self._dl(B, M, M, 64, _p(dS), M, M * M, _p(kv), 128, M * 128, 0, None, 0, _p(ws["dq"]), 64, M * 64,
+                                      None, 0, 0, None, 0, 0, self.st), "dQ")
+            # dK = dS^T . Q -> dkv[:, 0:64]
+            self._tn(B, M, M, 64, dS, 0, M, M * M, q, 0, 64, M * 64, dkv, 0, 128, M * 128, 0)
+            dup128 = ws["dup128"]
+            self._lin_bwd(ws["up128"], 0, 128, ps + "PointShuffle/conv_kv", 0, kv, 0, 128, dkv, 0, dup128)
+            self._lin_bwd(ws["up128"], 0, 128, ps + "PointShuffle/conv_query", 0, q, 0, 64, ws["dq"], 0, dup128, 0, acc_dx=True)
+        dgf, gf = ws["dgf"], ws["gf"]
+        # skip branch (a second branch): its max_k gradient WRITES dgf, the local cell's convs then accumulate into it
+        with self._branch(1):
+            self._lin_bwd(ws["gmax"], 0, 134, ps + "skip", 1, ws["skip"], 0, 256, ws["dskip"], 0, ws["dgmax"], premasked=True)
+            _lib.check(L.dispu_max_k_grad(rm, k, 134, _p(gf), 134, _p(ws["gmax"]), 134, _p(ws["dgmax"]), 134, _p(dgf), 134, 0, self.st),
+                       "max_k_grad")
         # local cell
         self._lin_bwd(ws["hp"], 0, 2048, ps + "after_conv", 1, ws["aft"], 0, 256, ws["daft"], 0, ws["dhp"], premasked=True)
         _lib.check(L.dispu_ps_point_matmul_grad(rm, k, 128, 16, _p(ws["h1"]), 128, _p(ws["wv"]), _p(ws["dhp"]), 2048, _p(ws["dh1"]),
-                                                128, _p(ws["dwv"]), st), "point_matmul_grad")
+                                                128, _p(ws["dwv"]), self.st), "point_matmul_grad")
         _lib.check(L.dispu_bn_train_grad(rm * k, 16, _p(ws["wl"]), 16, _p(ws["wv"]), 16, _p(ws["dwv"]), 16, _p(ws["bn_stats"]),
                                          _p(P[BN + "gamma"]), 1, _p(ws["dwl"]), 16, _p(G[BN + "gamma"]), _p(G[BN + "beta"]),
-                                         _p(ws["bn_sums"]), _p(self._bn_scratch), self._bn_scratch.numel() * 8, st), "bn_train_grad")
-        dgf, gf = ws["dgf"], ws["gf"]
-        # skip branch first: its max_k gradient WRITES dgf, the convs then accumulate
-        self._lin_bwd(ws["gmax"], 0, 134, ps + "skip", 1, ws["skip"], 0, 256, ws["dskip"], 0, ws["dgmax"], premasked=True)
-        _lib.check(L.dispu_max_k_grad(rm, k, 134, _p(gf), 134, _p(ws["gmax"]), 134, _p(ws["dgmax"]), 134, _p(dgf), 134, 0, st), "max_k_grad")
+                                         _p(ws["bn_sums"]), _p(self._bn_scratch), self._bn_scratch.numel() * 8, self.st), "bn_train_grad")
+        self._merge(1)
         self._lin_bwd(gf, 0, 3, ps + "weight_net/wconv0", 0, ws["wl"], 0, 16, ws["dwl"], 0, dgf, 0, acc_dx=True)
         self._lin_bwd(ws["h0"], 0, 128, ps + "conv1", 1, ws["h1"], 0, 128, ws["dh1"], 0, ws["dh0"])
         self._lin_bwd(gf, 0, 134, ps + "conv0", 1, ws["h0"], 0, 128, ws["dh0"], 0, dgf, 0, acc_dx=True)
 
-        # non-local cell
-        self._lin_bwd(ws["att"], 0, 64, ps + "PointShuffle/conv_back_project", 1, ws["nl"], 0, 256, ws["dnl"], 0, ws["datt"],
-                      premasked=True)
-        S, dS, kv, dkv, q = ws["S"], ws["dS"], ws["kv"], ws["dkv"], ws["q"]
-        # dP = dO . V^T
-        _lib.check(self._dl(B, M, 64, M, _p(ws["datt"]), 64, M * 64, _p(kv, 64), 128, M * 128, 1, None, 0, _p(dS), M, M * M,
-                                  None, 0, 0, None, 0, 0, st), "dP")
-        # dV = P^T . dO  -> dkv[:, 64:128]
-        self._tn(B, M, M, 64, S, 0, M, M * M, ws["datt"], 0, 64, M * 64, dkv, 64, 128, M * 128, 0)
-        _lib.check(L.dispu_softmax_rows_grad(rm, M, 0.125, _p(S), M, _p(dS), M, st), "softmax_grad")
-        # dQ = dS . K
-        _lib.check(self._dl(B, M, M, 64, _p(dS), M, M * M, _p(kv), 128, M * 128, 0, None, 0, _p(ws["dq"]), 64, M * 64,
-                                  None, 0, 0, None, 0, 0, st), "dQ")
-        # dK = dS^T . Q -> dkv[:, 0:64]
-        self._tn(B, M, M, 64, dS, 0, M, M * M, q, 0, 64, M * 64, dkv, 0, 128, M * 128, 0)
-        dup128 = ws["dup128"]
-        self._lin_bwd(ws["up128"], 0, 128, ps + "PointShuffle/conv_kv", 0, kv, 0, 128, dkv, 0, dup128)
-        self._lin_bwd(ws["up128"], 0, 128, ps + "PointShuffle/conv_query", 0, q, 0, 64, ws["dq"], 0, dup128, 0, acc_dx=True)
         # grouping: dgf -> dcoarse, dup128
-        _lib.check(L.dispu_ps_group_grad(rm, M, k, 128, _p(ws["psidx"]), _p(dgf), 134, _p(dcoarse), _p(dup128), 128, st), "ps_group_grad")
+        self._merge(0)
+        _lib.check(L.dispu_ps_group_grad(rm, M, k, 128, _p(ws["psidx"]), _p(dgf), 134, _p(dcoarse), _p(dup128), 128, self.st), "ps_group_grad")
 
         # coarse regressor
         cs = "generator/coarse_coordinate_regressor/"
@@ -443,7 +523,7 @@ class Trainer(object):
         self._act_bias_grad(rm, 256, ws["dup256"], 0, ws["up256"], 0, 1, ws["dup256"], 0, None)
         self._tn(1, rm, 2, 256, ws["gcode"], 0, 2, 0, ws["dup256"], 0, 256, 0, dw1, 480 * 256, 256, 0, 1,
                  dbias=G["generator/upshuffle_0/conv1/biases"])
-        _lib.check(L.dispu_dup_sum_grad(B, N, 256, self.up_ratio, _p(ws["dup256"]), 256, _p(ws["dh256"]), 256, st), "dup_sum_grad")
+        _lib.check(L.dispu_dup_sum_grad(B, N, 256, self.up_ratio, _p(ws["dup256"]), 256, _p(ws["dh256"]), 256, self.st), "dup_sum_grad")
         feat, dfeat = ws["feat"], ws["dfeat"]
         self._lin_bwd(feat, 0, 480, None, 0, None, 0, 256, ws["dh256"], 0, dfeat, 0, bias=False, W=w1, dW=dw1)
 
@@ -453,8 +533,9 @@ class Trainer(object):
         for (d, C, col, in_col, width) in reversed(self._blocks):
             Eb = ws["edge"][d]
             lde = dE.stride(0)
-            dE.zero_()
-            _lib.check(L.dispu_max_k_grad(rn, k, width, _p(Eb), Eb.stride(0), _p(feat, col), 480, _p(dfeat, col), 480, _p(dE), lde, 0, st),
+            self._join()                 # dE / dprep are shared by the blocks: the previous block's dW products read them
+            dE.zero_()                   # max_k_grad writes columns [0, width); the neighbour half of the edge feature only accumulates
+            _lib.check(L.dispu_max_k_grad(rn, k, width, _p(Eb), Eb.stride(0), _p(feat, col), 480, _p(dfeat, col), 480, _p(dE), lde, 0, self.st),
                        "max_k_grad")
             sc = fe + "layer%d" % d
             self._lin_bwd(Eb, 24, 48 + C, sc + "/l2", 0, Eb, 0, 24, dE, 0, dE, 24, acc_dx=True)
@@ -465,13 +546,14 @@ class Trainer(object):
             else:
                 dF, dfoff = ws["dprep"], 0
                 dF.zero_()
-            _lib.check(L.dispu_edge_feature_grad(rn, N, k, C, _p(dE, 72), lde, _p(ws["kidx"][d]), k + 1, 1, _p(dF, dfoff), dF.stride(0), st),
+            _lib.check(L.dispu_edge_feature_grad(rn, N, k, C, _p(dE, 72), lde, _p(ws["kidx"][d]), k + 1, 1, _p(dF, dfoff), dF.stride(0), self.st),
                        "edge_feature_grad")
             if d > 1:
                 self._lin_bwd(feat, in_col, 480 - in_col, fe + "layer%d_prep" % d, 1, ws["prep"][d], 0, 48, ws["dprep"], 0,
                               dfeat, in_col, acc_dx=True)
         # layer0 (no activation, input has no gradient)
         self._lin_bwd(self._x.view(rn, 3), 0, 3, fe + "layer0", 0, feat, 456, 24, dfeat, 456, None)
+        self._join()                     # every dW is in the flat gradient buffer from here on (all-reduce, Adam)
 
     # -------------------------------------------------------------------------------------------------- step ----
     def zero_grad(self):

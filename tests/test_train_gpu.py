@@ -369,6 +369,41 @@ def test_loss_decreases(dev):
     assert losses[-1] < 0.7 * losses[0], losses
 
 
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_weight_gradients_on_second_stream(dev, dtype):
+    """The dW products of a step run on a second HIP stream next to the dX chain (train.py:_fork/_join).  Same kernels, same
+    operands: the gradients equal the single-stream step's up to the order-free fp32 atomics of the scatter gradients
+    (max_k / group / nn_distance, like the reference's) -- 1e-5 of each tensor's largest entry, run to run as well."""
+    from dispu_amd import synth
+    from dispu_amd.train import Trainer
+    P = OG.init_params(seed=1234, bias_scale=0.05)
+    x, gt = synth.patch_with_gt(4, 256, 1024, seed=11)
+    xs, gs, rs = dv(x, dev), dv(gt, dev), torch.ones(4, device=dev)
+
+    def passes(overlap):
+        tr = Trainer(params=P, device=dev, dtype=dtype)
+        tr.overlap_dw = overlap
+        out = []
+        for _ in range(3):                       # same parameters every pass: no Adam in between
+            tr.zero_grad()
+            tr.forward(xs)
+            tr.loss_backward(gs, rs)
+            tr.backward()
+            torch.cuda.synchronize()
+            out.append({k: v.clone() for k, v in tr.G.items()})
+        return tr, out
+
+    tr_o, g_o = passes(True)
+    tr_s, g_s = passes(False)
+    assert tr_o._side is not None and tr_s._side is None
+    # bf16 products: an fp32 ulp of atomics noise upstream can flip an operand's bf16 rounding (2^-9 relative) downstream
+    tol = 1e-5 if dtype == "f32" else 1e-3
+    for k in g_o[0]:
+        scale = float(g_s[0][k].abs().max()) + 1e-12
+        for a in (g_o[0], g_o[1], g_o[2], g_s[1]):
+            assert float((a[k] - g_s[0][k]).abs().max()) <= tol * scale + 2e-6, k     # + rounding noise of gradients that are 0
+
+
 def test_repulsion_term_equals_loss_utils(step, dev):
     """Trainer's repulsion term and loss_utils.get_repulsion_loss use the same ball-query arithmetic (CONTRACT, the
     nvcc form of tf_grouping_g.cu:3-36) -> the same value on the same cloud (loss_utils.py:271-298)."""
