@@ -14,7 +14,9 @@ What is different from the reference's execution (not its results):
     16x fewer FLOPs; reassociated -> tolerance-checked).
 Everything up to and including `coarse` is bit-identical to oracle/generator.py (fp32 MFMA == fmaf chain).
 """
+import contextlib
 import math
+import os
 
 import numpy as np
 import torch
@@ -75,7 +77,9 @@ class Generator(object):
         # tolerance-checked).  Off by default; bench.py --split-bf16 reports it beside the strict-fp32 line.
         self.split_bf16 = False
         self._planes = {}
-        self.split_up3 = bool(int(__import__('os').environ.get('DISPU_SPLIT_UP3', '1')))
+        self.split_up3 = bool(int(os.environ.get('DISPU_SPLIT_UP3', '1')))
+        self.branches = bool(int(os.environ.get('DISPU_BRANCHES', '0')))   # non-local cell on a second stream (measured: see DESIGN.md)
+        self._aux = None
         self.fused_residual = bool(int(__import__('os').environ.get('DISPU_FUSED_RES', '1')))
         self.fused_heads = bool(int(__import__('os').environ.get('DISPU_FUSED_HEADS', '1')))   # one launch per head chain
         self.keep_intermediates = False   # fused heads: also write the aggregation output (tests compare it)
@@ -284,48 +288,66 @@ class Generator(object):
         # ---- PointShuffle2 (ops.py:1012-1087)
         ps = "refine/PointShuffle/"
         up128 = ws["up128"]
+        # The non-local cell reads up128 only.  With self.branches it runs on a second stream next to the grouping / skip / local
+        # cell (fork here; the local cell waits for up3 = conv0's feature part, after_conv for nl): the small launches of one side
+        # fill the CUs the other leaves idle.  Captured into the same hipGraph as two parallel branches.
+        br = self.branches
+        if br:
+            if self._aux is None:
+                self._aux = (torch.cuda.Stream(device=self.device), torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event())
+            aux, ev_fork, ev_up3, ev_nl = self._aux
+            ev_fork.record(torch.cuda.current_stream(self.device))
+            aux.wait_event(ev_fork)
+        with (torch.cuda.stream(aux) if br else contextlib.nullcontext()):
+            sb = _lib.C.c_void_p(aux.cuda_stream) if br else st
+            # PointNonLocalCell (ops.py:302-346)
+            if self.split_up3:
+                # N = 320 as 256 + 64 columns: each launch reads up128 ONCE (128 x 256 / 128 x 64 tiles); one launch with 128 x 64
+                # tiles re-read it five times (128 MB of counter traffic against 59 MB algorithmic in round 1)
+                self._linear(sb, up128, 128, self.w_up3, self.b_up3, 0, ws["up3"], 256)
+                self._linear(sb, up128, 128, self.w_up3, self.b_up3[256:], 0, ws["up3"], 64, woff=256, yoff=256)
+            else:
+                self._linear(sb, up128, 128, self.w_up3, self.b_up3, 0, ws["up3"], 320)  # K|V, Q and conv0's feature part at once
+            if br:
+                ev_up3.record(aux)
+            w_bp, b_bp = self._w(ps + "PointShuffle/conv_back_project")
+            projected = False
+            if self.fused_attention and M % 32 == 0 and self.fused_project:
+                # softmax(Q.K^T / 8).V.W_bp on chip: neither the [B, M, M] logits nor the [B*M, 64] attention output reach HBM
+                self._call("attention_project", L.dispu_attention_project, B, M, M, 64, ptr(ws["q"]), 320, ptr(ws["kv"]), 320,
+                           off(ws["kv"], 64), 320, 0.125, ptr(w_bp), ptr(b_bp), 256, ptr(ws["nl"]), 256, sb)
+                projected = True
+            elif self.fused_attention and M % 32 == 0:
+                # softmax(Q.K^T / 8).V on chip (flash style): the [B, M, M] logits never exist in HBM
+                self._call("attention", L.dispu_attention, B, M, M, 64, ptr(ws["q"]), 320, ptr(ws["kv"]), 320, off(ws["kv"], 64), 320,
+                           0.125, ptr(ws["att"]), 64, sb)
+            else:
+                key = ("scores", B, N)
+                if key not in self._ws:
+                    self._ws[key] = torch.empty((B, M, M), dtype=torch.float32, device=self.device)
+                s = self._ws[key]
+                self._linear(sb, ws["q"], 64, ws["kv"], None, 0, s, M, M=M, ldx=320, ldw=320, ldy=M, batch=B, sx=M * 320,
+                             sw=M * 320, sy=M * M, transb=1)
+                self._call("softmax", L.dispu_softmax_rows, rm, M, 0.125, ptr(s), M, sb)
+                self._linear(sb, s, M, ws["kv"], None, 0, ws["att"], 64, M=M, ldx=M, ldw=320, ldy=64, batch=B, sx=M * M,
+                             sw=M * 320, sy=M * 64, woff=64)
+            if not projected:
+                self._linear(sb, ws["att"], 64, w_bp, b_bp, 1, ws["nl"], 256)
+            if br:
+                ev_nl.record(aux)
         nb = L.dispu_knn_xyz_scratch_bytes(B, M, M, k)             # > 0 for M > 1024 (second pass of 16x upsampling): chunked search
         if nb and ws.get("knn_scratch") is None:
             ws["knn_scratch"] = torch.empty((nb,), dtype=torch.uint8, device=self.device)
         self._call("knn_xyz", L.dispu_knn_xyz_ws, B, M, M, k, ptr(coarse), ptr(coarse), ptr(ws["psidx"]), None,
                    ptr(ws["knn_scratch"]) if nb else None, nb, _lib.ARITH_PLAIN, st)
-        # PointNonLocalCell (ops.py:302-346)
-        if self.split_up3:
-            # N = 320 as 256 + 64 columns: each launch reads up128 ONCE (128 x 256 / 128 x 64 tiles); one launch with 128 x 64
-            # tiles re-read it five times (128 MB of counter traffic against 59 MB algorithmic in round 1)
-            self._linear(st, up128, 128, self.w_up3, self.b_up3, 0, ws["up3"], 256)
-            self._linear(st, up128, 128, self.w_up3, self.b_up3[256:], 0, ws["up3"], 64, woff=256, yoff=256)
-        else:
-            self._linear(st, up128, 128, self.w_up3, self.b_up3, 0, ws["up3"], 320)  # K|V, Q and conv0's feature part at once
-        w_bp, b_bp = self._w(ps + "PointShuffle/conv_back_project")
-        projected = False
-        if self.fused_attention and M % 32 == 0 and self.fused_project:
-            # softmax(Q.K^T / 8).V.W_bp on chip: neither the [B, M, M] logits nor the [B*M, 64] attention output reach HBM
-            self._call("attention_project", L.dispu_attention_project, B, M, M, 64, ptr(ws["q"]), 320, ptr(ws["kv"]), 320,
-                       off(ws["kv"], 64), 320, 0.125, ptr(w_bp), ptr(b_bp), 256, ptr(ws["nl"]), 256, st)
-            projected = True
-        elif self.fused_attention and M % 32 == 0:
-            # softmax(Q.K^T / 8).V on chip (flash style): the [B, M, M] logits never exist in HBM
-            self._call("attention", L.dispu_attention, B, M, M, 64, ptr(ws["q"]), 320, ptr(ws["kv"]), 320, off(ws["kv"], 64), 320,
-                       0.125, ptr(ws["att"]), 64, st)
-        else:
-            key = ("scores", B, N)
-            if key not in self._ws:
-                self._ws[key] = torch.empty((B, M, M), dtype=torch.float32, device=self.device)
-            s = self._ws[key]
-            self._linear(st, ws["q"], 64, ws["kv"], None, 0, s, M, M=M, ldx=320, ldw=320, ldy=M, batch=B, sx=M * 320,
-                         sw=M * 320, sy=M * M, transb=1)
-            self._call("softmax", L.dispu_softmax_rows, rm, M, 0.125, ptr(s), M, st)
-            self._linear(st, s, M, ws["kv"], None, 0, ws["att"], 64, M=M, ldx=M, ldw=320, ldy=64, batch=B, sx=M * M,
-                         sw=M * 320, sy=M * 64, woff=64)
-        if not projected:
-            self._linear(st, ws["att"], 64, w_bp, b_bp, 1, ws["nl"], 256)
         # skip connection
         self._call("skip_max", L.dispu_ps_skip_max, rm, M, k, 128, ptr(ws["psidx"]), ptr(coarse), ptr(up128), 128, ptr(ws["skipin"]), 144, st)
         _, b = self._w(ps + "skip")
         # K padded 134 -> 144 with zero columns / zero weight rows (exact) so the GEMM takes its predicate-free path
         self._linear(st, ws["skipin"], 144, self.w_skip_pad, b, 1, ws["skip"], 256)
         # local cell: conv0 per source point, conv1 per pair
+        if br:
+            torch.cuda.current_stream(self.device).wait_event(ev_up3)
         w0, b0 = self._w(ps + "conv0")
         self._call("ps_prep", L.dispu_ps_prep, rm, 128, ptr(coarse), ptr(w0), ptr(b0), ptr(ws["gm"]), 320, ptr(ws["am"]), 128, st)
         w1, b1 = self._w(ps + "conv1")
@@ -343,6 +365,8 @@ class Generator(object):
                        ptr(self.bn_scale), ptr(self.bn_shift), ptr(wv), st)
             self._call("point_matmul", L.dispu_ps_point_matmul, rm, k, 128, 16, ptr(x2), 128, ptr(wv), ptr(ws["fp"]), 2048, st)
         w, b = self._w(ps + "after_conv")
+        if br:
+            torch.cuda.current_stream(self.device).wait_event(ev_nl)
         if self.split_bf16 and rm % 128 == 0:
             pl = self._planes.get("after_conv")
             if pl is None:
