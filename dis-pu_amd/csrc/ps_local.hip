@@ -21,6 +21,7 @@
 namespace dispu {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int PL_BM = 128, PL_BN = 128, PL_BK = 32, PL_K = 128, PL_NT = 256;
 constexpr int PL_LDA = PL_BM + 1, PL_LDB = PL_BN + 4;
@@ -208,8 +209,19 @@ __device__ __forceinline__ float pl_quad(float v) {      // v from the lane give
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
 }
 
+// Barrier of the slab pipeline: the waves exchange data through LDS only, so only the LDS counter has to drain.  __syncthreads()
+// also waits for vmcnt(0): the helpers would sit out the latency of the gathers they have just issued for the NEXT slab (and the
+// MFMA waves that of their F' stores) at every barrier -- measured 900 cycles per barrier on the MFMA waves (PL_STAMPS).
+__device__ __forceinline__ void pl_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 constexpr int PW_WRES = PL_K * PL_LDB;                               // resident W1 [128 k][132]
-constexpr int PW_ASTG = PL_BK * PL_LDA;                              // one A slab, k-major [32][129]
+// One A slab, ROW-major [128 pair rows][16 even k | 16 odd k (+4)]: a helper thread owns 4 consecutive k of a row = two 8-byte LDS
+// stores (k-major needed four 4-byte stores, 8-way bank conflicted); the helpers share their SIMD's issue port with a wave that
+// issues MFMAs back to back, so their instruction count is what the MFMA waves end up waiting for (PL_STAMPS: 900 cycles per
+// barrier before).  An MFMA lane (row fi, k parity fk) reads its 16 k of the slab as FOUR 16-byte loads instead of sixteen
+// 4-byte ones (2-way bank conflicts at a 36-float pitch).
+constexpr int PW_LDAR = PL_BK + 4;
+constexpr int PW_ASTG = PL_BM * PW_LDAR;
 constexpr int PW_FLOATS = PW_WRES + 2 * PW_ASTG + 2 * 2048 + 2 * 1024 + 512;
 constexpr size_t PW_LDS_BYTES = (size_t)PW_FLOATS * sizeof(float);
 
@@ -221,7 +233,7 @@ __global__ __launch_bounds__(512) void ps_local_ws_kernel(long npoints, int n_pe
                                                            const float* __restrict__ shift, float* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* wres = lds;                                               // [128][PL_LDB]
-    float* astg = wres + PW_WRES;                                    // [2][32][PL_LDA]
+    float* astg = wres + PW_WRES;                                    // [2][128][PW_LDAR]
     float* wvbuf = astg + 2 * PW_ASTG;                               // [2][8 points][16 s][16 t]
     float* abuf = wvbuf + 2 * 2048;                                  // [2][8 points][128]
     float* cxbuf = abuf + 2 * 1024;                                  // [128 pairs][4]: x_j - x_i
@@ -233,6 +245,7 @@ __global__ __launch_bounds__(512) void ps_local_ws_kernel(long npoints, int n_pe
 
     if (wave >= 4) {
         // ------------------------------------------------------------------------------------- helper waves
+        __builtin_amdgcn_s_setprio(3);
         const int ht = threadIdx.x - 256;
         const int kq = ht & 7;
         // A-tile rows of this thread: r = rho + 32 * it, rho = ht >> 3.  Row rho of a 32-row block holds contraction index
@@ -250,21 +263,34 @@ __global__ __launch_bounds__(512) void ps_local_ws_kernel(long npoints, int n_pe
                 go[it] = (cloud_base(i) + idx[i * 16 + rs]) * ldg + kq * 4;
             }
         };
-        float4 pg[4];
-        auto load_g = [&](int k0, const int (&go)[4]) {
+        int ri[4];                                                   // neighbour ids of the next group: loaded one interval before use
+        auto rows_load = [&](int g) {
+#pragma unroll
+            for (int it = 0; it < 4; ++it) ri[it] = idx[clampi(g * 8 + 2 * it + rq) * 16 + rs];
+        };
+        auto rows_finish = [&](int g, int (&go)[4]) {
+#pragma unroll
+            for (int it = 0; it < 4; ++it) go[it] = (cloud_base(clampi(g * 8 + 2 * it + rq)) + ri[it]) * ldg + kq * 4;
+        };
+        // two register sets: the gathers of a slab are issued TWO slab intervals before they are consumed (one interval =
+        // 4300 cycles of MFMAs; a gather from the 17 MB working set of G takes about that long: with one set the helpers spent the
+        // whole interval waiting in store_a and the MFMA waves 900 cycles at every barrier, PL_STAMPS)
+        float4 pg0[4], pg1[4];
+        auto load_g = [&](float4 (&pg)[4], int k0, const int (&go)[4]) {
 #pragma unroll
             for (int it = 0; it < 4; ++it) pg[it] = *reinterpret_cast<const float4*>(Gm + go[it] + k0);
         };
-        auto store_a = [&](int stage, int k0, const float* ab) {     // relu(G_j - A_i) -> slab `stage`, k-major
+        auto store_a = [&](const float4 (&pg)[4], int stage, int k0, const float* ab) {     // relu(G_j - A_i) -> slab `stage`
             float* As = astg + stage * PW_ASTG;
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
                 const float4 av = *reinterpret_cast<const float4*>(ab + (2 * it + rq) * PL_K + k0 + kq * 4);
                 const int r = rho + 32 * it;
-                As[(kq * 4 + 0) * PL_LDA + r] = fmaxf(pg[it].x - av.x, 0.f);
-                As[(kq * 4 + 1) * PL_LDA + r] = fmaxf(pg[it].y - av.y, 0.f);
-                As[(kq * 4 + 2) * PL_LDA + r] = fmaxf(pg[it].z - av.z, 0.f);
-                As[(kq * 4 + 3) * PL_LDA + r] = fmaxf(pg[it].w - av.w, 0.f);
+                const f32x2 dlo = f32x2{pg[it].x, pg[it].y} - f32x2{av.x, av.y};      // v_pk_add_f32 with neg
+                const f32x2 dhi = f32x2{pg[it].z, pg[it].w} - f32x2{av.z, av.w};
+                // k = 4 kq + {0, 2} -> even half, slots 2 kq, 2 kq + 1;  k = 4 kq + {1, 3} -> odd half
+                *reinterpret_cast<float2*>(&As[r * PW_LDAR + kq * 2]) = make_float2(fmaxf(dlo.x, 0.f), fmaxf(dhi.x, 0.f));
+                *reinterpret_cast<float2*>(&As[r * PW_LDAR + 16 + kq * 2]) = make_float2(fmaxf(dlo.y, 0.f), fmaxf(dhi.y, 0.f));
             }
         };
         // A rows of the 8 points of a group: 8 x 128 floats = 256 float4, one per helper thread
@@ -296,6 +322,7 @@ __global__ __launch_bounds__(512) void ps_local_ws_kernel(long npoints, int n_pe
             if (ht < 128) {
 #pragma unroll
                 for (int c = 0; c < 3; ++c) cxbuf[ht * 4 + c] = px[c] - px[3 + c];
+                cxbuf[ht * 4 + 3] = 0.f;                              // read as part of a float4
             }
         };
         auto wn_d = [&](int g, float* wv) {
@@ -303,11 +330,11 @@ __global__ __launch_bounds__(512) void ps_local_ws_kernel(long npoints, int n_pe
             for (int u = 0; u < 8; ++u) {
                 float v = 0.f;
                 if (g * 8 + u < np) {
-                    const float* cx = cxbuf + (u * 16 + wsn) * 4;
+                    const float4 cx = *reinterpret_cast<const float4*>(cxbuf + (u * 16 + wsn) * 4);
                     float acc = 0.f;
-                    acc = __builtin_fmaf(cx[0], ww0, acc);
-                    acc = __builtin_fmaf(cx[1], ww1, acc);
-                    acc = __builtin_fmaf(cx[2], ww2, acc);
+                    acc = __builtin_fmaf(cx.x, ww0, acc);
+                    acc = __builtin_fmaf(cx.y, ww1, acc);
+                    acc = __builtin_fmaf(cx.z, ww2, acc);
                     acc = acc + wbw;
                     acc = acc * wsc + wsh;
                     v = fmaxf(acc, 0.f);
@@ -330,42 +357,72 @@ __global__ __launch_bounds__(512) void ps_local_ws_kernel(long npoints, int n_pe
         wn_a(g);
         wn_b();
         wn_c();
-        load_g(0, goff);
+        load_g(pg0, 0, goff);
+        load_g(pg1, PL_BK, goff);
         __syncthreads();                                             // #1: abuf, cxbuf, wres visible
         wn_d(g, wvbuf);
-        store_a(0, 0, abuf);
-        load_g(PL_BK, goff);
+        store_a(pg0, 0, 0, abuf);
+        load_g(pg0, 2 * PL_BK, goff);
         __syncthreads();                                             // #2: slab 0 and wv of the first group ready
         int n = 0;
+#ifdef PL_STAMPS
+        unsigned long long h_sa = 0, h_rest = 0, h_bar = 0;
+#define PL_H(v) const unsigned long long v = __builtin_readcyclecounter()
+#else
+#define PL_H(v)
+#endif
         for (; g < ng; g += gstep, ++n) {
             const int gn = g + gstep;
             const bool has_next = gn < ng;
             const float* ab = abuf + (n & 1) * 1024;
             float* ab_n = abuf + ((n + 1) & 1) * 1024;
             // slab 0 interval
-            store_a(1, PL_BK, ab);
-            load_g(2 * PL_BK, goff);
-            if (has_next) { rows_of(gn, goff_n); load_arow(gn); wn_a(gn); }
-            __syncthreads();
+            PL_H(a0);
+            store_a(pg1, 1, PL_BK, ab);
+            PL_H(a1);
+            load_g(pg1, 3 * PL_BK, goff);
+            if (has_next) { rows_load(gn); load_arow(gn); wn_a(gn); }
+            PL_H(a2);
+            pl_lds_barrier();
             // slab 1 interval
-            store_a(0, 2 * PL_BK, ab);
-            load_g(3 * PL_BK, goff);
-            if (has_next) { store_arow(ab_n); wn_b(); }
-            __syncthreads();
+            PL_H(b0);
+            store_a(pg0, 0, 2 * PL_BK, ab);
+            PL_H(b1);
+            if (has_next) { rows_finish(gn, goff_n); load_g(pg0, 0, goff_n); store_arow(ab_n); wn_b(); }
+            PL_H(b2);
+            pl_lds_barrier();
             // slab 2 interval
-            store_a(1, 3 * PL_BK, ab);
-            if (has_next) { load_g(0, goff_n); wn_c(); }
-            __syncthreads();
+            PL_H(c0);
+            store_a(pg1, 1, 3 * PL_BK, ab);
+            PL_H(c1);
+            if (has_next) { load_g(pg1, PL_BK, goff_n); wn_c(); }
+            PL_H(c2);
+            pl_lds_barrier();
             // slab 3 interval: slab buffer 0 is free again (read during slab 2) -> next group's first slab
+            PL_H(d0);
             if (has_next) {
-                store_a(0, 0, ab_n);
-                load_g(PL_BK, goff_n);
+                store_a(pg0, 0, 0, ab_n);
+            }
+            PL_H(d1);
+            if (has_next) {
+                load_g(pg0, 2 * PL_BK, goff_n);
                 wn_d(gn, wvbuf + ((n + 1) & 1) * 2048);                // that buffer's last reader was the contraction of group n-1
             }
-            __syncthreads();
+            PL_H(d2);
+            pl_lds_barrier();
+#ifdef PL_STAMPS
+            { PL_H(e0); h_sa += (a1 - a0) + (b1 - b0) + (c1 - c0) + (d1 - d0); h_rest += (a2 - a1) + (b2 - b1) + (c2 - c1) + (d2 - d1);
+              h_bar += (b0 - a2) + (c0 - b2) + (d0 - c2) + (e0 - d2); }
+#endif
 #pragma unroll
             for (int it = 0; it < 4; ++it) goff[it] = goff_n[it];
         }
+#ifdef PL_STAMPS
+        if (blockIdx.x == 5 && (threadIdx.x & 63) == 0) {
+            unsigned long long* st = reinterpret_cast<unsigned long long*>(out + (size_t)npoints * 2048) + 20 + (wave - 4) * 4;
+            st[0] = h_sa; st[1] = h_rest; st[2] = h_bar; st[3] = n;
+        }
+#endif
         return;
     }
 
@@ -398,20 +455,28 @@ __global__ __launch_bounds__(512) void ps_local_ws_kernel(long npoints, int n_pe
             const float* Bs = wres + (t * PL_BK) * PL_LDB;
             PL_T(s0);
 #pragma unroll
-            for (int kk = 0; kk < PL_BK; kk += 2) {
-                float af[2], bf[2];
-#pragma unroll
-                for (int i = 0; i < 2; ++i) af[i] = As[(kk + fk) * PL_LDA + wm * 64 + i * 32 + fi];
-#pragma unroll
-                for (int j = 0; j < 2; ++j) bf[j] = Bs[(kk + fk) * PL_LDB + wn * 64 + j * 32 + fi];
+            for (int k4 = 0; k4 < PL_BK; k4 += 8) {                   // 4 k-steps per 16-byte fragment load
+                float4 a4[2];
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
+                    a4[i] = *reinterpret_cast<const float4*>(&As[(wm * 64 + i * 32 + fi) * PW_LDAR + fk * 16 + (k4 >> 1)]);
 #pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    const int kk = k4 + 2 * q4;
+                    float af[2], bf[2];
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) af[i] = q4 == 0 ? a4[i].x : q4 == 1 ? a4[i].y : q4 == 2 ? a4[i].z : a4[i].w;
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) bf[j] = Bs[(kk + fk) * PL_LDB + wn * 64 + j * 32 + fi];
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+                }
             }
             PL_T(s1);
-            __syncthreads();
+            pl_lds_barrier();
             PL_T(s2);
 #ifdef PL_STAMPS
             c_mma += s1 - s0; c_bar += s2 - s1;

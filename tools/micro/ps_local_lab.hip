@@ -32,5 +32,9 @@ int main() {
     for (int w = 0; w < 4; ++w)
         printf("  mfma wave %d over %llu groups, cycles per group: mma %.0f  slab-barriers %.0f  park+barrier %.0f  contraction+store %.0f\n", w, st[w * 5 + 4],
                st[w * 5] / (double)st[w * 5 + 4], st[w * 5 + 1] / (double)st[w * 5 + 4], st[w * 5 + 2] / (double)st[w * 5 + 4], st[w * 5 + 3] / (double)st[w * 5 + 4]);
+    for (int w = 0; w < 4; ++w)
+        printf("  helper wave %d over %llu groups, cycles per group: store_a (incl. waiting for its gathers) %.0f  issue loads / weight net %.0f  barriers %.0f\n", w,
+               st[20 + w * 4 + 3], st[20 + w * 4] / (double)st[20 + w * 4 + 3], st[20 + w * 4 + 1] / (double)st[20 + w * 4 + 3],
+               st[20 + w * 4 + 2] / (double)st[20 + w * 4 + 3]);
     return 0;
 }
