@@ -22,6 +22,8 @@ namespace dispu {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int PL_BM = 128, PL_BN = 128, PL_BK = 32, PL_K = 128, PL_NT = 256;
 constexpr int PL_LDA = PL_BM + 1, PL_LDB = PL_BN + 4;
@@ -214,14 +216,15 @@ __device__ __forceinline__ float pl_quad(float v) {      // v from the lane give
 // MFMA waves that of their F' stores) at every barrier -- measured 900 cycles per barrier on the MFMA waves (PL_STAMPS).
 __device__ __forceinline__ void pl_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-constexpr int PW_WRES = PL_K * PL_LDB;                               // resident W1 [128 k][132]
-// One A slab, ROW-major [128 pair rows][16 even k | 16 odd k (+4)]: a helper thread owns 4 consecutive k of a row = two 8-byte LDS
-// stores (k-major needed four 4-byte stores, 8-way bank conflicted); the helpers share their SIMD's issue port with a wave that
-// issues MFMAs back to back, so their instruction count is what the MFMA waves end up waiting for (PL_STAMPS: 900 cycles per
-// barrier before).  An MFMA lane (row fi, k parity fk) reads its 16 k of the slab as FOUR 16-byte loads instead of sixteen
-// 4-byte ones (2-way bank conflicts at a 36-float pitch).
+// One A slab, ROW-major [128 pair rows][32 k (+4)]: a helper thread owns 4 consecutive k of a row = ONE 16-byte LDS store (the
+// k-major slab of round 1 needed four 4-byte stores, 8-way bank conflicted); the helpers share their SIMD's issue port with a
+// wave that issues MFMAs back to back, so their instruction count is what the MFMA waves end up waiting for (PL_STAMPS: 900
+// cycles per barrier before).  A 16x16x4 fragment read (16 rows x 4 consecutive k) is 2-way conflicted at the 36-float pitch,
+// the resident W1 (pitch 144: k-groups 16 banks apart) likewise: 64 lanes x 4 B over 32 banks cannot do better.
 constexpr int PW_LDAR = PL_BK + 4;
 constexpr int PW_ASTG = PL_BM * PW_LDAR;
+constexpr int PW_LDB = PL_BN + 16;
+constexpr int PW_WRES = PL_K * PW_LDB;                               // resident W1 [128 k][144]
 constexpr int PW_FLOATS = PW_WRES + 2 * PW_ASTG + 2 * 2048 + 2 * 1024 + 512;
 constexpr size_t PW_LDS_BYTES = (size_t)PW_FLOATS * sizeof(float);
 
@@ -232,7 +235,7 @@ __global__ __launch_bounds__(512) void ps_local_ws_kernel(long npoints, int n_pe
                                                            const float* __restrict__ bw, const float* __restrict__ scale,
                                                            const float* __restrict__ shift, float* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* wres = lds;                                               // [128][PL_LDB]
+    float* wres = lds;                                               // [128][PW_LDB]
     float* astg = wres + PW_WRES;                                    // [2][128][PW_LDAR]
     float* wvbuf = astg + 2 * PW_ASTG;                               // [2][8 points][16 s][16 t]
     float* abuf = wvbuf + 2 * 2048;                                  // [2][8 points][128]
@@ -245,14 +248,12 @@ __global__ __launch_bounds__(512) void ps_local_ws_kernel(long npoints, int n_pe
 
     if (wave >= 4) {
         // ------------------------------------------------------------------------------------- helper waves
-        __builtin_amdgcn_s_setprio(3);
         const int ht = threadIdx.x - 256;
         const int kq = ht & 7;
-        // A-tile rows of this thread: r = rho + 32 * it, rho = ht >> 3.  Row rho of a 32-row block holds contraction index
-        // k = 16 * q' + s  with  rho = (k>>1 & 3) + 8 (k>>3) + 4 (k & 1); block `it` holds points 2 it, 2 it + 1.
+        // A-tile rows of this thread: r = rho + 32 * it, rho = ht >> 3.  The 16 tile rows of a point hold its neighbours in the
+        // order the 16x16 MFMA result layout dictates: row 4 a + b of the block <-> s = 4 b + a (see the MFMA waves).
         const int rho = ht >> 3;
-        const int kc = ((rho >> 2) & 1) | ((rho & 3) << 1) | ((rho >> 3) << 3);
-        const int rq = kc >> 4, rs = kc & 15;
+        const int rq = rho >> 4, rs = 4 * (rho & 3) + ((rho >> 2) & 3);
         auto clampi = [&](int i) { return i < np ? i : np - 1; };
         auto cloud_base = [&](int i) { return (int)((unsigned)i / (unsigned)n_per_cloud) * n_per_cloud; };
         int goff[4], goff_n[4];                                      // element offsets of the gathered G rows (+ kq * 4)
@@ -288,9 +289,8 @@ __global__ __launch_bounds__(512) void ps_local_ws_kernel(long npoints, int n_pe
                 const int r = rho + 32 * it;
                 const f32x2 dlo = f32x2{pg[it].x, pg[it].y} - f32x2{av.x, av.y};      // v_pk_add_f32 with neg
                 const f32x2 dhi = f32x2{pg[it].z, pg[it].w} - f32x2{av.z, av.w};
-                // k = 4 kq + {0, 2} -> even half, slots 2 kq, 2 kq + 1;  k = 4 kq + {1, 3} -> odd half
-                *reinterpret_cast<float2*>(&As[r * PW_LDAR + kq * 2]) = make_float2(fmaxf(dlo.x, 0.f), fmaxf(dhi.x, 0.f));
-                *reinterpret_cast<float2*>(&As[r * PW_LDAR + 16 + kq * 2]) = make_float2(fmaxf(dlo.y, 0.f), fmaxf(dhi.y, 0.f));
+                *reinterpret_cast<float4*>(&As[r * PW_LDAR + kq * 4]) =
+                    make_float4(fmaxf(dlo.x, 0.f), fmaxf(dlo.y, 0.f), fmaxf(dhi.x, 0.f), fmaxf(dhi.y, 0.f));
             }
         };
         // A rows of the 8 points of a group: 8 x 128 floats = 256 float4, one per helper thread
@@ -348,7 +348,7 @@ __global__ __launch_bounds__(512) void ps_local_ws_kernel(long npoints, int n_pe
         for (int it = 0; it < 16; ++it) {
             const int e = ht + it * PL_NT;                            // 4096 float4
             const int kr = e >> 5, nq = e & 31;
-            *reinterpret_cast<float4*>(&wres[kr * PL_LDB + nq * 4]) = *reinterpret_cast<const float4*>(W1 + (size_t)kr * PL_BN + nq * 4);
+            *reinterpret_cast<float4*>(&wres[kr * PW_LDB + nq * 4]) = *reinterpret_cast<const float4*>(W1 + (size_t)kr * PL_BN + nq * 4);
         }
         int g = blockIdx.x;
         rows_of(g, goff);
@@ -427,11 +427,18 @@ __global__ __launch_bounds__(512) void ps_local_ws_kernel(long npoints, int n_pe
     }
 
     // ----------------------------------------------------------------------------------------------- MFMA waves
+    // v_mfma_f32_16x16x4_f32 (same 256 flop/cycle/CU as 32x32x2, bit-identical to the ascending-k fmaf chain as well): a wave owns
+    // 4 points (64 pair rows) x 64 channels = 4 x 4 accumulator tiles of 16 x 16.  Lane (c = lane % 16, a = lane / 16) of a tile holds
+    // rows 4 a + b (b = register 0..3) of column c; the helpers put neighbour s = 4 b + a of the point in that row, so register b of
+    // relu(acc + b1) IS the A operand (channel c, k = a) of contraction step b over s = 4 b .. 4 b + 3:
+    //     F'[ch][t] = sum_s X2[s][ch] * wv[s][t]   =  4 MFMAs of [16 ch x 4 s] x [4 s x 16 t] per (point, channel block)
+    // -- no padding zeros (the 32x32x2 form spent half its contraction MFMAs on a block-diagonal B), s ascending.  The result
+    // tiles are written out DURING the next group's product loop (one tile every other k-step, in the shadow of its MFMAs).
     const int wm = wave >> 1, wn = wave & 1;
-    const int fi = lane & 31, fk = lane >> 5;
-    float bias[2];
+    const int lc = lane & 15, la = lane >> 4;
+    float bias[4];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) bias[j] = b1[wn * 64 + j * 32 + fi];
+    for (int cb = 0; cb < 4; ++cb) bias[cb] = b1[wn * 64 + cb * 16 + lc];
     __syncthreads();                                                 // #1
     __syncthreads();                                                 // #2
     int n = 0;
@@ -441,39 +448,64 @@ __global__ __launch_bounds__(512) void ps_local_ws_kernel(long npoints, int n_pe
 #else
 #define PL_T(v)
 #endif
+    f32x4 o[4][4];                                                   // F' tiles of the previous group, [point][channel block]
+#pragma unroll
+    for (int pt = 0; pt < 4; ++pt)
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) o[pt][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(out, 0, (int)((unsigned)np * 8192u), 0x00020000);
+    int g_prev = 0;
+    const int tq = lc & 3, t0 = lc & ~3;
+    // tile (pt, cb) of group gp -> F': lane (c = t, a) holds channels 16 cb + 4 a + b (b = 0..3) at t; a 4 x 4 transpose inside the
+    // quad of lanes t = 4 q .. 4 q + 3 (two DPP quad_perm exchanges) gives every lane ONE channel with four consecutive t = one
+    // 16-byte store
+    auto flush_tile = [&](int gp, int pt, int cb, bool live) {
+        const int pi = gp * 8 + 4 * wm + pt;
+        const float a0 = o[pt][cb][0], a1 = o[pt][cb][1], a2 = o[pt][cb][2], a3 = o[pt][cb][3];
+        const bool odd = tq & 1;                                      // exchange across lane bit 0 (quad_perm [1,0,3,2])
+        const float s0 = pl_quad<0xB1>(odd ? a0 : a1), s2 = pl_quad<0xB1>(odd ? a2 : a3);
+        const float b0 = odd ? s0 : a0, b1v = odd ? a1 : s0, b2 = odd ? s2 : a2, b3 = odd ? a3 : s2;
+        const bool hi = tq & 2;                                       // exchange across lane bit 1 (quad_perm [2,3,0,1])
+        const float u0 = pl_quad<0x4E>(hi ? b0 : b2), u1 = pl_quad<0x4E>(hi ? b1v : b3);
+        f32x4 v;
+        v.x = hi ? u0 : b0; v.y = hi ? u1 : b1v; v.z = hi ? b2 : u0; v.w = hi ? b3 : u1;
+        const int ch = wn * 64 + cb * 16 + 4 * la + tq;
+        // a BUFFER store: an offset beyond the resource's range is dropped by the hardware, so "nothing to flush yet" (first group)
+        // and "point beyond np" (ragged last group) need no branch -- a branch here ends the scheduling region and the tile's
+        // ~25 VALU instructions run after the k-step's MFMAs instead of between them (+200 cycles per tile, measured)
+        const unsigned off = (live && pi < np) ? ((unsigned)pi * 2048u + (unsigned)(ch * 16 + t0)) * 4u : 0xFFFFFFF0u;
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), out_rsrc, (int)off, 0, 0);
+    };
     for (int g = blockIdx.x; g < ng; g += gstep, ++n) {
-        f32x16 acc[2][2];
+        const bool have_prev = n > 0;
+        f32x4 acc[4][4];
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int pt = 0; pt < 4; ++pt)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int cb = 0; cb < 4; ++cb) acc[pt][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int t = 0; t < NTILE; ++t) {
             const float* As = astg + (t & 1) * PW_ASTG;
-            const float* Bs = wres + (t * PL_BK) * PL_LDB;
+            const float* Bs = wres + (t * PL_BK) * PW_LDB;
             PL_T(s0);
 #pragma unroll
-            for (int k4 = 0; k4 < PL_BK; k4 += 8) {                   // 4 k-steps per 16-byte fragment load
-                float4 a4[2];
+            for (int k0 = 0; k0 < PL_BK; k0 += 4) {
+                float af[4], bf[4];
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
-                    a4[i] = *reinterpret_cast<const float4*>(&As[(wm * 64 + i * 32 + fi) * PW_LDAR + fk * 16 + (k4 >> 1)]);
+                for (int pt = 0; pt < 4; ++pt) af[pt] = As[(wm * 64 + pt * 16 + lc) * PW_LDAR + k0 + la];
 #pragma unroll
-                for (int q4 = 0; q4 < 4; ++q4) {
-                    const int kk = k4 + 2 * q4;
-                    float af[2], bf[2];
+                for (int cb = 0; cb < 4; ++cb) bf[cb] = Bs[(k0 + la) * PW_LDB + wn * 64 + cb * 16 + lc];
 #pragma unroll
-                    for (int i = 0; i < 2; ++i) af[i] = q4 == 0 ? a4[i].x : q4 == 1 ? a4[i].y : q4 == 2 ? a4[i].z : a4[i].w;
+                for (int pt = 0; pt < 4; ++pt)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) bf[j] = Bs[(kk + fk) * PL_LDB + wn * 64 + j * 32 + fi];
-#pragma unroll
-                    for (int i = 0; i < 2; ++i)
-#pragma unroll
-                        for (int j = 0; j < 2; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+                    for (int cb = 0; cb < 4; ++cb)
+                        acc[pt][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[pt], bf[cb], acc[pt][cb], 0, 0, 0);
+#ifndef PL_NOFLUSH
+                if (((k0 >> 2) & 1) == 0) {                          // 16 tiles over the 32 k-steps of a group
+                    const int u = t * 4 + (k0 >> 3);
+                    flush_tile(g_prev, u >> 2, u & 3, have_prev);
                 }
+#endif
             }
             PL_T(s1);
             pl_lds_barrier();
@@ -483,56 +515,28 @@ __global__ __launch_bounds__(512) void ps_local_ws_kernel(long npoints, int n_pe
 #endif
         }
         PL_T(p0s);
-        // contraction: this wave owns row blocks i (points 2 (2 wm + i) + q) and channel blocks j
         const float* wv = wvbuf + (n & 1) * 2048;
-        const int q = fi >> 4, tt = fi & 15;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int pblk = 2 * (2 * wm + i);                        // first point of the pair
-            f32x16 o[2];
+        for (int pt = 0; pt < 4; ++pt) {
+            float bw[4];
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int b = 0; b < 4; ++b) bw[b] = wv[(4 * wm + pt) * 256 + (4 * b + la) * 16 + lc];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) o[j][r] = 0.f;
+            for (int cb = 0; cb < 4; ++cb) {
+                f32x4 r = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int ks = 0; ks < 16; ++ks) {
-                const int k = 2 * ks + fk;                            // (q', s) = (k >> 4, k & 15)
-                const float bvv = ((k >> 4) == q) ? wv[(pblk + q) * 256 + (k & 15) * 16 + tt] : 0.f;
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const float av = fmaxf(acc[i][j][ks] + bias[j], 0.f);      // X2 of tile row rho(k), channel wn*64 + j*32 + fi
-                    o[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bvv, o[j], 0, 0, 0);
-                }
+                for (int b = 0; b < 4; ++b)
+                    r = __builtin_amdgcn_mfma_f32_16x16x4f32(fmaxf(acc[pt][cb][b] + bias[cb], 0.f), bw[b], r, 0, 0, 0);
+                o[pt][cb] = r;
             }
-            // F' leaves as float4: the four lanes of a quad hold t = 4a .. 4a + 3 of four CONSECUTIVE channels (registers
-            // 4 g4 .. 4 g4 + 3); a 4 x 4 transpose inside the quad (two DPP quad_perm exchanges) gives every lane one channel
-            // with four consecutive t = one 16-byte store.  16 stores per lane and (i, j) pair became 4: the MFMA waves issue
-            // 16 vector-memory instructions per group instead of 64.
-            const int pi = g * 8 + pblk + q;
-            const int tq = tt & 3, t0 = tt & ~3;
-            float* dst = out + (size_t)(pi < np ? pi : 0) * 2048 + t0;
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4) {
-                    const float a0 = o[j][4 * g4 + 0], a1 = o[j][4 * g4 + 1], a2 = o[j][4 * g4 + 2], a3 = o[j][4 * g4 + 3];
-                    // exchange across lane bit 0 (quad_perm [1,0,3,2])
-                    const bool odd = tq & 1;
-                    const float s0 = pl_quad<0xB1>(odd ? a0 : a1), s2 = pl_quad<0xB1>(odd ? a2 : a3);
-                    const float b0 = odd ? s0 : a0, b1 = odd ? a1 : s0, b2 = odd ? s2 : a2, b3 = odd ? a3 : s2;
-                    // exchange across lane bit 1 (quad_perm [2,3,0,1])
-                    const bool hi = tq & 2;
-                    const float u0 = pl_quad<0x4E>(hi ? b0 : b2), u1 = pl_quad<0x4E>(hi ? b1 : b3);
-                    float4 v;
-                    v.x = hi ? u0 : b0; v.y = hi ? u1 : b1; v.z = hi ? b2 : u0; v.w = hi ? b3 : u1;
-                    const int c = wn * 64 + j * 32 + 8 * g4 + 4 * fk + tq;
-                    if (pi < np) *reinterpret_cast<float4*>(dst + c * 16) = v;
-                }
         }
+        g_prev = g;
 #ifdef PL_STAMPS
         { PL_T(p2s); c_con += p2s - p0s; }
 #endif
     }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) flush_tile(g_prev, u >> 2, u & 3, n > 0);
 #ifdef PL_STAMPS
     if (blockIdx.x == 5 && lane == 0) {
         unsigned long long* st = reinterpret_cast<unsigned long long*>(out + (size_t)npoints * 2048) + wave * 5;
