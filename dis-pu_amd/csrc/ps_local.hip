@@ -488,21 +488,28 @@ __global__ __launch_bounds__(512) void ps_local_ws_kernel(long npoints, int n_pe
             const float* As = astg + (t & 1) * PW_ASTG;
             const float* Bs = wres + (t * PL_BK) * PW_LDB;
             PL_T(s0);
+            // operand fragments ping-pong: the reads of k-step ks + 1 are issued before the MFMAs of k-step ks (left to itself the
+            // scheduler read each B pair right before its 8 MFMAs and waited out the LDS latency 4 times per k-step)
+            float af[2][4], bf[2][4];
+            auto load_frags = [&](int k0, float (&a)[4], float (&b)[4]) {
 #pragma unroll
-            for (int k0 = 0; k0 < PL_BK; k0 += 4) {
-                float af[4], bf[4];
+                for (int pt = 0; pt < 4; ++pt) a[pt] = As[(wm * 64 + pt * 16 + lc) * PW_LDAR + k0 + la];
 #pragma unroll
-                for (int pt = 0; pt < 4; ++pt) af[pt] = As[(wm * 64 + pt * 16 + lc) * PW_LDAR + k0 + la];
+                for (int cb = 0; cb < 4; ++cb) b[cb] = Bs[(k0 + la) * PW_LDB + wn * 64 + cb * 16 + lc];
+            };
+            load_frags(0, af[0], bf[0]);
 #pragma unroll
-                for (int cb = 0; cb < 4; ++cb) bf[cb] = Bs[(k0 + la) * PW_LDB + wn * 64 + cb * 16 + lc];
+            for (int ks = 0; ks < PL_BK / 4; ++ks) {
+                const int cur = ks & 1;
+                if (ks + 1 < PL_BK / 4) load_frags(4 * (ks + 1), af[cur ^ 1], bf[cur ^ 1]);
 #pragma unroll
                 for (int pt = 0; pt < 4; ++pt)
 #pragma unroll
                     for (int cb = 0; cb < 4; ++cb)
-                        acc[pt][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[pt], bf[cb], acc[pt][cb], 0, 0, 0);
+                        acc[pt][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[cur][pt], bf[cur][cb], acc[pt][cb], 0, 0, 0);
 #ifndef PL_NOFLUSH
-                if (((k0 >> 2) & 1) == 0) {                          // 16 tiles over the 32 k-steps of a group
-                    const int u = t * 4 + (k0 >> 3);
+                if ((ks & 1) == 0) {                                 // 16 tiles over the 32 k-steps of a group
+                    const int u = t * 4 + (ks >> 1);
                     flush_tile(g_prev, u >> 2, u & 3, have_prev);
                 }
 #endif
@@ -522,13 +529,12 @@ __global__ __launch_bounds__(512) void ps_local_ws_kernel(long npoints, int n_pe
 #pragma unroll
             for (int b = 0; b < 4; ++b) bw[b] = wv[(4 * wm + pt) * 256 + (4 * b + la) * 16 + lc];
 #pragma unroll
-            for (int cb = 0; cb < 4; ++cb) {
-                f32x4 r = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int cb = 0; cb < 4; ++cb) o[pt][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int b = 0; b < 4; ++b)
-                    r = __builtin_amdgcn_mfma_f32_16x16x4f32(fmaxf(acc[pt][cb][b] + bias[cb], 0.f), bw[b], r, 0, 0, 0);
-                o[pt][cb] = r;
-            }
+            for (int b = 0; b < 4; ++b)                               // four independent chains (cb) between dependent MFMAs
+#pragma unroll
+                for (int cb = 0; cb < 4; ++cb)
+                    o[pt][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(fmaxf(acc[pt][cb][b] + bias[cb], 0.f), bw[b], o[pt][cb], 0, 0, 0);
         }
         g_prev = g;
 #ifdef PL_STAMPS
