@@ -67,6 +67,46 @@ def test_fused_local_cell_equals_unfused_chain(dev):
         assert np.array_equal(a, b)
 
 
+@pytest.mark.parametrize("clouds,n", [(1, 20), (3, 170), (2, 1024), (5, 256), (300, 24)])
+def test_ps_local_abi_ragged_groups(dev, clouds, n):
+    """dispu_ps_local through the C ABI on point counts that are NOT a multiple of the kernel's 8-point groups (the last group is
+    ragged: its missing points' stores are dropped by the buffer range check), on one group only, and on more groups than
+    persistent workgroups (300 x 24 points = 900 groups over 256 workgroups) -- bit-identical to the unfused
+    gather_sub_relu / dispu_linear / weight_net / point_matmul chain, and nothing written past the end of `out`."""
+    from dispu_amd import _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(clouds * 1000 + n)
+    npts = clouds * n
+    xyz = torch.from_numpy(rng.random((npts, 3)).astype(np.float32)).to(dev)
+    idx = torch.from_numpy(rng.integers(0, n, (npts, 16)).astype(np.int32)).to(dev)
+    G = torch.from_numpy(rng.standard_normal((npts, 320)).astype(np.float32)).to(dev)
+    A = torch.from_numpy(rng.standard_normal((npts, 128)).astype(np.float32)).to(dev)
+    W1 = torch.from_numpy((rng.standard_normal((128, 128)) * 0.1).astype(np.float32)).to(dev)
+    b1 = torch.from_numpy((rng.standard_normal(128) * 0.1).astype(np.float32)).to(dev)
+    Ww = torch.from_numpy(rng.standard_normal((3, 16)).astype(np.float32)).to(dev)
+    bw = torch.from_numpy(rng.standard_normal(16).astype(np.float32)).to(dev)
+    sc = torch.from_numpy((1 + 0.1 * rng.standard_normal(16)).astype(np.float32)).to(dev)
+    sh = torch.from_numpy((0.1 * rng.standard_normal(16)).astype(np.float32)).to(dev)
+    st = _lib.stream_ptr(dev)
+    P = lambda t, off=0: t.data_ptr() + 4 * off
+    pad = 4096
+    out = torch.full((npts * 2048 + pad,), -7.0, device=dev)                      # canary behind the result
+    _lib.check(L.dispu_ps_local(npts, n, 16, 128, P(idx), P(xyz), P(G, 192), 320, P(A), P(W1), P(b1), P(Ww), P(bw), P(sc), P(sh),
+                                P(out), st), "dispu_ps_local")
+    x1 = torch.empty((npts * 16, 128), device=dev)
+    x2 = torch.empty((npts * 16, 128), device=dev)
+    wv = torch.empty((npts * 16, 16), device=dev)
+    ref = torch.empty((npts, 2048), device=dev)
+    _lib.check(L.dispu_ps_gather_sub_relu(npts, n, 16, 128, P(idx), P(G, 192), 320, P(A), 128, P(x1), 128, st), "gather_sub_relu")
+    _lib.check(L.dispu_linear(1, npts * 16, 128, 128, P(x1), 128, 0, P(W1), 128, 0, 0, P(b1), 1, P(x2), 128, 0, None, 0, 0, None, 0, 0, st),
+               "dispu_linear")
+    _lib.check(L.dispu_ps_weight_net(npts, n, 16, 16, P(idx), P(xyz), P(Ww), P(bw), P(sc), P(sh), P(wv), st), "weight_net")
+    _lib.check(L.dispu_ps_point_matmul(npts, 16, 128, 16, P(x2), 128, P(wv), P(ref), 2048, st), "point_matmul")
+    got = out[:npts * 2048].view(npts, 2048)
+    assert torch.equal(got, ref), int((got != ref).any(1).nonzero()[0])
+    assert bool((out[npts * 2048:] == -7.0).all())
+
+
 @pytest.mark.parametrize("b,m", [(2, 1024), (3, 160), (1, 4096)])
 def test_fused_attention(dev, b, m):
     """dispu_attention (flash-style, logits on chip) vs a float64 softmax(QK^T/8)V and vs the 3-kernel path."""
