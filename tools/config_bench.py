@@ -46,6 +46,14 @@ def main():
     gen = Generator(params=P, device=dev)
     gen.return_views = True
     out = {}
+    c5 = {}
+    xt, gtt = synth.patch_with_gt(8, 256, 1024, seed=5000)
+    xt, gtt, r = torch.from_numpy(xt).to(dev), torch.from_numpy(gtt).to(dev), torch.ones(8, device=dev)
+    for dt in ("f32", "bf16"):
+        tr = None                                     # one trainer (and its streams) alive at a time
+        tr = Trainer(params=P, device=dev, dtype=dt)
+        t = wall(lambda: tr.train_step(xt, gtt, r), reps=20, warm=3)
+        c5["C5 train step, 8 patches per GPU, %s" % dt] = {"ms": t * 1e3, "patches_per_s": 8 / t}
 
     x1 = torch.from_numpy(synth.patches(1, 256, seed=1000)).to(dev)
     t = _timeit(lambda: gen(x1), reps=20)
@@ -74,12 +82,7 @@ def main():
         t = wall(lambda: U.upsample_clouds(gen, pcs), reps=3, warm=1)
         out["whole clouds 2048->8192, C=%d" % C] = {"ms_per_batch": t * 1e3, "ms_per_cloud": t * 1e3 / C, "points_per_s": C * 8192 / t}
 
-    xt, gtt = synth.patch_with_gt(8, 256, 1024, seed=5000)
-    xt, gtt, r = torch.from_numpy(xt).to(dev), torch.from_numpy(gtt).to(dev), torch.ones(8, device=dev)
-    for dt in ("f32", "bf16"):
-        tr = Trainer(params=P, device=dev, dtype=dt)
-        t = wall(lambda: tr.train_step(xt, gtt, r), reps=20, warm=3)
-        out["C5 train step, 8 patches per GPU, %s" % dt] = {"ms": t * 1e3, "patches_per_s": 8 / t}
+    out.update(c5)
     print(json.dumps(out, indent=1))
 
 
