@@ -577,10 +577,18 @@ DISPU_EXPORT int dispu_ps_local(long npoints, int n_per_cloud, int k, int c, con
         hipLaunchKernelGGL(ps_local_kernel, dim3((unsigned)((npoints + 7) / 8)), dim3(PL_NT), PL_LDS_BYTES, (hipStream_t)stream, npoints,
                            n_per_cloud, idx, xyz, G, ldg, A, W1, b1, Ww, bw, scale, shift, out);
     } else {
-        const long ngroups = (npoints + 7) / 8;
-        const unsigned grid = (unsigned)(ngroups < 256 ? ngroups : 256);      // one persistent workgroup per CU
-        hipLaunchKernelGGL(ps_local_ws_kernel, dim3(grid), dim3(512), PW_LDS_BYTES, (hipStream_t)stream, npoints, n_per_cloud, idx, xyz,
-                           G, (int)ldg, A, W1, b1, Ww, bw, scale, shift, out);
+        // the F' tiles leave through a buffer resource whose byte range is a 32-bit field: launches of at most 2^18 points
+        // (2 GB of F'), cut at cloud boundaries (neighbour ids are cloud-local, the kernel derives a point's cloud from its index)
+        const long max_pts = 262144;
+        if (n_per_cloud > max_pts) return (int)hipErrorInvalidValue;
+        const long per = npoints <= max_pts ? npoints : (max_pts / n_per_cloud) * (long)n_per_cloud;
+        for (long p0 = 0; p0 < npoints; p0 += per) {
+            const long np = (npoints - p0 < per) ? npoints - p0 : per;
+            const long ngroups = (np + 7) / 8;
+            const unsigned grid = (unsigned)(ngroups < 256 ? ngroups : 256);      // one persistent workgroup per CU
+            hipLaunchKernelGGL(ps_local_ws_kernel, dim3(grid), dim3(512), PW_LDS_BYTES, (hipStream_t)stream, np, n_per_cloud, idx + p0 * 16,
+                               xyz + p0 * 3, G + p0 * ldg, (int)ldg, A + p0 * PL_K, W1, b1, Ww, bw, scale, shift, out + p0 * 2048);
+        }
     }
     return (int)hipGetLastError();
 }

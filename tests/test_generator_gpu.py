@@ -67,11 +67,12 @@ def test_fused_local_cell_equals_unfused_chain(dev):
         assert np.array_equal(a, b)
 
 
-@pytest.mark.parametrize("clouds,n", [(1, 20), (3, 170), (2, 1024), (5, 256), (300, 24)])
+@pytest.mark.parametrize("clouds,n", [(1, 20), (3, 170), (2, 1024), (5, 256), (300, 24), (1200, 256)])
 def test_ps_local_abi_ragged_groups(dev, clouds, n):
     """dispu_ps_local through the C ABI on point counts that are NOT a multiple of the kernel's 8-point groups (the last group is
     ragged: its missing points' stores are dropped by the buffer range check), on one group only, and on more groups than
-    persistent workgroups (300 x 24 points = 900 groups over 256 workgroups) -- bit-identical to the unfused
+    persistent workgroups (300 x 24 points = 900 groups over 256 workgroups), and on more than 2^18 points (1200 x 256: the
+    entry point cuts the launch at a cloud boundary, the F' buffer resource has a 32-bit byte range) -- bit-identical to the unfused
     gather_sub_relu / dispu_linear / weight_net / point_matmul chain, and nothing written past the end of `out`."""
     from dispu_amd import _lib
     L = _lib.lib()
