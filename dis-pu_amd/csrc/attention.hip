@@ -32,6 +32,9 @@ constexpr int FA_STAGE = FA_TK * FA_LDK + FA_TK * FA_D;     // floats: K tile [3
 // reaches HBM and the separate 64 -> 256 GEMM launch (28 % of the MFMA peak, 21 % of HBM: bound by neither) disappears.
 // d is contracted in the order 0,4,1,5,... (not ascending): like the softmax itself this branch is tolerance-checked.
 constexpr int FA_BPN = 256;
+#ifdef FA_STAMPS
+__device__ unsigned long long fa_stamps[16];
+#endif
 
 template <bool BP>
 __global__ __launch_bounds__(512) void flash_attention_kernel(int m, int nk, const float* __restrict__ Q, long ldq,
@@ -103,12 +106,13 @@ __global__ __launch_bounds__(512) void flash_attention_kernel(int m, int nk, con
     const bool qok = qrow < m;
     const float* __restrict__ qp = Q + ((size_t)cloud * m + (qok ? qrow : 0)) * ldq;
 
-    float qf[32];                                    // Q[q][2s + kh]
+    const float scale2 = scale * 1.4426950408889634f;  // logits in the log2 domain
+    float qf[32];                                    // Q[q][2s + kh] * scale2
 #pragma unroll
     for (int s4 = 0; s4 < 16; ++s4) {
         const float4 v = *reinterpret_cast<const float4*>(qp + s4 * 4);
-        qf[2 * s4] = kh ? v.y : v.x;
-        qf[2 * s4 + 1] = kh ? v.w : v.z;
+        qf[2 * s4] = (kh ? v.y : v.x) * scale2;
+        qf[2 * s4 + 1] = (kh ? v.w : v.z) * scale2;
     }
 
     f32x16 oacc[2];
@@ -119,7 +123,14 @@ __global__ __launch_bounds__(512) void flash_attention_kernel(int m, int nk, con
     float mrun = -__builtin_inff(), lsum = 0.f;
 
     __syncthreads();
+#ifdef FA_STAMPS   // tools/micro/attention_lab.hip: cycles per phase of one MFMA wave
+    unsigned long long fa_s = 0, fa_sm = 0, fa_pv = 0, fa_bar = 0;
+#define FA_T(v) __builtin_amdgcn_sched_barrier(0); const unsigned long long v = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0)
+#else
+#define FA_T(v)
+#endif
     for (int t = 0; t < ntile; ++t) {
+        FA_T(c0);
         const float* Kt = lds + (t & 1) * FA_STAGE;
         const float* Vt = Kt + FA_TK * FA_LDK;
         // S^T tile: 32 keys x 32 queries, d ascending
@@ -128,22 +139,30 @@ __global__ __launch_bounds__(512) void flash_attention_kernel(int m, int nk, con
         for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
 #pragma unroll
         for (int s = 0; s < 32; ++s) sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(Kt[li * FA_LDK + 2 * s + kh], qf[s], sacc, 0, 0, 0);
-        // online softmax for this lane's query over the tile's 32 keys (16 here, 16 in lane ^ 32)
-        float mx = -__builtin_inff();
+        FA_T(c1);
+        // online softmax for this lane's query over the tile's 32 keys (16 here, 16 in lane ^ 32), in the log2 domain: Q was
+        // multiplied by scale * log2(e) when it was loaded, so the accumulators ARE the log2-logits and p = 2^(s - m) is one
+        // v_exp_f32 per logit (tools/micro/attention_lab.hip: the softmax is 730 of a tile's 5200 cycles, 256 of them the 16
+        // quarter-rate exponentials; the two products run at 2120 / 2205 cycles for 2048 of pipe time)
+        float mx = fmaxf(fmaxf(sacc[0], sacc[1]), sacc[2]);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { sacc[r] = sacc[r] * scale; mx = fmaxf(mx, sacc[r]); }
+        for (int r = 3; r < 15; r += 2) mx = fmaxf(fmaxf(mx, sacc[r]), sacc[r + 1]);      // v_max3_f32
+        mx = fmaxf(mx, sacc[15]);
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         const float mnew = fmaxf(mrun, mx);
-        const float alpha = __expf(mrun - mnew);
+        const float alpha = __builtin_amdgcn_exp2f(mrun - mnew);
         float rs = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { sacc[r] = __expf(sacc[r] - mnew); rs += sacc[r]; }
+        for (int r = 0; r < 16; ++r) { sacc[r] = __builtin_amdgcn_exp2f(sacc[r] - mnew); rs += sacc[r]; }
         lsum = lsum * alpha + rs;
         mrun = mnew;
+        if (__any(alpha != 1.0f)) {                  // after the first tiles the running maximum rarely moves: x * 1.0f is x
 #pragma unroll
-        for (int c = 0; c < 2; ++c)
+            for (int c = 0; c < 2; ++c)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) oacc[c][r] = oacc[c][r] * alpha;
+                for (int r = 0; r < 16; ++r) oacc[c][r] = oacc[c][r] * alpha;
+        }
+        FA_T(c2);
         // O^T += V^T . P^T : step r pairs key rows kr and kr + 4 (= the rows half 0 / half 1 hold in register r)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -152,8 +171,17 @@ __global__ __launch_bounds__(512) void flash_attention_kernel(int m, int nk, con
             for (int c = 0; c < 2; ++c)
                 oacc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(Vt[key * FA_D + c * 32 + li], sacc[r], oacc[c], 0, 0, 0);
         }
+        FA_T(c3);
         __syncthreads();
+#ifdef FA_STAMPS
+        { FA_T(c4); fa_s += c1 - c0; fa_sm += c2 - c1; fa_pv += c3 - c2; fa_bar += c4 - c3; }
+#endif
     }
+#ifdef FA_STAMPS
+    if (blockIdx.x == 3 && blockIdx.y == 1 && lane == 0) {
+        fa_stamps[wave * 4 + 0] = fa_s; fa_stamps[wave * 4 + 1] = fa_sm; fa_stamps[wave * 4 + 2] = fa_pv; fa_stamps[wave * 4 + 3] = fa_bar;
+    }
+#endif
     const float ltot = lsum + __shfl_xor(lsum, 32, 64);
     const float inv = 1.0f / ltot;
     float* __restrict__ op = O + ((size_t)cloud * m + (qok ? qrow : 0)) * ldo;
