@@ -1,13 +1,18 @@
+#!/bin/bash
+# Run on the GPU box (through gpurun): the end-of-round evidence in one call -- the GPU test suite, smoke(), the bench with its
+# rocprofv3 kernel statistics and PMC passes, the per-op table, the other BASELINE configurations, the train and FPS benches.
+# Usage: tools/final_round.sh [tag]   -> gpurun_out/<tag>/..., gpurun_out/<tag>_pmc/pmc_summary.json  (copy what is kept to profiles/)
+TAG=${1:-r02_f}
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/r02_f
-timeout 2400 python -m pytest tests -m gpu -q -x 2>&1 | tail -5 > gpurun_out/r02_f/pytest_gpu.txt
-cat gpurun_out/r02_f/pytest_gpu.txt
+mkdir -p gpurun_out/$TAG
+timeout 2400 python -m pytest tests -m gpu -q -x 2>&1 | tail -5 > gpurun_out/$TAG/pytest_gpu.txt
+cat gpurun_out/$TAG/pytest_gpu.txt
 timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
-bash tools/prof_bench.sh r02_f > gpurun_out/r02_f/prof.log 2>&1; tail -2 gpurun_out/r02_f/prof.log | cut -c1-600
-bash tools/pmc_traffic.sh r02_f_pmc > gpurun_out/r02_f/pmc.log 2>&1; tail -c 600 gpurun_out/r02_f/pmc.log
-timeout 900 python tools/ops_bench.py > gpurun_out/r02_f/ops_microbench.json 2> gpurun_out/r02_f/ops.log; tail -c 300 gpurun_out/r02_f/ops_microbench.json
-timeout 600 python tools/config_bench.py > gpurun_out/r02_f/configs.json 2>> gpurun_out/r02_f/ops.log
-timeout 300 python tools/train_bench.py > gpurun_out/r02_f/train_b8_bench.json 2>> gpurun_out/r02_f/ops.log
-timeout 300 python tools/train_bench.py --dtype bf16 > gpurun_out/r02_f/train_b8_bf16_bench.json 2>> gpurun_out/r02_f/ops.log
-timeout 300 python tools/fps_bench.py > gpurun_out/r02_f/fps_bench.txt 2>> gpurun_out/r02_f/ops.log
+bash tools/prof_bench.sh $TAG > gpurun_out/$TAG/prof.log 2>&1; tail -2 gpurun_out/$TAG/prof.log | cut -c1-600
+bash tools/pmc_traffic.sh $TAG_pmc > gpurun_out/$TAG/pmc.log 2>&1; tail -c 600 gpurun_out/$TAG/pmc.log
+timeout 900 python tools/ops_bench.py > gpurun_out/$TAG/ops_microbench.json 2> gpurun_out/$TAG/ops.log; tail -c 300 gpurun_out/$TAG/ops_microbench.json
+timeout 600 python tools/config_bench.py > gpurun_out/$TAG/configs.json 2>> gpurun_out/$TAG/ops.log
+timeout 300 python tools/train_bench.py > gpurun_out/$TAG/train_b8_bench.json 2>> gpurun_out/$TAG/ops.log
+timeout 300 python tools/train_bench.py --dtype bf16 > gpurun_out/$TAG/train_b8_bf16_bench.json 2>> gpurun_out/$TAG/ops.log
+timeout 300 python tools/fps_bench.py > gpurun_out/$TAG/fps_bench.txt 2>> gpurun_out/$TAG/ops.log
 echo done
