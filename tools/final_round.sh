@@ -9,7 +9,7 @@ timeout 2400 python -m pytest tests -m gpu -q -x 2>&1 | tail -5 > gpurun_out/$TA
 cat gpurun_out/$TAG/pytest_gpu.txt
 timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
 bash tools/prof_bench.sh $TAG > gpurun_out/$TAG/prof.log 2>&1; tail -2 gpurun_out/$TAG/prof.log | cut -c1-600
-bash tools/pmc_traffic.sh $TAG_pmc > gpurun_out/$TAG/pmc.log 2>&1; tail -c 600 gpurun_out/$TAG/pmc.log
+bash tools/pmc_traffic.sh ${TAG}_pmc > gpurun_out/$TAG/pmc.log 2>&1; tail -c 600 gpurun_out/$TAG/pmc.log
 timeout 900 python tools/ops_bench.py > gpurun_out/$TAG/ops_microbench.json 2> gpurun_out/$TAG/ops.log; tail -c 300 gpurun_out/$TAG/ops_microbench.json
 timeout 600 python tools/config_bench.py > gpurun_out/$TAG/configs.json 2>> gpurun_out/$TAG/ops.log
 timeout 300 python tools/train_bench.py > gpurun_out/$TAG/train_b8_bench.json 2>> gpurun_out/$TAG/ops.log
