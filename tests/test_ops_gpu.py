@@ -163,6 +163,26 @@ def test_fps_large_clouds_index_exact(ops, dev, b, n, m, kind):
             break                                          # one flavour is enough at the big shapes (the oracle takes seconds)
 
 
+def test_fps_abi_with_and_without_scratch(dev):
+    """dispu_fps through the C ABI at a wave-skipping size: with the scratch dispu_fps_scratch_bytes asks for (the permutation of
+    csrc/fps_wave.hip) and without any (NULL: the dense register kernel answers) -- same indices, equal to the oracle's."""
+    from dispu_amd import _lib
+    L = _lib.lib()
+    b, n, m = 2, 10000, 300
+    x = np.random.default_rng(77).random((b, n, 3)).astype(np.float32)
+    tx = T(x, dev)
+    nbytes = L.dispu_fps_scratch_bytes(b, n, m)
+    assert nbytes == b * n * 4
+    outs = []
+    for scratch in (torch.empty(nbytes // 4, dtype=torch.float32, device=dev), None):
+        out = torch.full((b, m), -1, dtype=torch.int32, device=dev)
+        _lib.check(L.dispu_fps(b, n, m, tx.data_ptr(), scratch.data_ptr() if scratch is not None else None, out.data_ptr(),
+                               CONTRACT, _lib.stream_ptr(dev)), "dispu_fps")
+        outs.append(N(out))
+    assert np.array_equal(outs[0], outs[1])
+    assert np.array_equal(outs[0], O.farthest_point_sample(m, x, contract=CONTRACT))
+
+
 def test_fps_ties_and_duplicates(ops, dev):
     """Adversarial: grids (many exact ties), duplicated points, more samples than distinct points."""
     gx = np.stack(np.meshgrid(np.arange(10), np.arange(10), np.arange(7), indexing="ij"), -1).reshape(1, -1, 3).astype(np.float32)
