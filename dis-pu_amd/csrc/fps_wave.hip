@@ -15,10 +15,13 @@
 //   * the other waves do the dense update exactly as before.  After the first few dozen samples a new sample reaches a few
 //     of the 16 regions, and consecutive Morton ranges sit on different SIMDs (wave w -> SIMD w mod 4).
 // Results are IDENTICAL to the dense kernel: skipped updates are provably no-ops and ties are decided by the original index.
-// Measured (MI355X, tools/fps_bench.py): (8, 24576, 8192) 17.4 -> 9.6 ms (sphere) / 10.3 ms (cube); (8, 8192, 2048) 2.43 -> 1.6 ms;
+// Measured (MI355X, tools/fps_bench.py): (8, 24576, 8192) 17.4 -> 9.6 ms (sphere) / 10.3 ms (cube), with four regions per wave
+// (fps_wave4_kernel below) 8.5 / 9.5 ms; (8, 8192, 2048) 2.43 -> 1.5 ms;
 // (32, 4097, 1024) 1.22 -> 0.75 ms.  tools/micro/fps_wave_prof.hip splits a round (2900 cycles at n = 24576): dense update of
 // the busiest wave 1330, its arg-max 575, slot + barrier 120, cross-wave winner 460 - 1100 (16 waves, oldest first).
 #include "common.h"
+
+#include <cstdlib>
 
 #ifndef FPSW_TICK            // tools/micro/fps_wave_prof.hip includes this file with cycle-counter hooks; none in the library
 #define FPSW_TICK(i)
@@ -137,21 +140,29 @@ __global__ __launch_bounds__(1024) void fps_wavesort_kernel(int n, int chunk, co
     __syncthreads();
     for (int k = tid; k < n; k += 1024) sorted[atomicAdd(&cnt[cell(k)], 1u)] = k;
     __syncthreads();
-    // (2) per wave range: ascending tie priority
-    for (int c0p = 0; c0p < n; c0p += chunk) {
-        const int len = min(chunk, n - c0p);
-        for (int e = tid; e < 2048; e += 1024) keys[e] = (e < len) ? fpsw_order(sorted[c0p + e]) : 0xFFFFFFFFu;
+    // (2) every range of `chunk` positions (one wave of fps_wave_kernel, or one of a wave's four groups in fps_wave4_kernel): ascending
+    // tie priority.  Chunks of <= 512 positions are sorted four at a time (the network stops at width 512, the final merge of
+    // every 512-block ascending); larger ones one at a time in the 2048-wide network.
+    const int W = (chunk <= 512) ? 512 : 2048, per = 2048 / W;
+    for (int c0p = 0; c0p < n; c0p += chunk * per) {
+        for (int e = tid; e < 2048; e += 1024) {
+            const int blk = e / W, r = e - blk * W, pos = c0p + blk * chunk + r;
+            keys[e] = (r < chunk && pos < n) ? fpsw_order(sorted[pos]) : 0xFFFFFFFFu;
+        }
         __syncthreads();
-        for (int size = 2; size <= 2048; size <<= 1)
+        for (int size = 2; size <= W; size <<= 1)
             for (int stride = size >> 1; stride > 0; stride >>= 1) {
                 const int t = tid;                                   // 1024 pairs
                 const int l = 2 * t - (t & (stride - 1)), h = l + stride;
-                const bool up = ((l & size) == 0);
+                const bool up = (size == W) || ((l & size) == 0);
                 const unsigned a = keys[l], b = keys[h];
                 if ((a > b) == up) { keys[l] = b; keys[h] = a; }
                 __syncthreads();
             }
-        for (int e = tid; e < len; e += 1024) pm[c0p + e] = (int)(keys[e] & 0x3FFFFFu);
+        for (int e = tid; e < 2048; e += 1024) {
+            const int blk = e / W, r = e - blk * W, pos = c0p + blk * chunk + r;
+            if (r < chunk && pos < n) pm[pos] = (int)(keys[e] & 0x3FFFFFu);
+        }
         __syncthreads();
     }
 }
@@ -294,6 +305,199 @@ __global__ __launch_bounds__(FW_BS) void fps_wave_kernel(int n, int m, const flo
     FPSW_PROF_END
 }
 
+// ---- four skip regions per wave ------------------------------------------------------------------------------------------
+// fps_wave_kernel skips whole waves (64 P points).  Its round at n = 24576 (tools/micro/fps_wave_prof.hip) is led by the dense
+// update of the busiest wave (1330 of 2900 cycles): a new sample usually touches a corner of that wave's region only.  Here a
+// wave's P slots form G = 4 groups of PG = P / 4 slots = 64 PG consecutive sorted positions each (the pre-pass orders every
+// GROUP's range by tie priority), with their own bounding boxes (kept in lanes 0..3 of six VGPRs: ONE 14-instruction bound test
+// serves the four groups, its ballot bits steer scalar branches).  A group whose box is farther from the new sample than the
+// wave's largest running distance is skipped; every lane caches its best (distance, slot) per group, so the candidates of skipped
+// groups are still there.  Equal distances in different groups of one lane, or in different lanes, go to a (rare) path that
+// compares the reference's tie keys of every (lane, group) candidate.  Sorted positions are written to `out` during the loop
+// and replaced by the original indices at the end (the position -> index table is read from global memory: it is needed for the
+// rare ties and the final pass only, which frees 96 KB of LDS for the coordinates of 8 of the 24 slots).
+template <int P, int PL, bool FMA>
+__global__ __launch_bounds__(FW_BS) void fps_wave4_kernel(int n, int m, const float* __restrict__ xyz, const int* __restrict__ perm,
+                                                          int* __restrict__ out) {
+    constexpr int G = 4, PG = P / G, PR = P - PL;
+    static_assert(P % G == 0, "groups must tile the slots");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* slot = reinterpret_cast<float*>(smem);                             // [2][FW_W][8]: distance key, position, x, y, z
+    float* xl = slot + 2 * FW_W * 8;                                          // [PL][3][FW_BS]
+    const int cloud = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const float* __restrict__ p = xyz + (size_t)cloud * n * 3;
+    const int* __restrict__ pm = perm + (size_t)cloud * n;
+    int* __restrict__ o = out + (size_t)cloud * m;
+    const int wbase = wave * 64 * P;
+
+    float x[PR], y[PR], z[PR], td[P];
+    float blx = 3e38f, bly = 3e38f, blz = 3e38f, bhx = -3e38f, bhy = -3e38f, bhz = -3e38f;   // lane g < 4: box of group g
+    {
+        int kk[P];
+#pragma unroll
+        for (int i = 0; i < P; ++i) kk[i] = pm[min(wbase + i * 64 + lane, n - 1)];
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            float lx = 3e38f, ly = 3e38f, lz = 3e38f, hx = -3e38f, hy = -3e38f, hz = -3e38f;
+#pragma unroll
+            for (int s = 0; s < PG; ++s) {
+                const int i = g * PG + s;
+                const bool ok = wbase + i * 64 + lane < n;
+                const int k = kk[i];
+                const float px = p[k * 3 + 0], py = p[k * 3 + 1], pz = p[k * 3 + 2];
+                if (i < PR) { x[i < PR ? i : 0] = px; y[i < PR ? i : 0] = py; z[i < PR ? i : 0] = pz; }
+                else { float* c = xl + (size_t)(i - PR) * 3 * FW_BS + tid; c[0] = px; c[FW_BS] = py; c[2 * FW_BS] = pz; }
+                td[i] = ok ? 1e38f : -1.0f;
+                if (ok) { lx = fminf(lx, px); hx = fmaxf(hx, px); ly = fminf(ly, py); hy = fmaxf(hy, py); lz = fminf(lz, pz); hz = fmaxf(hz, pz); }
+            }
+            lx = fpsw_all_min(lx); ly = fpsw_all_min(ly); lz = fpsw_all_min(lz);
+            hx = fpsw_all_max(hx); hy = fpsw_all_max(hy); hz = fpsw_all_max(hz);
+            if (lane == g) { blx = lx; bly = ly; blz = lz; bhx = hx; bhy = hy; bhz = hz; }
+        }
+    }
+    float gbd[G];                                         // per lane: best running distance of its PG slots in group g ...
+    int gbi[G];                                           // ... and the slot (0 .. PG - 1) that holds it
+#pragma unroll
+    for (int g = 0; g < G; ++g) { gbd[g] = -1.0f; gbi[g] = 0; }
+    float wtd = (wbase < n) ? 1e38f : -1.0f;
+    uint32_t rk = 0u;
+    float rx = 0.f, ry = 0.f, rz = 0.f;
+    int rpos = 0;
+    float x1 = p[0], y1 = p[1], z1 = p[2];
+    __syncthreads();                                      // xl complete
+    for (int j = 1; j < m; ++j) {
+        const float ex = fmaxf(fmaxf(blx - x1, x1 - bhx), 0.f);
+        const float ey = fmaxf(fmaxf(bly - y1, y1 - bhy), 0.f);
+        const float ez = fmaxf(fmaxf(blz - z1, z1 - bhz), 0.f);
+        const float lb = __builtin_fmaf(ez, ez, __builtin_fmaf(ey, ey, ex * ex));
+        const unsigned act = (unsigned)__ballot(lane < G && lb * 0.99999f <= wtd) & 0xFu;      // wave-uniform group mask
+        if (act) {
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                if (act & (1u << g)) {
+                    float bd = -1.0f;
+                    int bi = 0;
+#pragma unroll
+                    for (int s = 0; s < PG; ++s) {        // slots of a group in ascending tie priority: strict '>' keeps the reference's winner
+                        const int i = g * PG + s;
+                        float px, py, pz;
+                        if (i < PR) { px = x[i < PR ? i : 0]; py = y[i < PR ? i : 0]; pz = z[i < PR ? i : 0]; }
+                        else { const float* c = xl + (size_t)(i - PR) * 3 * FW_BS + tid; px = c[0]; py = c[FW_BS]; pz = c[2 * FW_BS]; }
+                        const float d = sqdist3<FMA>(px - x1, py - y1, pz - z1);
+                        const float t = fminf(d, td[i]);
+                        td[i] = t;
+                        const bool gt = t > bd;
+                        bd = gt ? t : bd; bi = gt ? s : bi;
+                    }
+                    gbd[g] = bd; gbi[g] = bi;
+                }
+            }
+            // the lane's best over its four groups; `amb`: two groups tie for it (their tie keys have to decide)
+            float bd = gbd[0];
+            int bs = gbi[0];
+            bool amb = false;
+#pragma unroll
+            for (int g = 1; g < G; ++g) {
+                const bool gt = gbd[g] > bd, eq = gbd[g] == bd;
+                amb = gt ? false : (amb || eq);
+                bs = gt ? g * PG + gbi[g] : bs;
+                bd = gt ? gbd[g] : bd;
+            }
+            const uint32_t ub = fpsw_dkey(bd);
+            const uint32_t um = fpsw_wave_max_u32(ub);
+            const unsigned long long tm = __ballot(ub == um);
+            int wl = (int)__builtin_ctzll(tm);
+            int sbi = __builtin_amdgcn_readlane(bs, wl);
+            if ((tm & (tm - 1)) || __ballot(amb && ub == um)) {
+                // several (lane, group) candidates share the maximum: the reference's tie rule on their original indices
+                uint32_t bk = 0u;
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    const bool in = fpsw_dkey(gbd[g]) == um;
+                    const int pos = wbase + (g * PG + gbi[g]) * 64 + lane;
+                    const uint32_t key = in ? fpsw_tiekey(pm[min(pos, n - 1)]) : 0u;
+                    const uint32_t mk = fpsw_wave_max_u32(key);
+                    if (mk > bk) {                        // wave-uniform
+                        bk = mk;
+                        wl = (int)__builtin_ctzll(__ballot(in && key == mk));
+                        sbi = g * PG + __builtin_amdgcn_readlane(gbi[g], wl);
+                    }
+                }
+            }
+            float cx = 0.f, cy = 0.f, cz = 0.f;
+            switch (sbi) {
+#define FPSW_CASE(I) case I: if constexpr ((I) < PR) { cx = x[(I) < PR ? (I) : 0]; cy = y[(I) < PR ? (I) : 0]; cz = z[(I) < PR ? (I) : 0]; asm volatile("" : "+v"(cx), "+v"(cy), "+v"(cz)); } break;
+                FPSW_CASE(0) FPSW_CASE(1) FPSW_CASE(2) FPSW_CASE(3) FPSW_CASE(4) FPSW_CASE(5) FPSW_CASE(6) FPSW_CASE(7)
+                FPSW_CASE(8) FPSW_CASE(9) FPSW_CASE(10) FPSW_CASE(11) FPSW_CASE(12) FPSW_CASE(13) FPSW_CASE(14) FPSW_CASE(15)
+                FPSW_CASE(16) FPSW_CASE(17) FPSW_CASE(18) FPSW_CASE(19) FPSW_CASE(20) FPSW_CASE(21) FPSW_CASE(22) FPSW_CASE(23)
+#undef FPSW_CASE
+                default: break;
+            }
+            if (PL > 0 && sbi >= PR) { const float* c = xl + (size_t)(sbi - PR) * 3 * FW_BS + tid; cx = c[0]; cy = c[FW_BS]; cz = c[2 * FW_BS]; }
+            wtd = fpsw_dkey_value(um);
+            rk = um;
+            rpos = wbase + sbi * 64 + wl;
+            rx = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(cx), wl));
+            ry = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(cy), wl));
+            rz = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(cz), wl));
+        }
+        const int par = j & 1;
+        if (lane == 0) {
+            float* s = slot + (size_t)(par * FW_W + wave) * 8;
+            *reinterpret_cast<float4*>(s) = make_float4(__uint_as_float(rk), __int_as_float(rpos), rx, ry);
+            s[4] = rz;
+        }
+        __syncthreads();
+        {   // winner among the waves
+            uint32_t sk = 0u;
+            float sx = 0.f, sy = 0.f, sz = 0.f;
+            int spos = 0;
+            if (lane < FW_W) {
+                const float* s = slot + (size_t)(par * FW_W + lane) * 8;
+                const float4 a = *reinterpret_cast<const float4*>(s);
+                sk = __float_as_uint(a.x); spos = __float_as_int(a.y); sx = a.z; sy = a.w; sz = s[4];
+            }
+            const uint32_t gm = fpsw_row0_max_u32(sk);
+            const unsigned long long tm = __ballot(sk == gm);
+            int gl = (int)__builtin_ctzll(tm);
+            if (tm & (tm - 1)) {
+                const bool in = sk == gm;
+                const uint32_t key = in ? fpsw_tiekey(pm[min(spos, n - 1)]) : 0u;
+                const uint32_t mk = fpsw_wave_max_u32(key);
+                gl = (int)__builtin_ctzll(__ballot(in && key == mk));
+            }
+            x1 = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(sx), gl));
+            y1 = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(sy), gl));
+            z1 = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(sz), gl));
+            if (tid == 0) o[j] = __builtin_amdgcn_readlane(spos, gl);        // a sorted POSITION; translated below
+        }
+    }
+    __syncthreads();                                      // thread 0's stores are visible to the workgroup
+    for (int j = 1 + tid; j < m; j += FW_BS) o[j] = pm[o[j]];
+    if (tid == 0) o[0] = 0;                               // sample 0 is point 0 (tf_sampling_g.cu:122-124)
+}
+
+template <int P, int PL>
+static int launch_fps_wave4(int b, int n, int m, const float* xyz, int* perm, int* out, int arith, hipStream_t s) {
+    const size_t sort_bytes = (size_t)n * 4 + 4096 * 4 + 2048 * 4;
+    const size_t bytes = 2 * FW_W * 8 * 4 + (size_t)PL * 3 * FW_BS * 4;
+    static bool attr = false;
+    if (!attr) {
+        DISPU_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fps_wavesort_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 24576 * 4 + 4096 * 4 + 2048 * 4));
+        DISPU_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fps_wave4_kernel<P, PL, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+        DISPU_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fps_wave4_kernel<P, PL, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+        attr = true;
+    }
+    hipLaunchKernelGGL(fps_wavesort_kernel, dim3(b), dim3(1024), sort_bytes, s, n, 64 * (P / 4), xyz, perm);
+    DISPU_CHECK_LAUNCH();
+    if ((arith & DISPU_ARITH_CONTRACT))
+        hipLaunchKernelGGL((fps_wave4_kernel<P, PL, true>), dim3(b), dim3(FW_BS), bytes, s, n, m, xyz, perm, out);
+    else
+        hipLaunchKernelGGL((fps_wave4_kernel<P, PL, false>), dim3(b), dim3(FW_BS), bytes, s, n, m, xyz, perm, out);
+    return (int)hipGetLastError();
+}
+
 template <int P, int PL>
 static int launch_fps_wave(int b, int n, int m, const float* xyz, int* perm, int* out, int arith, hipStream_t s) {
     const size_t sort_bytes = (size_t)n * 4 + 4096 * 4 + 2048 * 4;
@@ -320,9 +524,14 @@ bool fps_wave_wants_scratch(int n, int m) { return n > 4096 && n <= FW_BS * 24 &
 int fps_wave_dispatch(int b, int n, int m, const float* xyz, void* temp, int* out, int arith, hipStream_t s) {
     if (!temp || !fps_wave_wants_scratch(n, m)) return -1;
     int* perm = reinterpret_cast<int*>(temp);
+    static const bool whole_waves = [] { const char* e = getenv("DISPU_FPS_WAVE1"); return e && e[0] == '1'; }();   // A/B: skip whole waves only
     if (n <= FW_BS * 8) return launch_fps_wave<8, 0>(b, n, m, xyz, perm, out, arith, s);
-    if (n <= FW_BS * 16) return launch_fps_wave<16, 0>(b, n, m, xyz, perm, out, arith, s);
-    return launch_fps_wave<24, 4>(b, n, m, xyz, perm, out, arith, s);
+    if (whole_waves) {
+        if (n <= FW_BS * 16) return launch_fps_wave<16, 0>(b, n, m, xyz, perm, out, arith, s);
+        return launch_fps_wave<24, 4>(b, n, m, xyz, perm, out, arith, s);
+    }
+    if (n <= FW_BS * 16) return launch_fps_wave4<16, 0>(b, n, m, xyz, perm, out, arith, s);
+    return launch_fps_wave4<24, 8>(b, n, m, xyz, perm, out, arith, s);
 }
 
 }  // namespace dispu
