@@ -27,6 +27,7 @@
 #define FPSW_TICK(i)
 #define FPSW_PROF_BEGIN
 #define FPSW_PROF_ACTIVE
+#define FPSW_PROF_GROUPS(mask)
 #define FPSW_PROF_END
 #endif
 
@@ -366,13 +367,18 @@ __global__ __launch_bounds__(FW_BS) void fps_wave4_kernel(int n, int m, const fl
     int rpos = 0;
     float x1 = p[0], y1 = p[1], z1 = p[2];
     __syncthreads();                                      // xl complete
+    FPSW_PROF_BEGIN
     for (int j = 1; j < m; ++j) {
+        FPSW_TICK(0)
         const float ex = fmaxf(fmaxf(blx - x1, x1 - bhx), 0.f);
         const float ey = fmaxf(fmaxf(bly - y1, y1 - bhy), 0.f);
         const float ez = fmaxf(fmaxf(blz - z1, z1 - bhz), 0.f);
         const float lb = __builtin_fmaf(ez, ez, __builtin_fmaf(ey, ey, ex * ex));
         const unsigned act = (unsigned)__ballot(lane < G && lb * 0.99999f <= wtd) & 0xFu;      // wave-uniform group mask
+        FPSW_TICK(1)
         if (act) {
+            FPSW_PROF_ACTIVE
+            FPSW_PROF_GROUPS(act)
 #pragma unroll
             for (int g = 0; g < G; ++g) {
                 if (act & (1u << g)) {
@@ -393,6 +399,7 @@ __global__ __launch_bounds__(FW_BS) void fps_wave4_kernel(int n, int m, const fl
                     gbd[g] = bd; gbi[g] = bi;
                 }
             }
+            FPSW_TICK(2)
             // the lane's best over its four groups; `amb`: two groups tie for it (their tie keys have to decide)
             float bd = gbd[0];
             int bs = gbi[0];
@@ -442,13 +449,16 @@ __global__ __launch_bounds__(FW_BS) void fps_wave4_kernel(int n, int m, const fl
             ry = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(cy), wl));
             rz = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(cz), wl));
         }
+        FPSW_TICK(3)
         const int par = j & 1;
         if (lane == 0) {
             float* s = slot + (size_t)(par * FW_W + wave) * 8;
             *reinterpret_cast<float4*>(s) = make_float4(__uint_as_float(rk), __int_as_float(rpos), rx, ry);
             s[4] = rz;
         }
+        FPSW_TICK(4)
         __syncthreads();
+        FPSW_TICK(5)
         {   // winner among the waves
             uint32_t sk = 0u;
             float sx = 0.f, sy = 0.f, sz = 0.f;
@@ -472,7 +482,9 @@ __global__ __launch_bounds__(FW_BS) void fps_wave4_kernel(int n, int m, const fl
             z1 = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(sz), gl));
             if (tid == 0) o[j] = __builtin_amdgcn_readlane(spos, gl);        // a sorted POSITION; translated below
         }
+        FPSW_TICK(6)
     }
+    FPSW_PROF_END
     __syncthreads();                                      // thread 0's stores are visible to the workgroup
     for (int j = 1 + tid; j < m; j += FW_BS) o[j] = pm[o[j]];
     if (tid == 0) o[0] = 0;                               // sample 0 is point 0 (tf_sampling_g.cu:122-124)

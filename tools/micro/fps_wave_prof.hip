@@ -7,11 +7,12 @@
 #include <cmath>
 #include <vector>
 __device__ unsigned long long fpsw_prof[16][8];
-#define FPSW_PROF_BEGIN unsigned long long pt_[7] = {0, 0, 0, 0, 0, 0, 0}, pa_[7] = {0, 0, 0, 0, 0, 0, 0}; unsigned long long pact_ = 0; bool pwas_ = false;
+#define FPSW_PROF_BEGIN unsigned long long pt_[7] = {0, 0, 0, 0, 0, 0, 0}, pa_[7] = {0, 0, 0, 0, 0, 0, 0}; unsigned long long pact_ = 0, pgrp_ = 0; bool pwas_ = false;
 #define FPSW_TICK(i) { pt_[i] = __builtin_amdgcn_s_memtime(); if ((i) == 0) pwas_ = false; \
     if ((i) == 6) { pa_[0] += pt_[1] - pt_[0]; if (pwas_) { pa_[1] += pt_[2] - pt_[1]; pa_[2] += pt_[3] - pt_[2]; } pa_[3] += pt_[4] - pt_[3]; pa_[4] += pt_[5] - pt_[4]; pa_[5] += pt_[6] - pt_[5]; } }
 #define FPSW_PROF_ACTIVE pwas_ = true; ++pact_;
-#define FPSW_PROF_END if (lane == 0) { for (int q = 0; q < 6; ++q) fpsw_prof[wave][q] = pa_[q]; fpsw_prof[wave][6] = pact_; }
+#define FPSW_PROF_GROUPS(mask) pgrp_ += __builtin_popcount(mask);
+#define FPSW_PROF_END if (lane == 0) { for (int q = 0; q < 6; ++q) fpsw_prof[wave][q] = pa_[q]; fpsw_prof[wave][6] = pact_; fpsw_prof[wave][7] = pgrp_; }
 #include "fps_wave.hip"
 
 int main(int argc, char** argv) {
@@ -41,7 +42,7 @@ int main(int argc, char** argv) {
     printf("wave  active  lbtest  dense(act)  wavered(act)  slot->bar  barrier  final   [s_memtime ticks per round]\n");
     for (int w = 0; w < 16; ++w) {
         const double R = m - 1, A = p[w][6] ? (double)p[w][6] : 1;
-        printf("%2d   %6llu  %7.1f  %7.1f  %7.1f  %7.1f  %7.1f  %7.1f\n", w, p[w][6], p[w][0] / R, p[w][1] / A, p[w][2] / A, p[w][3] / R, p[w][4] / R, p[w][5] / R);
+        printf("%2d   %6llu (%.2f regions)  %7.1f  %7.1f  %7.1f  %7.1f  %7.1f  %7.1f\n", w, p[w][6], p[w][7] / A, p[w][0] / R, p[w][1] / A, p[w][2] / A, p[w][3] / R, p[w][4] / R, p[w][5] / R);
     }
     return 0;
 }
