@@ -373,6 +373,20 @@ __global__ void act_mask_kernel(long rows, int n, const float* __restrict__ dY, 
     }
 }
 
+// the same mask on float4 quads (n % 4 == 0, 16-byte aligned rows): 32-bit index arithmetic, one division per FOUR elements
+// (the scalar kernel divides a 64-bit index per element: 10 us for 2 M elements, launched 23 times per training step)
+__global__ void act_mask_v4_kernel(unsigned quads, unsigned n4, const float* __restrict__ dY, unsigned lddy, const float* __restrict__ Y,
+                                   unsigned ldy, float* __restrict__ dZ, unsigned lddz) {
+    for (unsigned e = blockIdx.x * blockDim.x + threadIdx.x; e < quads; e += gridDim.x * blockDim.x) {
+        const unsigned r = e / n4, c = (e - r * n4) * 4;
+        const float4 g = *reinterpret_cast<const float4*>(dY + (size_t)r * lddy + c);
+        const float4 y = *reinterpret_cast<const float4*>(Y + (size_t)r * ldy + c);
+        float4 o;
+        o.x = (y.x > 0.f) ? g.x : 0.f; o.y = (y.y > 0.f) ? g.y : 0.f; o.z = (y.z > 0.f) ? g.z : 0.f; o.w = (y.w > 0.f) ? g.w : 0.f;
+        *reinterpret_cast<float4*>(dZ + (size_t)r * lddz + c) = o;
+    }
+}
+
 // out[j] = (accumulate ? out[j] : 0) + sum_s part[s][j]  (s ascending)
 __global__ void colsum_reduce_kernel(int n, int nparts, const float* __restrict__ part, float* __restrict__ out, int accumulate) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
@@ -488,6 +502,14 @@ DISPU_EXPORT int dispu_act_bias_grad(long rows, int n, const float* dY, long ldd
     if (!dbias) {
         if (!act || !dZ) return 0;
         const size_t total = (size_t)rows * n;
+        if ((n & 3) == 0 && (lddy & 3) == 0 && (ldy & 3) == 0 && (lddz & 3) == 0 && total / 4 < 0x7fffffffull && lddy < 0x7fffffffl &&
+            ldy < 0x7fffffffl && lddz < 0x7fffffffl && ((((uintptr_t)dY) | ((uintptr_t)Y) | ((uintptr_t)dZ)) & 15) == 0) {
+            const unsigned quads = (unsigned)(total / 4);
+            const unsigned gq = (quads + 255) / 256;
+            hipLaunchKernelGGL(act_mask_v4_kernel, dim3(gq > 16384 ? 16384 : gq), dim3(256), 0, s, quads, (unsigned)(n / 4), dY, (unsigned)lddy, Y,
+                               (unsigned)ldy, dZ, (unsigned)lddz);
+            return (int)hipGetLastError();
+        }
         const size_t g = (total + 255) / 256;
         hipLaunchKernelGGL(act_mask_kernel, dim3((unsigned)(g > 32768 ? 32768 : g)), dim3(256), 0, s, rows, n, dY, lddy, Y, ldy, dZ, lddz);
         return (int)hipGetLastError();
