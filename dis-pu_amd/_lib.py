@@ -84,6 +84,7 @@ SIGNATURES = {
     "dispu_act_bias_grad": (_i, [_l, _i, _vp, _l, _vp, _l, _i, _vp, _l, _vp, _i, _vp, _l, _vp]),
     "dispu_max_k": (_i, [_l, _i, _i, _vp, _l, _vp, _l, _vp]),
     "dispu_max_k_grad": (_i, [_l, _i, _i, _vp, _l, _vp, _l, _vp, _l, _vp, _l, _i, _vp]),
+    "dispu_max_k_grad_tail": (_i, [_l, _i, _i, _i, _vp, _l, _vp, _l, _vp, _l, _vp, _l, _vp]),
     "dispu_edge_feature_grad": (_i, [_l, _i, _i, _i, _vp, _l, _vp, _i, _i, _vp, _l, _vp]),
     "dispu_dup_sum_grad": (_i, [_i, _i, _i, _i, _vp, _l, _vp, _l, _vp]),
     "dispu_ps_group": (_i, [_l, _i, _i, _i, _vp, _vp, _vp, _l, _vp, _l, _vp]),

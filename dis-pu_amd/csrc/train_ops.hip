@@ -49,6 +49,30 @@ __global__ void max_k_grad_kernel(long rows, int ns, int c, const float* __restr
     }
 }
 
+// max_k_grad into columns [0, c) plus zeros into the `tail` columns behind them: the gradient buffer of a dense block's edge
+// tensor is [l2 | l1 | l0 | centre | neighbour - centre]; the pooled part gets the max gradient, the rest only accumulates
+// afterwards and used to be cleared by a separate fill of the whole buffer (22 MB, once per block and step)
+__global__ void max_k_grad_tail_kernel(long rows, int ns, int c, int tail, const float* __restrict__ X, long ldx, const float* __restrict__ Y,
+                                       long ldy, const float* __restrict__ dY, long lddy, float* __restrict__ dX, long lddx) {
+    const unsigned w = (unsigned)(c + tail);
+    const size_t total = (size_t)rows * w;
+    for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const size_t i = e / w;
+        const int ch = (int)(e - i * w);
+        float* dx = dX + i * ns * lddx + ch;
+        if (ch >= c) {
+            for (int s = 0; s < ns; ++s) dx[(size_t)s * lddx] = 0.f;
+            continue;
+        }
+        const float* x = X + i * ns * ldx + ch;
+        const float y = Y[i * ldy + ch], g = dY[i * lddy + ch];
+        int cnt = 0;
+        for (int s = 0; s < ns; ++s) cnt += (x[(size_t)s * ldx] == y) ? 1 : 0;
+        const float share = g / (float)cnt;
+        for (int s = 0; s < ns; ++s) dx[(size_t)s * lddx] = (x[(size_t)s * ldx] == y) ? share : 0.f;
+    }
+}
+
 // ---- get_edge_feature (ops.py:1856-1877): E[(i,s)] = [F_i | F_j - F_i] --------------------------------------------
 // dF_i += sum_s (dE[(i,s), ch] - dE[(i,s), c + ch]);  dF_j += dE[(i,s), c + ch].
 __global__ void edge_feature_grad_kernel(long rows, int n_per_cloud, int k, int c, const float* __restrict__ dE, long lde,
@@ -437,6 +461,13 @@ DISPU_EXPORT int dispu_max_k_grad(long rows, int ns, int c, const float* X, long
     if (rows < 0 || ns <= 0 || c <= 0) return (int)hipErrorInvalidValue;
     if (rows == 0) return 0;
     LAUNCH1D(max_k_grad_kernel, (size_t)rows * c, rows, ns, c, X, ldx, Y, ldy, dY, lddy, dX, lddx, accumulate);
+}
+
+DISPU_EXPORT int dispu_max_k_grad_tail(long rows, int ns, int c, int tail, const float* X, long ldx, const float* Y, long ldy,
+                                       const float* dY, long lddy, float* dX, long lddx, void* stream) {
+    if (rows < 0 || ns <= 0 || c <= 0 || tail < 0) return (int)hipErrorInvalidValue;
+    if (rows == 0) return 0;
+    LAUNCH1D(max_k_grad_tail_kernel, (size_t)rows * (c + tail), rows, ns, c, tail, X, ldx, Y, ldy, dY, lddy, dX, lddx);
 }
 
 DISPU_EXPORT int dispu_edge_feature_grad(long rows, int n_per_cloud, int k, int c, const float* dE, long lde, const int* idx,

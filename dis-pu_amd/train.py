@@ -534,8 +534,8 @@ class Trainer(object):
             Eb = ws["edge"][d]
             lde = dE.stride(0)
             self._join()                 # dE / dprep are shared by the blocks: the previous block's dW products read them
-            dE.zero_()                   # max_k_grad writes columns [0, width); the neighbour half of the edge feature only accumulates
-            _lib.check(L.dispu_max_k_grad(rn, k, width, _p(Eb), Eb.stride(0), _p(feat, col), 480, _p(dfeat, col), 480, _p(dE), lde, 0, self.st),
+            # max gradient into the pooled columns [0, width), zeros into the neighbour half of the edge feature behind them
+            _lib.check(L.dispu_max_k_grad_tail(rn, k, width, C, _p(Eb), Eb.stride(0), _p(feat, col), 480, _p(dfeat, col), 480, _p(dE), lde, self.st),
                        "max_k_grad")
             sc = fe + "layer%d" % d
             self._lin_bwd(Eb, 24, 48 + C, sc + "/l2", 0, Eb, 0, 24, dE, 0, dE, 24, acc_dx=True)

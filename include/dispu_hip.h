@@ -305,6 +305,10 @@ int dispu_max_k(long rows, int ns, int c, const float* X, long ldx, float* out, 
 /* its gradient (math_grad._MinOrMaxGrad: shared evenly by tied maxima). */
 int dispu_max_k_grad(long rows, int ns, int c, const float* X, long ldx, const float* Y, long ldy, const float* dY, long lddy,
                      float* dX, long lddx, int accumulate, void* stream);
+/* the same, overwriting, plus zeros into the `tail` columns behind the c pooled ones (the part of a dense block's gradient
+ * buffer that only accumulates afterwards: saves a separate fill). */
+int dispu_max_k_grad_tail(long rows, int ns, int c, int tail, const float* X, long ldx, const float* Y, long ldy, const float* dY,
+                          long lddy, float* dX, long lddx, void* stream);
 /* gradient of get_edge_feature (ops.py:1856-1877): dF accumulates (atomics); dE [(rows*k), 2c]. */
 int dispu_edge_feature_grad(long rows, int n_per_cloud, int k, int c, const float* dE, long lde, const int* idx, int ldi,
                             int ioff, float* dF, long lddf, void* stream);

@@ -125,6 +125,10 @@ def test_max_k_and_grad(dev, L):
     T.max_even(xt, 1).backward(torch.tensor(g, dtype=F64))
     close(N_(dx).reshape(rows, ns, ld)[:, :, :c], xt.grad.numpy(), 1e-6, "max_k_grad")
     assert not N_(dx)[:, c:].any()
+    # the variant that also clears `tail` columns behind the pooled ones (and nothing past them)
+    dx2 = torch.full((rows * ns, ld), 7.0, dtype=torch.float32, device=dev)
+    L.check(L.lib().dispu_max_k_grad_tail(rows, ns, c, 20, p(x), ld, p(y), c, p(dv(g, dev)), c, p(dx2), ld, st), "max_k_grad_tail")
+    assert torch.equal(dx2[:, :c], dx[:, :c]) and not bool(dx2[:, c:c + 20].any()) and bool((dx2[:, c + 20:] == 7.0).all())
 
 
 def test_edge_feature_grad(dev, L):
