@@ -163,6 +163,35 @@ def test_fps_large_clouds_index_exact(ops, dev, b, n, m, kind):
             break                                          # one flavour is enough at the big shapes (the oracle takes seconds)
 
 
+def test_fps_region_kernels_random_shapes(ops, dev):
+    """Seeded random shapes over the whole range of the region-skipping kernels (4096 < n <= 24576, both register layouts, ragged
+    last wave / region) on clouds built to provoke ties: points duplicated 2 - 6 times, points snapped to a coarse lattice (many
+    equal distances across regions and waves), thin slabs -- indices equal to the oracle's."""
+    rng = np.random.default_rng(20260928)
+    for case in range(14):
+        n = int(rng.integers(4097, 24577))
+        m = int(rng.integers(64, 360))
+        b = int(rng.integers(1, 4))
+        kind = case % 4
+        if kind == 0:
+            x = rng.random((b, n, 3))
+        elif kind == 1:                                   # duplicates
+            rep = int(rng.integers(2, 7))
+            base = rng.random((b, (n + rep - 1) // rep, 3))
+            x = np.repeat(base, rep, axis=1)[:, :n]
+            x = x[:, rng.permutation(n)]
+        elif kind == 2:                                   # lattice: exact ties everywhere
+            q = int(rng.integers(6, 30))
+            x = np.round(rng.random((b, n, 3)) * q) / q
+        else:                                             # a thin slab
+            x = rng.random((b, n, 3)) * np.array([1.0, 1.0, 0.01])
+        x = x.astype(np.float32)
+        arith = CONTRACT if case % 2 == 0 else PLAIN
+        got = N(ops["S"].farthest_point_sample(m, T(x, dev), arith=arith))
+        want = O.farthest_point_sample(m, x, contract=arith)
+        assert np.array_equal(got, want), (case, b, n, m, kind, int(np.argmax((got != want).any(0))))
+
+
 def test_fps_abi_with_and_without_scratch(dev):
     """dispu_fps through the C ABI at a wave-skipping size: with the scratch dispu_fps_scratch_bytes asks for (the permutation of
     csrc/fps_wave.hip) and without any (NULL: the dense register kernel answers) -- same indices, equal to the oracle's."""
