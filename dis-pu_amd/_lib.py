@@ -8,6 +8,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libdispu_hip.so")
 
+ABI_VERSION = 3       # include/dispu_hip.h: dispu_version()
 ARITH_PLAIN = 0
 ARITH_CONTRACT = 1
 ARITH_PINNED_EXP = 2   # OR-able, approx_match only (bit-reproducible exp; parity mode)
@@ -20,6 +21,9 @@ SIGNATURES = {
     "dispu_error_string": (C.c_char_p, [_i]),
     "dispu_fps_scratch_bytes": (_sz, [_i, _i, _i]),
     "dispu_fps": (_i, [_i, _i, _i, _vp, _vp, _vp, _i, _vp]),
+    "dispu_fps_ws": (_i, [_i, _i, _i, _vp, _vp, _sz, _vp, _i, _vp]),
+    "dispu_prob_sample": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "dispu_selection_sort": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "dispu_gather_point": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp]),
     "dispu_gather_point_grad": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp]),
     "dispu_query_ball": (_i, [_i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp]),
@@ -41,9 +45,11 @@ SIGNATURES = {
     "dispu_approx_match_scratch_bytes": (_sz, [_i, _i, _i]),
     "dispu_approx_match": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp]),
     "dispu_match_cost_scratch_bytes": (_sz, [_i, _i, _i]),
-    "dispu_match_cost": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
+    "dispu_match_cost": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp]),
+    "dispu_match_cost_ws": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "dispu_match_cost_grad_scratch_bytes": (_sz, [_i, _i, _i]),
-    "dispu_match_cost_grad": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
+    "dispu_match_cost_grad": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
+    "dispu_match_cost_grad_ws": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "dispu_linear": (_i, [_i, _i, _i, _i, _vp, _l, _l, _vp, _l, _l, _i, _vp, _i, _vp, _l, _l, _vp, _l, _l, _vp, _l, _l, _vp]),
     "dispu_linear_bn": (_i, [_i, _i, _i, _i, _vp, _l, _l, _vp, _l, _l, _i, _vp, _vp, _vp, _i, _vp, _l, _l, _vp, _l, _l, _vp, _l, _l,
                              _vp]),
@@ -125,6 +131,9 @@ def lib():
             fn = getattr(l, name)
             fn.restype = res
             fn.argtypes = args
+        if l.dispu_version() < ABI_VERSION:
+            raise DispuError("libdispu_hip.so at %s has ABI version %d, this package needs >= %d -- rebuild it with "
+                             "`python dis-pu_amd/build.py`" % (LIB_PATH, l.dispu_version(), ABI_VERSION))
         _LIB = l
     return _LIB
 

@@ -311,6 +311,53 @@ __global__ __launch_bounds__(256) void match_cost_final_kernel(int nparts, const
     if (threadIdx.x == 0) cost[blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
 }
 
+// Scratch-free form for the reference's launcher signature (dispu_match_cost: no scratch argument): ONE workgroup per cloud
+// walks the same (256 k) x (128 l) tiles in (row block, chunk) order and adds each tile's workgroup sum to a running total --
+// the association of match_cost_tile_kernel + match_cost_final_kernel for a cloud with <= 256 tiles is different (there the
+// partials are summed by lanes), so the two entries agree to rounding, not bit for bit.  HBM-latency bound (one workgroup
+// per cloud, like the reference's kernel); dispu_match_cost_ws is the fast path.
+template <bool FMA>
+__global__ __launch_bounds__(AM_ROWS) void match_cost_cloud_kernel(int n, int m, const float* __restrict__ xyz1,
+                                                                    const float* __restrict__ xyz2,
+                                                                    const float* __restrict__ match, float* __restrict__ cost) {
+    __shared__ float4 tile[MC_CH];
+    __shared__ float wsum[AM_ROWS / kWave];
+    const int cloud = blockIdx.x, tid = threadIdx.x;
+    const float* __restrict__ p1 = xyz1 + (size_t)cloud * n * 3;
+    const float* __restrict__ p2 = xyz2 + (size_t)cloud * m * 3;
+    float total = 0.f;
+    for (int k0 = 0; k0 < n; k0 += AM_ROWS) {
+        const int k = k0 + tid;
+        float x1 = 0.f, y1 = 0.f, z1 = 0.f;
+        if (k < n) { x1 = p1[k * 3 + 0]; y1 = p1[k * 3 + 1]; z1 = p1[k * 3 + 2]; }
+        for (int l0 = 0; l0 < m; l0 += MC_CH) {
+            const int len = min(MC_CH, m - l0);
+            __syncthreads();
+            if (tid < len) tile[tid] = make_float4(p2[(l0 + tid) * 3 + 0], p2[(l0 + tid) * 3 + 1], p2[(l0 + tid) * 3 + 2], 0.f);
+            __syncthreads();
+            float s = 0.f;
+            if (k < n) {
+                const float* __restrict__ mt = match + (size_t)cloud * n * m + (size_t)l0 * n + k;
+#pragma unroll 8
+                for (int i = 0; i < len; ++i) {
+                    const float4 q = tile[i];
+                    const float d = __builtin_amdgcn_sqrtf(sqdist3<FMA>(q.x - x1, q.y - y1, q.z - z1));
+                    const float w = __builtin_nontemporal_load(mt + (size_t)i * n);
+                    if constexpr (FMA) s = __builtin_fmaf(d, w, s);
+                    else s = s + d * w;
+                }
+            }
+            s = wave_sum_f32(s);
+            if ((tid & (kWave - 1)) == 0) wsum[tid / kWave] = s;
+            __syncthreads();
+            float r = wsum[0];
+            for (int w = 1; w < AM_ROWS / kWave; ++w) r += wsum[w];
+            total += r;
+        }
+    }
+    if (tid == 0) cost[cloud] = total;
+}
+
 // grad1[b,k,:] = sum_l match[l*n+k] * (p1_k - p2_l) * rsqrt(max(d2,1e-20))   (matchcostgrad1, :270-291)
 // same tiling as the cost: partial sums per (chunk, k), combined in ascending chunk order by match_grad1_combine_kernel.
 template <bool FMA>
@@ -322,24 +369,32 @@ __global__ __launch_bounds__(AM_ROWS) void match_grad1_tile_kernel(int n, int m,
     const int cloud = blockIdx.z, c = blockIdx.y, rb = blockIdx.x, tid = threadIdx.x;
     const float* __restrict__ p1 = xyz1 + (size_t)cloud * n * 3;
     const float* __restrict__ p2 = xyz2 + (size_t)cloud * m * 3;
-    const int l0 = c * ch, len = min(ch, m - l0);
-    if (tid < len) tile[tid] = make_float4(p2[(l0 + tid) * 3 + 0], p2[(l0 + tid) * 3 + 1], p2[(l0 + tid) * 3 + 2], 0.f);
-    __syncthreads();
+    const int l0 = c * ch, lend = min(m, l0 + ch);          // ch > MC_CH (the scratch-free entry: ch = m): sub-tiles, same lane order
     const int k = rb * AM_ROWS + tid;
-    if (k >= n) return;
-    const float x1 = p1[k * 3 + 0], y1 = p1[k * 3 + 1], z1 = p1[k * 3 + 2];
-    const float* __restrict__ mt = match + (size_t)cloud * n * m + (size_t)l0 * n + k;
+    float x1 = 0.f, y1 = 0.f, z1 = 0.f;
+    if (k < n) { x1 = p1[k * 3 + 0]; y1 = p1[k * 3 + 1]; z1 = p1[k * 3 + 2]; }
     float gx = 0.f, gy = 0.f, gz = 0.f;
+    for (int lt = l0; lt < lend; lt += MC_CH) {
+        const int len = min(MC_CH, lend - lt);
+        if (lt != l0) __syncthreads();
+        if (tid < len) tile[tid] = make_float4(p2[(lt + tid) * 3 + 0], p2[(lt + tid) * 3 + 1], p2[(lt + tid) * 3 + 2], 0.f);
+        __syncthreads();
+        if (k < n) {
+            const float* __restrict__ mt = match + (size_t)cloud * n * m + (size_t)lt * n + k;
 #pragma unroll 8
-    for (int i = 0; i < len; ++i) {
-        const float4 q = tile[i];
-        const float ex = x1 - q.x, ey = y1 - q.y, ez = z1 - q.z;
-        const float d = __builtin_nontemporal_load(mt + (size_t)i * n) * rsqrtf(fmaxf(sqdist3<FMA>(ex, ey, ez), 1e-20f));
-        if constexpr (FMA) { gx = __builtin_fmaf(ex, d, gx); gy = __builtin_fmaf(ey, d, gy); gz = __builtin_fmaf(ez, d, gz); }
-        else { gx += ex * d; gy += ey * d; gz += ez * d; }
+            for (int i = 0; i < len; ++i) {
+                const float4 q = tile[i];
+                const float ex = x1 - q.x, ey = y1 - q.y, ez = z1 - q.z;
+                const float d = __builtin_nontemporal_load(mt + (size_t)i * n) * rsqrtf(fmaxf(sqdist3<FMA>(ex, ey, ez), 1e-20f));
+                if constexpr (FMA) { gx = __builtin_fmaf(ex, d, gx); gy = __builtin_fmaf(ey, d, gy); gz = __builtin_fmaf(ez, d, gz); }
+                else { gx += ex * d; gy += ey * d; gz += ez * d; }
+            }
+        }
     }
-    float* g = part + (((size_t)cloud * gridDim.y + c) * n + k) * 3;
-    g[0] = gx; g[1] = gy; g[2] = gz;
+    if (k < n) {
+        float* g = part + (((size_t)cloud * gridDim.y + c) * n + k) * 3;
+        g[0] = gx; g[1] = gy; g[2] = gz;
+    }
 }
 
 __global__ void match_grad1_combine_kernel(int n, int nc, const float* __restrict__ part, float* __restrict__ grad) {
@@ -437,8 +492,8 @@ DISPU_EXPORT size_t dispu_match_cost_scratch_bytes(int b, int n, int m) {
     return sizeof(float) * (size_t)b * rb * nc;
 }
 
-DISPU_EXPORT int dispu_match_cost(int b, int n, int m, const float* xyz1, const float* xyz2, const float* match,
-                                  float* cost, float* scratch, int arith, void* stream) {
+DISPU_EXPORT int dispu_match_cost_ws(int b, int n, int m, const float* xyz1, const float* xyz2, const float* match,
+                                     float* cost, float* scratch, int arith, void* stream) {
     if (b < 0 || n <= 0 || m <= 0) return (int)hipErrorInvalidValue;
     if (b == 0) return 0;
     if (!scratch) return (int)hipErrorInvalidValue;
@@ -460,8 +515,8 @@ DISPU_EXPORT size_t dispu_match_cost_grad_scratch_bytes(int b, int n, int m) {
     return sizeof(float) * (size_t)b * ((m + ch - 1) / ch) * (size_t)n * 3;
 }
 
-DISPU_EXPORT int dispu_match_cost_grad(int b, int n, int m, const float* xyz1, const float* xyz2, const float* match,
-                                       float* grad1, float* grad2, float* scratch, int arith, void* stream) {
+DISPU_EXPORT int dispu_match_cost_grad_ws(int b, int n, int m, const float* xyz1, const float* xyz2, const float* match,
+                                          float* grad1, float* grad2, float* scratch, int arith, void* stream) {
     if (b < 0 || n <= 0 || m <= 0) return (int)hipErrorInvalidValue;
     if (b == 0) return 0;
     if (!scratch) return (int)hipErrorInvalidValue;
@@ -478,5 +533,38 @@ DISPU_EXPORT int dispu_match_cost_grad(int b, int n, int m, const float* xyz1, c
         hipLaunchKernelGGL((match_grad2_kernel<false>), g2, dim3(256), 0, s, n, m, xyz1, xyz2, match, grad2);
     }
     hipLaunchKernelGGL(match_grad1_combine_kernel, gc, dim3(256), 0, s, n, nc, scratch, grad1);
+    return (int)hipGetLastError();
+}
+
+// ---- the reference's launcher signatures (no scratch argument; ABI version 1 of this library had exactly these) ------------
+// matchcostLauncher(b,n,m,xyz1,xyz2,match,out) / matchcostgradLauncher(b,n,m,xyz1,xyz2,match,grad1,grad2)
+// (tf_approxmatch.cpp:142-143).  Correct without scratch: the cost runs one workgroup per cloud, grad1 with a single partner
+// chunk (its "partial" is the result, written straight into grad1).  The *_ws entries above are the fast paths.
+DISPU_EXPORT int dispu_match_cost(int b, int n, int m, const float* xyz1, const float* xyz2, const float* match, float* cost,
+                                  int arith, void* stream) {
+    if (b < 0 || n <= 0 || m <= 0) return (int)hipErrorInvalidValue;
+    if (b == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    if ((arith & DISPU_ARITH_CONTRACT))
+        hipLaunchKernelGGL((match_cost_cloud_kernel<true>), dim3(b), dim3(AM_ROWS), 0, s, n, m, xyz1, xyz2, match, cost);
+    else
+        hipLaunchKernelGGL((match_cost_cloud_kernel<false>), dim3(b), dim3(AM_ROWS), 0, s, n, m, xyz1, xyz2, match, cost);
+    return (int)hipGetLastError();
+}
+
+DISPU_EXPORT int dispu_match_cost_grad(int b, int n, int m, const float* xyz1, const float* xyz2, const float* match,
+                                       float* grad1, float* grad2, int arith, void* stream) {
+    if (b < 0 || n <= 0 || m <= 0) return (int)hipErrorInvalidValue;
+    if (b == 0) return 0;
+    if (b > 65535) return (int)hipErrorInvalidValue;
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 g1((n + AM_ROWS - 1) / AM_ROWS, 1, b), g2((m + 3) / 4, b);
+    if ((arith & DISPU_ARITH_CONTRACT)) {
+        hipLaunchKernelGGL((match_grad1_tile_kernel<true>), g1, dim3(AM_ROWS), 0, s, n, m, m, xyz1, xyz2, match, grad1);
+        hipLaunchKernelGGL((match_grad2_kernel<true>), g2, dim3(256), 0, s, n, m, xyz1, xyz2, match, grad2);
+    } else {
+        hipLaunchKernelGGL((match_grad1_tile_kernel<false>), g1, dim3(AM_ROWS), 0, s, n, m, m, xyz1, xyz2, match, grad1);
+        hipLaunchKernelGGL((match_grad2_kernel<false>), g2, dim3(256), 0, s, n, m, xyz1, xyz2, match, grad2);
+    }
     return (int)hipGetLastError();
 }

@@ -259,11 +259,11 @@ DISPU_EXPORT int dispu_attention_project(int b, int m, int nk, int d, const floa
         return (int)hipErrorInvalidValue;
     if (b == 0) return 0;
     constexpr size_t bytes = (size_t)(2 * FA_STAGE + FA_D * FA_BPN) * sizeof(float);
-    static bool attr = false;
-    if (!attr) {
+    static DevOnce attr;      
+    if (attr.needed()) {
         DISPU_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(flash_attention_kernel<true>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-        attr = true;
+        attr.done();
     }
     hipLaunchKernelGGL((flash_attention_kernel<true>), dim3((m + 127) / 128, b), dim3(512), bytes, (hipStream_t)stream, m, nk, Q, ldq,
                        K, ldk, V, ldv, scale, Y, ldy, W, bias);

@@ -101,11 +101,11 @@ DISPU_EXPORT int dispu_knn_patch(int b, int n, int m, int k, const float* cloud,
     while (npad < n) npad <<= 1;
     if (npad < 2) npad = 2;
     const size_t bytes = (size_t)npad * 8;
-    static bool attr = false;
-    if (!attr) {
+    static DevOnce attr;      
+    if (attr.needed()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(knn_patch_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
         if (e != hipSuccess) return (int)e;
-        attr = true;
+        attr.done();
     }
     hipLaunchKernelGGL(knn_patch_kernel, dim3(m, b), dim3(256), bytes, (hipStream_t)stream, n, npad, m, k, cloud, queries, idx);
     return (int)hipGetLastError();

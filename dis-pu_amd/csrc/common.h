@@ -4,6 +4,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 
 #define DISPU_EXPORT extern "C" __attribute__((visibility("default")))
 
@@ -28,6 +29,16 @@
 namespace dispu {
 
 constexpr int kWave = 64;
+
+// "done once per DEVICE" flag for hipFuncSetAttribute (function attributes are per device: a process that drives several
+// GPUs must opt every one of them in to > 64 KB of dynamic LDS).  Two threads racing through the first call both set the
+// attribute, which is idempotent.
+struct DevOnce {
+    std::atomic<unsigned long long> mask{0};
+    static int cur() { int d = 0; (void)hipGetDevice(&d); return d & 63; }
+    bool needed() const { return !((mask.load(std::memory_order_acquire) >> cur()) & 1ull); }
+    void done() { mask.fetch_or(1ull << cur(), std::memory_order_release); }
+};
 
 template <bool FMA>
 __device__ __forceinline__ float sqdist3(float dx, float dy, float dz) {

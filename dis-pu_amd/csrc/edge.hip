@@ -290,13 +290,13 @@ DISPU_EXPORT int dispu_edge_dense_conv(int npoints, int n_per_cloud, int C, cons
         if (parts > (gpc + 7) / 8) parts = (gpc + 7) / 8;                 // at least one group per wave
         if (parts < 1) parts = 1;
         const size_t bytes = frag_bytes + feat_bytes;
-        static bool attr = false;
-        if (!attr) {
+        static DevOnce attr;      
+        if (attr.needed()) {
             DISPU_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(edge_dense_conv_mfma_kernel<24, true>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             DISPU_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(edge_dense_conv_mfma_kernel<48, true>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            attr = true;
+            attr.done();
         }
         if (C == 24)
             hipLaunchKernelGGL((edge_dense_conv_mfma_kernel<24, true>), dim3(clouds, parts), dim3(512), bytes, s, npoints, n_per_cloud, F, ldf, idx, ldi, ioff, W0, b0, W1, b1, W2, b2, Y, ldy);

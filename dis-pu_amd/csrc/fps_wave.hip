@@ -494,12 +494,12 @@ template <int P, int PL>
 static int launch_fps_wave4(int b, int n, int m, const float* xyz, int* perm, int* out, int arith, hipStream_t s) {
     const size_t sort_bytes = (size_t)n * 4 + 4096 * 4 + 2048 * 4;
     const size_t bytes = 2 * FW_W * 8 * 4 + (size_t)PL * 3 * FW_BS * 4;
-    static bool attr = false;
-    if (!attr) {
+    static DevOnce attr;      
+    if (attr.needed()) {
         DISPU_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fps_wavesort_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 24576 * 4 + 4096 * 4 + 2048 * 4));
         DISPU_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fps_wave4_kernel<P, PL, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
         DISPU_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fps_wave4_kernel<P, PL, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-        attr = true;
+        attr.done();
     }
     hipLaunchKernelGGL(fps_wavesort_kernel, dim3(b), dim3(1024), sort_bytes, s, n, 64 * (P / 4), xyz, perm);
     DISPU_CHECK_LAUNCH();
@@ -514,12 +514,12 @@ template <int P, int PL>
 static int launch_fps_wave(int b, int n, int m, const float* xyz, int* perm, int* out, int arith, hipStream_t s) {
     const size_t sort_bytes = (size_t)n * 4 + 4096 * 4 + 2048 * 4;
     const size_t bytes = (size_t)FW_BS * P * 4 + 2 * FW_W * 8 * 4 + (size_t)PL * 3 * FW_BS * 4;
-    static bool attr = false;
-    if (!attr) {
+    static DevOnce attr;      
+    if (attr.needed()) {
         DISPU_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fps_wavesort_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 24576 * 4 + 4096 * 4 + 2048 * 4));
         DISPU_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fps_wave_kernel<P, PL, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
         DISPU_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fps_wave_kernel<P, PL, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-        attr = true;
+        attr.done();
     }
     hipLaunchKernelGGL(fps_wavesort_kernel, dim3(b), dim3(1024), sort_bytes, s, n, 64 * P, xyz, perm);
     DISPU_CHECK_LAUNCH();

@@ -361,3 +361,48 @@ DISPU_EXPORT int dispu_group_point_grad(int b, int n, int c, int m, int nsample,
                        grad_out, idx, grad_points);
     return (int)hipGetLastError();
 }
+
+// ---- selection_sort (tf_grouping_g.cu:83-123; optional in the reference: select_top_k is never called by the shipped graph) ----
+// out / outi [b, m, n]: a copy of dist with its first k entries put in place by k rounds of "swap position s with the FIRST
+// minimum of positions s..n-1" (strict <, so the lowest position wins ties and position s itself wins against equal values).
+// The reference gives a row to one thread; here a row belongs to one wave: the lanes scan s..n-1 with a stride of 64, keep the
+// first minimum each, and a DPP arg-min over (ordered value, position) keys -- the position is the tie-break, which is the
+// serial scan's first-minimum rule -- names the winner; lane 0 swaps.  -0.0f is canonicalised to +0.0f in the KEY only (the
+// float compare treats them as equal), the values themselves are moved unchanged.
+namespace dispu {
+__global__ __launch_bounds__(kWave) void selection_sort_kernel(int n, int k, const float* __restrict__ dist, int* __restrict__ outi,
+                                                                float* __restrict__ out) {
+    const size_t row = blockIdx.x;
+    const int lane = threadIdx.x;
+    const float* __restrict__ d = dist + row * n;
+    float* o = out + row * n;
+    int* oi = outi + row * n;
+    for (int s = lane; s < n; s += kWave) { o[s] = d[s]; oi[s] = s; }
+    __syncthreads();                                              // single-wave workgroup: orders the wave's own stores and loads
+    const int rounds = k < n ? k : n;
+    for (int s = 0; s < rounds; ++s) {
+        uint64_t best = ~0ull;
+        for (int t = s + lane; t < n; t += kWave) {
+            const uint64_t key = ((uint64_t)f32_to_ordered(o[t] + 0.0f) << 32) | (uint32_t)t;
+            best = u64_min(best, key);
+        }
+        const uint64_t win = wave_min_u64(best);
+        const int mn = (int)(uint32_t)win;
+        if (lane == 0 && mn != s) {
+            const float tf = o[mn]; o[mn] = o[s]; o[s] = tf;
+            const int ti = oi[mn]; oi[mn] = oi[s]; oi[s] = ti;
+        }
+        __syncthreads();
+    }
+}
+}  // namespace dispu
+
+// selectionSortLauncher(b,n,m,k,dist,outi,out)   tf_grouping.cpp:112,141.
+DISPU_EXPORT int dispu_selection_sort(int b, int n, int m, int k, const float* dist, int* outi, float* out, void* stream) {
+    if (b < 0 || n <= 0 || m < 0 || k <= 0) return (int)hipErrorInvalidValue;
+    const size_t rows = (size_t)b * m;
+    if (rows == 0) return 0;
+    if (!dist || !outi || !out || rows > 0x7fffffffull) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(dispu::selection_sort_kernel, dim3((unsigned)rows), dim3(dispu::kWave), 0, (hipStream_t)stream, n, k, dist, outi, out);
+    return (int)hipGetLastError();
+}

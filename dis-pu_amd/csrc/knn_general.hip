@@ -166,11 +166,11 @@ int knn_general_launch(int mode, int b, int n, int m, int c, int k, long ldp, lo
     const dim3 grid(m, b);
 #define KG_LAUNCH(M)                                                                                                          \
     do {                                                                                                                      \
-        static bool attr = false;                                                                                             \
-        if (!attr) {                                                                                                          \
+        static DevOnce attr;                                                                                                   \
+        if (attr.needed()) {                                                                                                          \
             DISPU_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(knn_general_kernel<M>),                              \
                                           hipFuncAttributeMaxDynamicSharedMemorySize, KG_MAXK * 8 + KG_MAXC * 4));           \
-            attr = true;                                                                                                      \
+            attr.done();                                                                                                      \
         }                                                                                                                     \
         hipLaunchKernelGGL((knn_general_kernel<M>), grid, dim3(256), bytes, st, n, m, c, k, kpad, ldp, ldq, points, queries, \
                            dist, idx, neg, vec4);                                                                             \

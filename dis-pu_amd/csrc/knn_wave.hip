@@ -582,11 +582,11 @@ static int launch_feat_wave(int b, int n, int m, int c, int k, int ldp, int ldq,
     const int qpb = 16;         // 2 queries per wave; the cloud's features are re-staged per workgroup (L2-resident)
     dim3 grid((m + qpb - 1) / qpb, b);
     const size_t lds = (size_t)(CP / 4) * (n + 1) * 16 + (((size_t)n * 4 + 15) & ~15ull) + (R <= 4 ? (size_t)KF_NW * KF_SCRATCH * 8 : (size_t)KF_NW * R * 64 * 8) + (size_t)qpb * (CP + 4) * 4 + (R <= 4 ? (size_t)16 * (64 * R + 4) * 4 + 64 : (size_t)0);
-    static bool attr = false;           // per instantiation: opt in to more than 64 KB of dynamic LDS
-    if (!attr) {
+    static DevOnce attr;                 // per instantiation: opt in to more than 64 KB of dynamic LDS
+    if (attr.needed()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(knn_feat_wave_kernel<R, CP>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return (int)e;
-        attr = true;
+        attr.done();
     }
     hipLaunchKernelGGL((knn_feat_wave_kernel<R, CP>), grid, dim3(64 * KF_NW), lds, st, n, m, c, k, qpb, ldp, ldq, pstride, p, q, dist, idx);
     return (int)hipGetLastError();

@@ -418,11 +418,11 @@ static int launch_epi(const LinearArgs& a, dim3 grid, hipStream_t s) {
     constexpr size_t bytes = LinearLds<BM, BN, BK, TRANSB, EDGE>::BYTES;
     auto kern = linear_mfma_kernel<BM, BN, WM, WN, BK, TRANSB, EDGE, EPI>;
     if (bytes > 64 * 1024) {
-        static bool done = false;       // opt in to > 64 KiB of dynamic LDS once per instantiation
-        if (!done) {
+        static DevOnce done;      // opt in to > 64 KiB of dynamic LDS once per instantiation
+        if (done.needed()) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
             if (e != hipSuccess) return (int)e;
-            done = true;
+            done.done();
         }
     }
     hipLaunchKernelGGL(kern, grid, dim3(64 * (WM * WN + (LinearLds<BM, BN, BK, TRANSB, EDGE>::DMA ? 4 : WM * WN))), bytes, s, a);

@@ -189,10 +189,10 @@ DISPU_EXPORT int dispu_linear_bf16x3(int M, int K, int N, const float* X, long l
         ((((uintptr_t)X) | ((uintptr_t)planes)) & 15))
         return (int)hipErrorInvalidValue;
     if (M == 0) return 0;
-    static bool attr = false;
-    if (!attr) {
+    static DevOnce attr;      
+    if (attr.needed()) {
         DISPU_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)X3_LDS_BYTES));
-        attr = true;
+        attr.done();
     }
     X3Args a{M, N, K, X, ldx, reinterpret_cast<const __bf16*>(planes), bias, act, Y, ldy, R1, ldr1, R2, ldr2};
     hipLaunchKernelGGL(gemm_bf16x3_kernel, dim3((unsigned)((M / X3_BM) * (N / X3_BN))), dim3(256), X3_LDS_BYTES, (hipStream_t)stream, a);

@@ -259,13 +259,13 @@ DISPU_EXPORT int dispu_mlp_chain(long rows, int K0, int N1, int N2, int N3, cons
     ChainArgs a{rows, X, ldx, W1, b1, W2, b2, W3, b3, W4, b4, Y1, ldy1, R, ldr, out, ldo, mode};
     const dim3 grid((unsigned)(rows / MC_BM));
     hipStream_t s = (hipStream_t)stream;
-    static bool attr = false;
-    if (!attr) {
+    static DevOnce attr;      
+    if (attr.needed()) {
         DISPU_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_chain_kernel<256, 128, 256, 64>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)MC_LDS_BYTES));
         DISPU_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_chain_kernel<256, 256, 256, 64>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)MC_LDS_BYTES));
-        attr = true;
+        attr.done();
     }
     if (K0 == 256 && N1 == 128 && N2 == 256 && N3 == 64)
         hipLaunchKernelGGL((mlp_chain_kernel<256, 128, 256, 64>), grid, dim3(512), MC_LDS_BYTES, s, a);

@@ -563,15 +563,15 @@ DISPU_EXPORT int dispu_ps_local(long npoints, int n_per_cloud, int k, int c, con
     if (npoints == 0) return 0;
     static int mode = -1;               // DISPU_PS_LOCAL=0: single-role kernel (A/B tests); default: wave-specialised persistent kernel
     if (mode < 0) { const char* e = getenv("DISPU_PS_LOCAL"); mode = e ? atoi(e) : 1; }
-    static bool attr = false;
-    if (!attr) {
+    static DevOnce attr;      
+    if (attr.needed()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ps_local_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)PL_LDS_BYTES);
         if (e != hipSuccess) return (int)e;
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(ps_local_ws_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)PW_LDS_BYTES);
         if (e != hipSuccess) return (int)e;
-        attr = true;
+        attr.done();
     }
     if (mode == 0) {
         hipLaunchKernelGGL(ps_local_kernel, dim3((unsigned)((npoints + 7) / 8)), dim3(PL_NT), PL_LDS_BYTES, (hipStream_t)stream, npoints,

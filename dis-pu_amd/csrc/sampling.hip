@@ -178,6 +178,101 @@ static bool fps_dense_only() {
     return v;
 }
 
+// the dense (scratch-free for n <= 24576) kernels
+static int fps_dense(int b, int n, int m, const float* inp, float* temp, int* out, int arith, hipStream_t s) {
+    if (n <= 64) return launch_fps_reg<64, 1>(b, n, m, inp, out, arith, s);
+    if (n <= 128) return launch_fps_reg<64, 2>(b, n, m, inp, out, arith, s);
+    if (n <= 256) return launch_fps_reg<64, 4>(b, n, m, inp, out, arith, s);
+    if (n <= 512) return launch_fps_reg<256, 2>(b, n, m, inp, out, arith, s);
+    if (n <= 1024) return launch_fps_reg<256, 4>(b, n, m, inp, out, arith, s);
+    if (n <= 2048) return launch_fps_reg<256, 8>(b, n, m, inp, out, arith, s);
+    if (n <= 4096) return launch_fps_reg<1024, 4>(b, n, m, inp, out, arith, s);
+    if (n <= 8192) return launch_fps_reg<1024, 8>(b, n, m, inp, out, arith, s);
+    if (n <= 16384) return launch_fps_reg<1024, 16>(b, n, m, inp, out, arith, s);
+    if (n <= 24576) return launch_fps_reg<1024, 24>(b, n, m, inp, out, arith, s);
+    if (!temp) return (int)hipErrorInvalidValue;
+    if ((arith & DISPU_ARITH_CONTRACT))
+        hipLaunchKernelGGL((fps_mem_kernel<true>), dim3(b), dim3(1024), 0, s, n, m, inp, temp, out);
+    else
+        hipLaunchKernelGGL((fps_mem_kernel<false>), dim3(b), dim3(1024), 0, s, n, m, inp, temp, out);
+    return (int)hipGetLastError();
+}
+
+// ---- prob_sample: cumulative sums + binary search (tf_sampling_g.cu:7-104) ----------------------------------------------
+// One workgroup per row.  The association of the sums is part of the result (an index flips when a cumulative sum moves by
+// one ulp across r * total), so the kernel keeps the reference's: chunks of 8192 values; per aligned quad
+// (v0, v0+v1, v2+(v0+v1), (v3+v2)+(v0+v1)); the 2048 quad totals through a work-efficient scan in LDS (up-sweep
+// t[((2k+2)<<u)-1] += t[((2k+1)<<u)-1], then down-sweep t[((2k+3)<<u)-1] += t[((2k+2)<<u)-1], a pair taking part iff its
+// target exists); element = (inquad + t[quad-1]) + running; the running total is carried between chunks with its
+// compensation term.  Restated in oracle/dispu_oracle.c:orc_prob_sample.
+constexpr int PSM_CH = 8192, PSM_Q = PSM_CH / 4, PSM_BS = 1024;
+
+__global__ __launch_bounds__(PSM_BS) void prob_cumsum_kernel(int n, const float* __restrict__ inp, float* __restrict__ out) {
+    __shared__ float in4[PSM_CH];
+    __shared__ float tot[PSM_Q];
+    const int tid = threadIdx.x;
+    const float* __restrict__ x = inp + (size_t)blockIdx.x * n;
+    float* __restrict__ cum = out + (size_t)blockIdx.x * n;
+    float running = 0.0f, comp = 0.0f;                  // wave-uniform: every thread tracks the same two values
+    for (int j = 0; j < n; j += PSM_CH) {
+        const int cnt = min(n - j, PSM_CH);
+        const int n24 = (cnt + 3) & ~3, n2 = n24 >> 2;
+        for (int q = tid; q < n2; q += PSM_BS) {
+            const int k = q * 4;
+            if (k + 3 < cnt) {
+                const float v1 = x[j + k];
+                const float v2 = x[j + k + 1] + v1;
+                float v3 = x[j + k + 2];
+                float v4 = x[j + k + 3] + v3;
+                v3 = v3 + v2;
+                v4 = v4 + v2;
+                in4[k] = v1; in4[k + 1] = v2; in4[k + 2] = v3; in4[k + 3] = v4;
+                tot[q] = v4;
+            } else {
+                float v = 0.0f;
+                for (int k2 = k; k2 < n24; ++k2) {
+                    if (k2 < cnt) v = v + x[j + k2];
+                    in4[k2] = v;
+                }
+                tot[q] = v;
+            }
+        }
+        int levels = 0;
+        while ((2 << levels) <= n2) ++levels;
+        for (int u = 0; u < levels; ++u) {
+            __syncthreads();
+            for (int k = tid; k < (n2 >> (u + 1)); k += PSM_BS) tot[((2 * k + 2) << u) - 1] += tot[((2 * k + 1) << u) - 1];
+        }
+        for (int u = levels - 1; u >= 0; --u) {
+            __syncthreads();
+            for (int k = tid; k < ((n2 - (1 << u)) >> (u + 1)); k += PSM_BS) tot[((2 * k + 3) << u) - 1] += tot[((2 * k + 2) << u) - 1];
+        }
+        __syncthreads();
+        for (int k = tid; k < cnt; k += PSM_BS) {
+            float v = in4[k];
+            if (k >= 4) v = v + tot[(k >> 2) - 1];
+            cum[j + k] = v + running;
+        }
+        const float t = tot[n2 - 1] + comp;
+        const float r2 = running + t;
+        comp = t - (r2 - running);
+        running = r2;
+        __syncthreads();
+    }
+}
+
+__global__ void prob_search_kernel(int n, int m, int base, const float* __restrict__ cum, const float* __restrict__ r,
+                                   int* __restrict__ out) {
+    const float* __restrict__ c = cum + (size_t)blockIdx.y * n;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= m) return;
+    const float q = r[(size_t)blockIdx.y * m + j] * c[n - 1];
+    int pos = n - 1;
+    for (int k = base; k >= 1; k >>= 1)
+        if (pos >= k && c[pos - k] >= q) pos -= k;
+    out[(size_t)blockIdx.y * m + j] = pos;
+}
+
 }  // namespace dispu
 
 using namespace dispu;
@@ -187,30 +282,49 @@ DISPU_EXPORT size_t dispu_fps_scratch_bytes(int b, int n, int m) {
     return 0;
 }
 
-DISPU_EXPORT int dispu_fps(int b, int n, int m, const float* inp, float* temp, int* out, int arith, void* stream) {
+DISPU_EXPORT int dispu_fps_ws(int b, int n, int m, const float* inp, float* temp, size_t temp_bytes, int* out, int arith,
+                              void* stream) {
     if (b < 0 || n <= 0 || m <= 0) return (int)hipErrorInvalidValue;
     if (b == 0) return 0;                              // empty tensors carry null pointers
     if (!inp || !out) return (int)hipErrorInvalidValue;
     hipStream_t s = (hipStream_t)stream;
-    if (n <= 64) return launch_fps_reg<64, 1>(b, n, m, inp, out, arith, s);
-    if (n <= 128) return launch_fps_reg<64, 2>(b, n, m, inp, out, arith, s);
-    if (n <= 256) return launch_fps_reg<64, 4>(b, n, m, inp, out, arith, s);
-    if (n <= 512) return launch_fps_reg<256, 2>(b, n, m, inp, out, arith, s);
-    if (n <= 1024) return launch_fps_reg<256, 4>(b, n, m, inp, out, arith, s);
-    if (n <= 2048) return launch_fps_reg<256, 8>(b, n, m, inp, out, arith, s);
-    if (n <= 4096) return launch_fps_reg<1024, 4>(b, n, m, inp, out, arith, s);
-    if (!fps_dense_only()) {                           // without scratch the dense kernels below still answer
+    const size_t need = (size_t)b * n * sizeof(float);
+    if (!temp) temp_bytes = 0;
+    if (n > 4096 && n <= 24576 && !fps_dense_only() && temp_bytes >= need) {   // region skipping needs the b*n-int permutation
         const int r = fps_wave_dispatch(b, n, m, inp, temp, out, arith, s);
         if (r >= 0) return r;
     }
-    if (n <= 8192) return launch_fps_reg<1024, 8>(b, n, m, inp, out, arith, s);
-    if (n <= 16384) return launch_fps_reg<1024, 16>(b, n, m, inp, out, arith, s);
-    if (n <= 24576) return launch_fps_reg<1024, 24>(b, n, m, inp, out, arith, s);
-    if (!temp) return (int)hipErrorInvalidValue;
-    if ((arith & DISPU_ARITH_CONTRACT))
-        hipLaunchKernelGGL((fps_mem_kernel<true>), dim3(b), dim3(1024), 0, s, n, m, inp, temp, out);
-    else
-        hipLaunchKernelGGL((fps_mem_kernel<false>), dim3(b), dim3(1024), 0, s, n, m, inp, temp, out);
+    if (n > 24576 && temp_bytes < need) return (int)hipErrorInvalidValue;       // running distances of the streaming kernel
+    return fps_dense(b, n, m, inp, temp, out, arith, s);
+}
+
+// The reference's launcher signature: its op allocates temp as {32, n} floats whatever b is (tf_sampling.cpp:115), so this entry
+// never touches more than min(b, 32) * n floats of it: batches above 32 clouds run as consecutive groups of 32 on the stream.
+DISPU_EXPORT int dispu_fps(int b, int n, int m, const float* inp, float* temp, int* out, int arith, void* stream) {
+    if (b < 0 || n <= 0 || m <= 0) return (int)hipErrorInvalidValue;
+    for (int lo = 0; lo < b; lo += 32) {
+        const int nb = b - lo < 32 ? b - lo : 32;
+        const int r = dispu_fps_ws(nb, n, m, inp ? inp + (size_t)lo * n * 3 : nullptr, temp,
+                                   temp ? (size_t)nb * n * sizeof(float) : 0, out ? out + (size_t)lo * m : nullptr, arith, stream);
+        if (r != 0) return r;
+    }
+    return 0;
+}
+
+// probsampleLauncher(b,n,m,inp_p,inp_r,temp,out)  tf_sampling.cpp:65,83-89: temp [b, n] receives the cumulative sums.
+DISPU_EXPORT int dispu_prob_sample(int b, int n, int m, const float* inp_p, const float* inp_r, float* temp, int* out,
+                                   void* stream) {
+    if (b < 0 || n <= 0 || m < 0) return (int)hipErrorInvalidValue;
+    if (b == 0) return 0;
+    if (!inp_p || !temp || (m > 0 && (!inp_r || !out))) return (int)hipErrorInvalidValue;
+    if (b > 65535) return (int)hipErrorInvalidValue;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(prob_cumsum_kernel, dim3(b), dim3(PSM_BS), 0, s, n, inp_p, temp);
+    DISPU_CHECK_LAUNCH();
+    if (m == 0) return 0;
+    int base = 1;
+    while (base < n) base <<= 1;
+    hipLaunchKernelGGL(prob_search_kernel, dim3((m + 255) / 256, b), dim3(256), 0, s, n, m, base, temp, inp_r, out);
     return (int)hipGetLastError();
 }
 

@@ -67,6 +67,8 @@ class Generator(object):
             raise NotImplementedError("the shipped generator graph is built for up_ratio 4 (DisPU/configs.py)")
         self.out_num_point = self.num_point * self.up_ratio
         self.device = torch.device(device if device is not None else "cuda:0")
+        if self.device.type == "cuda" and self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
         self.P = {}
         self._ws = {}
         self.profile = None          # set to [] to collect (name, start_event, end_event) per launch

@@ -34,8 +34,8 @@ def match_cost_grad(xyz1, xyz2, match, arith=_lib.ARITH_CONTRACT):
     g2 = torch.empty((b, m, 3), dtype=torch.float32, device=xyz1.device)
     L = _lib.lib()
     scratch = torch.empty((max(L.dispu_match_cost_grad_scratch_bytes(b, n, m) // 4, 1),), dtype=torch.float32, device=xyz1.device)
-    _lib.check(L.dispu_match_cost_grad(b, n, m, _lib.ptr(xyz1), _lib.ptr(xyz2), _lib.ptr(match), _lib.ptr(g1), _lib.ptr(g2),
-                                       _lib.ptr(scratch), int(arith), _lib.stream_ptr(xyz1.device)), "dispu_match_cost_grad")
+    _lib.check(L.dispu_match_cost_grad_ws(b, n, m, _lib.ptr(xyz1), _lib.ptr(xyz2), _lib.ptr(match), _lib.ptr(g1), _lib.ptr(g2),
+                                       _lib.ptr(scratch), int(arith), _lib.stream_ptr(xyz1.device)), "dispu_match_cost_grad_ws")
     return g1, g2
 
 
@@ -47,8 +47,8 @@ class _MatchCost(torch.autograd.Function):
         cost = torch.empty((b,), dtype=torch.float32, device=xyz1.device)
         L = _lib.lib()
         scratch = torch.empty((max(L.dispu_match_cost_scratch_bytes(b, n, m) // 4, 1),), dtype=torch.float32, device=xyz1.device)
-        _lib.check(L.dispu_match_cost(b, n, m, _lib.ptr(xyz1), _lib.ptr(xyz2), _lib.ptr(match), _lib.ptr(cost), _lib.ptr(scratch),
-                                      int(arith), _lib.stream_ptr(xyz1.device)), "dispu_match_cost")
+        _lib.check(L.dispu_match_cost_ws(b, n, m, _lib.ptr(xyz1), _lib.ptr(xyz2), _lib.ptr(match), _lib.ptr(cost), _lib.ptr(scratch),
+                                      int(arith), _lib.stream_ptr(xyz1.device)), "dispu_match_cost_ws")
         ctx.save_for_backward(xyz1, xyz2, match)
         ctx.arith = arith
         return cost

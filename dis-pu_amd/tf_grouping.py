@@ -33,6 +33,22 @@ def query_ball_point(radius, nsample, xyz, new_xyz, arith=_lib.ARITH_CONTRACT):
     return idx, cnt
 
 
+def select_top_k(k, dist):
+    """(k, dist[b,m,n] f32) -> (idx[b,m,n] i32, dist_out[b,m,n] f32): the first k entries of every row are the k SMALLEST
+    distances in ascending order with their positions, the rest is what k rounds of selection sort leave behind
+    (tf_grouping.py:33-42 -> SelectionSort, tf_grouping.cpp:112-143; optional op, unused by the shipped graph; no gradient)."""
+    dist = f32(dist, "dist")
+    req(int(k) > 0, "SelectionSort expects positive k")
+    req(dist.dim() == 3, "SelectionSort expects (b,m,n) dist shape.")
+    b, m, n = dist.shape
+    outi = torch.empty((b, m, n), dtype=torch.int32, device=dist.device)
+    out = torch.empty((b, m, n), dtype=torch.float32, device=dist.device)
+    if b * m * n:
+        _lib.check(_lib.lib().dispu_selection_sort(b, n, m, int(k), _lib.ptr(dist), _lib.ptr(outi), _lib.ptr(out),
+                                                   _lib.stream_ptr(dist.device)), "dispu_selection_sort")
+    return outi, out
+
+
 class _GroupPoint(torch.autograd.Function):
     @staticmethod
     def forward(ctx, points, idx):

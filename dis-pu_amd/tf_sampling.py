@@ -18,8 +18,24 @@ def farthest_point_sample(npoint, inp, arith=_lib.ARITH_CONTRACT):
     L = _lib.lib()
     nbytes = L.dispu_fps_scratch_bytes(b, n, int(npoint))
     temp = torch.empty((nbytes // 4,), dtype=torch.float32, device=inp.device) if nbytes else None
-    _lib.check(L.dispu_fps(b, n, int(npoint), _lib.ptr(inp), _lib.ptr(temp), _lib.ptr(out), int(arith),
-                           _lib.stream_ptr(inp.device)), "dispu_fps")
+    _lib.check(L.dispu_fps_ws(b, n, int(npoint), _lib.ptr(inp), _lib.ptr(temp), nbytes, _lib.ptr(out), int(arith),
+                              _lib.stream_ptr(inp.device)), "dispu_fps_ws")
+    return out
+
+
+def prob_sample(inp, inpr):
+    """(inp[b,ncategory] f32 weights, inpr[b,npoints] f32 uniform randoms) -> [b,npoints] i32   tf_sampling.py:12-20
+    (optional op, unused by the shipped graph; no gradient :21): the index of the first cumulative weight >= r * total."""
+    inp, inpr = f32(inp, "inp"), f32(inpr, "inpr")
+    req(inp.dim() == 2, "ProbSample expects (batch_size,num_choices) inp shape")
+    req(inpr.dim() == 2 and inpr.shape[0] == inp.shape[0], "ProbSample expects (batch_size,num_points) inpr shape")
+    b, n = inp.shape
+    m = inpr.shape[1]
+    req(n > 0, "ProbSample expects (batch_size,num_choices) inp shape")
+    out = torch.empty((b, m), dtype=torch.int32, device=inp.device)
+    temp = torch.empty((b, n), dtype=torch.float32, device=inp.device)      # the op's allocate_temp {b, n}: cumulative sums
+    _lib.check(_lib.lib().dispu_prob_sample(b, n, m, _lib.ptr(inp), _lib.ptr(inpr), _lib.ptr(temp), _lib.ptr(out),
+                                            _lib.stream_ptr(inp.device)), "dispu_prob_sample")
     return out
 
 

@@ -77,6 +77,8 @@ class Trainer(object):
         self.bf16 = dtype == "bf16"
         self.opts = opts if opts is not None else TrainOpts()
         self.device = torch.device(device if device is not None else "cuda:0")
+        if self.device.type == "cuda" and self.device.index is None:       # torch.device("cuda") != torch.device("cuda:0")
+            self.device = torch.device("cuda", torch.cuda.current_device())
         self.up_ratio = int(self.opts.up_ratio)
         if self.up_ratio != 4:
             raise NotImplementedError("the shipped generator graph is built for up_ratio 4")

@@ -43,7 +43,12 @@ extern "C" {
  * used for n <= 1024 (identical results; A/B tests and profiling). */
 #define DISPU_KNN_LANE_PER_QUERY 4
 
-/* Library / ABI version (1 = round 1; 2 = round 2: scratch arguments of dispu_match_cost(_grad), the *_ws k-NN entries, dispu_attention_project, the bf16 GEMMs). */
+/* Library / ABI version.  1 = round 1.  2 = round 2: the *_ws k-NN entries, dispu_attention_project, the bf16 GEMMs (and a
+ * scratch argument inserted into dispu_match_cost(_grad) under the same names -- an in-place signature change, withdrawn in 3).
+ * 3 = round 3: dispu_match_cost / dispu_match_cost_grad are the reference's launcher signatures again (as in version 1, no
+ * scratch) and the scratch-taking fast paths are dispu_match_cost_ws / dispu_match_cost_grad_ws; dispu_fps_ws (scratch with an
+ * explicit size), dispu_prob_sample, dispu_selection_sort; the fused training kernels.  A symbol never changes signature again:
+ * new forms get new names. */
 int dispu_version(void);
 /* hipGetErrorString for the codes returned below. */
 const char* dispu_error_string(int code);
@@ -51,10 +56,22 @@ const char* dispu_error_string(int code);
 /* ---- tf_ops/sampling ------------------------------------------------------------------------ */
 
 /* farthestpointsamplingLauncher(b,n,m,inp,temp,out)   tf_ops/sampling/tf_sampling.cpp:94,118;
- * kernel tf_sampling_g.cu:105-170.  out[b,m] int32; out[:,0] = 0.  `temp` ([b,n] floats) is only
- * touched when n > 24576 (dispu_fps_scratch_bytes says how much); pass NULL otherwise. */
+ * kernel tf_sampling_g.cu:105-170.  out[b,m] int32; out[:,0] = 0.
+ * dispu_fps keeps the reference launcher's contract for `temp`: the op allocates it as {32, n} floats whatever b is
+ * (tf_sampling.cpp:115), so this entry never touches more than min(b,32)*n floats of it -- batches above 32 clouds run as
+ * consecutive groups of 32 on the stream.  temp may be NULL for n <= 24576 (the dense register kernels need none).
+ * dispu_fps_ws is the same op with the scratch size stated: `temp_bytes` >= dispu_fps_scratch_bytes(b,n,m) (= 4*b*n for
+ * 4096 < n <= 24576 with m >= 64: the Morton-sorted permutation of the region-skipping kernels, csrc/fps_wave.hip; and for
+ * n > 24576: the running distances) selects the fastest kernel; with less (or NULL) the dense kernels answer (n <= 24576)
+ * with identical results, and n > 24576 is refused (hipErrorInvalidValue) instead of writing out of bounds. */
 size_t dispu_fps_scratch_bytes(int b, int n, int m);
 int dispu_fps(int b, int n, int m, const float* inp, float* temp, int* out, int arith, void* stream);
+int dispu_fps_ws(int b, int n, int m, const float* inp, float* temp, size_t temp_bytes, int* out, int arith, void* stream);
+
+/* probsampleLauncher(b,n,m,inp_p,inp_r,temp,out)   tf_sampling.cpp:65,83-89; kernels tf_sampling_g.cu:7-104 (cumulative sums
+ * of the weights inp_p[b,n] into temp[b,n], then out[b,m] = the first position whose cumulative weight is >= inp_r * total).
+ * Optional op of the reference (never called by the shipped graph).  The association of the sums is the reference's. */
+int dispu_prob_sample(int b, int n, int m, const float* inp_p, const float* inp_r, float* temp, int* out, void* stream);
 
 /* gatherpointLauncher(b,n,m,inp,idx,out)   tf_sampling.cpp:125; kernel tf_sampling_g.cu:172-181. */
 int dispu_gather_point(int b, int n, int m, const float* inp, const int* idx, float* out, void* stream);
@@ -77,6 +94,11 @@ int dispu_group_point(int b, int n, int c, int m, int nsample, const float* poin
 /* groupPointGradLauncher(b,n,c,m,nsample,grad_out,idx,grad_points)   tf_grouping.cpp:177,208; kernel :61-78. */
 int dispu_group_point_grad(int b, int n, int c, int m, int nsample, const float* grad_out, const int* idx,
                            float* grad_points, void* stream);
+
+/* selectionSortLauncher(b,n,m,k,dist,outi,out)   tf_grouping.cpp:112,141; kernel tf_grouping_g.cu:83-123.  dist/outi/out [b,m,n]:
+ * out is a copy of dist whose first k entries per row are the k smallest in ascending order (k rounds of selection sort: swap
+ * position s with the FIRST minimum of positions s..n-1), outi the matching positions.  Optional op of the reference. */
+int dispu_selection_sort(int b, int n, int m, int k, const float* dist, int* outi, float* out, void* stream);
 
 /* tf_grouping.knn_point(k, xyz1[b,n,c], xyz2[b,m,c]) -> (val = -d2 [b,m,k], idx [b,m,k])
  * tf_ops/grouping/tf_grouping.py:116-141 (pure TF: broadcast-subtract, reduce_sum, top_k).  Any k <= n, c up to 4096 (k <= 32 and c <= 128: register-resident
@@ -149,15 +171,22 @@ size_t dispu_approx_match_scratch_bytes(int b, int n, int m);
 int dispu_approx_match(int b, int n, int m, const float* xyz1, const float* xyz2, float* match, float* temp, int arith,
                        void* stream);
 /* matchcostLauncher(b,n,m,xyz1,xyz2,match,out)   tf_approxmatch.cpp:142; kernel tf_approxmatch_g.cu:183-228.
- * `scratch`: dispu_match_cost_scratch_bytes(b,n,m) bytes (one partial per (256 x 128) tile of `match`). */
+ * dispu_match_cost: the launcher's own signature, no scratch (one workgroup per cloud, like the reference's kernel).
+ * dispu_match_cost_ws: the fast path; `scratch`: dispu_match_cost_scratch_bytes(b,n,m) bytes (one partial per tile of `match`).
+ * The two differ in the association of the sum only (both within 1e-5 of the reference's). */
+int dispu_match_cost(int b, int n, int m, const float* xyz1, const float* xyz2, const float* match, float* cost, int arith,
+                     void* stream);
 size_t dispu_match_cost_scratch_bytes(int b, int n, int m);
-int dispu_match_cost(int b, int n, int m, const float* xyz1, const float* xyz2, const float* match, float* cost,
-                     float* scratch, int arith, void* stream);
+int dispu_match_cost_ws(int b, int n, int m, const float* xyz1, const float* xyz2, const float* match, float* cost,
+                        float* scratch, int arith, void* stream);
 /* matchcostgradLauncher(b,n,m,xyz1,xyz2,match,grad1,grad2)   tf_approxmatch.cpp:143; kernels :229-295.
- * `scratch`: dispu_match_cost_grad_scratch_bytes(b,n,m) bytes (grad1 partials per chunk of 128 cloud-2 points). */
-size_t dispu_match_cost_grad_scratch_bytes(int b, int n, int m);
+ * dispu_match_cost_grad: the launcher's signature, no scratch.  dispu_match_cost_grad_ws: grad1 as partial sums per chunk of
+ * cloud-2 points (`scratch`: dispu_match_cost_grad_scratch_bytes(b,n,m) bytes), more workgroups for small b. */
 int dispu_match_cost_grad(int b, int n, int m, const float* xyz1, const float* xyz2, const float* match, float* grad1,
-                          float* grad2, float* scratch, int arith, void* stream);
+                          float* grad2, int arith, void* stream);
+size_t dispu_match_cost_grad_scratch_bytes(int b, int n, int m);
+int dispu_match_cost_grad_ws(int b, int n, int m, const float* xyz1, const float* xyz2, const float* match, float* grad1,
+                             float* grad2, float* scratch, int arith, void* stream);
 
 /* ---- per-point MLP stacks (Common/tf_util.py conv1d/conv2d 1x1, Common/ops.py blocks) --------------
  * The reference builds these from TensorFlow core ops (conv2d -> bias_add -> relu, matmul, softmax,

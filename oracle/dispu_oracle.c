@@ -68,11 +68,25 @@ static inline float pinned_exp(float x) {
 
 ORC_API int orc_version(void) { return 1; }
 
+/* Thread policy (cpu_baseline only; results never depend on it): the loops below run ONE CLOUD PER THREAD, the way the
+ * reference parallelises its only multi-threaded CPU op (libs/nearest_neighbors/knn_.cxx:108, "#pragma omp parallel for"
+ * over the batch).  A region never gets more threads than it has clouds: waking 256 hardware threads for a 32-cloud
+ * loop costs more than the loop (round-2 measurement: "all cores" slower than one thread). */
+int orc_g_threads = 0;          /* 0 = OpenMP default; shared with mlp_oracle.c */
+int orc_nt(long items) {
+#ifdef _OPENMP
+    int t = orc_g_threads > 0 ? orc_g_threads : omp_get_max_threads();
+#else
+    int t = 1;
+#endif
+    if (items < t) t = items > 0 ? (int)items : 1;
+    return t;
+}
+
 ORC_API void orc_set_threads(int t) {
+    orc_g_threads = t > 0 ? t : 0;
 #ifdef _OPENMP
     if (t > 0) omp_set_num_threads(t);
-#else
-    (void)t;
 #endif
 }
 
@@ -89,7 +103,7 @@ ORC_API void orc_set_threads(int t) {
 ORC_API void orc_fps(int b, int n, int m, const float *xyz, int *idx, int contract, int bs) {
     if (m <= 0 || n <= 0) return;
     if (bs <= 0) bs = 512;
-#pragma omp parallel for schedule(dynamic)
+#pragma omp parallel for schedule(dynamic) num_threads(orc_nt(b))
     for (int i = 0; i < b; ++i) {
         const float *p = xyz + (size_t)i * n * 3;
         float *temp = (float *)malloc(sizeof(float) * (size_t)n);
@@ -151,7 +165,7 @@ ORC_API void orc_gather_point_grad(int b, int n, int m, const float *out_g, cons
 ORC_API void orc_query_ball(int b, int n, int m, const float *radius, int nsample, const float *xyz1,
                             const float *xyz2, int *idx, int *pts_cnt, int contract) {
     const float r = radius[0];
-#pragma omp parallel for schedule(dynamic)
+#pragma omp parallel for schedule(dynamic) num_threads(orc_nt(b))
     for (int i = 0; i < b; ++i) {
         const float *p1 = xyz1 + (size_t)i * n * 3;
         const float *p2 = xyz2 + (size_t)i * m * 3;
@@ -217,7 +231,7 @@ static inline void topk_insert(float *bd, int *bi, int k, float d, int id) {
  * Requires k <= n.  dist may be NULL. */
 ORC_API void orc_knn_xyz(int b, int n, int m, int k, const float *support, const float *query, int *idx,
                          float *dist, int contract) {
-#pragma omp parallel for schedule(dynamic)
+#pragma omp parallel for schedule(dynamic) num_threads(orc_nt(b))
     for (int i = 0; i < b; ++i) {
         const float *s = support + (size_t)i * n * 3;
         const float *q = query + (size_t)i * m * 3;
@@ -246,7 +260,7 @@ ORC_API void orc_knn_xyz(int b, int n, int m, int k, const float *support, const
  * ("parity unpinned" at that boundary); left-to-right is the restated order. */
 ORC_API void orc_knn_point(int b, int n, int m, int c, int k, const float *xyz1, const float *xyz2, float *val,
                            int *idx) {
-#pragma omp parallel for schedule(dynamic)
+#pragma omp parallel for schedule(dynamic) num_threads(orc_nt(b))
     for (int i = 0; i < b; ++i) {
         float *bd = (float *)malloc(sizeof(float) * k);
         int *bi = (int *)malloc(sizeof(int) * k);
@@ -276,7 +290,7 @@ ORC_API void orc_knn_point(int b, int n, int m, int c, int k, const float *xyz1,
  * reduce_sum order is not pinned in the reference ("parity unpinned"). */
 ORC_API void orc_knn_feat(int b, int n, int m, int c, int k, const float *points, const float *queries,
                           float *dist, int *idx) {
-#pragma omp parallel for schedule(dynamic)
+#pragma omp parallel for schedule(dynamic) num_threads(orc_nt(b))
     for (int i = 0; i < b; ++i) {
         float *rp = (float *)malloc(sizeof(float) * n);
         float *bd = (float *)malloc(sizeof(float) * k);
@@ -318,7 +332,7 @@ ORC_API void orc_knn_feat(int b, int n, int m, int c, int k, const float *points
  * then report idx 0 and dist = (float)1e40 = +inf in the reference as well. */
 ORC_API void orc_three_nn(int b, int n, int m, const float *xyz1, const float *xyz2, float *dist, int *idx,
                           int contract) {
-#pragma omp parallel for schedule(dynamic)
+#pragma omp parallel for schedule(dynamic) num_threads(orc_nt(b))
     for (int i = 0; i < b; ++i) {
         const float *p1 = xyz1 + (size_t)i * n * 3;
         const float *p2 = xyz2 + (size_t)i * m * 3;
@@ -379,7 +393,7 @@ ORC_API void orc_three_interpolate_grad(int b, int n, int c, int m, const float 
  * lowest index.  Both directions, like NmDistanceKernelLauncher :128-131. */
 static void nnsearch_dir(int b, int n, int m, const float *xyz1, const float *xyz2, float *dist, int *idx,
                          int contract) {
-#pragma omp parallel for schedule(dynamic)
+#pragma omp parallel for schedule(dynamic) num_threads(orc_nt(b))
     for (int i = 0; i < b; ++i)
         for (int j = 0; j < n; ++j) {
             const float *p = xyz1 + ((size_t)i * n + j) * 3;
@@ -457,7 +471,7 @@ ORC_API void orc_approx_match_chunked(int b, int n, int m, const float *xyz1, co
     const float multiR = (n >= m) ? (float)(n / m) : 1.0f;
     const int seq = chunk <= 0;                 /* sequential: pass 1's chain starts at 1e-9f, as the reference's does */
     if (seq) chunk = (n > m ? n : m);
-#pragma omp parallel for schedule(dynamic)
+#pragma omp parallel for schedule(dynamic) num_threads(orc_nt(b))
     for (int i = 0; i < b; ++i) {
         const float *p1 = xyz1 + (size_t)i * n * 3;
         const float *p2 = xyz2 + (size_t)i * m * 3;
@@ -537,7 +551,7 @@ ORC_API void orc_approx_match(int b, int n, int m, const float *xyz1, const floa
 ORC_API void orc_match_cost(int b, int n, int m, const float *xyz1, const float *xyz2, const float *match,
                             float *cost, int contract, int bs) {
     if (bs <= 0) bs = 512;
-#pragma omp parallel for schedule(dynamic)
+#pragma omp parallel for schedule(dynamic) num_threads(orc_nt(b))
     for (int i = 0; i < b; ++i) {
         const float *p1 = xyz1 + (size_t)i * n * 3;
         const float *p2 = xyz2 + (size_t)i * m * 3;
@@ -566,7 +580,7 @@ ORC_API void orc_match_cost(int b, int n, int m, const float *xyz1, const float 
 ORC_API void orc_match_cost_grad(int b, int n, int m, const float *xyz1, const float *xyz2, const float *match,
                                  float *grad1, float *grad2, int contract) {
     const int bs = 256;
-#pragma omp parallel for schedule(dynamic)
+#pragma omp parallel for schedule(dynamic) num_threads(orc_nt(b))
     for (int i = 0; i < b; ++i) {
         const float *p1 = xyz1 + (size_t)i * n * 3;
         const float *p2 = xyz2 + (size_t)i * m * 3;
@@ -623,4 +637,76 @@ ORC_API void orc_selection_sort(int b, int n, int m, int k, const float *dist, i
             }
         }
     }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * prob_sample (optional / dead in the reference graph; boundary completeness).
+ * Restates probsampleLauncher = cumsumKernel + binarysearchKernel, tf_ops/sampling/tf_sampling_g.cu:7-104.
+ *   cumulative sums of inp[b, n] in chunks of 8192 values (:8,14): inside a chunk every aligned quad is summed as
+ *   (v0, v0+v1, v2+(v0+v1), (v3+v2)+(v0+v1)) (:19-33; a ragged last quad sequentially from 0, :35-44), the quad totals go
+ *   through a work-efficient scan -- up-sweep: total[((2k+2)<<u)-1] += total[((2k+1)<<u)-1] (:47-56), down-sweep:
+ *   total[((2k+3)<<u)-1] += total[((2k+2)<<u)-1] for u descending (:57-67); a pair takes part iff its target index exists --
+ *   element j of the chunk is then (inquad[j] + total[j/4 - 1]) + runningsum (:69-80), and the running sum is carried from
+ *   chunk to chunk with a compensation term (:81-84).  The steps of one level touch disjoint pairs, so executing them one
+ *   after the other gives the parallel kernel's values.  temp = the cumulative sums (the op's allocate_temp {b,n}).
+ *   search (:90-104): q = r * cum[n-1]; idx = the first position whose cumulative sum is >= q, found by descending
+ *   power-of-two steps from n-1.
+ * PARITY UNPINNED against the .cu (no CUDA here, no CPU twin): self-checks in tests/ (cumsum within fp32 rounding of a
+ * float64 cumsum; the result equals numpy.searchsorted on temp).
+ * ------------------------------------------------------------------------------------------ */
+ORC_API void orc_prob_sample(int b, int n, int m, const float *inp, const float *inpr, float *temp, int *out) {
+    enum { CH = 8192 };
+    float *in4 = (float *)malloc(sizeof(float) * CH);
+    float *tot = (float *)malloc(sizeof(float) * (CH / 4));
+    for (int i = 0; i < b; ++i) {
+        const float *x = inp + (size_t)i * n;
+        float *cum = temp + (size_t)i * n;
+        float running = 0.0f, comp = 0.0f;
+        for (int j = 0; j < n; j += CH) {
+            const int cnt = n - j < CH ? n - j : CH;
+            const int n24 = (cnt + 3) & ~3, n2 = n24 >> 2;
+            for (int k = 0; k < cnt; k += 4) {
+                if (k + 3 < cnt) {
+                    const float v1 = x[j + k];
+                    const float v2 = x[j + k + 1] + v1;
+                    float v3 = x[j + k + 2];
+                    float v4 = x[j + k + 3] + v3;
+                    v3 = v3 + v2;
+                    v4 = v4 + v2;
+                    in4[k] = v1; in4[k + 1] = v2; in4[k + 2] = v3; in4[k + 3] = v4;
+                    tot[k >> 2] = v4;
+                } else {
+                    float v = 0.0f;
+                    for (int k2 = k; k2 < cnt; ++k2) { v = v + x[j + k2]; in4[k2] = v; }
+                    for (int k2 = cnt; k2 < n24; ++k2) in4[k2] = v;
+                    tot[k >> 2] = v;
+                }
+            }
+            int u = 0;
+            for (; (2 << u) <= n2; ++u)
+                for (int k = 0; k < (n2 >> (u + 1)); ++k) tot[(((k << 1) + 2) << u) - 1] += tot[(((k << 1) + 1) << u) - 1];
+            for (--u; u >= 0; --u)
+                for (int k = 0; k < ((n2 - (1 << u)) >> (u + 1)); ++k) tot[(((k << 1) + 3) << u) - 1] += tot[(((k << 1) + 2) << u) - 1];
+            for (int k = 0; k < cnt; ++k) {
+                float v = in4[k];
+                if (k >= 4) v = v + tot[(k >> 2) - 1];
+                cum[j + k] = v + running;
+            }
+            const float t = tot[n2 - 1] + comp;
+            const float r2 = running + t;
+            comp = t - (r2 - running);
+            running = r2;
+        }
+        int base = 1;
+        while (base < n) base <<= 1;
+        for (int jq = 0; jq < m; ++jq) {
+            const float q = inpr[(size_t)i * m + jq] * cum[n - 1];
+            int r = n - 1;
+            for (int k = base; k >= 1; k >>= 1)
+                if (r >= k && cum[r - k] >= q) r -= k;
+            out[(size_t)i * m + jq] = r;
+        }
+    }
+    free(in4);
+    free(tot);
 }

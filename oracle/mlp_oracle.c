@@ -17,11 +17,13 @@
 
 #define ORC_API __attribute__((visibility("default")))
 
+int orc_nt(long items);     /* dispu_oracle.c: min(configured threads, items) */
+
 /* y[r, 0:n] (row stride ldy) = act( x[r, 0:k] (row stride ldx) . w[k, n] + bias ), act: 0 none, 1 relu.
  * bias may be NULL (no add at all, the raw chain). */
 ORC_API void orc_linear(long m, int k, int n, const float *x, long ldx, const float *w, const float *bias, int act,
                         float *y, long ldy) {
-#pragma omp parallel
+#pragma omp parallel num_threads(orc_nt(m / 16))
     {
         float *acc = (float *)malloc(sizeof(float) * (size_t)n);
 #pragma omp for schedule(static)
@@ -48,7 +50,7 @@ ORC_API void orc_linear(long m, int k, int n, const float *x, long ldx, const fl
 /* c[b, i, j] = chain_k a[b, i, k] * bt[b, j, k]   (A . B^T per batch; the attention logits
  * Q.K^T of PointNonLocalCell, Common/ops.py:326) */
 ORC_API void orc_matmul_nt(int b, int m, int n, int k, const float *a, const float *bt, float *c) {
-#pragma omp parallel for collapse(2) schedule(static)
+#pragma omp parallel for collapse(2) schedule(static) num_threads(orc_nt((long)b * m / 16))
     for (int bb = 0; bb < b; ++bb)
         for (int i = 0; i < m; ++i) {
             const float *ar = a + ((size_t)bb * m + i) * k;
@@ -63,8 +65,9 @@ ORC_API void orc_matmul_nt(int b, int m, int n, int k, const float *a, const flo
 
 /* c[b, i, j] = chain_k a[b, i, k] * bm[b, k, j]   (A . B per batch: attention . V, ops.py:339, and the
  * per-point feature x weight product of PointShuffle2, ops.py:1066-1067) */
+static long bb_items(long b, int m) { return m >= 16 ? b : b / 16; }
 ORC_API void orc_matmul_nn(long b, int m, int n, int k, const float *a, const float *bm, float *c) {
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(orc_nt(bb_items(b, m)))
     for (long bb = 0; bb < b; ++bb)
         for (int i = 0; i < m; ++i) {
             const float *ar = a + ((size_t)bb * m + i) * k;

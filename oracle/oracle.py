@@ -55,6 +55,17 @@ def farthest_point_sample(npoint, inp, contract=1, block=512):
     return out
 
 
+def prob_sample(inp, inpr, return_temp=False):
+    """tf_sampling.prob_sample (tf_sampling.py:12-27): inp [b, ncategory] weights, inpr [b, npoints] uniform randoms."""
+    inp, inpr = _f(inp), _f(inpr)
+    b, n = inp.shape
+    m = inpr.shape[1]
+    temp = np.empty((b, n), np.float32)
+    out = np.empty((b, m), np.int32)
+    lib().orc_prob_sample(b, n, m, _p(inp), _p(inpr), _p(temp), _p(out))
+    return (out, temp) if return_temp else out
+
+
 def gather_point(inp, idx):
     inp, idx = _f(inp), _i(idx)
     b, n, _ = inp.shape

@@ -600,3 +600,131 @@ def test_knn_point_2_chunked_path(ops, dev, n, m, c, k):
     d2, i2 = ops["G"].knn_point_2(k, T(a, dev), T(q, dev))
     od, oi2 = O.knn_point_2(k, a, q)
     assert np.array_equal(N(i2), oi2) and np.array_equal(N(d2), od)
+
+
+# ---------------------------------------------------------------- round 3: optional ops, reference-signature entries ----
+def test_select_top_k_vs_reference_golden_and_oracle(ops, dev, golden_dir):
+    """tf_grouping.select_top_k (SelectionSort): the reference's own known answer (selection_sort.cpp:65-94, golden generated by
+    the compiled reference) and seeded rows with ties / negative zero / k >= n against the oracle, bit for bit."""
+    z = g(golden_dir, "ref_selection_sort.npz")
+    oi, o = ops["G"].select_top_k(int(z["k"]), T(z["dist"], dev))
+    assert np.array_equal(N(oi), z["outi"]) and np.array_equal(N(o), z["out"])
+    rng = np.random.default_rng(5)
+    for (b, m, n, k) in [(2, 3, 1, 1), (1, 5, 7, 3), (3, 17, 64, 16), (2, 9, 200, 5), (1, 4, 1000, 40), (2, 2, 130, 500)]:
+        d = rng.random((b, m, n)).astype(np.float32)
+        d[..., ::3] = np.round(d[..., ::3], 1)                 # plenty of exact ties: the FIRST minimum must win
+        if n > 4:
+            d[0, 0, 1], d[0, 0, 3] = 0.0, -0.0                # -0.0 == 0.0 for the compare: position 1 wins, the values move as they are
+        oi, o = ops["G"].select_top_k(k, T(d, dev))
+        ri, ro = O.select_top_k(k, d)
+        assert np.array_equal(N(oi), ri), (b, m, n, k)
+        assert np.array_equal(N(o).view(np.uint32), ro.view(np.uint32)), (b, m, n, k)
+    with pytest.raises(ValueError):
+        ops["G"].select_top_k(0, T(np.zeros((1, 1, 4), np.float32), dev))
+
+
+@pytest.mark.parametrize("b,n,m", [(1, 1, 5), (2, 2, 3), (3, 3, 9), (2, 5, 40), (2, 64, 100), (3, 1000, 257), (2, 8192, 300), (2, 8193, 300),
+                                   (1, 20000, 1000), (2, 16387, 64)])
+def test_prob_sample_index_exact(ops, dev, b, n, m):
+    """tf_sampling.prob_sample: cumulative sums bit-identical to the oracle's restatement of cumsumKernel's association (chunks
+    of 8192, quads, work-efficient scan, compensated carry), indices exact; plus oracle-independent checks: the sums are within
+    fp32 rounding of a float64 cumsum and the indices are numpy.searchsorted on them."""
+    from dispu_amd import _lib
+    rng = np.random.default_rng(n * 7 + m)
+    w = rng.random((b, n)).astype(np.float32)
+    r = rng.random((b, m)).astype(np.float32)
+    r[:, 0], r[:, -1] = 0.0, 1.0
+    ro, rt = O.prob_sample(w, r, return_temp=True)
+    out = ops["S"].prob_sample(T(w, dev), T(r, dev))
+    assert np.array_equal(N(out), ro)
+    L = _lib.lib()
+    tw, tr = T(w, dev), T(r, dev)
+    temp = torch.empty((b, n), dtype=torch.float32, device=dev)
+    o2 = torch.empty((b, m), dtype=torch.int32, device=dev)
+    _lib.check(L.dispu_prob_sample(b, n, m, tw.data_ptr(), tr.data_ptr(), temp.data_ptr(), o2.data_ptr(), _lib.stream_ptr(dev)), "prob_sample")
+    assert np.array_equal(N(temp), rt) and np.array_equal(N(o2), ro)
+    ref = np.cumsum(w.astype(np.float64), axis=1)
+    assert np.abs(N(temp) - ref).max() <= 4e-7 * ref.max()
+    for i in range(b):
+        q = r[i] * N(temp)[i, -1]
+        assert np.array_equal(N(o2)[i], np.minimum(np.searchsorted(N(temp)[i], q, "left"), n - 1))
+
+
+def test_fps_reference_signature_with_reference_sized_temp(dev):
+    """dispu_fps keeps the reference launcher's contract: temp is the op's {32, n} allocation (tf_sampling.cpp:115) whatever b
+    is.  b = 40 clouds at a region-skipping size: nothing behind 32*n floats is written (canary), indices equal the oracle's and
+    dispu_fps_ws's (full-size scratch, too-small scratch, no scratch)."""
+    from dispu_amd import _lib
+    L = _lib.lib()
+    b, n, m = 40, 5000, 70
+    x = np.random.default_rng(3).random((b, n, 3)).astype(np.float32)
+    tx = T(x, dev)
+    want = O.farthest_point_sample(m, x, contract=CONTRACT)
+    temp = torch.full((32 * n + 4096,), -7.0, dtype=torch.float32, device=dev)
+    out = torch.full((b, m), -1, dtype=torch.int32, device=dev)
+    _lib.check(L.dispu_fps(b, n, m, tx.data_ptr(), temp.data_ptr(), out.data_ptr(), CONTRACT, _lib.stream_ptr(dev)), "dispu_fps")
+    assert np.array_equal(N(out), want)
+    assert bool((temp[32 * n:] == -7.0).all()), "dispu_fps wrote behind the reference's {32, n} temp"
+    need = L.dispu_fps_scratch_bytes(b, n, m)
+    assert need == b * n * 4
+    for nbytes in (need, need - 4, 0):
+        sc = torch.full((need // 4 + 1024,), -7.0, dtype=torch.float32, device=dev)
+        out = torch.full((b, m), -1, dtype=torch.int32, device=dev)
+        _lib.check(L.dispu_fps_ws(b, n, m, tx.data_ptr(), sc.data_ptr() if nbytes else None, nbytes, out.data_ptr(), CONTRACT,
+                                  _lib.stream_ptr(dev)), "dispu_fps_ws")
+        assert np.array_equal(N(out), want), nbytes
+        assert bool((sc[need // 4:] == -7.0).all())
+        if nbytes < need:
+            assert bool((sc == -7.0).all()), "a scratch smaller than dispu_fps_scratch_bytes must not be touched"
+    # n > 24576 needs the running distances: refused without them instead of writing out of bounds
+    big = torch.rand((1, 25000, 3), device=dev)
+    o = torch.empty((1, 8), dtype=torch.int32, device=dev)
+    assert L.dispu_fps_ws(1, 25000, 8, big.data_ptr(), None, 0, o.data_ptr(), CONTRACT, _lib.stream_ptr(dev)) != 0
+
+
+@pytest.mark.parametrize("b,n,m", [(2, 300, 200), (1, 1024, 1024), (3, 129, 513), (1, 2048, 700)])
+def test_match_cost_reference_signature_entries(dev, b, n, m):
+    """dispu_match_cost / dispu_match_cost_grad (the launcher's own signature, no scratch) against the *_ws fast paths and the
+    oracle: cost 1e-5 relative, gradients 3e-5 absolute (grad2 and grad1-per-lane sums are the same arithmetic -> equal)."""
+    from dispu_amd import _lib
+    L = _lib.lib()
+    x1, x2 = synth_patches(b, n, seed=n), synth_patches(b, m, seed=m + 3)
+    mo = O.approx_match(x1, x2)
+    t1, t2, tm = T(x1, dev), T(x2, dev), T(mo, dev)
+    st = _lib.stream_ptr(dev)
+    cost = torch.empty((b,), dtype=torch.float32, device=dev)
+    _lib.check(L.dispu_match_cost(b, n, m, t1.data_ptr(), t2.data_ptr(), tm.data_ptr(), cost.data_ptr(), CONTRACT, st), "match_cost")
+    sc = torch.empty((max(L.dispu_match_cost_scratch_bytes(b, n, m) // 4, 1),), dtype=torch.float32, device=dev)
+    cost_ws = torch.empty((b,), dtype=torch.float32, device=dev)
+    _lib.check(L.dispu_match_cost_ws(b, n, m, t1.data_ptr(), t2.data_ptr(), tm.data_ptr(), cost_ws.data_ptr(), sc.data_ptr(), CONTRACT, st),
+               "match_cost_ws")
+    co = O.match_cost(x1, x2, mo)
+    assert np.allclose(N(cost), co, rtol=1e-5) and np.allclose(N(cost_ws), co, rtol=1e-5)
+    g1, g2 = torch.empty((b, n, 3), device=dev), torch.empty((b, m, 3), device=dev)
+    _lib.check(L.dispu_match_cost_grad(b, n, m, t1.data_ptr(), t2.data_ptr(), tm.data_ptr(), g1.data_ptr(), g2.data_ptr(), CONTRACT, st),
+               "match_cost_grad")
+    sg = torch.empty((max(L.dispu_match_cost_grad_scratch_bytes(b, n, m) // 4, 1),), dtype=torch.float32, device=dev)
+    h1, h2 = torch.empty((b, n, 3), device=dev), torch.empty((b, m, 3), device=dev)
+    _lib.check(L.dispu_match_cost_grad_ws(b, n, m, t1.data_ptr(), t2.data_ptr(), tm.data_ptr(), h1.data_ptr(), h2.data_ptr(), sg.data_ptr(),
+                                          CONTRACT, st), "match_cost_grad_ws")
+    o1, o2 = O.match_cost_grad(x1, x2, mo)
+    assert np.allclose(N(g1), o1, atol=3e-5) and np.allclose(N(g2), o2, atol=3e-5)
+    assert np.allclose(N(h1), o1, atol=3e-5) and np.array_equal(N(h2), N(g2))
+
+
+def test_approx_match_4096_against_the_sequential_order(ops, dev):
+    """the 2-D tiled auction sums in chunks of 128 partners; its bit-parity oracle (chunk = 128) is the same
+    restatement.  Tie it to the REFERENCE's sequential order (oracle chunk = 0 = tf_approxmatch_g.cu's one chain per thread) at
+    the size the tiling targets, (1, 4096, 4096): EMD within 1e-5 relative, row / column sums of the plan within 1e-4 of the
+    sequential plan's, plan entries 1e-3 absolute."""
+    n = 4096
+    x1, x2 = synth_patches(1, n, seed=41), synth_patches(1, n, seed=42)
+    seq = O.approx_match(x1, x2, contract=1, pinned_exp=True, chunk=0)
+    got = N(ops["A"].approx_match(T(x1, dev), T(x2, dev), arith=CONTRACT | PINNED_EXP))
+    assert np.abs(got - seq).max() < 1e-3
+    assert np.abs(got.sum(1) - seq.sum(1)).max() < 1e-4 and np.abs(got.sum(2) - seq.sum(2)).max() < 1e-4
+    c_seq = O.match_cost(x1, x2, seq)
+    cost = N(ops["A"].match_cost(T(x1, dev), T(x2, dev), T(got, dev)))
+    assert np.allclose(cost, c_seq, rtol=1e-5)
+    prod = N(ops["A"].match_cost(T(x1, dev), T(x2, dev), ops["A"].approx_match(T(x1, dev), T(x2, dev))))     # hardware exp
+    assert np.allclose(prod, c_seq, rtol=1e-5)

@@ -180,3 +180,23 @@ def test_approxmatch_chunked_golden(golden_dir):
     m = O.approx_match(z["xyz1"], z["xyz2"], contract=1, pinned_exp=True, chunk=int(z["chunk"]))
     assert np.array_equal(m, z["match_pinned"])
     assert np.allclose(O.match_cost(z["xyz1"], z["xyz2"], m, contract=1), z["cost"], rtol=1e-6)
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 5, 64, 1000, 8192, 8193, 20000])
+def test_prob_sample_oracle_self_checks(n):
+    """orc_prob_sample restates cumsumKernel + binarysearchKernel (tf_sampling_g.cu:7-104); no CPU twin exists in the reference
+    (parity unpinned vs the .cu), so it is pinned structurally: cumulative sums within fp32 rounding of a float64 cumsum,
+    non-decreasing for non-negative weights, and the sampled index is the first position whose cumulative weight reaches
+    r * total (numpy.searchsorted on the oracle's own sums)."""
+    rng = np.random.default_rng(n)
+    w = rng.random((3, n), dtype=np.float32)
+    r = rng.random((3, 41), dtype=np.float32)
+    r[:, 0], r[:, -1] = 0.0, 1.0
+    out, temp = O.prob_sample(w, r, return_temp=True)
+    ref = np.cumsum(w.astype(np.float64), axis=1)
+    assert np.abs(temp - ref).max() <= 4e-7 * ref.max()
+    assert (np.diff(temp, axis=1) >= 0).all()
+    for i in range(3):
+        q = r[i] * temp[i, -1]
+        assert np.array_equal(out[i], np.minimum(np.searchsorted(temp[i], q, "left"), n - 1))
+    assert (out[:, 0] == 0).all() and (out[:, -1] == n - 1).all() or n == 1
