@@ -66,42 +66,56 @@ def step_macs_per_patch():
 
 REFERENCE_FLOPS_PER_PATCH = 3.616e9      # the graph as the reference writes it
 
+# launch label (Generator._call) -> the kernel name rocprofv3 reports for it
+ROCPROF_NAME = {"ps_local": "dispu::ps_local_ws_kernel", "mlp_chain[coarse]": "dispu::mlp_chain_kernel<256, 128, 256, 64>",
+                "mlp_chain[fine]": "dispu::mlp_chain_kernel<256, 256, 256, 64>", "attention_project": "dispu::flash_attention_kernel<true>",
+                "edge_dense_conv": "dispu::edge_dense_conv_mfma_kernel", "knn_feat": "dispu::knn_feat_wave_kernel",
+                "knn_xyz": "dispu::knn_xyz_wave_kernel", "skip_max": "dispu::ps_skip_max16_kernel"}
 
-def cpu_baseline(params, target_seconds=12.0, with_ops=True):
-    """The CPU oracle (oracle/generator.py + oracle/dispu_oracle.c, a port of the reference algorithm; OpenMP over rows /
-    clouds) on the host cores: end to end with 1 thread and with every core, and per op."""
-    import numpy as np
-    from dispu_amd import synth
-    from oracle import generator as OG
-    from oracle import oracle as O
-    sys.path.insert(0, os.path.join(ROOT, "tools"))
-    import ops_bench
-    model, avail = ops_bench.cpu_info()
-    x = synth.patches(256, NPOINT, seed=1000)
-    OG.generator_forward(params, x[:1])                       # warm-up / page-in
-    per = {}
-    for c in sorted({avail, min(avail, 64), min(avail, 16), 1}, reverse=True):
-        O.set_threads(c)
-        t = time.perf_counter()
-        OG.generator_forward(params, x[:2])
-        per[c] = (time.perf_counter() - t) / 2
-    # the oracle's OpenMP loops are short, so every core is not always the fastest setting: `value` is the best one,
-    # the 1-thread and all-core figures are reported next to it
-    cores = min(per, key=per.get)
-    O.set_threads(cores)
-    n = int(max(2, min(256, target_seconds / max(per[cores], 1e-3))))
-    t = time.perf_counter()
-    OG.generator_forward(params, x[:n])
-    dt = time.perf_counter() - t
-    pts = NPOINT * UP
-    out = {"value": n * pts / dt, "unit": "points/s", "cores": cores, "kind": "port", "cpu_model": model, "host_cores": avail,
-           "points_per_s_1_thread": pts / per[1], "points_per_s_all_cores": pts / per[avail],
-           "points_per_s_by_threads": {str(c): round(pts / v, 1) for c, v in sorted(per.items())},
-           "sample": "%d patches of %d points (same synthetic workload), oracle/generator.py with %d OpenMP threads "
-                     "(fastest of %s threads on a host with %d cores: %s), %.1f s"
-                     % (n, NPOINT, cores, sorted(per), avail, model, dt)}
-    if with_ops:
-        out["ops"] = ops_bench.cpu_ops()["ops"]
+
+def launch_flops(name, B):
+    """ALGORITHMIC flops of one launch of the MFMA kernels of the step, by launch label (shapes: SURVEY.md Appendix A,
+    Common/ops.py:1012-1087, :302-346, :1089-1110, :1856-1915).  None: not an MFMA kernel (k-NN selection, gathers, heads)."""
+    n, m, k = NPOINT, NPOINT * UP, 16
+    if name.startswith("linear<"):
+        return linear_flops(name)
+    if name == "ps_local":                       # conv1 128 -> 128 over 16 neighbours, weight net 3 -> 16, feature x weight 16 x 16 x 128
+        return 2.0 * B * m * k * (128 * 128 + 3 * 16 + 16 * 128)
+    if name == "mlp_chain[coarse]":
+        return 2.0 * B * m * (256 * 128 + 128 * 256 + 256 * 64 + 64 * 3)
+    if name == "mlp_chain[fine]":
+        return 2.0 * B * m * (256 * 256 + 256 * 256 + 256 * 64 + 64 * 3)
+    if name == "attention_project":              # logits + PV + conv_back_project
+        return B * (4.0 * m * m * 64 + 2.0 * m * 64 * 256)
+    return None
+
+
+def cpu_baseline(target_seconds=14.0, with_ops=True):
+    """The CPU oracle (oracle/generator.py + oracle/dispu_oracle.c, a port of the reference algorithm) timed on the host cores
+    by oracle/cpu_bench.py in a SUBPROCESS (its worker processes must be forked from an interpreter without the HIP runtime):
+    end to end with one thread and batch-parallel (one patch per single-threaded process over min(cores, 256) processes, the way
+    the reference parallelises its only threaded CPU op, knn_.cxx:108), and per op with 1 thread / one cloud per thread."""
+    import subprocess
+    cmd = [sys.executable, os.path.join(ROOT, "oracle", "cpu_bench.py"), "--seconds", str(target_seconds)]
+    if not with_ops:
+        cmd.append("--no-ops")
+    env = dict(os.environ)
+    for k in ("OMP_NUM_THREADS", "OMP_PROC_BIND", "OMP_PLACES"):
+        env.pop(k, None)
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, env=env)
+    if r.returncode != 0:
+        raise RuntimeError("oracle/cpu_bench.py failed: %s" % r.stderr.decode(errors="replace")[-400:])
+    d = json.loads(r.stdout.decode().strip().splitlines()[-1])
+    best_all = d["points_per_s_all_cores"] >= d["points_per_s_1_thread"]
+    out = {"value": max(d["points_per_s_all_cores"], d["points_per_s_1_thread"]), "unit": "points/s",
+           "cores": d["processes"] if best_all else 1, "kind": "port", "cpu_model": d["cpu_model"], "host_cores": d["host_cores"],
+           "points_per_s_1_thread": d["points_per_s_1_thread"], "points_per_s_all_cores": d["points_per_s_all_cores"],
+           "sample": "%d patches of %d points (the bench's synthetic workload) through oracle/generator.py, one patch per "
+                     "single-threaded process over %d processes, %.1f s; 1-thread figure from %.2f s per patch; host: %d cores, %s"
+                     % (d["patches_timed"], NPOINT, d["processes"], d["seconds_timed"], d["s_per_patch_1_thread"],
+                        d["host_cores"], d["cpu_model"])}
+    if "ops" in d:
+        out["ops"] = d["ops"]
     return out
 
 
@@ -240,27 +254,42 @@ def main():
         gen.profile = None
         # group the instrumented launches by the kernel name rocprofv3 reports (one template instantiation each)
         by_kernel = {}
+        edge_c = [24, 48, 48, 48]                                           # dense block d reads C = 24 / 48 / 48 / 48 channels
+        edge_seen = 0
         for name, (t, c) in acc.items():
-            kern = name.split("[")[0]
-            g = by_kernel.setdefault(kern, [0.0, 0, 0.0])
+            kern = name.split("[")[0] if name.startswith("linear<") else name
+            g = by_kernel.setdefault(kern, [0.0, 0, 0.0, True])
             g[0] += t / reps
             g[1] += c / reps
-            if name.startswith("linear<"):
-                g[2] += linear_flops(name) * c / reps
+            fl = launch_flops(name, PATCHES_PER_GPU)
+            if name == "edge_dense_conv":                                   # four launches share the label: l0 / l1 / l2 over [n, 16] pairs
+                fl = sum(2.0 * PATCHES_PER_GPU * NPOINT * 16 * 24 * (4 * C + 72) for C in edge_c) / 4.0
+            if fl is None:
+                g[3] = False
+            else:
+                g[2] += fl * c / reps
         t_all = sum(g[0] for g in by_kernel.values())
-        dom = max(by_kernel.items(), key=lambda kv: kv[1][0])              # dominant kernel = most time per step
-        kern, (t_k, n_k, fl_k) = dom
-        if not kern.startswith("linear<"):                                  # roofline is quoted on the MFMA GEMM
-            kern, (t_k, n_k, fl_k) = max(((k, v) for k, v in by_kernel.items() if k.startswith("linear<")),
-                                          key=lambda kv: kv[1][0])
-        achieved = fl_k / t_k / 1e12
-        traffic, traffic_src = pmc_traffic(kern)
-        roof = {"bound": "mfma", "kernel": "dispu::linear_mfma_kernel" + kern[len("linear"):],
+        # dominant kernel = the launch label with the most time per step, whatever it is (round-2 code filtered on `linear<`)
+        kern, (t_k, n_k, fl_k, is_mfma) = max(by_kernel.items(), key=lambda kv: kv[1][0])
+        kname = ("dispu::linear_mfma_kernel" + kern[len("linear"):]) if kern.startswith("linear<") else ROCPROF_NAME.get(kern, kern)
+        achieved = fl_k / t_k / 1e12 if is_mfma else None
+        traffic, traffic_src = pmc_traffic(kern) if kern.startswith("linear<") else (None, None)
+        roof = {"bound": "mfma" if is_mfma else "valu", "kernel": kname,
                 "launches_per_step": round(n_k), "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
+                "frac": achieved / FP32_MFMA_PEAK_TFLOPS if achieved is not None else None, "traffic": traffic, "traffic_source": traffic_src,
                 "avg_launch_us": t_k / n_k * 1e6, "flops_per_launch": fl_k / n_k, "share_of_step": t_k / t_all,
                 "per_kernel_us_per_step": {k: round(v[0] * 1e6, 1) for k, v in
                                            sorted(by_kernel.items(), key=lambda kv: -kv[1][0])[:8]}}
+        # the decomposition of step_frac: every launch label of the step with its time, algorithmic flops and MFMA fraction
+        roof["kernels"] = [
+            {"kernel": ("dispu::linear_mfma_kernel" + k[len("linear"):]) if k.startswith("linear<") else ROCPROF_NAME.get(k, k),
+             "launches_per_step": round(v[1]), "us_per_step": round(v[0] * 1e6, 2), "avg_launch_us": round(v[0] / max(v[1], 1) * 1e6, 2),
+             "gflop_per_step": round(v[2] / 1e9, 3) if v[3] else None,
+             "mfma_frac": round(v[2] / v[0] / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4) if v[3] else None}
+            for k, v in sorted(by_kernel.items(), key=lambda kv: -kv[1][0])]
+        roof["kernels_note"] = ("HIP-event time of every launch of one eager step, grouped by kernel instantiation; mfma_frac = algorithmic flops "
+                                "/ time / %.1f TFLOP/s (fp32 MFMA peak); null = not an MFMA kernel (k-NN selection, gathers, 3-wide heads)"
+                                % FP32_MFMA_PEAK_TFLOPS)
 
     if rank == 0:
         # step-level fraction of the fp32 MFMA peak: every flop the step executes (dense contractions are 97 % of them)
@@ -282,7 +311,10 @@ def main():
                 roof["ops"] = None
                 roof["ops_error"] = "%s: %s" % (type(e).__name__, e)
             roof["ops_peaks"] = {"hbm_B_per_s": ops_bench.HBM_PEAK, "valu_lane_ops_per_s": ops_bench.VALU_PEAK,
-                                 "exp_per_s": ops_bench.EXP_PEAK}
+                                 "exp_per_s": ops_bench.EXP_PEAK, "valu_datasheet": ops_bench.VALU_PEAK_DATASHEET,
+                                 "exp_datasheet": ops_bench.EXP_PEAK_DATASHEET,
+                                 "note": "VALU / exp peaks are MEASURED issue rates (tools/micro/valu_rate.hip); frac_datasheet prices "
+                                         "the row against the datasheet-derived figure"}
         pts = world * PATCHES_PER_GPU * NPOINT * UP
         out = {"metric": "upsampled points/sec (256->1024, 4x)", "value": pts * args.steps / dt, "unit": "points/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -298,7 +330,7 @@ def main():
                "roofline": roof}
         if world == 1 and not args.no_cpu_baseline:
             try:
-                out["cpu_baseline"] = cpu_baseline(params, with_ops=not args.no_ops)
+                out["cpu_baseline"] = cpu_baseline(with_ops=not args.no_ops)
             except Exception as e:                             # noqa: BLE001
                 out["cpu_baseline"] = {"value": None, "unit": "points/s", "cores": 0, "kind": "port", "sample": "failed: %s: %s" % (type(e).__name__, e)}
         print(json.dumps(out))

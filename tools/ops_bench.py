@@ -7,10 +7,12 @@ the resource that bounds the op:
   valu  FPS / k-NN / ball query / 3-NN / nn_distance                      lane-ops / time / VALU issue peak
   exp   approx_match                                                      exponentials / time / transcendental peak
 
-VALU issue peak = 256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz = 39.3 T lane-ops/s (one non-packed wave64 VALU
-instruction per 4 cycles per SIMD; the 157.3 TFLOP/s fp32 vector figure counts an FMA as 2 and assumes packed
-issue).  Transcendental peak = a quarter of that (v_exp_f32 is a quarter-rate instruction) = 9.8 T/s.  FPS is also
-bound by the latency of its m-1 dependent rounds: its row carries ns/round next to the VALU fraction.
+VALU issue peak = 54.0 T lane-results/s, MEASURED on MI355X with a dependent-free v_fma_f32 loop (tools/micro/valu_rate.hip;
+the datasheet's 157.3 TFLOP/s fp32 vector figure is 78.6 T FMA lanes/s and assumes packed dual issue: v_pk_fma_f32 measured
+62.7 T).  Rounds 1-2 priced these rows against 39.3 T (256 CU x 4 SIMD x 16 lanes x 2.4 GHz), which flattered them by 1.37x.
+Transcendental peak = 14.4 T exp/s, measured the same way (v_mul + v_exp_f32 pairs: 11.4 T pairs/s).  `frac_datasheet` prices
+the same row against 78.6 T / 19.7 T.  FPS is also bound by the latency of its m-1 dependent rounds: its row carries
+ns/round next to the VALU fraction.
 
 bench.py imports gpu_ops() / cpu_ops() for the `roofline.ops` and `cpu_baseline.ops` sections of its JSON line.
 Stand-alone:  python tools/ops_bench.py [--cpu] > gpurun_out/ops_bench.json
@@ -23,9 +25,12 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 HBM_PEAK = 8.0e12
-VALU_PEAK = 256 * 4 * 16 * 2.4e9
-EXP_PEAK = VALU_PEAK / 4
+VALU_PEAK = 54.0e12            # measured v_fma_f32 lane-results/s (tools/micro/valu_rate.hip)
+EXP_PEAK = 14.4e12             # measured v_exp_f32 results/s
+VALU_PEAK_DATASHEET = 78.6e12  # 157.3 TFLOP/s fp32 vector / 2
+EXP_PEAK_DATASHEET = VALU_PEAK_DATASHEET / 4
 PEAK = {"hbm": (HBM_PEAK, "B/s"), "valu": (VALU_PEAK, "lane-op/s"), "exp": (EXP_PEAK, "exp/s")}
+PEAK_DATASHEET = {"hbm": HBM_PEAK, "valu": VALU_PEAK_DATASHEET, "exp": EXP_PEAK_DATASHEET}
 
 
 def _timeit(fn, reps=20, warm=3, graph=True):
@@ -70,7 +75,8 @@ def _row(name, shape, seconds, nbytes, bound, work, note=""):
     peak, unit = PEAK[bound]
     return {"op": name, "shape": list(shape), "us": round(seconds * 1e6, 2), "algorithmic_bytes": int(nbytes),
             "hbm_frac": round(nbytes / seconds / HBM_PEAK, 4), "bound": bound, "work": float(work), "work_unit": unit,
-            "achieved": work / seconds, "peak": peak, "frac": round(work / seconds / peak, 4), "note": note}
+            "achieved": work / seconds, "peak": peak, "frac": round(work / seconds / peak, 4),
+            "frac_datasheet": round(work / seconds / PEAK_DATASHEET[bound], 4), "note": note}
 
 
 def gpu_ops(dev=None, quick=False):
@@ -145,60 +151,12 @@ def gpu_ops(dev=None, quick=False):
     return out
 
 
-def cpu_info():
-    model = "unknown"
-    try:
-        with open("/proc/cpuinfo") as f:
-            for line in f:
-                if line.startswith("model name"):
-                    model = line.split(":", 1)[1].strip()
-                    break
-    except OSError:
-        pass
-    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    return model, avail
-
-
-def cpu_ops(budget_s=12.0):
-    """The CPU oracle (oracle/dispu_oracle.c, `kind: port`) per op at bounded shapes: once with 1 thread (the reference's CPU
-    ops are single-threaded) and once with every available core (OpenMP over clouds / rows) -- BASELINE.md section 2."""
-    import numpy as np
-    from oracle import oracle as O
-    model, avail = cpu_info()
-    rng = np.random.default_rng(7)
-    R = lambda *s: rng.random(s, dtype=np.float32)
-    x1k, y1k = R(32, 1024, 3), R(32, 1024, 3)
-    idx = rng.integers(0, 1024, (32, 1024, 16)).astype(np.int32)
-    feats = rng.standard_normal((32, 1024, 128)).astype(np.float32)
-    xs, ys = R(4, 1024, 3), R(4, 1024, 3)
-    cases = [
-        ("farthest_point_sample", (32, 1024, 384), lambda: O.farthest_point_sample(384, x1k)),
-        ("knn_xyz (self query)", (32, 1024, 16), lambda: O.knn_batch(x1k, x1k, 16)),
-        ("query_ball_point", (32, 1024, 1024, 20), lambda: O.query_ball_point(0.07, 20, x1k, x1k)),
-        ("group_point", (32, 1024, 1024, 16, 128), lambda: O.group_point(feats, idx)),
-        ("three_nn", (32, 1024, 256), lambda: O.three_nn(x1k, y1k[:, :256])),
-        ("nn_distance (both directions)", (32, 1024, 1024), lambda: O.nn_distance(x1k, y1k)),
-        ("approx_match", (4, 1024, 1024), lambda: O.approx_match(xs, ys)),
-    ]
-    rows, t_start = [], time.perf_counter()
-    for name, shape, fn in cases:
-        r = {"op": name, "shape": list(shape)}
-        for label, c in (("ms_1_thread", 1), ("ms_all_cores", avail)):
-            if time.perf_counter() - t_start > budget_s:
-                r[label] = None
-                continue
-            O.set_threads(c)
-            fn()
-            best = None
-            for _ in range(2):
-                t = time.perf_counter()
-                fn()
-                dt = time.perf_counter() - t
-                best = dt if best is None else min(best, dt)
-            r[label] = round(best * 1e3, 3)
-        rows.append(r)
-    O.set_threads(avail)
-    return {"cpu_model": model, "cores": avail, "kind": "port", "ops": rows}
+def cpu_ops():
+    """per-op CPU figures: oracle/cpu_bench.py (test infrastructure) in a subprocess."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "oracle", "cpu_bench.py"), "--seconds", "4"], stdout=subprocess.PIPE, check=True)
+    return json.loads(r.stdout.decode().strip().splitlines()[-1])
 
 
 if __name__ == "__main__":
