@@ -24,6 +24,9 @@ struct ChainArgs {
     const float* W3; const float* b3;               // [N2, N3]
     const float* W4; const float* b4;               // [N3, 3]
     float* Y1; long ldy1;                           // optional copy of the first layer's output [rows, N1]
+    float* Y2; long ldy2;                           // optional copies of the second / third layer's outputs and of the head's
+    float* Y3; long ldy3;                           // pre-activation output [rows, 3] (training: the backward pass reads them)
+    float* Z; long ldz;
     const float* R; long ldr;                       // mode 1: out = R + sigmoid(.) - 0.5
     float* out; long ldo;                           // [rows, 3]
     int mode;
@@ -217,8 +220,8 @@ __global__ __launch_bounds__(512) void mlp_chain_kernel(ChainArgs a) {
 #endif
     __syncthreads();
     chain_layer<K0, N1>(act, wst, 0, a.b1, a.Y1, a.ldy1, row0, wm, wn, fi, fk MC_WAIT_ARG);
-    chain_layer<N1, N2>(act, wst, S1, a.b2, nullptr, 0, row0, wm, wn, fi, fk MC_WAIT_ARG);
-    chain_layer<N2, N3>(act, wst, S1 + S2, a.b3, nullptr, 0, row0, wm, wn, fi, fk MC_WAIT_ARG);
+    chain_layer<N1, N2>(act, wst, S1, a.b2, a.Y2, a.ldy2, row0, wm, wn, fi, fk MC_WAIT_ARG);
+    chain_layer<N2, N3>(act, wst, S1 + S2, a.b3, a.Y3, a.ldy3, row0, wm, wn, fi, fk MC_WAIT_ARG);
 #ifdef MC_CLOCK
     if (blockIdx.x == 7 && threadIdx.x == 0) { mc_clock_ticks[0] = __builtin_readcyclecounter() - mc_t0; mc_clock_ticks[1] = G; mc_clock_ticks[2] = mc_wait_local; }
 #endif
@@ -238,6 +241,7 @@ __global__ __launch_bounds__(512) void mlp_chain_kernel(ChainArgs a) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             float w = v[c];
+            if (a.Z) a.Z[gr * a.ldz + c] = w;
             if (a.mode == 1) w = a.R[gr * a.ldr + c] + (1.0f / (1.0f + expf(-w)) - 0.5f);
             a.out[gr * a.ldo + c] = w;
         }
@@ -249,14 +253,28 @@ __global__ __launch_bounds__(512) void mlp_chain_kernel(ChainArgs a) {
 using namespace dispu;
 
 // rows % 128 == 0; (K0, N1, N2, N3) in {(256,128,256,64), (256,256,256,64)}; 16-byte aligned X / W*, ldx % 4 == 0.
+DISPU_EXPORT int dispu_mlp_chain_stash(long rows, int K0, int N1, int N2, int N3, const float* X, long ldx, const float* W1, const float* b1,
+                                       const float* W2, const float* b2, const float* W3, const float* b3, const float* W4, const float* b4,
+                                       float* Y1, long ldy1, float* Y2, long ldy2, float* Y3, long ldy3, float* Z, long ldz, int mode,
+                                       const float* R, long ldr, float* out, long ldo, void* stream);
+
 DISPU_EXPORT int dispu_mlp_chain(long rows, int K0, int N1, int N2, int N3, const float* X, long ldx, const float* W1, const float* b1,
                                  const float* W2, const float* b2, const float* W3, const float* b3, const float* W4, const float* b4,
                                  float* Y1, long ldy1, int mode, const float* R, long ldr, float* out, long ldo, void* stream) {
+    return dispu_mlp_chain_stash(rows, K0, N1, N2, N3, X, ldx, W1, b1, W2, b2, W3, b3, W4, b4, Y1, ldy1, nullptr, 0, nullptr, 0, nullptr, 0,
+                                 mode, R, ldr, out, ldo, stream);
+}
+
+// The same chain with every intermediate activation also written to HBM (training forward: the backward pass needs them).
+DISPU_EXPORT int dispu_mlp_chain_stash(long rows, int K0, int N1, int N2, int N3, const float* X, long ldx, const float* W1, const float* b1,
+                                       const float* W2, const float* b2, const float* W3, const float* b3, const float* W4, const float* b4,
+                                       float* Y1, long ldy1, float* Y2, long ldy2, float* Y3, long ldy3, float* Z, long ldz, int mode,
+                                       const float* R, long ldr, float* out, long ldo, void* stream) {
     if (rows < 0 || (rows % MC_BM) != 0 || (ldx & 3) || !X || !W1 || !W2 || !W3 || !W4 || !b1 || !b2 || !b3 || !b4 || !out ||
         (mode == 1 && !R) || ((((uintptr_t)X) | ((uintptr_t)W1) | ((uintptr_t)W2) | ((uintptr_t)W3)) & 15))
         return (int)hipErrorInvalidValue;
     if (rows == 0) return 0;
-    ChainArgs a{rows, X, ldx, W1, b1, W2, b2, W3, b3, W4, b4, Y1, ldy1, R, ldr, out, ldo, mode};
+    ChainArgs a{rows, X, ldx, W1, b1, W2, b2, W3, b3, W4, b4, Y1, ldy1, Y2, ldy2, Y3, ldy3, Z, ldz, R, ldr, out, ldo, mode};
     const dim3 grid((unsigned)(rows / MC_BM));
     hipStream_t s = (hipStream_t)stream;
     static DevOnce attr;      

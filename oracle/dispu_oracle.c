@@ -192,6 +192,7 @@ ORC_API void orc_query_ball(int b, int n, int m, const float *radius, int nsampl
  * (atomic adds into a zero-filled buffer, tf_grouping.cpp:208); CPU twins
  * query_ball_point.cpp:52-84. */
 ORC_API void orc_group_point(int b, int n, int c, int m, int ns, const float *points, const int *idx, float *out) {
+#pragma omp parallel for schedule(dynamic) num_threads(orc_nt(b))
     for (int i = 0; i < b; ++i)
         for (int j = 0; j < m; ++j)
             for (int k = 0; k < ns; ++k) {
