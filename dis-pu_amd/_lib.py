@@ -106,6 +106,19 @@ SIGNATURES = {
     "dispu_add3": (_i, [_l, _vp, _vp, _vp, _vp, _vp]),
     "dispu_fill_rows": (_i, [_i, _i, _vp, C.c_float, _vp, _vp]),
     "dispu_mlp_chain": (_i, [_l, _i, _i, _i, _i, _vp, _l, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _l, _i, _vp, _l, _vp, _l, _vp]),
+    "dispu_linear_masked": (_i, [_i, _i, _i, _i, _vp, _l, _l, _vp, _l, _l, _i, _vp, _i, _vp, _l, _l, _vp, _l, _l, _vp, _l, _i, _vp]),
+    "dispu_linear_bf16_masked": (_i, [_i, _i, _i, _i, _vp, _l, _l, _vp, _l, _l, _i, _vp, _i, _vp, _l, _l, _vp, _l, _l, _vp, _l, _i, _vp]),
+    "dispu_mlp_chain_stash": (_i, [_l, _i, _i, _i, _i, _vp, _l, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _l, _vp, _l, _vp, _l, _vp, _l,
+                                   _i, _vp, _l, _vp, _l, _vp]),
+    "dispu_mask3": (_i, [_l, _i, _vp, _l, _vp, _l, _vp, _l, _vp, _l, _vp, _vp, _vp, _l, _vp]),
+    "dispu_ps_wnet_scratch_bytes": (_l, [_l]),
+    "dispu_ps_wnet_bn_stats": (_i, [_l, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, C.c_float, C.c_float, _vp, _vp, _vp, _vp, _vp, _vp, _l, _vp]),
+    "dispu_ps_wnet_grad": (_i, [_l, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _l, _vp]),
+    "dispu_knn_invert": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp]),
+    "dispu_ps_conv0_gather_grad": (_i, [_l, _i, _i, _i, _vp, _vp, _vp, _l, _vp, _l, _vp, _l, _vp]),
+    "dispu_ps_prep_grad": (_i, [_l, _i, _vp, _vp, _vp, _l, _vp, _l, _vp, _vp, _vp]),
+    "dispu_ps_skip_max_grad": (_i, [_l, _i, _i, _i, _vp, _vp, _vp, _l, _vp, _l, _vp, _l, _vp, _vp, _l, _vp]),
+    "dispu_ps_point_matmul_grad_relu": (_i, [_l, _i, _i, _i, _vp, _l, _vp, _vp, _l, _vp, _l, _vp, _vp]),
     "dispu_augment": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "dispu_adam": (_i, [_l, _vp, _vp, _vp, _vp, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _vp]),
 }

@@ -35,6 +35,8 @@ struct LinearArgs {
     int act;                             // 0 none, 1 relu
     const float* scale;                  // optional inference BatchNorm folded to v*scale[n] + shift[n], applied
     const float* shift;                  // between the bias add and the activation (tf_util.py:176-185 order)
+    const float* Mk; long ldm; int mcols;  // optional ReLU-gradient mask, applied LAST: Y[m][n] = 0 where Mk[m][n] <= 0, for the
+                                           // columns n < mcols (training: dX = dZ.W^T masked by the layer input's activation)
 };
 
 // DMA mode (interior 128 x 256 x 16 tiles, B not transposed): the loader waves issue global_load_lds_dwordx4 - global
@@ -376,8 +378,17 @@ __global__ __launch_bounds__(64 * (WM * WN + (LinearLds<BM, BN, BK, TRANSB, EDGE
         for (int i = 0; i < TM; ++i) {
             // residuals of one 32x32 tile are fetched as a batch (16 + 16 loads in flight), then consumed: testing
             // R1 / R2 per element serialises load -> wait -> add -> store 128 times (+110 us on the after_conv GEMM)
-            float r1v[16], r2v[16];
-            if constexpr (EPI == 4) {
+            float r1v[16], r2v[16], mkv[16];
+            if constexpr (EPI == 5) {                                             // EPI 5 = EPI 4 + the ReLU-gradient mask
+                const bool msk = a.Mk != nullptr && colu < a.mcols;               // wave-uniform
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int rowu = rbase + i * 32 + (r & 3) + 8 * (r >> 2);
+                    const bool ok = msk && col < a.mcols && col_ok && (!EDGE || rowu + 4 * fk < M);
+                    mkv[r] = ok ? a.Mk[(size_t)(rowu + 4 * fk) * a.ldm + col] : 1.f;
+                }
+            }
+            if constexpr (EPI >= 4) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int rowu = rbase + i * 32 + (r & 3) + 8 * (r >> 2);
@@ -401,14 +412,15 @@ __global__ __launch_bounds__(64 * (WM * WN + (LinearLds<BM, BN, BK, TRANSB, EDGE
                         if (a.scale) v = v * sc + sh;
                     }
                     v = fmaxf(v, lo);
-                    if constexpr (EPI == 4) {
+                    if constexpr (EPI >= 4) {
                         if (R1) v = v + r1v[r];
                         if (R2) v = v + r2v[r];
                     }
+                    if constexpr (EPI == 5) v = (mkv[r] > 0.f) ? v : 0.f;
                     (Y + (size_t)rowu * ldy + colu)[offy] = v;
                 }
             }
-            if constexpr (EPI == 4) __builtin_amdgcn_sched_barrier(0);
+            if constexpr (EPI >= 4) __builtin_amdgcn_sched_barrier(0);
         }
     }
 }
@@ -431,8 +443,9 @@ static int launch_epi(const LinearArgs& a, dim3 grid, hipStream_t s) {
 
 template <int BM, int BN, int WM, int WN, int BK, bool TRANSB, bool EDGE>
 static int launch_one(const LinearArgs& a, dim3 grid, hipStream_t s) {
-    if (!a.scale && !a.R1 && !a.R2) return launch_epi<BM, BN, WM, WN, BK, TRANSB, EDGE, 0>(a, grid, s);
-    if (a.scale && !a.R1 && !a.R2) return launch_epi<BM, BN, WM, WN, BK, TRANSB, EDGE, 1>(a, grid, s);
+    if (!a.scale && !a.R1 && !a.R2 && !a.Mk) return launch_epi<BM, BN, WM, WN, BK, TRANSB, EDGE, 0>(a, grid, s);
+    if (a.scale && !a.R1 && !a.R2 && !a.Mk) return launch_epi<BM, BN, WM, WN, BK, TRANSB, EDGE, 1>(a, grid, s);
+    if (a.Mk) return launch_epi<BM, BN, WM, WN, BK, TRANSB, EDGE, 5>(a, grid, s);
     return launch_epi<BM, BN, WM, WN, BK, TRANSB, EDGE, 4>(a, grid, s);
 }
 
@@ -451,7 +464,8 @@ static int launch_linear(const LinearArgs& a, int batch, bool transb, hipStream_
 }
 
 int linear_skinny_dispatch(int M, int K, int N, const float* X, long ldx, const float* W, long ldw, int transb, const float* bias,
-                           int act, float* Y, long ldy, const float* R1, long ldr1, hipStream_t st);   // linear_skinny.hip
+                           int act, float* Y, long ldy, const float* R1, long ldr1, const float* Mk, long ldm, int mcols,
+                           hipStream_t st);   // linear_skinny.hip
 
 static int tile_override() {            // DISPU_LINEAR_TILE=<code>: force one variant (benchmarking only)
     static int v = -2;
@@ -478,17 +492,27 @@ DISPU_EXPORT int dispu_linear_tile(int batch, int M, int N) {
     return mb128 >= 256 ? 128064 : 64064;
 }
 
-DISPU_EXPORT int dispu_linear_bn(int batch, int M, int K, int N, const float* X, long ldx, long sx, const float* W,
-                                 long ldw, long sw, int transb, const float* bias, const float* scale, const float* shift,
-                                 int act, float* Y, long ldy, long sy, const float* R1, long ldr1, long sr1,
-                                 const float* R2, long ldr2, long sr2, void* stream);
+static int linear_impl(int batch, int M, int K, int N, const float* X, long ldx, long sx, const float* W, long ldw, long sw, int transb,
+                       const float* bias, const float* scale, const float* shift, int act, float* Y, long ldy, long sy, const float* R1,
+                       long ldr1, long sr1, const float* R2, long ldr2, long sr2, const float* Mk, long ldm, int mcols, void* stream);
 
 // Y = R2 + R1 + act(X.W + bias); see include/dispu_hip.h for the argument contract.
 DISPU_EXPORT int dispu_linear(int batch, int M, int K, int N, const float* X, long ldx, long sx, const float* W,
                               long ldw, long sw, int transb, const float* bias, int act, float* Y, long ldy, long sy,
                               const float* R1, long ldr1, long sr1, const float* R2, long ldr2, long sr2, void* stream) {
-    return dispu_linear_bn(batch, M, K, N, X, ldx, sx, W, ldw, sw, transb, bias, nullptr, nullptr, act, Y, ldy, sy, R1, ldr1,
-                           sr1, R2, ldr2, sr2, stream);
+    return linear_impl(batch, M, K, N, X, ldx, sx, W, ldw, sw, transb, bias, nullptr, nullptr, act, Y, ldy, sy, R1, ldr1,
+                       sr1, R2, ldr2, sr2, nullptr, 0, 0, stream);
+}
+
+// dispu_linear followed by a ReLU-gradient mask: Y[m][n] = 0 where Mk[m][n] <= 0, for the columns n < mcols of this product.
+// Training step: dX = dZ . W^T (+ R1, the gradient accumulated so far) of a layer whose INPUT was a ReLU output Mk -- the
+// relu_grad of the layer below rides in this epilogue instead of a separate pass over dX (tf_util.py:100-115 backward).
+DISPU_EXPORT int dispu_linear_masked(int batch, int M, int K, int N, const float* X, long ldx, long sx, const float* W,
+                                     long ldw, long sw, int transb, const float* bias, int act, float* Y, long ldy, long sy,
+                                     const float* R1, long ldr1, long sr1, const float* Mk, long ldm, int mcols, void* stream) {
+    if (Mk && batch != 1) return (int)hipErrorInvalidValue;
+    return linear_impl(batch, M, K, N, X, ldx, sx, W, ldw, sw, transb, bias, nullptr, nullptr, act, Y, ldy, sy, R1, ldr1,
+                       sr1, nullptr, 0, 0, Mk, ldm, Mk ? mcols : 0, stream);
 }
 
 // dispu_linear with an inference-BatchNorm epilogue: Y = R2 + R1 + act( (X.W + bias) * scale + shift ).
@@ -496,6 +520,13 @@ DISPU_EXPORT int dispu_linear_bn(int batch, int M, int K, int N, const float* X,
                                  long ldw, long sw, int transb, const float* bias, const float* scale, const float* shift,
                                  int act, float* Y, long ldy, long sy, const float* R1, long ldr1, long sr1,
                                  const float* R2, long ldr2, long sr2, void* stream) {
+    return linear_impl(batch, M, K, N, X, ldx, sx, W, ldw, sw, transb, bias, scale, shift, act, Y, ldy, sy, R1, ldr1, sr1, R2, ldr2, sr2,
+                       nullptr, 0, 0, stream);
+}
+
+static int linear_impl(int batch, int M, int K, int N, const float* X, long ldx, long sx, const float* W, long ldw, long sw, int transb,
+                       const float* bias, const float* scale, const float* shift, int act, float* Y, long ldy, long sy, const float* R1,
+                       long ldr1, long sr1, const float* R2, long ldr2, long sr2, const float* Mk, long ldm, int mcols, void* stream) {
     if (batch < 0 || M < 0 || K <= 0 || N <= 0 || !X || !W || !Y || act < 0 || act > 1 || ((scale == nullptr) != (shift == nullptr)))
         return (int)hipErrorInvalidValue;
     if (batch == 0 || M == 0) return 0;
@@ -512,7 +543,7 @@ DISPU_EXPORT int dispu_linear_bn(int batch, int M, int K, int N, const float* X,
         }
     }
     if (batch == 1 && !scale && !R2 && tile_override() <= 0) {
-        const int rc = linear_skinny_dispatch(M, K, N, X, ldx, W, ldw, transb, bias, act, Y, ldy, R1, ldr1, s);   // latency-bound shapes
+        const int rc = linear_skinny_dispatch(M, K, N, X, ldx, W, ldw, transb, bias, act, Y, ldy, R1, ldr1, Mk, ldm, mcols, s);   // latency-bound shapes
         if (rc >= 0) return rc;
         // a few columns past a multiple of 128 (N = 134: the PointShuffle conv0 gradient): the tiled kernel would spend a second,
         // almost empty column of 128-wide edge tiles on them.  Columns are independent: the multiple of 128 goes to the tiled
@@ -521,12 +552,13 @@ DISPU_EXPORT int dispu_linear_bn(int batch, int M, int K, int N, const float* X,
         if (n0 > 0 && tail > 0 && tail <= 32) {
             const float* Wt = transb ? W + (size_t)n0 * ldw : W + n0;
             if (linear_skinny_dispatch(M, K, tail, X, ldx, Wt, ldw, transb, bias ? bias + n0 : nullptr, act, Y + n0, ldy,
-                                       R1 ? R1 + n0 : nullptr, ldr1, s) >= 0)
-                return dispu_linear_bn(batch, M, K, n0, X, ldx, sx, W, ldw, sw, transb, bias, scale, shift, act, Y, ldy, sy, R1, ldr1, sr1,
-                                       R2, ldr2, sr2, stream);
+                                       R1 ? R1 + n0 : nullptr, ldr1, Mk ? Mk + n0 : nullptr, ldm, mcols - n0, s) >= 0)
+                return linear_impl(batch, M, K, n0, X, ldx, sx, W, ldw, sw, transb, bias, scale, shift, act, Y, ldy, sy, R1, ldr1, sr1,
+                                   R2, ldr2, sr2, Mk, ldm, mcols, stream);
         }
     }
-    LinearArgs a{M, K, N, X, ldx, sx, W, ldw, sw, bias, Y, ldy, sy, R1, ldr1, sr1, R2, ldr2, sr2, act, scale, shift};
+    LinearArgs a{M, K, N, X, ldx, sx, W, ldw, sw, bias, Y, ldy, sy, R1, ldr1, sr1, R2, ldr2, sr2, act, scale, shift,
+                 (Mk && mcols > 0) ? Mk : nullptr, ldm, mcols};
     const bool tb = transb != 0;
     switch (dispu_linear_tile(batch, M, N)) {
         case 128257: return launch_linear<128, 256, 2, 2, 16>(a, batch, tb, s);

@@ -40,6 +40,7 @@ struct GbArgs {
     int splits, k_per_split;           // splits > 1: partial tiles to `part` [z][split][M (+1)][N]
     float* part;
     float* colsum; int colsum_acc;     // TN only: column sums of B (fp32, un-rounded) = the bias gradient; NULL = not wanted
+    const float* Mk; long ldm; int mcols;   // optional ReLU-gradient mask, applied last (dispu_linear_bf16_masked)
 };
 
 // four consecutive elements along the operand's contiguous direction, zero beyond `valid`
@@ -236,6 +237,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GbArgs a) {
                 if (a.act == 1) v = fmaxf(v, 0.f);
                 if (R1) v += R1[(long)row * a.ldr1 + col];
                 if (R2) v += R2[(long)row * a.ldr2 + col];
+                if (a.Mk && col < a.mcols) v = (a.Mk[(long)row * a.ldm + col] > 0.f) ? v : 0.f;
                 C[(long)row * a.ldc + col] = v;
             }
         }
@@ -309,7 +311,20 @@ DISPU_EXPORT int dispu_linear_bf16(int batch, int M, int K, int N, const float* 
     int per = ((K + GB_KALIGN - 1) / GB_KALIGN) * GB_KALIGN;
     if (per == 0) per = GB_KALIGN;
     GbArgs a{M, N, K, X, ldx, 1, sx, W, transb ? ldw : 1, transb ? 1 : ldw, sw, Y, ldy, sy, bias, act, R1, ldr1, sr1, R2, ldr2, sr2,
-             1, per, nullptr, nullptr, 0};
+             1, per, nullptr, nullptr, 0, nullptr, 0, 0};
+    return transb ? gb_launch<true, true>(a, batch, (hipStream_t)stream) : gb_launch<true, false>(a, batch, (hipStream_t)stream);
+}
+
+// dispu_linear_masked (include/dispu_hip.h) with bf16 products: Y = mask(R1 + act(X . W + bias)), Y = 0 where Mk <= 0 (columns < mcols).
+DISPU_EXPORT int dispu_linear_bf16_masked(int batch, int M, int K, int N, const float* X, long ldx, long sx, const float* W, long ldw,
+                                          long sw, int transb, const float* bias, int act, float* Y, long ldy, long sy, const float* R1,
+                                          long ldr1, long sr1, const float* Mk, long ldm, int mcols, void* stream) {
+    if (batch < 0 || M < 0 || K < 0 || N < 0 || !X || !W || !Y || (act != 0 && act != 1) || (Mk && batch != 1)) return (int)hipErrorInvalidValue;
+    if (batch == 0 || M == 0 || N == 0) return 0;
+    int per = ((K + GB_KALIGN - 1) / GB_KALIGN) * GB_KALIGN;
+    if (per == 0) per = GB_KALIGN;
+    GbArgs a{M, N, K, X, ldx, 1, sx, W, transb ? ldw : 1, transb ? 1 : ldw, sw, Y, ldy, sy, bias, act, R1, ldr1, sr1, nullptr, 0, 0,
+             1, per, nullptr, nullptr, 0, (Mk && mcols > 0) ? Mk : nullptr, ldm, mcols};
     return transb ? gb_launch<true, true>(a, batch, (hipStream_t)stream) : gb_launch<true, false>(a, batch, (hipStream_t)stream);
 }
 

@@ -23,6 +23,7 @@ struct SkinnyArgs {
     int act;
     float* Y; long ldy;
     const float* R1; long ldr1;       // optional residual added after the activation
+    const float* Mk; long ldm; int mcols;   // optional ReLU-gradient mask (dispu_linear_masked): Y = 0 where Mk <= 0, columns < mcols
 };
 
 __device__ __forceinline__ void swap32(float& a, float& b) {      // a's lanes 32..63 <-> b's lanes 0..31
@@ -118,6 +119,7 @@ __global__ __launch_bounds__(256) void linear_skinny_kernel(SkinnyArgs a) {
             if (a.bias) v = v + bb;
             v = fmaxf(v, lo);
             if (a.R1) v = v + a.R1[(size_t)row * a.ldr1 + col];
+            if (a.Mk && col < a.mcols) v = (a.Mk[(size_t)row * a.ldm + col] > 0.f) ? v : 0.f;
             a.Y[(size_t)row * a.ldy + col] = v;
         }
     }
@@ -133,7 +135,8 @@ static void launch_skinny(const SkinnyArgs& a, bool transb, hipStream_t st) {
 
 // Returns -1 when the shape is outside this path (the caller then uses the tiled kernel).
 int linear_skinny_dispatch(int M, int K, int N, const float* X, long ldx, const float* W, long ldw, int transb, const float* bias,
-                           int act, float* Y, long ldy, const float* R1, long ldr1, hipStream_t st) {
+                           int act, float* Y, long ldy, const float* R1, long ldr1, const float* Mk, long ldm, int mcols,
+                           hipStream_t st) {
     if (K > 384 || K < 4 || (K & 3) || (ldx & 3) || (((uintptr_t)X) & 15)) return -1;
     if (transb && ((ldw & 3) || (((uintptr_t)W) & 15))) return -1;
     if ((long)M * ldx >= (1l << 29) || (long)(transb ? N : K) * ldw >= (1l << 29)) return -1;     // 32-bit byte offsets (buffer loads)
@@ -141,7 +144,7 @@ int linear_skinny_dispatch(int M, int K, int N, const float* X, long ldx, const 
     // a tile, or a contraction shorter than one K-slab (then it only moves data, mostly through predicated edge paths)
     const long tiles64 = (long)((M + 63) / 64) * ((N + 63) / 64);
     if (!(N <= 64 && tiles64 < 256) && !(N <= 32) && !(K <= 32 && N <= 128)) return -1;
-    SkinnyArgs a{M, K, N, X, ldx, W, ldw, bias, act, Y, ldy, R1, ldr1};
+    SkinnyArgs a{M, K, N, X, ldx, W, ldw, bias, act, Y, ldy, R1, ldr1, (Mk && mcols > 0) ? Mk : nullptr, ldm, mcols};
     if (K <= 32) launch_skinny<2>(a, transb != 0, st);
     else if (K <= 128) launch_skinny<8>(a, transb != 0, st);
     else if (K <= 256) launch_skinny<16>(a, transb != 0, st);

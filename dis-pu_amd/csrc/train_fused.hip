@@ -1,0 +1,557 @@
+// Training step, round 3: the PointShuffle2 local cell and skip branch WITHOUT their [B*M*16, 134] pair tensors.
+//
+// The reference graph (Common/ops.py:1012-1087) groups [xyz_j - xyz_i | xyz_j | feat_j] into a [B, M, 16, 134] tensor and runs
+// conv0 / the skip max / weight_net over it; TF1 autodiff then walks the same tensors backwards.  Round 2's training step
+// materialised all of them (ps_group -> gf, dgf, h0, h1, wl, wv ...: ~0.5 GB of traffic at 8 patches, 113 us of float
+// atomics in ps_group_grad alone).  Here the forward is the inference path (conv0 evaluated per SOURCE point:
+// relu(G[j] - A[i]), csrc/mlp_misc.hip:ps_prep; local cell fused in csrc/ps_local.hip; skip = gather-max) with BatchNorm on
+// batch statistics, and the backward differentiates THAT form:
+//   * weight_net (3 -> 16, BN, ReLU): batch statistics and all of its gradients come from the neighbour offsets directly
+//     (ps_wnet_* kernels); wl is never stored;
+//   * conv0: dz0[(i,s)] scatters to dG[j] and -dA[i]; the k-NN graph is INVERTED once per step (per-cloud CSR built in LDS,
+//     lists sorted by pair id) so dG is a deterministic gather-sum of coalesced 512-byte rows instead of 16.8 M atomics;
+//     dW0 / dup128 / dcoarse then come from [B*M, 128] matrices (16x fewer rows than the pair tensors);
+//   * skip: the max gradient goes straight to the arg-max neighbours (ties share evenly, math_grad._MinOrMaxGrad).
+// Every kernel cites the forward op whose gradient it is.  Streaming / gather kernels: lanes along the channel axis.
+#include "common.h"
+
+namespace dispu {
+
+static inline int tf_grid(size_t total, int block) {
+    size_t g = (total + block - 1) / block;
+    return (int)(g > 16384 ? 16384 : (g < 1 ? 1 : g));
+}
+
+__device__ __forceinline__ double tf_wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// ---- sum = relu(after_conv) + relu(skip) + relu(non-local) (ops.py:1072-1075): the three branch gradients in one pass ------
+// o_i = d * (Y_i > 0); float4 over [rows, n] matrices (n % 4 == 0, 16-byte aligned rows).
+__global__ void mask3_kernel(size_t total4, int n4, const float* __restrict__ d, long ldd, const float* __restrict__ y1, long ld1,
+                             const float* __restrict__ y2, long ld2, const float* __restrict__ y3, long ld3, float* __restrict__ o1,
+                             float* __restrict__ o2, float* __restrict__ o3, long ldo) {
+    for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total4; e += (size_t)gridDim.x * blockDim.x) {
+        const size_t r = e / n4;
+        const int q = (int)(e - r * n4) * 4;
+        const float4 g = *reinterpret_cast<const float4*>(d + r * ldd + q);
+        const float4 a = *reinterpret_cast<const float4*>(y1 + r * ld1 + q);
+        const float4 b = *reinterpret_cast<const float4*>(y2 + r * ld2 + q);
+        const float4 c = *reinterpret_cast<const float4*>(y3 + r * ld3 + q);
+        *reinterpret_cast<float4*>(o1 + r * ldo + q) = make_float4(a.x > 0.f ? g.x : 0.f, a.y > 0.f ? g.y : 0.f, a.z > 0.f ? g.z : 0.f, a.w > 0.f ? g.w : 0.f);
+        *reinterpret_cast<float4*>(o2 + r * ldo + q) = make_float4(b.x > 0.f ? g.x : 0.f, b.y > 0.f ? g.y : 0.f, b.z > 0.f ? g.z : 0.f, b.w > 0.f ? g.w : 0.f);
+        *reinterpret_cast<float4*>(o3 + r * ldo + q) = make_float4(c.x > 0.f ? g.x : 0.f, c.y > 0.f ? g.y : 0.f, c.z > 0.f ? g.z : 0.f, c.w > 0.f ? g.w : 0.f);
+    }
+}
+
+// ---- weight_net_hidden in training mode (ops.py:181-191: conv 3 -> 16, contrib batch_norm on batch statistics, ReLU) -------
+// One workgroup = 256 threads = the 16 neighbours x 16 channels of ONE point per pass.  wl[(i,s), t] is the fmaf chain of
+// ps_weight_net_kernel (csrc/mlp_misc.hip) so forward and backward agree bit for bit on every ReLU decision.
+constexpr int WN_K = 16, WN_T = 16;
+
+__device__ __forceinline__ float wn_wl(const float* __restrict__ xyz, long i, long j, const float* __restrict__ Ww, const float* __restrict__ bw,
+                                       int t, float& dx, float& dy, float& dz) {
+    dx = xyz[j * 3 + 0] - xyz[i * 3 + 0]; dy = xyz[j * 3 + 1] - xyz[i * 3 + 1]; dz = xyz[j * 3 + 2] - xyz[i * 3 + 2];
+    float acc = 0.f;
+    acc = __builtin_fmaf(dx, Ww[0 * WN_T + t], acc);
+    acc = __builtin_fmaf(dy, Ww[1 * WN_T + t], acc);
+    acc = __builtin_fmaf(dz, Ww[2 * WN_T + t], acc);
+    return acc + bw[t];
+}
+
+// part[blk][0][16] = sum wl, part[blk][1][16] = sum wl^2 (double), over the points blk, blk + grid, ...
+__global__ __launch_bounds__(256) void ps_wnet_stats_kernel(long rows, int n_per_cloud, const int* __restrict__ idx, const float* __restrict__ xyz,
+                                                             const float* __restrict__ Ww, const float* __restrict__ bw,
+                                                             double* __restrict__ part) {
+    __shared__ double red[2][256];
+    const int s = threadIdx.x >> 4, t = threadIdx.x & 15;
+    double s1 = 0.0, s2 = 0.0;
+    for (long i = blockIdx.x; i < rows; i += gridDim.x) {
+        const long j = (i / n_per_cloud) * n_per_cloud + idx[i * WN_K + s];
+        float dx, dy, dz;
+        const double v = wn_wl(xyz, i, j, Ww, bw, t, dx, dy, dz);
+        s1 += v;
+        s2 += v * v;
+    }
+    red[0][threadIdx.x] = s1;
+    red[1][threadIdx.x] = s2;
+    __syncthreads();
+    if (threadIdx.x < WN_T) {
+        double a = 0.0, b = 0.0;
+        for (int g = 0; g < WN_K; ++g) { a += red[0][g * WN_T + threadIdx.x]; b += red[1][g * WN_T + threadIdx.x]; }
+        part[((size_t)blockIdx.x * 2 + 0) * WN_T + threadIdx.x] = a;
+        part[((size_t)blockIdx.x * 2 + 1) * WN_T + threadIdx.x] = b;
+    }
+}
+
+// stats[0:16] mean | [16:32] biased variance | [32:48] 1/sqrt(var + eps); scale = gamma * inv_std, shift = beta - mean * scale
+// (what ps_local / ps_weight_net apply as wl * scale + shift); moving statistics as bn_finalize_kernel (fused-BN semantics:
+// Bessel-corrected variance into the moving average).  One wave per channel.
+__global__ __launch_bounds__(64) void ps_wnet_stats_finalize_kernel(long count, int nparts, const double* __restrict__ part, const float* __restrict__ gamma,
+                                                                     const float* __restrict__ beta, float eps, float decay, float* __restrict__ stats,
+                                                                     float* __restrict__ scale, float* __restrict__ shift,
+                                                                     float* __restrict__ moving_mean, float* __restrict__ moving_var) {
+    const int ch = blockIdx.x;
+    double a = 0.0, b = 0.0;
+    for (int p = threadIdx.x; p < nparts; p += 64) {
+        a += part[((size_t)p * 2 + 0) * WN_T + ch];
+        b += part[((size_t)p * 2 + 1) * WN_T + ch];
+    }
+    a = tf_wave_sum(a);
+    b = tf_wave_sum(b);
+    if (threadIdx.x != 0) return;
+    const double mean = a / (double)count;
+    double var = b / (double)count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const double is = 1.0 / sqrt(var + (double)eps);
+    stats[ch] = (float)mean;
+    stats[WN_T + ch] = (float)var;
+    stats[2 * WN_T + ch] = (float)is;
+    const float sc = (float)((double)gamma[ch] * is);
+    scale[ch] = sc;
+    shift[ch] = (float)((double)beta[ch] - mean * (double)sc);
+    if (moving_mean) moving_mean[ch] = (float)((double)decay * moving_mean[ch] + (1.0 - (double)decay) * mean);
+    if (moving_var) {
+        const double unbiased = count > 1 ? var * ((double)count / (double)(count - 1)) : var;
+        moving_var[ch] = (float)((double)decay * moving_var[ch] + (1.0 - (double)decay) * unbiased);
+    }
+}
+
+// backward, pass 1: u = dwv * (wv > 0) with wv = relu(wl * scale + shift) recomputed; part[blk][0][16] = sum u,
+// part[blk][1][16] = sum u * xhat, xhat = (wl - mean) * inv_std
+__global__ __launch_bounds__(256) void ps_wnet_grad_stats_kernel(long rows, int n_per_cloud, const int* __restrict__ idx, const float* __restrict__ xyz,
+                                                                  const float* __restrict__ Ww, const float* __restrict__ bw,
+                                                                  const float* __restrict__ stats, const float* __restrict__ scale,
+                                                                  const float* __restrict__ shift, const float* __restrict__ dwv,
+                                                                  double* __restrict__ part) {
+    __shared__ double red[2][256];
+    const int s = threadIdx.x >> 4, t = threadIdx.x & 15;
+    const float mu = stats[t], is = stats[2 * WN_T + t], sc = scale[t], sh = shift[t];
+    double s1 = 0.0, s2 = 0.0;
+    for (long i = blockIdx.x; i < rows; i += gridDim.x) {
+        const long j = (i / n_per_cloud) * n_per_cloud + idx[i * WN_K + s];
+        float dx, dy, dz;
+        const float wl = wn_wl(xyz, i, j, Ww, bw, t, dx, dy, dz);
+        const float wv = wl * sc + sh;
+        const float u = (wv > 0.f) ? dwv[(i * WN_K + s) * WN_T + t] : 0.f;
+        const float xh = (wl - mu) * is;
+        s1 += (double)u;
+        s2 += (double)u * (double)xh;
+    }
+    red[0][threadIdx.x] = s1;
+    red[1][threadIdx.x] = s2;
+    __syncthreads();
+    if (threadIdx.x < WN_T) {
+        double a = 0.0, b = 0.0;
+        for (int g = 0; g < WN_K; ++g) { a += red[0][g * WN_T + threadIdx.x]; b += red[1][g * WN_T + threadIdx.x]; }
+        part[((size_t)blockIdx.x * 2 + 0) * WN_T + threadIdx.x] = a;
+        part[((size_t)blockIdx.x * 2 + 1) * WN_T + threadIdx.x] = b;
+    }
+}
+
+// sums[0:16] = sum u, sums[16:32] = sum u * xhat;  dbeta += sum u, dgamma += sum u * xhat
+__global__ __launch_bounds__(64) void ps_wnet_grad_finalize_kernel(int nparts, const double* __restrict__ part, float* __restrict__ sums,
+                                                                    float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    const int ch = blockIdx.x;
+    double a = 0.0, b = 0.0;
+    for (int p = threadIdx.x; p < nparts; p += 64) {
+        a += part[((size_t)p * 2 + 0) * WN_T + ch];
+        b += part[((size_t)p * 2 + 1) * WN_T + ch];
+    }
+    a = tf_wave_sum(a);
+    b = tf_wave_sum(b);
+    if (threadIdx.x != 0) return;
+    sums[ch] = (float)a;
+    sums[WN_T + ch] = (float)b;
+    if (dbeta) dbeta[ch] += (float)a;
+    if (dgamma) dgamma[ch] += (float)b;
+}
+
+// backward, pass 2: dwl = gamma inv_std (u - sum_u / n - xhat sum_uxhat / n)  (the batch_norm gradient), then the 3 -> 16 conv:
+// dWw[c][t] += sum offset_c dwl_t, dbw[t] += sum dwl_t, and d offset_c = sum_t dwl_t Ww[c][t] goes to the two points of the pair:
+// dxyz[j] += d offset, dxyz[i] -= d offset.  Workgroup = one point at a time (16 neighbours x 16 channels), looping over points;
+// the weight gradients are kept per thread over the loop, reduced once per workgroup through LDS, and leave as 64 atomics.
+__global__ __launch_bounds__(256) void ps_wnet_grad_apply_kernel(long rows, int n_per_cloud, const int* __restrict__ idx, const float* __restrict__ xyz,
+                                                                  const float* __restrict__ Ww, const float* __restrict__ bw,
+                                                                  const float* __restrict__ stats, const float* __restrict__ scale,
+                                                                  const float* __restrict__ shift, const float* __restrict__ gamma,
+                                                                  const float* __restrict__ sums, const float* __restrict__ dwv,
+                                                                  float* __restrict__ dWw, float* __restrict__ dbw, float* __restrict__ dxyz) {
+    __shared__ float red[4][256];
+    __shared__ float pi[WN_K][3];
+    const int s = threadIdx.x >> 4, t = threadIdx.x & 15;
+    const float mu = stats[t], is = stats[2 * WN_T + t], sc = scale[t], sh = shift[t];
+    const float inv_n = 1.0f / (float)(rows * WN_K);
+    const float m1 = sums[t] * inv_n, m2 = sums[WN_T + t] * inv_n, gi = gamma[t] * is;
+    const float w0 = Ww[0 * WN_T + t], w1 = Ww[1 * WN_T + t], w2 = Ww[2 * WN_T + t];
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, ab = 0.f;
+    for (long i = blockIdx.x; i < rows; i += gridDim.x) {
+        const long j = (i / n_per_cloud) * n_per_cloud + idx[i * WN_K + s];
+        float dx, dy, dz;
+        const float wl = wn_wl(xyz, i, j, Ww, bw, t, dx, dy, dz);
+        const float wv = wl * sc + sh;
+        const float u = (wv > 0.f) ? dwv[(i * WN_K + s) * WN_T + t] : 0.f;
+        const float xh = (wl - mu) * is;
+        const float dwl = gi * ((u - m1) - xh * m2);
+        a0 = __builtin_fmaf(dx, dwl, a0); a1 = __builtin_fmaf(dy, dwl, a1); a2 = __builtin_fmaf(dz, dwl, a2);
+        ab += dwl;
+        // d offset: sum over the 16 channels (= the 16 lanes of a DPP row)
+        float o0 = dwl * w0, o1 = dwl * w1, o2 = dwl * w2;
+#pragma unroll
+        for (int m = 8; m > 0; m >>= 1) { o0 += __shfl_xor(o0, m, 16); o1 += __shfl_xor(o1, m, 16); o2 += __shfl_xor(o2, m, 16); }
+        if (t == 0) {
+            unsafeAtomicAdd(dxyz + j * 3 + 0, o0); unsafeAtomicAdd(dxyz + j * 3 + 1, o1); unsafeAtomicAdd(dxyz + j * 3 + 2, o2);
+            pi[s][0] = o0; pi[s][1] = o1; pi[s][2] = o2;
+        }
+        __syncthreads();
+        if (threadIdx.x < 3) {
+            float v = 0.f;
+            for (int q = 0; q < WN_K; ++q) v += pi[q][threadIdx.x];
+            unsafeAtomicAdd(dxyz + i * 3 + threadIdx.x, -v);
+        }
+        __syncthreads();
+    }
+    red[0][threadIdx.x] = a0; red[1][threadIdx.x] = a1; red[2][threadIdx.x] = a2; red[3][threadIdx.x] = ab;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int which = threadIdx.x >> 4, tt = threadIdx.x & 15;
+        float v = 0.f;
+        for (int g = 0; g < WN_K; ++g) v += red[which][g * WN_T + tt];
+        if (which < 3) unsafeAtomicAdd(dWw + which * WN_T + tt, v);
+        else if (dbw) unsafeAtomicAdd(dbw + tt, v);
+    }
+}
+
+// ---- the k-NN graph inverted (DisPU PointShuffle2 grouping, ops.py:154-179: idx[i, s] = s-th neighbour of point i) -----------
+// Per cloud (n <= 4096 points, k neighbours each): off[j] .. off[j+1] delimit, inside inv[], the pair ids i*k + s (cloud-local i)
+// with idx[i, s] == j, ascending.  One workgroup per cloud: LDS histogram -> exclusive scan -> fill -> every list sorted
+// (insertion sort; lists average k entries), which makes the gather-sum below deterministic.
+constexpr int INV_MAXN = 4096;
+__global__ __launch_bounds__(1024) void knn_invert_kernel(int n, int k, const int* __restrict__ idx, int* __restrict__ off, int* __restrict__ inv) {
+    __shared__ int cnt[INV_MAXN + 1];
+    __shared__ int cur[INV_MAXN];
+    __shared__ int wsum[16];
+    const int cloud = blockIdx.x, tid = threadIdx.x;
+    const int* __restrict__ id = idx + (size_t)cloud * n * k;
+    int* __restrict__ o = off + (size_t)cloud * (n + 1);
+    int* __restrict__ iv = inv + (size_t)cloud * n * k;
+    for (int e = tid; e <= n; e += 1024) cnt[e] = 0;
+    __syncthreads();
+    for (int e = tid; e < n * k; e += 1024) atomicAdd(&cnt[id[e]], 1);
+    __syncthreads();
+    // exclusive scan of cnt[0..n): thread t owns the 4 entries 4t .. 4t+3 (n <= 4096)
+    int v[4], local = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { const int e = tid * 4 + q; v[q] = e < n ? cnt[e] : 0; local += v[q]; }
+    int incl = local;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int up = __shfl_up(incl, d, 64); if ((tid & 63) >= d) incl += up; }
+    if ((tid & 63) == 63) wsum[tid >> 6] = incl;
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < (tid >> 6); ++w) base += wsum[w];
+    int run = base + incl - local;
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int e = tid * 4 + q;
+        if (e < n) { cnt[e] = run; cur[e] = run; o[e] = run; }
+        run += v[q];
+    }
+    if (tid == 1023) { o[n] = n * k; }
+    __syncthreads();
+    for (int e = tid; e < n * k; e += 1024) {
+        const int pos = atomicAdd(&cur[id[e]], 1);
+        iv[pos] = e;
+    }
+    __syncthreads();
+    __threadfence_block();
+    for (int j = tid; j < n; j += 1024) {
+        const int lo = cnt[j], hi = (j + 1 < n) ? cnt[j + 1] : n * k;
+        for (int a = lo + 1; a < hi; ++a) {
+            const int key = iv[a];
+            int b = a - 1;
+            while (b >= lo && iv[b] > key) { iv[b + 1] = iv[b]; --b; }
+            iv[b + 1] = key;
+        }
+    }
+}
+
+// ---- conv0 per source point, backward (h0 = relu(G[j] - A[i]), csrc/mlp_misc.hip:ps_prep) ---------------------------------------
+// dz0 [(i,s), c] (c = 128, already masked by h0 > 0) ->  dG[p] = sum over the in-edges of p (pairs (i,s) with idx[i,s] = p) of
+// dz0[(i,s)],  dAneg[p] = -sum_s dz0[(p,s)].  32 lanes per point, one float4 of the 512-byte rows each; the in-edge rows are
+// fetched 4 at a time.  No atomics: a point's sums are formed in a fixed order.
+__global__ __launch_bounds__(256) void ps_conv0_gather_grad_kernel(long rows, int n_per_cloud, int k, const int* __restrict__ off,
+                                                                    const int* __restrict__ inv, const float* __restrict__ dz0, long ldz,
+                                                                    float* __restrict__ dG, long ldg, float* __restrict__ dAneg, long lda) {
+    const int sub = threadIdx.x & 31;
+    const long p = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 5;
+    if (p >= rows) return;
+    const long cloud = p / n_per_cloud, pl = p - cloud * n_per_cloud;
+    const float* __restrict__ zc = dz0 + (size_t)cloud * n_per_cloud * k * ldz;        // this cloud's pair rows
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int s = 0; s < k; ++s) {
+        const float4 v = *reinterpret_cast<const float4*>(zc + (size_t)(pl * k + s) * ldz + sub * 4);
+        a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+    *reinterpret_cast<float4*>(dAneg + p * lda + sub * 4) = make_float4(-a.x, -a.y, -a.z, -a.w);
+    const int* __restrict__ o = off + cloud * (n_per_cloud + 1);
+    const int* __restrict__ iv = inv + cloud * (size_t)n_per_cloud * k;
+    const int lo = o[pl], hi = o[pl + 1];
+    float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+    int e = lo;
+    for (; e + 4 <= hi; e += 4) {
+        const int e0 = iv[e], e1 = iv[e + 1], e2 = iv[e + 2], e3 = iv[e + 3];
+        const float4 v0 = *reinterpret_cast<const float4*>(zc + (size_t)e0 * ldz + sub * 4);
+        const float4 v1 = *reinterpret_cast<const float4*>(zc + (size_t)e1 * ldz + sub * 4);
+        const float4 v2 = *reinterpret_cast<const float4*>(zc + (size_t)e2 * ldz + sub * 4);
+        const float4 v3 = *reinterpret_cast<const float4*>(zc + (size_t)e3 * ldz + sub * 4);
+        g.x += v0.x; g.y += v0.y; g.z += v0.z; g.w += v0.w;
+        g.x += v1.x; g.y += v1.y; g.z += v1.z; g.w += v1.w;
+        g.x += v2.x; g.y += v2.y; g.z += v2.z; g.w += v2.w;
+        g.x += v3.x; g.y += v3.y; g.z += v3.z; g.w += v3.w;
+    }
+    for (; e < hi; ++e) {
+        const float4 v = *reinterpret_cast<const float4*>(zc + (size_t)iv[e] * ldz + sub * 4);
+        g.x += v.x; g.y += v.y; g.z += v.z; g.w += v.w;
+    }
+    *reinterpret_cast<float4*>(dG + p * ldg + sub * 4) = g;
+}
+
+// G[p] = feat_p.Wf + xyz_p.(Wc + Wr) + b0,  A[p] = xyz_p.Wc  (W0 rows 0:3 = Wc, 3:6 = Wr; ps_prep).  The xyz side of the backward:
+//   dxyz[p] += dG[p].(Wc + Wr)^T + dAneg[p].Wc^T;   dW0[0:3] += xyz^T (dG + dAneg);   dW0[3:6] += xyz^T dG.
+// One wave per point (lane = 2 channels); the weight-gradient sums stay in registers over the wave's points, are combined
+// across the 4 waves through LDS and leave as 6 x 128 atomics per workgroup.
+__global__ __launch_bounds__(256) void ps_prep_grad_kernel(long rows, const float* __restrict__ xyz, const float* __restrict__ W0 /*[134,128]*/,
+                                                            const float* __restrict__ dG, long ldg, const float* __restrict__ dAneg, long lda,
+                                                            float* __restrict__ dxyz, float* __restrict__ dW0) {
+    constexpr int C = 128;
+    __shared__ float red[4][6][C];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c0 = lane * 2;
+    float wc[3][2], wr[3][2];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        wc[r][0] = W0[r * C + c0]; wc[r][1] = W0[r * C + c0 + 1];
+        wr[r][0] = W0[(3 + r) * C + c0]; wr[r][1] = W0[(3 + r) * C + c0 + 1];
+    }
+    float acc[6][2];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) acc[r][0] = acc[r][1] = 0.f;
+    for (long p = (long)blockIdx.x * 4 + wave; p < rows; p += (long)gridDim.x * 4) {
+        const float2 g = *reinterpret_cast<const float2*>(dG + p * ldg + c0);
+        const float2 a = *reinterpret_cast<const float2*>(dAneg + p * lda + c0);
+        const float x[3] = {xyz[p * 3 + 0], xyz[p * 3 + 1], xyz[p * 3 + 2]};
+        const float sx = g.x + a.x, sy = g.y + a.y;
+        float o[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            acc[r][0] = __builtin_fmaf(x[r], sx, acc[r][0]); acc[r][1] = __builtin_fmaf(x[r], sy, acc[r][1]);
+            acc[3 + r][0] = __builtin_fmaf(x[r], g.x, acc[3 + r][0]); acc[3 + r][1] = __builtin_fmaf(x[r], g.y, acc[3 + r][1]);
+            // dxyz_r = sum_c dG_c (Wc + Wr)[r][c] + dAneg_c Wc[r][c]
+            float v = g.x * (wc[r][0] + wr[r][0]) + g.y * (wc[r][1] + wr[r][1]);
+            v = __builtin_fmaf(a.x, wc[r][0], v);
+            v = __builtin_fmaf(a.y, wc[r][1], v);
+            o[r] = wave_sum_f32(v);
+        }
+        if (lane < 3) unsafeAtomicAdd(dxyz + p * 3 + lane, lane == 0 ? o[0] : lane == 1 ? o[1] : o[2]);
+    }
+#pragma unroll
+    for (int r = 0; r < 6; ++r) { red[wave][r][c0] = acc[r][0]; red[wave][r][c0 + 1] = acc[r][1]; }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 6 * C; e += 256) {
+        const int r = e / C, c = e - r * C;
+        const float v = (red[0][r][c] + red[1][r][c]) + (red[2][r][c] + red[3][r][c]);
+        unsafeAtomicAdd(dW0 + r * C + c, v);
+    }
+}
+
+// ---- skip branch: gmax[i] = max_s [xyz_j - xyz_i | xyz_j | feat_j] (ops.py:1049; forward = ps_skip_max16_kernel) -----------------
+// backward without the grouped tensor: the 16 candidates of every channel are gathered again (same loads, same subtraction:
+// bit-equal to what the forward compared), the gradient is shared evenly by the entries equal to the maximum
+// (math_grad._MinOrMaxGrad) and goes straight to its sources: dfeat[j][c] (atomics), dxyz[j] / dxyz[i].
+// 32 lanes per point: lane q owns feature channels 4q .. 4q+3, lanes 0..5 the six xyz channels as well.
+__global__ __launch_bounds__(256) void ps_skip_max_grad_kernel(long rows, int n_per_cloud, const int* __restrict__ idx, const float* __restrict__ xyz,
+                                                                const float* __restrict__ feat, long ldf, const float* __restrict__ gmax, long ldm,
+                                                                const float* __restrict__ dgmax, long ldd, float* __restrict__ dxyz,
+                                                                float* __restrict__ dfeat, long lddf) {
+    const int sub = threadIdx.x & 31;
+    const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 5;
+    if (i >= rows) return;
+    const long base = (i / n_per_cloud) * n_per_cloud;
+    const int mine = idx[i * 16 + (sub & 15)];
+    const float ci = (sub < 3) ? xyz[i * 3 + sub] : 0.f;
+    const int xc = sub < 3 ? sub : sub - 3;
+    float4 v[16];
+    float pj[16];
+    long jj[16];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+        jj[s] = base + __shfl(mine, s, 32);
+        v[s] = *reinterpret_cast<const float4*>(feat + jj[s] * ldf + sub * 4);
+        pj[s] = (sub < 6) ? xyz[jj[s] * 3 + xc] : 0.f;
+    }
+    const float* mrow = gmax + i * ldm;
+    const float* grow = dgmax + i * ldd;
+    const float mf[4] = {mrow[6 + sub * 4], mrow[7 + sub * 4], mrow[8 + sub * 4], mrow[9 + sub * 4]};
+    const float gf[4] = {grow[6 + sub * 4], grow[7 + sub * 4], grow[8 + sub * 4], grow[9 + sub * 4]};
+    int cnt[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+        cnt[0] += v[s].x == mf[0]; cnt[1] += v[s].y == mf[1]; cnt[2] += v[s].z == mf[2]; cnt[3] += v[s].w == mf[3];
+    }
+    const float sh[4] = {gf[0] / (float)cnt[0], gf[1] / (float)cnt[1], gf[2] / (float)cnt[2], gf[3] / (float)cnt[3]};
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+        float* d = dfeat + jj[s] * lddf + sub * 4;
+        if (v[s].x == mf[0] && sh[0] != 0.f) unsafeAtomicAdd(d + 0, sh[0]);
+        if (v[s].y == mf[1] && sh[1] != 0.f) unsafeAtomicAdd(d + 1, sh[1]);
+        if (v[s].z == mf[2] && sh[2] != 0.f) unsafeAtomicAdd(d + 2, sh[2]);
+        if (v[s].w == mf[3] && sh[3] != 0.f) unsafeAtomicAdd(d + 3, sh[3]);
+    }
+    if (sub < 6) {
+        const float mx = mrow[sub], gx = grow[sub];
+        int c = 0;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) c += ((sub < 3 ? pj[s] - ci : pj[s]) == mx);
+        const float share = gx / (float)c;
+        float self = 0.f;
+#pragma unroll
+        for (int s = 0; s < 16; ++s)
+            if ((sub < 3 ? pj[s] - ci : pj[s]) == mx) {
+                unsafeAtomicAdd(dxyz + jj[s] * 3 + xc, share);
+                self += share;
+            }
+        if (sub < 3) unsafeAtomicAdd(dxyz + i * 3 + sub, -self);
+    }
+}
+
+// ---- feature x weight product backward with the ReLU of conv1 folded in (csrc/train_ops.hip:ps_point_matmul_grad_kernel) -------
+// dz1[(i,s), c] = (h1 > 0) * sum_t dout[i, c*16 + t] wv[(i,s), t];  dwv[(i,s), t] = sum_c h1[(i,s), c] dout[i, c*16 + t]
+__global__ __launch_bounds__(256) void ps_point_matmul_grad_relu_kernel(long rows, const float* __restrict__ X2, long ldx2,
+                                                                         const float* __restrict__ wv, const float* __restrict__ dout,
+                                                                         long ldo, float* __restrict__ dX2, long lddx2,
+                                                                         float* __restrict__ dwv) {
+    constexpr int K = 16, T = 16, C = 128;
+    __shared__ float s_do[C * (T + 1)];
+    __shared__ float s_x[K][C + 1];
+    __shared__ float s_w[K][T + 1];
+    for (long i = blockIdx.x; i < rows; i += gridDim.x) {
+        for (int e = threadIdx.x; e < C * T; e += 256) s_do[(e >> 4) * (T + 1) + (e & 15)] = dout[i * ldo + e];
+        for (int e = threadIdx.x; e < K * C; e += 256) s_x[e / C][e % C] = X2[(i * K + e / C) * ldx2 + e % C];
+        s_w[threadIdx.x >> 4][threadIdx.x & 15] = wv[(i * K) * T + threadIdx.x];
+        __syncthreads();
+        for (int e = threadIdx.x; e < K * C; e += 256) {
+            const int s = e / C, c = e - s * C;
+            float a = 0.f;
+#pragma unroll
+            for (int t = 0; t < T; ++t) a = __builtin_fmaf(s_do[c * (T + 1) + t], s_w[s][t], a);
+            dX2[(i * K + s) * lddx2 + c] = (s_x[s][c] > 0.f) ? a : 0.f;
+        }
+        {
+            const int s = threadIdx.x >> 4, t = threadIdx.x & 15;
+            float a = 0.f;
+            for (int c = 0; c < C; ++c) a = __builtin_fmaf(s_x[s][c], s_do[c * (T + 1) + t], a);
+            dwv[(i * K + s) * T + t] = a;
+        }
+        __syncthreads();
+    }
+}
+
+static int wn_blocks(long rows) { return (int)(rows < 1024 ? rows : 1024); }
+
+}  // namespace dispu
+
+using namespace dispu;
+
+DISPU_EXPORT int dispu_mask3(long rows, int n, const float* dY, long lddy, const float* Y1, long ld1, const float* Y2, long ld2,
+                             const float* Y3, long ld3, float* o1, float* o2, float* o3, long ldo, void* stream) {
+    if (rows < 0 || n <= 0 || (n & 3) || ((lddy | ld1 | ld2 | ld3 | ldo) & 3)) return (int)hipErrorInvalidValue;
+    if (rows == 0) return 0;
+    const size_t total4 = (size_t)rows * (n / 4);
+    hipLaunchKernelGGL(mask3_kernel, dim3(tf_grid(total4, 256)), dim3(256), 0, (hipStream_t)stream, total4, n / 4, dY, lddy, Y1, ld1, Y2, ld2,
+                       Y3, ld3, o1, o2, o3, ldo);
+    return (int)hipGetLastError();
+}
+
+DISPU_EXPORT long dispu_ps_wnet_scratch_bytes(long rows) { return rows <= 0 ? 0 : (long)wn_blocks(rows) * 2 * WN_T * (long)sizeof(double); }
+
+DISPU_EXPORT int dispu_ps_wnet_bn_stats(long rows, int n_per_cloud, int k, int t_n, const int* idx, const float* xyz, const float* Ww,
+                                        const float* bw, const float* gamma, const float* beta, float eps, float decay, float* stats,
+                                        float* scale, float* shift, float* moving_mean, float* moving_var, void* scratch,
+                                        long scratch_bytes, void* stream) {
+    if (rows <= 0 || k != WN_K || t_n != WN_T || n_per_cloud <= 0 || !scratch || scratch_bytes < dispu_ps_wnet_scratch_bytes(rows))
+        return (int)hipErrorInvalidValue;
+    hipStream_t s = (hipStream_t)stream;
+    const int nb = wn_blocks(rows);
+    hipLaunchKernelGGL(ps_wnet_stats_kernel, dim3(nb), dim3(256), 0, s, rows, n_per_cloud, idx, xyz, Ww, bw, (double*)scratch);
+    DISPU_CHECK_LAUNCH();
+    hipLaunchKernelGGL(ps_wnet_stats_finalize_kernel, dim3(WN_T), dim3(64), 0, s, rows * WN_K, nb, (const double*)scratch, gamma, beta, eps,
+                       decay, stats, scale, shift, moving_mean, moving_var);
+    return (int)hipGetLastError();
+}
+
+DISPU_EXPORT int dispu_ps_wnet_grad(long rows, int n_per_cloud, int k, int t_n, const int* idx, const float* xyz, const float* Ww,
+                                    const float* bw, const float* stats, const float* scale, const float* shift, const float* gamma,
+                                    const float* dwv, float* dWw, float* dbw, float* dgamma, float* dbeta, float* dxyz, float* sums,
+                                    void* scratch, long scratch_bytes, void* stream) {
+    if (rows <= 0 || k != WN_K || t_n != WN_T || n_per_cloud <= 0 || !scratch || !sums || scratch_bytes < dispu_ps_wnet_scratch_bytes(rows))
+        return (int)hipErrorInvalidValue;
+    hipStream_t s = (hipStream_t)stream;
+    const int nb = wn_blocks(rows);
+    hipLaunchKernelGGL(ps_wnet_grad_stats_kernel, dim3(nb), dim3(256), 0, s, rows, n_per_cloud, idx, xyz, Ww, bw, stats, scale, shift, dwv,
+                       (double*)scratch);
+    DISPU_CHECK_LAUNCH();
+    hipLaunchKernelGGL(ps_wnet_grad_finalize_kernel, dim3(WN_T), dim3(64), 0, s, nb, (const double*)scratch, sums, dgamma, dbeta);
+    DISPU_CHECK_LAUNCH();
+    hipLaunchKernelGGL(ps_wnet_grad_apply_kernel, dim3(nb), dim3(256), 0, s, rows, n_per_cloud, idx, xyz, Ww, bw, stats, scale, shift, gamma,
+                       sums, dwv, dWw, dbw, dxyz);
+    return (int)hipGetLastError();
+}
+
+DISPU_EXPORT int dispu_knn_invert(int b, int n, int k, const int* idx, int* off, int* inv, void* stream) {
+    if (b < 0 || n <= 0 || n > INV_MAXN || k <= 0 || !idx || !off || !inv) return (int)hipErrorInvalidValue;
+    if (b == 0) return 0;
+    hipLaunchKernelGGL(knn_invert_kernel, dim3(b), dim3(1024), 0, (hipStream_t)stream, n, k, idx, off, inv);
+    return (int)hipGetLastError();
+}
+
+DISPU_EXPORT int dispu_ps_conv0_gather_grad(long rows, int n_per_cloud, int k, int c, const int* off, const int* inv, const float* dz0,
+                                            long ldz, float* dG, long ldg, float* dAneg, long lda, void* stream) {
+    if (rows < 0 || c != 128 || n_per_cloud <= 0 || rows % n_per_cloud != 0 || ((ldz | ldg | lda) & 3)) return (int)hipErrorInvalidValue;
+    if (rows == 0) return 0;
+    hipLaunchKernelGGL(ps_conv0_gather_grad_kernel, dim3((unsigned)((rows * 32 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, rows,
+                       n_per_cloud, k, off, inv, dz0, ldz, dG, ldg, dAneg, lda);
+    return (int)hipGetLastError();
+}
+
+DISPU_EXPORT int dispu_ps_prep_grad(long rows, int co, const float* xyz, const float* W0, const float* dG, long ldg, const float* dAneg,
+                                    long lda, float* dxyz, float* dW0, void* stream) {
+    if (rows < 0 || co != 128 || ((ldg | lda) & 1)) return (int)hipErrorInvalidValue;
+    if (rows == 0) return 0;
+    const int nb = (int)((rows + 3) / 4 < 256 ? (rows + 3) / 4 : 256);
+    hipLaunchKernelGGL(ps_prep_grad_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, rows, xyz, W0, dG, ldg, dAneg, lda, dxyz, dW0);
+    return (int)hipGetLastError();
+}
+
+DISPU_EXPORT int dispu_ps_skip_max_grad(long rows, int n_per_cloud, int k, int cf, const int* idx, const float* xyz, const float* feat,
+                                        long ldf, const float* gmax, long ldm, const float* dgmax, long ldd, float* dxyz, float* dfeat,
+                                        long lddf, void* stream) {
+    if (rows < 0 || k != 16 || cf != 128 || n_per_cloud <= 0 || (ldf & 3)) return (int)hipErrorInvalidValue;
+    if (rows == 0) return 0;
+    hipLaunchKernelGGL(ps_skip_max_grad_kernel, dim3((unsigned)((rows * 32 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, rows, n_per_cloud,
+                       idx, xyz, feat, ldf, gmax, ldm, dgmax, ldd, dxyz, dfeat, lddf);
+    return (int)hipGetLastError();
+}
+
+DISPU_EXPORT int dispu_ps_point_matmul_grad_relu(long rows, int k, int c, int t_n, const float* X2, long ldx2, const float* wv,
+                                                 const float* dout, long ldo, float* dX2, long lddx2, float* dwv, void* stream) {
+    if (rows < 0 || k != 16 || c != 128 || t_n != 16) return (int)hipErrorInvalidValue;
+    if (rows == 0) return 0;
+    const int nb = (int)(rows < 16384 ? rows : 16384);
+    hipLaunchKernelGGL(ps_point_matmul_grad_relu_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, rows, X2, ldx2, wv, dout, ldo, dX2,
+                       lddx2, dwv);
+    return (int)hipGetLastError();
+}

@@ -88,6 +88,7 @@ class Trainer(object):
         self._ws = {}
         self._scratch = {}                    # per stream: scratch of the split reductions / column sums
         self._bn_scratch = None
+        self._stash_ready = False
         # weight-gradient products (dW = X^T dZ) are off the backward chain: only Adam reads them.  They run on a second
         # HIP stream next to the dX products that ARE the chain (both read dZ; at 8 patches neither fills 256 CUs alone).
         self.overlap_dw = os.environ.get("DISPU_TRAIN_OVERLAP", "1") != "0"
@@ -148,15 +149,20 @@ class Trainer(object):
         Z = lambda *shape: torch.zeros(shape, dtype=f32, device=dev)
         ws = dict(
             feat=E(rn, 480), dfeat=E(rn, 480),
-            prep=[None, None] + [E(rn, 48) for _ in range(2, DENSE_BLOCKS + 1)], dprep=E(rn, 48),
+            prep=[None, None] + [E(rn, 48) for _ in range(2, DENSE_BLOCKS + 1)],
+            dprep=[None, None] + [E(rn, 48) for _ in range(2, DENSE_BLOCKS + 1)],      # per block: the dW products on the second stream read them
             kidx=[None] + [E(rn, k + 1, dtype=i32) for _ in range(DENSE_BLOCKS)],
-            edge=[None, E(rn * k, 72 + 48)] + [E(rn * k, 72 + 96) for _ in range(2, DENSE_BLOCKS + 1)], dedge=E(rn * k, 72 + 96),
+            edge=[None, E(rn * k, 72 + 48)] + [E(rn * k, 72 + 96) for _ in range(2, DENSE_BLOCKS + 1)],
+            dedge=[None, E(rn * k, 72 + 48)] + [E(rn * k, 72 + 96) for _ in range(2, DENSE_BLOCKS + 1)],
             h256=E(rn, 256), dh256=E(rn, 256), gcode=E(rm, 2),
             up256=E(rm, 256), dup256=E(rm, 256), up128=E(rm, 128), dup128=E(rm, 128),
             c256=E(rm, 256), dc256=E(rm, 256), c64=E(rm, 64), dc64=E(rm, 64), coarse=E(B, M, 3), dcoarse=E(B, M, 3),
-            psidx=E(rm, k, dtype=i32), gf=E(rm * k, 134), dgf=E(rm * k, 134), gmax=E(rm, 134), dgmax=E(rm, 134),
-            skip=E(rm, 256), dskip=E(rm, 256), h0=E(rm * k, 128), dh0=E(rm * k, 128), h1=E(rm * k, 128), dh1=E(rm * k, 128),
-            wl=E(rm * k, 16), dwl=E(rm * k, 16), wv=E(rm * k, 16), dwv=E(rm * k, 16), bn_stats=E(48), bn_sums=E(32),
+            psidx=E(rm, k, dtype=i32), inv_off=E(B, M + 1, dtype=i32), inv=E(B, M * k, dtype=i32),
+            gmax=Z(rm, 144), dgmax=E(rm, 136), skip=E(rm, 256), dskip=E(rm, 256),
+            # local cell: conv0 per source point (G, A), the pair tensors h0 / h1 / wv are RECOMPUTED for the backward pass
+            gm=E(rm, 128), am=E(rm, 128), dG=E(rm, 128), dAneg=E(rm, 128),
+            h0=E(rm * k, 128), h1=E(rm * k, 128), dz1=E(rm * k, 128), dz0=E(rm * k, 128), wv=E(rm * k, 16), dwv=E(rm * k, 16),
+            bn_stats=E(48), bn_scale=E(16), bn_shift=E(16), bn_sums=E(32),
             hp=E(rm, 2048), dhp=E(rm, 2048), aft=E(rm, 256), daft=E(rm, 256),
             kv=E(rm, 128), dkv=E(rm, 128), q=E(rm, 64), dq=E(rm, 64), S=E(B, M, M), dS=E(B, M, M), att=E(rm, 64), datt=E(rm, 64),
             nl=E(rm, 256), dnl=E(rm, 256), sum=E(rm, 256), dsum=E(rm, 256), agg=E(rm, 256), dagg=E(rm, 256),
@@ -266,22 +272,35 @@ class Trainer(object):
                                          dZ.stride(0) if dZ is not None else 0, _p(dbias), 1, _p(sc), sc.numel(), self.st),
                    "dispu_act_bias_grad")
 
-    def _lin_bwd(self, X, xoff, K, wname, act, Y, yoff, N, dY, dyoff, dX=None, dxoff=0, acc_dx=False, M=None, bias=True,
-                 W=None, dW=None, woff=0, premasked=False):
-        """backward of _lin: dY[:, dyoff:dyoff+N] is masked in place (unless premasked), db += colsum, dW += X^T dZ,
-        dX[:, dxoff:dxoff+K] (+)= dZ . W^T."""
+    def _dx(self, M, N, K, dY, dyoff, W, woff, dX, dxoff, acc, mask=None):
+        """dX[:, dxoff:dxoff+K] (+)= dY[:, dyoff:dyoff+N] . W^T, then zeroed where mask <= 0: mask = (tensor, column offset, columns) is the
+        ReLU output that fed this layer -- the relu_grad of the layer below rides in the GEMM epilogue (no separate pass over dX)."""
         L = _lib.lib()
+        bf = self.bf16 and K > 4 and N > 4
+        r1 = _p(dX, dxoff) if acc else None
+        ldr = dX.stride(0) if acc else 0
+        if mask is None:
+            fn = L.dispu_linear_bf16 if bf else L.dispu_linear
+            _lib.check(fn(1, M, N, K, _p(dY, dyoff), dY.stride(0), 0, _p(W, woff), W.stride(0), 0, 1, None, 0, _p(dX, dxoff), dX.stride(0), 0,
+                          r1, ldr, 0, None, 0, 0, self.st), "dispu_linear(dX)")
+        else:
+            mt, moff, mcols = mask
+            fn = L.dispu_linear_bf16_masked if bf else L.dispu_linear_masked
+            _lib.check(fn(1, M, N, K, _p(dY, dyoff), dY.stride(0), 0, _p(W, woff), W.stride(0), 0, 1, None, 0, _p(dX, dxoff), dX.stride(0), 0,
+                          r1, ldr, 0, _p(mt, moff), mt.stride(0), int(mcols), self.st), "dispu_linear_masked(dX)")
+
+    def _lin_bwd(self, X, xoff, K, wname, N, dY, dyoff, dX=None, dxoff=0, acc_dx=False, M=None, bias=True, W=None, dW=None, woff=0,
+                 mask=None, db=None):
+        """backward of _lin given dZ = dY[:, dyoff:dyoff+N] ALREADY multiplied by the layer's own relu' (its producer did that):
+        db += colsum dZ and dW += X^T dZ on the second stream, dX[:, dxoff:dxoff+K] (+)= dZ . W^T with `mask` (see _dx)."""
         M = X.shape[0] if M is None else M
         W = self.P[wname + "/weights"] if W is None else W
         dW = self.G[wname + "/weights"] if dW is None else dW
-        db = self.G[wname + "/biases"] if bias else None
-        if act and not premasked:
-            self._act_bias_grad(M, N, dY, dyoff, Y, yoff, act, dY, dyoff, None)          # relu_grad, in place
+        if db is None and bias:
+            db = self.G[wname + "/biases"]
         self._tn(1, M, K, N, X, xoff, X.stride(0), 0, dY, dyoff, dY.stride(0), 0, dW, woff, dW.stride(0), 0, 1, dbias=db, side=True)
         if dX is not None:
-            _lib.check(self._dl(1, M, N, K, _p(dY, dyoff), dY.stride(0), 0, _p(W, woff), W.stride(0), 0, 1, None, 0,
-                                      _p(dX, dxoff), dX.stride(0), 0, _p(dX, dxoff) if acc_dx else None,
-                                      dX.stride(0) if acc_dx else 0, 0, None, 0, 0, self.st), "dispu_linear(dX)")
+            self._dx(M, N, K, dY, dyoff, W, woff, dX, dxoff, acc_dx, mask)
 
     # ----------------------------------------------------------------------------------------------- forward ----
     def forward(self, inputs):
@@ -331,61 +350,91 @@ class Trainer(object):
         self._lin(feat, 0, 480, None, 0, ws["h256"], 0, 256, bias=False, W=w1)
         _lib.check(L.dispu_dup_grid(B, N, 256, self.up_ratio, _p(ws["h256"]), 256, _p(w1, 480 * 256),
                                     _p(P["generator/upshuffle_0/conv1/biases"]), _p(self.grid), _p(ws["up256"]), 256, self.st), "dup_grid")
-        self._lin(ws["up256"], 0, 256, "generator/upshuffle_0/conv2", 1, ws["up128"], 0, 128)
-        # non-local cell with materialised attention (kept for the backward).  It reads up128 only: a branch next to the coarse
-        # regressor, the grouping, the skip and the local cell; merged before add3
+        # conv2 -> fc_layer0 -> fc_layer1 -> fc_layer2 in ONE launch (csrc/mlp_chain.hip), every intermediate stashed for the backward
+        cs = "generator/coarse_coordinate_regressor/"
+        coarse = ws["coarse"].view(rm, 3)
+        c2 = "generator/upshuffle_0/conv2"
+        _lib.check(L.dispu_mlp_chain_stash(rm, 256, 128, 256, 64, _p(ws["up256"]), 256, _p(P[c2 + "/weights"]), _p(P[c2 + "/biases"]),
+                                           _p(P[cs + "fc_layer0/weights"]), _p(P[cs + "fc_layer0/biases"]),
+                                           _p(P[cs + "fc_layer1/weights"]), _p(P[cs + "fc_layer1/biases"]),
+                                           _p(P[cs + "fc_layer2/weights"]), _p(P[cs + "fc_layer2/biases"]),
+                                           _p(ws["up128"]), 128, _p(ws["c256"]), 256, _p(ws["c64"]), 64, None, 0, 0, None, 0,
+                                           _p(coarse), 3, self.st), "mlp_chain[coarse]")
+        # non-local cell with materialised attention (kept for the backward).  It reads up128 only: a branch next to the grouping,
+        # the skip and the local cell; merged before add3
         ps = "refine/PointShuffle/"
         up128 = ws["up128"]
         S = ws["S"]
         with self._branch(0):
             self._lin(up128, 0, 128, ps + "PointShuffle/conv_kv", 0, ws["kv"], 0, 128)
             self._lin(up128, 0, 128, ps + "PointShuffle/conv_query", 0, ws["q"], 0, 64)
-            S = ws["S"]
             _lib.check(self._dl(B, M, 64, M, _p(ws["q"]), 64, M * 64, _p(ws["kv"]), 128, M * 128, 1, None, 0, _p(S), M, M * M,
                                       None, 0, 0, None, 0, 0, self.st), "scores")
             _lib.check(L.dispu_softmax_rows(rm, M, 0.125, _p(S), M, self.st), "softmax")
             _lib.check(self._dl(B, M, M, 64, _p(S), M, M * M, _p(ws["kv"], 64), 128, M * 128, 0, None, 0, _p(ws["att"]), 64,
                                       M * 64, None, 0, 0, None, 0, 0, self.st), "att.V")
             self._lin(ws["att"], 0, 64, ps + "PointShuffle/conv_back_project", 1, ws["nl"], 0, 256)
-        cs = "generator/coarse_coordinate_regressor/"
-        self._lin(ws["up128"], 0, 128, cs + "fc_layer0", 1, ws["c256"], 0, 256)
-        self._lin(ws["c256"], 0, 256, cs + "fc_layer1", 1, ws["c64"], 0, 64)
-        coarse = ws["coarse"].view(rm, 3)
-        self._lin(ws["c64"], 0, 64, cs + "fc_layer2", 0, coarse, 0, 3)
 
-        # PointShuffle2
-        ps = "refine/PointShuffle/"
-        up128 = ws["up128"]
+        # PointShuffle2 (ops.py:1012-1087) in the inference path's form: no [B, M, 16, 134] grouped tensor
         _lib.check(L.dispu_knn_xyz(B, M, M, k, _p(coarse), _p(coarse), _p(ws["psidx"]), None, _lib.ARITH_PLAIN, self.st), "knn_xyz")
-        gf = ws["gf"]
-        _lib.check(L.dispu_ps_group(rm, M, k, 128, _p(ws["psidx"]), _p(coarse), _p(up128), 128, _p(gf), 134, self.st), "ps_group")
-        # skip (a second branch next to the local cell)
+        # skip (a second branch next to the local cell): gather-max straight from xyz / up128, then 134 -> 256
         with self._branch(1):
-            _lib.check(L.dispu_max_k(rm, k, 134, _p(gf), 134, _p(ws["gmax"]), 134, self.st), "max_k")
+            _lib.check(L.dispu_ps_skip_max(rm, M, k, 128, _p(ws["psidx"]), _p(coarse), _p(up128), 128, _p(ws["gmax"]), 144, self.st), "skip_max")
             self._lin(ws["gmax"], 0, 134, ps + "skip", 1, ws["skip"], 0, 256)
-        # local cell
-        self._lin(gf, 0, 134, ps + "conv0", 1, ws["h0"], 0, 128)
-        self._lin(ws["h0"], 0, 128, ps + "conv1", 1, ws["h1"], 0, 128)
-        self._lin(gf, 0, 3, ps + "weight_net/wconv0", 0, ws["wl"], 0, 16)
-        nb = L.dispu_bn_scratch_bytes(rm * k, 16)
+        # local cell: conv0 per source point (G = up128.Wf + xyz.(Wc + Wr) + b0, A = xyz.Wc; h0 = relu(G[j] - A[i])), weight_net
+        # BatchNorm on batch statistics straight from the neighbour offsets, then the fused cell (conv1, weight_net, feature x weight)
+        w0 = P[ps + "conv0/weights"]
+        self._lin(up128, 0, 128, None, 0, ws["gm"], 0, 128, bias=False, W=w0, woff=6 * 128)
+        _lib.check(L.dispu_ps_prep(rm, 128, _p(coarse), _p(w0), _p(P[ps + "conv0/biases"]), _p(ws["gm"]), 128, _p(ws["am"]), 128, self.st), "ps_prep")
+        ww, bw = P[ps + "weight_net/wconv0/weights"], P[ps + "weight_net/wconv0/biases"]
+        nb = L.dispu_ps_wnet_scratch_bytes(rm)
         if self._bn_scratch is None or self._bn_scratch.numel() * 8 < nb:
             self._bn_scratch = torch.empty((nb + 7) // 8, dtype=torch.float64, device=self.device)
-        _lib.check(L.dispu_bn_train(rm * k, 16, _p(ws["wl"]), 16, _p(P[BN + "gamma"]), _p(P[BN + "beta"]), BN_EPS, BN_DECAY, 1,
-                                    _p(ws["wv"]), 16, _p(ws["bn_stats"]), _p(self.moving_mean), _p(self.moving_var),
-                                    _p(self._bn_scratch), self._bn_scratch.numel() * 8, self.st), "bn_train")
-        _lib.check(L.dispu_ps_point_matmul(rm, k, 128, 16, _p(ws["h1"]), 128, _p(ws["wv"]), _p(ws["hp"]), 2048, self.st), "point_matmul")
+        _lib.check(L.dispu_ps_wnet_bn_stats(rm, M, k, 16, _p(ws["psidx"]), _p(coarse), _p(ww), _p(bw), _p(P[BN + "gamma"]), _p(P[BN + "beta"]),
+                                            BN_EPS, BN_DECAY, _p(ws["bn_stats"]), _p(ws["bn_scale"]), _p(ws["bn_shift"]),
+                                            _p(self.moving_mean), _p(self.moving_var), _p(self._bn_scratch), self._bn_scratch.numel() * 8,
+                                            self.st), "ps_wnet_bn_stats")
+        _lib.check(L.dispu_ps_local(rm, M, k, 128, _p(ws["psidx"]), _p(coarse), _p(ws["gm"]), 128, _p(ws["am"]),
+                                    _p(P[ps + "conv1/weights"]), _p(P[ps + "conv1/biases"]), _p(ww), _p(bw), _p(ws["bn_scale"]),
+                                    _p(ws["bn_shift"]), _p(ws["hp"]), self.st), "ps_local")
         self._lin(ws["hp"], 0, 2048, ps + "after_conv", 1, ws["aft"], 0, 256)
         self._merge(0)
         self._merge(1)
         _lib.check(L.dispu_add3(rm * 256, _p(ws["aft"]), _p(ws["skip"]), _p(ws["nl"]), _p(ws["sum"]), self.st), "add3")
-        self._lin(ws["sum"], 0, 256, ps + "aggregation", 1, ws["agg"], 0, 256)
-        # fine regressor
+        # aggregation -> fine regressor (fc_layer0, fc_layer1, fc_layer2) -> coarse + sigmoid(.) - 0.5 in one launch
         fs = "refine/fine_coordinate_regressor/"
-        self._lin(ws["agg"], 0, 256, fs + "fc_layer0", 1, ws["f256"], 0, 256)
-        self._lin(ws["f256"], 0, 256, fs + "fc_layer1", 1, ws["f64"], 0, 64)
-        self._lin(ws["f64"], 0, 64, fs + "fc_layer2", 0, ws["z"], 0, 3)
-        _lib.check(L.dispu_sigmoid_offset(rm * 3, _p(ws["z"]), _p(coarse), _p(ws["fine"]), self.st), "sigmoid_offset")
+        ag = ps + "aggregation"
+        _lib.check(L.dispu_mlp_chain_stash(rm, 256, 256, 256, 64, _p(ws["sum"]), 256, _p(P[ag + "/weights"]), _p(P[ag + "/biases"]),
+                                           _p(P[fs + "fc_layer0/weights"]), _p(P[fs + "fc_layer0/biases"]),
+                                           _p(P[fs + "fc_layer1/weights"]), _p(P[fs + "fc_layer1/biases"]),
+                                           _p(P[fs + "fc_layer2/weights"]), _p(P[fs + "fc_layer2/biases"]),
+                                           _p(ws["agg"]), 256, _p(ws["f256"]), 256, _p(ws["f64"]), 64, _p(ws["z"]), 3, 1, _p(coarse), 3,
+                                           _p(ws["fine"]), 3, self.st), "mlp_chain[fine]")
+        self._stash_ready = False
         return ws["coarse"], ws["fine"]
+
+    def _recompute_pair_tensors(self):
+        """h0 = relu(G[j] - A[i]), h1 = relu(h0.W1 + b1), wv = relu(BN(offsets.Ww + bw)) [B*M*16, .] and the inverted k-NN graph: what
+        the local cell's backward reads.  The forward kernel (csrc/ps_local.hip) keeps them on chip; they are rebuilt here, on an
+        auxiliary stream next to the loss and the fine head's backward (same arithmetic, same ReLU decisions)."""
+        if self._stash_ready:
+            return
+        L = _lib.lib()
+        B, N = self._shape
+        M, k = N * self.up_ratio, K_NEIGH
+        rm = B * M
+        ws = self._workspace(B, N)
+        P = self.P
+        ps = "refine/PointShuffle/"
+        coarse = ws["coarse"].view(rm, 3)
+        _lib.check(L.dispu_knn_invert(B, M, k, _p(ws["psidx"]), _p(ws["inv_off"]), _p(ws["inv"]), self.st), "knn_invert")
+        _lib.check(L.dispu_ps_gather_sub_relu(rm, M, k, 128, _p(ws["psidx"]), _p(ws["gm"]), 128, _p(ws["am"]), 128, _p(ws["h0"]), 128, self.st),
+                   "gather_sub_relu")
+        self._lin(ws["h0"], 0, 128, ps + "conv1", 1, ws["h1"], 0, 128)
+        _lib.check(L.dispu_ps_weight_net(rm, M, k, 16, _p(ws["psidx"]), _p(coarse), _p(P[ps + "weight_net/wconv0/weights"]),
+                                         _p(P[ps + "weight_net/wconv0/biases"]), _p(ws["bn_scale"]), _p(ws["bn_shift"]), _p(ws["wv"]), self.st),
+                   "weight_net")
+        self._stash_ready = True
 
     # -------------------------------------------------------------------------------------------------- loss ----
     def _chamfer(self, pred, gt, inv_r, coef, dpred, slot):
@@ -425,6 +474,8 @@ class Trainer(object):
         gt, radius = self._check_targets(gt, radius, B, M)
         inv_r = (1.0 / radius).contiguous()
         wf = weight_fine(self.epoch)
+        with self._branch(2):                                   # off the chain: needed by the local cell's backward only
+            self._recompute_pair_tensors()
         with self._branch(0):                                   # the coarse term next to the fine term and the repulsion term
             cd_c = 1000.0 * self._chamfer(ws["coarse"], gt, inv_r, 1000.0, ws["dcoarse"], 0)
         cd_f = 1000.0 * self._chamfer(ws["fine"], gt, inv_r, 1000.0 * wf, ws["dfine"], 1)
@@ -449,7 +500,9 @@ class Trainer(object):
 
     # ---------------------------------------------------------------------------------------------- backward ----
     def backward(self):
-        """gradients of pu_loss w.r.t. every trainable variable, accumulated into the flat gradient buffer."""
+        """gradients of pu_loss w.r.t. every trainable variable, accumulated into the flat gradient buffer.
+        ReLU gradients never run as separate passes: the dX product of a layer applies the mask of the layer below in its epilogue
+        (`mask=`), so every dY arriving at _lin_bwd is already the pre-activation gradient dZ."""
         L = _lib.lib()
         B, N = self._shape
         M, k = N * self.up_ratio, K_NEIGH
@@ -460,23 +513,25 @@ class Trainer(object):
         dcoarse, dfine = ws["dcoarse"].view(rm, 3), ws["dfine"].view(rm, 3)
         ps = "refine/PointShuffle/"
         fs = "refine/fine_coordinate_regressor/"
+        if not self._stash_ready:                       # backward() without loss_backward(): rebuild the pair tensors here
+            with self._branch(2):
+                self._recompute_pair_tensors()
 
         # fine = coarse + sigmoid(z) - 0.5
         _lib.check(L.dispu_sigmoid_offset_grad(rm * 3, _p(ws["z"]), _p(dfine), _p(ws["dz"]), _p(dcoarse), self.st), "sigmoid_grad")
-        self._lin_bwd(ws["f64"], 0, 64, fs + "fc_layer2", 0, ws["z"], 0, 3, ws["dz"], 0, ws["df64"])
-        self._lin_bwd(ws["f256"], 0, 256, fs + "fc_layer1", 1, ws["f64"], 0, 64, ws["df64"], 0, ws["df256"])
-        self._lin_bwd(ws["agg"], 0, 256, fs + "fc_layer0", 1, ws["f256"], 0, 256, ws["df256"], 0, ws["dagg"])
-        self._lin_bwd(ws["sum"], 0, 256, ps + "aggregation", 1, ws["agg"], 0, 256, ws["dagg"], 0, ws["dsum"])
-        # sum = relu(after) + relu(skip) + relu(nl): the three branches share dsum, each masks its own copy
-        self._act_bias_grad(rm, 256, ws["dsum"], 0, ws["aft"], 0, 1, ws["daft"], 0, None)
-        self._act_bias_grad(rm, 256, ws["dsum"], 0, ws["skip"], 0, 1, ws["dskip"], 0, None)
-        self._act_bias_grad(rm, 256, ws["dsum"], 0, ws["nl"], 0, 1, ws["dnl"], 0, None)
+        self._lin_bwd(ws["f64"], 0, 64, fs + "fc_layer2", 3, ws["dz"], 0, ws["df64"], mask=(ws["f64"], 0, 64))
+        self._lin_bwd(ws["f256"], 0, 256, fs + "fc_layer1", 64, ws["df64"], 0, ws["df256"], mask=(ws["f256"], 0, 256))
+        self._lin_bwd(ws["agg"], 0, 256, fs + "fc_layer0", 256, ws["df256"], 0, ws["dagg"], mask=(ws["agg"], 0, 256))
+        self._lin_bwd(ws["sum"], 0, 256, ps + "aggregation", 256, ws["dagg"], 0, ws["dsum"])
+        # sum = relu(after) + relu(skip) + relu(nl): the three branch gradients in one pass
+        _lib.check(L.dispu_mask3(rm, 256, _p(ws["dsum"]), 256, _p(ws["aft"]), 256, _p(ws["skip"]), 256, _p(ws["nl"]), 256, _p(ws["daft"]),
+                                 _p(ws["dskip"]), _p(ws["dnl"]), 256, self.st), "mask3")
 
         # non-local cell: reads dnl, writes datt / dS / dkv / dq / dup128 -- nothing the local cell or the skip branch touches, so
-        # it runs as a branch next to them; merged before ps_group_grad accumulates into dup128
+        # it runs as a branch next to them; merged before anything else accumulates into dup128
+        dup128 = ws["dup128"]
         with self._branch(0):
-            self._lin_bwd(ws["att"], 0, 64, ps + "PointShuffle/conv_back_project", 1, ws["nl"], 0, 256, ws["dnl"], 0, ws["datt"],
-                          premasked=True)
+            self._lin_bwd(ws["att"], 0, 64, ps + "PointShuffle/conv_back_project", 256, ws["dnl"], 0, ws["datt"])
             S, dS, kv, dkv, q = ws["S"], ws["dS"], ws["kv"], ws["dkv"], ws["q"]
             # dP = dO . V^T
             _lib.check(self._dl(B, M, 64, M, _p(ws["datt"]), 64, M * 64, _p(kv, 64), 128, M * 128, 1, None, 0, _p(dS), M, M * M,
@@ -489,72 +544,75 @@ class Trainer(object):
                                       None, 0, 0, None, 0, 0, self.st), "dQ")
             # dK = dS^T . Q -> dkv[:, 0:64]
             self._tn(B, M, M, 64, dS, 0, M, M * M, q, 0, 64, M * 64, dkv, 0, 128, M * 128, 0)
-            dup128 = ws["dup128"]
-            self._lin_bwd(ws["up128"], 0, 128, ps + "PointShuffle/conv_kv", 0, kv, 0, 128, dkv, 0, dup128)
-            self._lin_bwd(ws["up128"], 0, 128, ps + "PointShuffle/conv_query", 0, q, 0, 64, ws["dq"], 0, dup128, 0, acc_dx=True)
-        dgf, gf = ws["dgf"], ws["gf"]
-        # skip branch (a second branch): its max_k gradient WRITES dgf, the local cell's convs then accumulate into it
+            self._lin_bwd(ws["up128"], 0, 128, ps + "PointShuffle/conv_kv", 128, dkv, 0, dup128)
+            self._lin_bwd(ws["up128"], 0, 128, ps + "PointShuffle/conv_query", 64, ws["dq"], 0, dup128, 0, acc_dx=True)
+        # skip branch (a second branch): 134 -> 256 backward; its max gradient is scattered after the merges below
         with self._branch(1):
-            self._lin_bwd(ws["gmax"], 0, 134, ps + "skip", 1, ws["skip"], 0, 256, ws["dskip"], 0, ws["dgmax"], premasked=True)
-            _lib.check(L.dispu_max_k_grad(rm, k, 134, _p(gf), 134, _p(ws["gmax"]), 134, _p(ws["dgmax"]), 134, _p(dgf), 134, 0, self.st),
-                       "max_k_grad")
+            self._lin_bwd(ws["gmax"], 0, 134, ps + "skip", 256, ws["dskip"], 0, ws["dgmax"])
         # local cell
-        self._lin_bwd(ws["hp"], 0, 2048, ps + "after_conv", 1, ws["aft"], 0, 256, ws["daft"], 0, ws["dhp"], premasked=True)
-        _lib.check(L.dispu_ps_point_matmul_grad(rm, k, 128, 16, _p(ws["h1"]), 128, _p(ws["wv"]), _p(ws["dhp"]), 2048, _p(ws["dh1"]),
-                                                128, _p(ws["dwv"]), self.st), "point_matmul_grad")
-        _lib.check(L.dispu_bn_train_grad(rm * k, 16, _p(ws["wl"]), 16, _p(ws["wv"]), 16, _p(ws["dwv"]), 16, _p(ws["bn_stats"]),
-                                         _p(P[BN + "gamma"]), 1, _p(ws["dwl"]), 16, _p(G[BN + "gamma"]), _p(G[BN + "beta"]),
-                                         _p(ws["bn_sums"]), _p(self._bn_scratch), self._bn_scratch.numel() * 8, self.st), "bn_train_grad")
+        self._lin_bwd(ws["hp"], 0, 2048, ps + "after_conv", 256, ws["daft"], 0, ws["dhp"])
+        self._merge(2)                                   # h0 / h1 / wv / the inverted graph are in place
+        _lib.check(L.dispu_ps_point_matmul_grad_relu(rm, k, 128, 16, _p(ws["h1"]), 128, _p(ws["wv"]), _p(ws["dhp"]), 2048, _p(ws["dz1"]),
+                                                     128, _p(ws["dwv"]), self.st), "point_matmul_grad")
+        ww, bw = P[ps + "weight_net/wconv0/weights"], P[ps + "weight_net/wconv0/biases"]
+        _lib.check(L.dispu_ps_wnet_grad(rm, M, k, 16, _p(ws["psidx"]), _p(coarse), _p(ww), _p(bw), _p(ws["bn_stats"]), _p(ws["bn_scale"]),
+                                        _p(ws["bn_shift"]), _p(P[BN + "gamma"]), _p(ws["dwv"]), _p(G[ps + "weight_net/wconv0/weights"]),
+                                        _p(G[ps + "weight_net/wconv0/biases"]), _p(G[BN + "gamma"]), _p(G[BN + "beta"]), _p(dcoarse),
+                                        _p(ws["bn_sums"]), _p(self._bn_scratch), self._bn_scratch.numel() * 8, self.st), "ps_wnet_grad")
+        self._lin_bwd(ws["h0"], 0, 128, ps + "conv1", 128, ws["dz1"], 0, ws["dz0"], mask=(ws["h0"], 0, 128))
+        # conv0 in its per-source-point form: dz0 -> dG (gather through the inverted graph), -dA; then [B*M, 128] products
+        _lib.check(L.dispu_ps_conv0_gather_grad(rm, M, k, 128, _p(ws["inv_off"]), _p(ws["inv"]), _p(ws["dz0"]), 128, _p(ws["dG"]), 128,
+                                                _p(ws["dAneg"]), 128, self.st), "conv0_gather_grad")
+        w0, dw0 = P[ps + "conv0/weights"], G[ps + "conv0/weights"]
+        self._merge(0)                                   # dup128 holds the non-local cell's part from here on
+        self._lin_bwd(ws["up128"], 0, 128, None, 128, ws["dG"], 0, dup128, 0, acc_dx=True, W=w0, dW=dw0, woff=6 * 128, bias=False,
+                      db=G[ps + "conv0/biases"])
+        _lib.check(L.dispu_ps_prep_grad(rm, 128, _p(coarse), _p(w0), _p(ws["dG"]), 128, _p(ws["dAneg"]), 128, _p(dcoarse), _p(dw0), self.st),
+                   "ps_prep_grad")
         self._merge(1)
-        self._lin_bwd(gf, 0, 3, ps + "weight_net/wconv0", 0, ws["wl"], 0, 16, ws["dwl"], 0, dgf, 0, acc_dx=True)
-        self._lin_bwd(ws["h0"], 0, 128, ps + "conv1", 1, ws["h1"], 0, 128, ws["dh1"], 0, ws["dh0"])
-        self._lin_bwd(gf, 0, 134, ps + "conv0", 1, ws["h0"], 0, 128, ws["dh0"], 0, dgf, 0, acc_dx=True)
-
-        # grouping: dgf -> dcoarse, dup128
-        self._merge(0)
-        _lib.check(L.dispu_ps_group_grad(rm, M, k, 128, _p(ws["psidx"]), _p(dgf), 134, _p(dcoarse), _p(dup128), 128, self.st), "ps_group_grad")
+        _lib.check(L.dispu_ps_skip_max_grad(rm, M, k, 128, _p(ws["psidx"]), _p(coarse), _p(ws["up128"]), 128, _p(ws["gmax"]), 144,
+                                            _p(ws["dgmax"]), 136, _p(dcoarse), _p(dup128), 128, self.st), "ps_skip_max_grad")
 
         # coarse regressor
         cs = "generator/coarse_coordinate_regressor/"
-        self._lin_bwd(ws["c64"], 0, 64, cs + "fc_layer2", 0, coarse, 0, 3, dcoarse, 0, ws["dc64"])
-        self._lin_bwd(ws["c256"], 0, 256, cs + "fc_layer1", 1, ws["c64"], 0, 64, ws["dc64"], 0, ws["dc256"])
-        self._lin_bwd(ws["up128"], 0, 128, cs + "fc_layer0", 1, ws["c256"], 0, 256, ws["dc256"], 0, dup128, 0, acc_dx=True)
+        self._lin_bwd(ws["c64"], 0, 64, cs + "fc_layer2", 3, dcoarse, 0, ws["dc64"], mask=(ws["c64"], 0, 64))
+        self._lin_bwd(ws["c256"], 0, 256, cs + "fc_layer1", 64, ws["dc64"], 0, ws["dc256"], mask=(ws["c256"], 0, 256))
+        # the last product that accumulates into dup128 applies conv2's relu' (up128 = relu(conv2))
+        self._lin_bwd(ws["up128"], 0, 128, cs + "fc_layer0", 256, ws["dc256"], 0, dup128, 0, acc_dx=True, mask=(ws["up128"], 0, 128))
         # duplicate_up
-        self._lin_bwd(ws["up256"], 0, 256, "generator/upshuffle_0/conv2", 1, ws["up128"], 0, 128, dup128, 0, ws["dup256"])
+        self._lin_bwd(ws["up256"], 0, 256, "generator/upshuffle_0/conv2", 128, dup128, 0, ws["dup256"], mask=(ws["up256"], 0, 256))
         w1, dw1 = P["generator/upshuffle_0/conv1/weights"], G["generator/upshuffle_0/conv1/weights"]
-        self._act_bias_grad(rm, 256, ws["dup256"], 0, ws["up256"], 0, 1, ws["dup256"], 0, None)
         self._tn(1, rm, 2, 256, ws["gcode"], 0, 2, 0, ws["dup256"], 0, 256, 0, dw1, 480 * 256, 256, 0, 1,
                  dbias=G["generator/upshuffle_0/conv1/biases"])
         _lib.check(L.dispu_dup_sum_grad(B, N, 256, self.up_ratio, _p(ws["dup256"]), 256, _p(ws["dh256"]), 256, self.st), "dup_sum_grad")
         feat, dfeat = ws["feat"], ws["dfeat"]
-        self._lin_bwd(feat, 0, 480, None, 0, None, 0, 256, ws["dh256"], 0, dfeat, 0, bias=False, W=w1, dW=dw1)
+        self._lin_bwd(feat, 0, 480, None, 256, ws["dh256"], 0, dfeat, 0, bias=False, W=w1, dW=dw1)
 
-        # dense blocks, last to first
+        # dense blocks, last to first (every block has its own dE / dprep: the dW products on the second stream read them while
+        # the chain moves on, no join inside the loop)
         fe = "generator/feature_extraction_coarse/"
-        dE = ws["dedge"]
         for (d, C, col, in_col, width) in reversed(self._blocks):
-            Eb = ws["edge"][d]
+            Eb, dE = ws["edge"][d], ws["dedge"][d]
             lde = dE.stride(0)
-            self._join()                 # dE / dprep are shared by the blocks: the previous block's dW products read them
             # max gradient into the pooled columns [0, width), zeros into the neighbour half of the edge feature behind them
             _lib.check(L.dispu_max_k_grad_tail(rn, k, width, C, _p(Eb), Eb.stride(0), _p(feat, col), 480, _p(dfeat, col), 480, _p(dE), lde, self.st),
                        "max_k_grad")
             sc = fe + "layer%d" % d
-            self._lin_bwd(Eb, 24, 48 + C, sc + "/l2", 0, Eb, 0, 24, dE, 0, dE, 24, acc_dx=True)
-            self._lin_bwd(Eb, 48, 24 + C, sc + "/l1", 1, Eb, 24, 24, dE, 24, dE, 48, acc_dx=True)
-            self._lin_bwd(Eb, 72, 2 * C, sc + "/l0", 1, Eb, 48, 24, dE, 48, dE, 72, acc_dx=True)
+            self._lin_bwd(Eb, 24, 48 + C, sc + "/l2", 24, dE, 0, dE, 24, acc_dx=True, mask=(Eb, 24, 24))     # columns 24:48 = l1: relu'
+            self._lin_bwd(Eb, 48, 24 + C, sc + "/l1", 24, dE, 24, dE, 48, acc_dx=True, mask=(Eb, 48, 24))    # columns 48:72 = l0: relu'
+            self._lin_bwd(Eb, 72, 2 * C, sc + "/l0", 24, dE, 48, dE, 72, acc_dx=True)
             if d == 1:
                 dF, dfoff = dfeat, 456
             else:
-                dF, dfoff = ws["dprep"], 0
+                dF, dfoff = ws["dprep"][d], 0
                 dF.zero_()
             _lib.check(L.dispu_edge_feature_grad(rn, N, k, C, _p(dE, 72), lde, _p(ws["kidx"][d]), k + 1, 1, _p(dF, dfoff), dF.stride(0), self.st),
                        "edge_feature_grad")
             if d > 1:
-                self._lin_bwd(feat, in_col, 480 - in_col, fe + "layer%d_prep" % d, 1, ws["prep"][d], 0, 48, ws["dprep"], 0,
-                              dfeat, in_col, acc_dx=True)
+                self._act_bias_grad(rn, 48, dF, 0, ws["prep"][d], 0, 1, dF, 0, None)        # prep = relu(.): its mask (dF came from atomics)
+                self._lin_bwd(feat, in_col, 480 - in_col, fe + "layer%d_prep" % d, 48, dF, 0, dfeat, in_col, acc_dx=True)
         # layer0 (no activation, input has no gradient)
-        self._lin_bwd(self._x.view(rn, 3), 0, 3, fe + "layer0", 0, feat, 456, 24, dfeat, 456, None)
+        self._lin_bwd(self._x.view(rn, 3), 0, 3, fe + "layer0", 24, dfeat, 456, None)
         self._join()                     # every dW is in the flat gradient buffer from here on (all-reduce, Adam)
 
     # -------------------------------------------------------------------------------------------------- step ----

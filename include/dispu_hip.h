@@ -380,6 +380,56 @@ int dispu_fill_rows(int b, int n, const float* val, float mul, float* out, void*
 int dispu_adam(long total, float* p, const float* g, float* m, float* v, float lr_t, float beta1, float beta2, float eps,
                float gscale, void* stream);
 
+/* ---- training step, round 3: fused forward + backward of the PointShuffle2 local cell / skip branch without the [B*M*16, 134]
+ * pair tensors (csrc/train_fused.hip), ReLU gradients folded into the GEMM epilogues, head chains with stashed activations ---- */
+/* dispu_linear followed by a ReLU-gradient mask: Y[m][n] = 0 where Mk[m][n] <= 0, for the columns n < mcols of this product
+ * (dX = dZ.W^T (+ R1) of a layer whose INPUT was the ReLU output Mk: relu_grad of the layer below, tf_util.py:100-115). */
+int dispu_linear_masked(int batch, int M, int K, int N, const float* X, long ldx, long sx, const float* W, long ldw, long sw,
+                        int transb, const float* bias, int act, float* Y, long ldy, long sy, const float* R1, long ldr1, long sr1,
+                        const float* Mk, long ldm, int mcols, void* stream);
+int dispu_linear_bf16_masked(int batch, int M, int K, int N, const float* X, long ldx, long sx, const float* W, long ldw, long sw,
+                             int transb, const float* bias, int act, float* Y, long ldy, long sy, const float* R1, long ldr1, long sr1,
+                             const float* Mk, long ldm, int mcols, void* stream);
+/* dispu_mlp_chain that also writes the second / third layer's outputs (Y2 [rows,N2], Y3 [rows,N3]) and the head's pre-activation
+ * output Z [rows,3]: the training forward of the two head chains in one launch each (any of Y1, Y2, Y3, Z may be NULL). */
+int dispu_mlp_chain_stash(long rows, int K0, int N1, int N2, int N3, const float* X, long ldx, const float* W1, const float* b1,
+                          const float* W2, const float* b2, const float* W3, const float* b3, const float* W4, const float* b4,
+                          float* Y1, long ldy1, float* Y2, long ldy2, float* Y3, long ldy3, float* Z, long ldz, int mode,
+                          const float* R, long ldr, float* out, long ldo, void* stream);
+/* o_i = dY * (Y_i > 0), i = 1..3: the gradients of sum = relu(after_conv) + relu(skip) + relu(non-local) (ops.py:1072-1075). */
+int dispu_mask3(long rows, int n, const float* dY, long lddy, const float* Y1, long ld1, const float* Y2, long ld2, const float* Y3,
+                long ld3, float* o1, float* o2, float* o3, long ldo, void* stream);
+/* weight_net_hidden in training mode (ops.py:181-191: conv 3 -> 16 of xyz_j - xyz_i, contrib batch_norm on BATCH statistics, ReLU)
+ * without storing its [rows*16, 16] input: stats[48] = mean | biased var | 1/sqrt(var+eps); scale/shift[16] = the folded BatchNorm
+ * dispu_ps_local / dispu_ps_weight_net apply; moving statistics updated in place (decay).  scratch: dispu_ps_wnet_scratch_bytes. */
+long dispu_ps_wnet_scratch_bytes(long rows);
+int dispu_ps_wnet_bn_stats(long rows, int n_per_cloud, int k, int t_n, const int* idx, const float* xyz, const float* Ww, const float* bw,
+                           const float* gamma, const float* beta, float eps, float decay, float* stats, float* scale, float* shift,
+                           float* moving_mean, float* moving_var, void* scratch, long scratch_bytes, void* stream);
+/* its gradient from dwv [rows*16, 16] (gradient w.r.t. the ReLU output): dWw [3,16], dbw, dgamma, dbeta accumulate; dxyz [rows,3]
+ * accumulates (atomics) the gradient w.r.t. both points of every pair; sums[32] receives (sum u | sum u*xhat). */
+int dispu_ps_wnet_grad(long rows, int n_per_cloud, int k, int t_n, const int* idx, const float* xyz, const float* Ww, const float* bw,
+                       const float* stats, const float* scale, const float* shift, const float* gamma, const float* dwv, float* dWw,
+                       float* dbw, float* dgamma, float* dbeta, float* dxyz, float* sums, void* scratch, long scratch_bytes, void* stream);
+/* the k-NN graph idx [b, n, k] (cloud-local ids) inverted per cloud: off [b, n+1], inv [b, n*k] = the pair ids i*k + s with
+ * idx[i,s] == j in off[j] .. off[j+1], ascending.  n <= 4096. */
+int dispu_knn_invert(int b, int n, int k, const int* idx, int* off, int* inv, void* stream);
+/* conv0 per source point (h0 = relu(G[j] - A[i]), dispu_ps_prep) backward: dG[p] = sum of dz0 over the in-edges of p (a
+ * deterministic gather through the inverted graph), dAneg[p] = -sum_s dz0[(p,s)].  c == 128. */
+int dispu_ps_conv0_gather_grad(long rows, int n_per_cloud, int k, int c, const int* off, const int* inv, const float* dz0, long ldz,
+                               float* dG, long ldg, float* dAneg, long lda, void* stream);
+/* the xyz side of dispu_ps_prep backward: dxyz += dG.(Wc+Wr)^T + dAneg.Wc^T (atomics); dW0[0:3] += xyz^T (dG + dAneg),
+ * dW0[3:6] += xyz^T dG (atomics).  W0 [134, 128] (rows 0:3 = Wc, 3:6 = Wr). */
+int dispu_ps_prep_grad(long rows, int co, const float* xyz, const float* W0, const float* dG, long ldg, const float* dAneg, long lda,
+                       float* dxyz, float* dW0, void* stream);
+/* gradient of dispu_ps_skip_max (max over the 16 neighbours of [xyz_j - xyz_i | xyz_j | feat_j], ops.py:1049) without the grouped
+ * tensor: shared evenly by the entries equal to the maximum, accumulated (atomics) into dxyz [rows,3] and dfeat [rows, cf]. */
+int dispu_ps_skip_max_grad(long rows, int n_per_cloud, int k, int cf, const int* idx, const float* xyz, const float* feat, long ldf,
+                           const float* gmax, long ldm, const float* dgmax, long ldd, float* dxyz, float* dfeat, long lddf, void* stream);
+/* dispu_ps_point_matmul_grad with conv1's ReLU gradient folded in: dX2 is zero where X2 <= 0. */
+int dispu_ps_point_matmul_grad_relu(long rows, int k, int c, int t_n, const float* X2, long ldx2, const float* wv, const float* dout,
+                                    long ldo, float* dX2, long lddx2, float* dwv, void* stream);
+
 /* ---- training data path (DisPU/dataset.py:118-143; Common/point_operation.py:32-123: numpy on the host in the
  * reference) ------------------------------------------------------------------------------------------------------
  * out[b,i,:] = ((in[b,i,:] + noise[b,i,:]) . rot[b]) * scale[b] + shift[b]   (jitter -> rotate -> scale [-> shift]);

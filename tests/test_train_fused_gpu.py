@@ -1,0 +1,297 @@
+"""GPU parity of the round-3 training kernels (csrc/train_fused.hip, the masked GEMM epilogues, the stashing head chains) against
+float64 torch autograd of the forward op each one differentiates -- 1e-5, like tests/test_train_gpu.py.  The reference has no
+native code here (TF1 autodiff, DisPU/model.py:158-178); the forward ops are Common/ops.py:1012-1087 (PointShuffle2)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import train_oracle as T
+
+pytestmark = pytest.mark.gpu
+F64 = torch.float64
+_KEEP = []
+
+
+def N_(t):
+    return t.detach().cpu().numpy()
+
+
+def dv(a, dev, dtype=torch.float32):
+    t = torch.from_numpy(np.ascontiguousarray(a)).to(dev).to(dtype)
+    _KEEP.append(t)
+    return t
+
+
+@pytest.fixture(autouse=True)
+def _release():
+    yield
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+    del _KEEP[:]
+
+
+def p(t, off=0):
+    return C.c_void_p(t.data_ptr() + 4 * off) if t is not None else C.c_void_p(0)
+
+
+def close(a, ref, rel, what=""):
+    scale = max(np.abs(ref).max(), 1e-30)
+    err = np.abs(np.asarray(a, np.float64) - ref).max()
+    assert err <= rel * scale, "%s: max err %.3e vs scale %.3e (rel %.2e)" % (what, err, scale, err / scale)
+
+
+@pytest.fixture(scope="module")
+def L():
+    from dispu_amd import _lib
+    return _lib
+
+
+@pytest.mark.parametrize("M,Kc,Nout,mcols,acc", [(1000, 24, 168, 24, 1), (4096, 256, 64, 64, 0), (3000, 3, 64, 64, 0), (2048, 256, 2048, 0, 0),
+                                                 (5000, 128, 128, 128, 1), (777, 64, 256, 100, 1), (8192, 256, 128, 128, 1)])
+@pytest.mark.parametrize("kind", ["f32", "bf16"])
+def test_linear_masked(dev, L, M, Kc, Nout, mcols, acc, kind):
+    """dX[M, Nout] = mask(R1 + dZ[M, Kc] . W[Nout, Kc]^T): the dX product of a layer with the ReLU gradient of the layer below in
+    its epilogue (tiled fp32 kernel, skinny kernel, bf16 kernel; masks over all / a prefix / none of the columns)."""
+    rng = np.random.default_rng(M + Kc)
+    dZ = rng.standard_normal((M, Kc)).astype(np.float32)
+    W = rng.standard_normal((Nout, Kc)).astype(np.float32)
+    R = rng.standard_normal((M, Nout)).astype(np.float32)
+    Mk = rng.standard_normal((M, Nout)).astype(np.float32)
+    Mk[rng.random((M, Nout)) < 0.2] = 0.0
+    out = dv(R if acc else np.zeros_like(R), dev)
+    fn = L.lib().dispu_linear_masked if kind == "f32" else L.lib().dispu_linear_bf16_masked
+    tz, tw, tm = dv(dZ, dev), dv(W, dev), dv(Mk, dev)
+    L.check(fn(1, M, Kc, Nout, p(tz), Kc, 0, p(tw), Kc, 0, 1, None, 0, p(out), Nout, 0, p(out) if acc else None, Nout if acc else 0, 0,
+               p(tm) if mcols else None, Nout, mcols, L.stream_ptr(dev)), "linear_masked")
+    if kind == "bf16":
+        r16 = lambda a: torch.from_numpy(a).to(torch.bfloat16).to(torch.float64).numpy()
+        ref = r16(dZ) @ r16(W).T
+    else:
+        ref = dZ.astype(np.float64) @ W.astype(np.float64).T
+    if acc:
+        ref = ref + R
+    keep = np.ones((M, Nout), bool)
+    keep[:, :mcols] = Mk[:, :mcols] > 0
+    ref = np.where(keep, ref, 0.0)
+    got = N_(out)
+    assert not got[~keep].any()                                    # masked entries are exactly zero
+    close(got, ref, 2e-6 * max(Kc, 8) ** 0.5, "masked dX")
+
+
+def test_mask3(dev, L):
+    rng = np.random.default_rng(1)
+    rows, n = 3000, 256
+    d = rng.standard_normal((rows, n)).astype(np.float32)
+    ys = [np.maximum(rng.standard_normal((rows, n)), 0).astype(np.float32) for _ in range(3)]
+    outs = [torch.empty((rows, n), dtype=torch.float32, device=dev) for _ in range(3)]
+    ty = [dv(y, dev) for y in ys]
+    L.check(L.lib().dispu_mask3(rows, n, p(dv(d, dev)), n, p(ty[0]), n, p(ty[1]), n, p(ty[2]), n, p(outs[0]), p(outs[1]), p(outs[2]), n,
+                                L.stream_ptr(dev)), "mask3")
+    for o, y in zip(outs, ys):
+        assert np.array_equal(N_(o), np.where(y > 0, d, 0).astype(np.float32))
+
+
+def _cloud(rng, B, n, k):
+    xyz = rng.standard_normal((B, n, 3)).astype(np.float32) * 0.3
+    d = ((xyz[:, :, None, :] - xyz[:, None, :, :]) ** 2).sum(-1)
+    idx = np.argsort(d, axis=-1, kind="stable")[:, :, :k].astype(np.int32)
+    return xyz, idx
+
+
+def test_wnet_bn_stats_and_grad(dev, L):
+    """weight_net_hidden in training mode (ops.py:181-191) without its stored input: batch statistics / folded scale+shift / moving
+    statistics against float64, then every gradient (dWw, dbw ~ 0, dgamma, dbeta, dxyz of both points of a pair)."""
+    rng = np.random.default_rng(3)
+    B, n, k, t = 2, 256, 16, 16
+    xyz, idx = _cloud(rng, B, n, k)
+    Ww = (rng.standard_normal((3, t)) * 2).astype(np.float32)
+    bw = (rng.standard_normal(t) * 0.1).astype(np.float32)
+    gamma = rng.uniform(0.5, 1.5, t).astype(np.float32)
+    beta = (rng.standard_normal(t) * 0.3).astype(np.float32)
+    mm0, mv0 = rng.standard_normal(t).astype(np.float32), rng.uniform(0.5, 1.5, t).astype(np.float32)
+    rows = B * n
+    lib, st = L.lib(), L.stream_ptr(dev)
+    di, dx = dv(idx, dev, torch.int32), dv(xyz, dev)
+    tw, tb, tg, tbe = dv(Ww, dev), dv(bw, dev), dv(gamma, dev), dv(beta, dev)
+    mm, mv = dv(mm0, dev), dv(mv0, dev)
+    stats = torch.empty(48, dtype=torch.float32, device=dev)
+    scale, shift = torch.empty(16, dtype=torch.float32, device=dev), torch.empty(16, dtype=torch.float32, device=dev)
+    nb = lib.dispu_ps_wnet_scratch_bytes(rows)
+    sc = torch.empty(nb // 8 + 1, dtype=torch.float64, device=dev)
+    L.check(lib.dispu_ps_wnet_bn_stats(rows, n, k, t, p(di), p(dx), p(tw), p(tb), p(tg), p(tbe), 1e-3, 0.95, p(stats), p(scale), p(shift),
+                                       p(mm), p(mv), p(sc), nb, st), "wnet_bn_stats")
+    # float64 reference through the oracle's batch_norm
+    xt = torch.tensor(xyz, dtype=F64, requires_grad=True)
+    it = torch.tensor(idx.astype(np.int64))
+    Pt = {"s/gamma": torch.tensor(gamma, dtype=F64, requires_grad=True), "s/beta": torch.tensor(beta, dtype=F64, requires_grad=True),
+          "s/moving_mean": torch.tensor(mm0, dtype=F64), "s/moving_variance": torch.tensor(mv0, dtype=F64)}
+    wt = torch.tensor(Ww, dtype=F64, requires_grad=True)
+    bt = torch.tensor(bw, dtype=F64, requires_grad=True)
+    off = T.gather(xt, it) - xt[:, :, None, :]
+    wl = off @ wt + bt
+    state = {}
+    wv = torch.relu(T.batch_norm(Pt, "s/", wl, True, state))
+    flat = wl.reshape(-1, t).detach()
+    close(N_(stats)[:16], flat.mean(0).numpy(), 1e-5, "mean")
+    close(N_(stats)[16:32], flat.var(0, unbiased=False).numpy(), 1e-5, "var")
+    close(N_(mm), state["moving_mean"].numpy(), 1e-6, "moving_mean")
+    close(N_(mv), state["moving_variance"].numpy(), 1e-6, "moving_variance")
+    # the folded form is what dispu_ps_weight_net applies: wv from the device == oracle forward
+    wvd = torch.empty((rows * k, t), dtype=torch.float32, device=dev)
+    L.check(lib.dispu_ps_weight_net(rows, n, k, t, p(di), p(dx), p(tw), p(tb), p(scale), p(shift), p(wvd), st), "weight_net")
+    close(N_(wvd).reshape(B, n, k, t), wv.detach().numpy(), 1e-5, "wv (batch statistics)")
+    g = rng.standard_normal((B, n, k, t)).astype(np.float32)
+    wv.backward(torch.tensor(g, dtype=F64))
+    dWw, dbw = torch.zeros((3, t), dtype=torch.float32, device=dev), torch.zeros(t, dtype=torch.float32, device=dev)
+    dga, dbe = torch.zeros(t, dtype=torch.float32, device=dev), torch.zeros(t, dtype=torch.float32, device=dev)
+    dxyz = torch.zeros((rows, 3), dtype=torch.float32, device=dev)
+    sums = torch.empty(32, dtype=torch.float32, device=dev)
+    L.check(lib.dispu_ps_wnet_grad(rows, n, k, t, p(di), p(dx), p(tw), p(tb), p(stats), p(scale), p(shift), p(tg), p(dv(g.reshape(-1, t), dev)),
+                                   p(dWw), p(dbw), p(dga), p(dbe), p(dxyz), p(sums), p(sc), nb, st), "wnet_grad")
+    close(N_(dWw), wt.grad.numpy(), 2e-5, "dWw")
+    close(N_(dga), Pt["s/gamma"].grad.numpy(), 1e-5, "dgamma")
+    close(N_(dbe), Pt["s/beta"].grad.numpy(), 1e-5, "dbeta")
+    close(N_(dxyz).reshape(B, n, 3), xt.grad.numpy(), 2e-5, "dxyz")
+    assert np.abs(N_(dbw)).max() <= 1e-4 * np.abs(wt.grad.numpy()).max()      # a bias in front of BatchNorm: identically 0
+
+
+@pytest.mark.parametrize("B,n,k", [(2, 256, 16), (3, 1024, 16), (1, 100, 7), (2, 4096, 4)])
+def test_knn_invert(dev, L, B, n, k):
+    rng = np.random.default_rng(n + k)
+    idx = rng.integers(0, n, (B, n, k)).astype(np.int32)
+    idx[0, :, 0] = 5 % n                                                       # one heavily shared neighbour, many empty lists
+    off = torch.empty((B, n + 1), dtype=torch.int32, device=dev)
+    inv = torch.empty((B, n * k), dtype=torch.int32, device=dev)
+    L.check(L.lib().dispu_knn_invert(B, n, k, p(dv(idx, dev, torch.int32)), p(off), p(inv), L.stream_ptr(dev)), "knn_invert")
+    o, iv = N_(off), N_(inv)
+    for b in range(B):
+        flat = idx[b].reshape(-1)
+        order = np.argsort(flat, kind="stable")                                # pair ids grouped by target, ascending inside a group
+        assert np.array_equal(iv[b], order.astype(np.int32))
+        assert np.array_equal(o[b], np.concatenate([[0], np.cumsum(np.bincount(flat, minlength=n))]).astype(np.int32))
+
+
+def test_conv0_per_source_point_backward(dev, L):
+    """h0 = relu(G[j] - A[i]) with G = feat.Wf + xyz.(Wc + Wr) + b0, A = xyz.Wc (csrc/mlp_misc.hip:ps_prep): dz0 -> dG / dAneg through the
+    inverted graph (no atomics: run twice, bit-identical), then dxyz and dW0[0:6] (ps_prep_grad) against float64 autograd."""
+    rng = np.random.default_rng(11)
+    B, n, k, c = 2, 256, 16, 128
+    xyz, idx = _cloud(rng, B, n, k)
+    rows = B * n
+    W0 = (rng.standard_normal((134, c)) * 0.2).astype(np.float32)
+    dz0 = rng.standard_normal((rows * k, c)).astype(np.float32)
+    dz0[rng.random((rows * k, c)) < 0.4] = 0.0
+    lib, st = L.lib(), L.stream_ptr(dev)
+    di = dv(idx, dev, torch.int32)
+    off = torch.empty((B, n + 1), dtype=torch.int32, device=dev)
+    inv = torch.empty((B, n * k), dtype=torch.int32, device=dev)
+    L.check(lib.dispu_knn_invert(B, n, k, p(di), p(off), p(inv), st), "knn_invert")
+    tz = dv(dz0, dev)
+    res = []
+    for _ in range(2):
+        dG, dA = torch.empty((rows, c), dtype=torch.float32, device=dev), torch.empty((rows, c), dtype=torch.float32, device=dev)
+        L.check(lib.dispu_ps_conv0_gather_grad(rows, n, k, c, p(off), p(inv), p(tz), c, p(dG), c, p(dA), c, st), "conv0_gather_grad")
+        res.append((N_(dG).copy(), N_(dA).copy()))
+        _KEEP.extend([dG, dA])
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+    z = dz0.reshape(B, n, k, c).astype(np.float64)
+    refG = np.zeros((B, n, c))
+    for b in range(B):
+        np.add.at(refG[b], idx[b].reshape(-1), z[b].reshape(-1, c))
+    close(res[0][0].reshape(B, n, c), refG, 1e-5, "dG")
+    close(res[0][1].reshape(B, n, c), -z.sum(2), 1e-5, "dAneg")
+    # xyz side: autograd of sum(dz0 * (G[j] - A[i])) w.r.t. xyz and W0[0:6], feature term excluded
+    xt = torch.tensor(xyz, dtype=F64, requires_grad=True)
+    wt = torch.tensor(W0[:6], dtype=F64, requires_grad=True)
+    it = torch.tensor(idx.astype(np.int64))
+    Gx = xt @ (wt[0:3] + wt[3:6])
+    Ax = xt @ wt[0:3]
+    pre = T.gather(Gx, it) - Ax[:, :, None, :]
+    (pre * torch.tensor(z)).sum().backward()
+    dxyz = torch.zeros((rows, 3), dtype=torch.float32, device=dev)
+    dW0 = torch.zeros((134, c), dtype=torch.float32, device=dev)
+    L.check(lib.dispu_ps_prep_grad(rows, c, p(dv(xyz, dev)), p(dv(W0, dev)), p(dv(res[0][0], dev)), c, p(dv(res[0][1], dev)), c, p(dxyz), p(dW0), st),
+            "ps_prep_grad")
+    close(N_(dxyz).reshape(B, n, 3), xt.grad.numpy(), 2e-5, "dxyz")
+    close(N_(dW0)[:6], wt.grad.numpy(), 2e-5, "dW0[0:6]")
+    assert not N_(dW0)[6:].any()
+
+
+def test_skip_max_grad(dev, L):
+    """max over the 16 neighbours of [xyz_j - xyz_i | xyz_j | feat_j] (ops.py:1049) backward without the grouped tensor; duplicate
+    neighbours make exact ties, which share the gradient evenly (math_grad._MinOrMaxGrad == oracle max_even)."""
+    rng = np.random.default_rng(13)
+    B, n, k, cf = 2, 256, 16, 128
+    xyz, idx = _cloud(rng, B, n, k)
+    idx[:, ::3, 5] = idx[:, ::3, 2]                                           # repeated neighbour: every channel it wins is a 2-way tie
+    feat = rng.standard_normal((B, n, cf)).astype(np.float32)
+    rows = B * n
+    lib, st = L.lib(), L.stream_ptr(dev)
+    di, dx, df = dv(idx, dev, torch.int32), dv(xyz, dev), dv(feat, dev)
+    gmax = torch.zeros((rows, 144), dtype=torch.float32, device=dev)
+    L.check(lib.dispu_ps_skip_max(rows, n, k, cf, p(di), p(dx), p(df), cf, p(gmax), 144, st), "skip_max")
+    xt = torch.tensor(xyz, dtype=F64, requires_grad=True)
+    ft = torch.tensor(feat, dtype=F64, requires_grad=True)
+    it = torch.tensor(idx.astype(np.int64))
+    gx = T.gather(xt, it)
+    grouped = torch.cat([gx - xt[:, :, None, :], gx, T.gather(ft, it)], -1)
+    ref = T.max_even(grouped, 2)
+    close(N_(gmax)[:, :134].reshape(B, n, 134), ref.detach().numpy(), 1e-6, "gmax")
+    g = rng.standard_normal((rows, 136)).astype(np.float32)
+    ref.backward(torch.tensor(g[:, :134].reshape(B, n, 134), dtype=F64))
+    dxyz = torch.zeros((rows, 3), dtype=torch.float32, device=dev)
+    dfeat = torch.zeros((rows, cf), dtype=torch.float32, device=dev)
+    L.check(lib.dispu_ps_skip_max_grad(rows, n, k, cf, p(di), p(dx), p(df), cf, p(gmax), 144, p(dv(g, dev)), 136, p(dxyz), p(dfeat), cf, st),
+            "skip_max_grad")
+    close(N_(dfeat).reshape(B, n, cf), ft.grad.numpy(), 1e-5, "dfeat")
+    close(N_(dxyz).reshape(B, n, 3), xt.grad.numpy(), 1e-5, "dxyz")
+
+
+def test_point_matmul_grad_relu(dev, L):
+    rng = np.random.default_rng(7)
+    rows, k, c, t = 37, 16, 128, 16
+    X2 = np.maximum(rng.standard_normal((rows * k, c)), 0).astype(np.float32)        # h1 = a ReLU output
+    wv = rng.standard_normal((rows * k, t)).astype(np.float32)
+    do = rng.standard_normal((rows, c * t)).astype(np.float32)
+    dX2 = torch.empty((rows * k, c), dtype=torch.float32, device=dev)
+    dwv = torch.empty((rows * k, t), dtype=torch.float32, device=dev)
+    L.check(L.lib().dispu_ps_point_matmul_grad_relu(rows, k, c, t, p(dv(X2, dev)), c, p(dv(wv, dev)), p(dv(do, dev)), c * t, p(dX2), c,
+                                                    p(dwv), L.stream_ptr(dev)), "point_matmul_grad_relu")
+    xt = torch.tensor(X2.reshape(rows, k, c), dtype=F64, requires_grad=True)
+    wt = torch.tensor(wv.reshape(rows, k, t), dtype=F64, requires_grad=True)
+    (xt.transpose(1, 2) @ wt).reshape(rows, c * t).backward(torch.tensor(do, dtype=F64))
+    close(N_(dX2).reshape(rows, k, c), xt.grad.numpy() * (X2.reshape(rows, k, c) > 0), 1e-5, "dz1")
+    close(N_(dwv).reshape(rows, k, t), wt.grad.numpy(), 1e-5, "dwv")
+
+
+@pytest.mark.parametrize("shape,mode", [((256, 128, 256, 64), 0), ((256, 256, 256, 64), 1)])
+def test_mlp_chain_stash_equals_separate_launches(dev, L, shape, mode):
+    """dispu_mlp_chain_stash: the stashed Y1 / Y2 / Y3 / Z and the head output are bit-identical to the dispu_linear /
+    dispu_linear_small_n launches of the same layers (the training forward of the two head chains, ops.py:1089-1110, 1186-1192)."""
+    rng = np.random.default_rng(sum(shape))
+    rows = 384
+    K0, N1, N2, N3 = shape
+    X = rng.standard_normal((rows, K0)).astype(np.float32)
+    Ws = [(rng.standard_normal((a, b)) / np.sqrt(a)).astype(np.float32) for a, b in ((K0, N1), (N1, N2), (N2, N3), (N3, 3))]
+    bs = [(rng.standard_normal(b) * 0.1).astype(np.float32) for b in (N1, N2, N3, 3)]
+    R = rng.standard_normal((rows, 3)).astype(np.float32)
+    lib, st = L.lib(), L.stream_ptr(dev)
+    tx, tr = dv(X, dev), dv(R, dev)
+    tw, tb = [dv(w, dev) for w in Ws], [dv(b, dev) for b in bs]
+    E = lambda n: torch.empty((rows, n), dtype=torch.float32, device=dev)
+    y1, y2, y3, z, out = E(N1), E(N2), E(N3), E(3), E(3)
+    L.check(lib.dispu_mlp_chain_stash(rows, K0, N1, N2, N3, p(tx), K0, p(tw[0]), p(tb[0]), p(tw[1]), p(tb[1]), p(tw[2]), p(tb[2]), p(tw[3]),
+                                      p(tb[3]), p(y1), N1, p(y2), N2, p(y3), N3, p(z), 3, mode, p(tr) if mode else None, 3, p(out), 3, st),
+            "mlp_chain_stash")
+    r1, r2, r3, rz, ro = E(N1), E(N2), E(N3), E(3), E(3)
+    lin = lambda x, k, w, b, act, y, n: L.check(lib.dispu_linear(1, rows, k, n, p(x), k, 0, p(w), n, 0, 0, p(b), act, p(y), n, 0, None, 0, 0,
+                                                                 None, 0, 0, st), "linear")
+    lin(tx, K0, tw[0], tb[0], 1, r1, N1)
+    lin(r1, N1, tw[1], tb[1], 1, r2, N2)
+    lin(r2, N2, tw[2], tb[2], 1, r3, N3)
+    L.check(lib.dispu_linear_small_n(rows, N3, 3, p(r3), N3, p(tw[3]), p(tb[3]), 0, None, 0, p(rz), 3, st), "head z")
+    L.check(lib.dispu_linear_small_n(rows, N3, 3, p(r3), N3, p(tw[3]), p(tb[3]), mode, p(tr) if mode else None, 3, p(ro), 3, st), "head")
+    for a, b, name in ((y1, r1, "Y1"), (y2, r2, "Y2"), (y3, r3, "Y3"), (z, rz, "Z"), (out, ro, "out")):
+        assert torch.equal(a, b), name
