@@ -115,10 +115,12 @@ SIGNATURES = {
     "dispu_ps_wnet_bn_stats": (_i, [_l, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, C.c_float, C.c_float, _vp, _vp, _vp, _vp, _vp, _vp, _l, _vp]),
     "dispu_ps_wnet_grad": (_i, [_l, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _l, _vp]),
     "dispu_knn_invert": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp]),
-    "dispu_ps_conv0_gather_grad": (_i, [_l, _i, _i, _i, _vp, _vp, _vp, _l, _vp, _l, _vp, _l, _vp]),
+    "dispu_ps_conv0_gather_grad": (_i, [_l, _i, _i, _i, _vp, _vp, _vp, _vp, _l, _vp, _l, _vp, _l, _vp, _l, _vp, _l, _vp]),
     "dispu_ps_prep_grad": (_i, [_l, _i, _vp, _vp, _vp, _l, _vp, _l, _vp, _vp, _vp]),
-    "dispu_ps_skip_max_grad": (_i, [_l, _i, _i, _i, _vp, _vp, _vp, _l, _vp, _l, _vp, _l, _vp, _vp, _l, _vp]),
+    "dispu_ps_skip_max_grad": (_i, [_l, _i, _i, _i, _vp, _vp, _vp, _l, _vp, _l, _vp, _l, _vp, _vp, _l, _i, _vp]),
     "dispu_ps_point_matmul_grad_relu": (_i, [_l, _i, _i, _i, _vp, _l, _vp, _vp, _l, _vp, _l, _vp, _vp]),
+    "dispu_chamfer_loss_grad": (_i, [_i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, C.c_float, _vp, _vp, _vp]),
+    "dispu_pu_loss_finalize": (_i, [_vp, _vp, _l, C.c_float, C.c_float, _vp, _vp]),
     "dispu_augment": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "dispu_adam": (_i, [_l, _vp, _vp, _vp, _vp, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _vp]),
 }

@@ -361,8 +361,9 @@ __global__ __launch_bounds__(64 * (WM * WN + (LinearLds<BM, BN, BK, TRANSB, EDGE
     // stores / residual loads of a lane then share three 32-bit offset registers instead of 128 64-bit pointers
     const int wm_u = __builtin_amdgcn_readfirstlane(wm), wn_u = __builtin_amdgcn_readfirstlane(wn);
     const int rbase = m0 + wm_u * (TM * 32), cbase = n0 + wn_u * (TN * 32);
-    const long ldy = a.ldy, ldr1 = a.ldr1, ldr2 = a.ldr2;
+    const long ldy = a.ldy, ldr1 = a.ldr1, ldr2 = a.ldr2, ldm = a.ldm;
     const unsigned offy = (unsigned)(4 * fk * ldy + fi), off1 = (unsigned)(4 * fk * ldr1 + fi), off2 = (unsigned)(4 * fk * ldr2 + fi);
+    const unsigned offm = (unsigned)(4 * fk * ldm + fi);
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int colu = cbase + j * 32;                      // wave-uniform first column of this 32-wide tile
@@ -380,12 +381,13 @@ __global__ __launch_bounds__(64 * (WM * WN + (LinearLds<BM, BN, BK, TRANSB, EDGE
             // R1 / R2 per element serialises load -> wait -> add -> store 128 times (+110 us on the after_conv GEMM)
             float r1v[16], r2v[16], mkv[16];
             if constexpr (EPI == 5) {                                             // EPI 5 = EPI 4 + the ReLU-gradient mask
-                const bool msk = a.Mk != nullptr && colu < a.mcols;               // wave-uniform
+                // same addressing as the residuals: wave-uniform row base + one 32-bit lane offset, 16 loads in flight
+                const bool msk = a.Mk != nullptr && col < a.mcols && col_ok;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int rowu = rbase + i * 32 + (r & 3) + 8 * (r >> 2);
-                    const bool ok = msk && col < a.mcols && col_ok && (!EDGE || rowu + 4 * fk < M);
-                    mkv[r] = ok ? a.Mk[(size_t)(rowu + 4 * fk) * a.ldm + col] : 1.f;
+                    const bool ok = msk && (!EDGE || rowu + 4 * fk < M);
+                    mkv[r] = ok ? (a.Mk + (size_t)rowu * ldm + colu)[offm] : 1.f;
                 }
             }
             if constexpr (EPI >= 4) {

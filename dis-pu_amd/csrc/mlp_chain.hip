@@ -32,8 +32,8 @@ struct ChainArgs {
     int mode;
 };
 
-constexpr int MC_BM = 128, MC_LDA = MC_BM + 1, MC_KMAX = 256, MC_NMAX = 256;
-constexpr int MC_ACT = MC_KMAX * MC_LDA;                          // floats
+constexpr int MC_BM = 128, MC_KMAX = 256, MC_NMAX = 256;          // MC_BM: rows per workgroup of the large-batch variant (BM = 64 below
+constexpr int MC_ACT = MC_KMAX * (MC_BM + 1);                     // 8192 rows: twice the workgroups, half the rows each); floats
 // a weight slab is bk(N) = 2048 / N rows of N floats (8 / 16 / 32 rows for N = 256 / 128 / 64): every slab carries the
 // same 32 MFMAs per wave, so the barrier cadence does not depend on the layer width
 __host__ __device__ constexpr int mc_bk(int n) { return 2048 / n; }
@@ -55,14 +55,15 @@ __device__ unsigned long long mc_clock_ticks[4];
 #define MC_WAIT_PARAM
 #define MC_WAIT_ARG
 #endif
-template <int K, int N>
+template <int K, int N, int BM>
 __device__ __forceinline__ void chain_layer(float* act, const float* wst, int g0, const float* __restrict__ bias, float* __restrict__ Yg,
                                             long ldy, long row0, int wm, int wn, int fi, int fk MC_WAIT_PARAM) {
-    constexpr int TNW = N / 64;                                   // 32-wide column blocks per wave (2 x 2 waves over 128 x N)
+    constexpr int TNW = N / 64;                                   // 32-wide column blocks per wave (2 x 2 waves over BM x N)
     constexpr int LDW = N + 4, BK = mc_bk(N);
-    f32x16 acc[2][TNW];
+    constexpr int RT = BM / 64, MC_LDA = BM + 1;                  // 32-row tiles per wave (a wave owns BM / 2 rows)
+    f32x16 acc[RT][TNW];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < RT; ++i)
 #pragma unroll
         for (int j = 0; j < TNW; ++j)
 #pragma unroll
@@ -72,13 +73,13 @@ __device__ __forceinline__ void chain_layer(float* act, const float* wst, int g0
         const float* as = act + (s * BK) * MC_LDA;
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 2) {
-            float af[2], bf[TNW];
+            float af[RT], bf[TNW];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) af[i] = as[(kk + fk) * MC_LDA + wm * 64 + i * 32 + fi];
+            for (int i = 0; i < RT; ++i) af[i] = as[(kk + fk) * MC_LDA + wm * (BM / 2) + i * 32 + fi];
 #pragma unroll
             for (int j = 0; j < TNW; ++j) bf[j] = ws[(kk + fk) * LDW + wn * (N / 2) + j * 32 + fi];
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < RT; ++i)
 #pragma unroll
                 for (int j = 0; j < TNW; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
         }
@@ -96,10 +97,10 @@ __device__ __forceinline__ void chain_layer(float* act, const float* wst, int g0
         const int n = wn * (N / 2) + j * 32 + fi;
         const float bv = bias[n];
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < RT; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
+                const int row = wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
                 const float v = fmaxf(acc[i][j][r] + bv, 0.f);
                 act[n * MC_LDA + row] = v;
                 if (Yg) Yg[(size_t)(row0 + row) * ldy + n] = v;
@@ -108,8 +109,9 @@ __device__ __forceinline__ void chain_layer(float* act, const float* wst, int g0
     __syncthreads();                                              // the next layer's input is complete
 }
 
-template <int K0, int N1, int N2, int N3>
+template <int K0, int N1, int N2, int N3, int BM>
 __global__ __launch_bounds__(512) void mlp_chain_kernel(ChainArgs a) {
+    constexpr int MC_LDA = BM + 1, XU = BM / 32;                  // XU: float4 loads per loader thread and 32-column input chunk
     static_assert(K0 <= MC_KMAX && N1 <= MC_KMAX && N2 <= MC_KMAX && N3 == 64, "chain shape outside the LDS plan");
     static_assert((K0 / mc_bk(N1)) % 2 == 0 && (N1 / mc_bk(N2)) % 2 == 0 && (N2 / mc_bk(N3)) % 2 == 0, "layers must start on stage 0");
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -117,7 +119,7 @@ __global__ __launch_bounds__(512) void mlp_chain_kernel(ChainArgs a) {
     float* wst = act + MC_ACT;                                    // [2][8][N + 4]
     float* whead = wst + 2 * MC_WST;                              // W4 [64][3] + b4
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const long row0 = (long)blockIdx.x * MC_BM;
+    const long row0 = (long)blockIdx.x * BM;
     constexpr int S1 = K0 / mc_bk(N1), S2 = N1 / mc_bk(N2), S3 = N2 / mc_bk(N3), G = S1 + S2 + S3;
 
     if (wave >= 4) {
@@ -125,17 +127,17 @@ __global__ __launch_bounds__(512) void mlp_chain_kernel(ChainArgs a) {
         const int tid = threadIdx.x - 256;
         // input tile [128][K0] -> k-major act, in chunks of 32 k-columns (128 B per row, 4 float4 per thread); chunk c feeds
         // layer-1 slabs from k = 32 c on, so only chunk 0 is loaded before the MFMA waves start
-        float4 xv[4];
+        float4 xv[XU];
         auto load_x = [&](int c) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int idx = tid + u * 256;                    // 128 rows x 8 quads
+            for (int u = 0; u < XU; ++u) {
+                const int idx = tid + u * 256;                    // BM rows x 8 quads
                 xv[u] = *reinterpret_cast<const float4*>(a.X + (size_t)(row0 + (idx >> 3)) * a.ldx + c * 32 + (idx & 7) * 4);
             }
         };
         auto store_x = [&](int c) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < XU; ++u) {
                 const int idx = tid + u * 256;
                 const int r = idx >> 3, k = c * 32 + (idx & 7) * 4;
                 act[(k + 0) * MC_LDA + r] = xv[u].x;
@@ -219,14 +221,14 @@ __global__ __launch_bounds__(512) void mlp_chain_kernel(ChainArgs a) {
     const unsigned long long mc_t0 = __builtin_readcyclecounter();
 #endif
     __syncthreads();
-    chain_layer<K0, N1>(act, wst, 0, a.b1, a.Y1, a.ldy1, row0, wm, wn, fi, fk MC_WAIT_ARG);
-    chain_layer<N1, N2>(act, wst, S1, a.b2, a.Y2, a.ldy2, row0, wm, wn, fi, fk MC_WAIT_ARG);
-    chain_layer<N2, N3>(act, wst, S1 + S2, a.b3, a.Y3, a.ldy3, row0, wm, wn, fi, fk MC_WAIT_ARG);
+    chain_layer<K0, N1, BM>(act, wst, 0, a.b1, a.Y1, a.ldy1, row0, wm, wn, fi, fk MC_WAIT_ARG);
+    chain_layer<N1, N2, BM>(act, wst, S1, a.b2, a.Y2, a.ldy2, row0, wm, wn, fi, fk MC_WAIT_ARG);
+    chain_layer<N2, N3, BM>(act, wst, S1 + S2, a.b3, a.Y3, a.ldy3, row0, wm, wn, fi, fk MC_WAIT_ARG);
 #ifdef MC_CLOCK
     if (blockIdx.x == 7 && threadIdx.x == 0) { mc_clock_ticks[0] = __builtin_readcyclecounter() - mc_t0; mc_clock_ticks[1] = G; mc_clock_ticks[2] = mc_wait_local; }
 #endif
     // head: 64 -> 3 per row, the arithmetic of linear_small_n_kernel (fmaf chain over k, + bias, optional sigmoid offset)
-    if (threadIdx.x < MC_BM) {
+    if (threadIdx.x < BM) {
         const int row = threadIdx.x;
         float o0 = 0.f, o1 = 0.f, o2 = 0.f;
 #pragma unroll 8
@@ -270,26 +272,37 @@ DISPU_EXPORT int dispu_mlp_chain_stash(long rows, int K0, int N1, int N2, int N3
                                        const float* W2, const float* b2, const float* W3, const float* b3, const float* W4, const float* b4,
                                        float* Y1, long ldy1, float* Y2, long ldy2, float* Y3, long ldy3, float* Z, long ldz, int mode,
                                        const float* R, long ldr, float* out, long ldo, void* stream) {
-    if (rows < 0 || (rows % MC_BM) != 0 || (ldx & 3) || !X || !W1 || !W2 || !W3 || !W4 || !b1 || !b2 || !b3 || !b4 || !out ||
+    if (rows < 0 || (rows % 64) != 0 || (ldx & 3) || !X || !W1 || !W2 || !W3 || !W4 || !b1 || !b2 || !b3 || !b4 || !out ||
         (mode == 1 && !R) || ((((uintptr_t)X) | ((uintptr_t)W1) | ((uintptr_t)W2) | ((uintptr_t)W3)) & 15))
         return (int)hipErrorInvalidValue;
     if (rows == 0) return 0;
     ChainArgs a{rows, X, ldx, W1, b1, W2, b2, W3, b3, W4, b4, Y1, ldy1, Y2, ldy2, Y3, ldy3, Z, ldz, R, ldr, out, ldo, mode};
-    const dim3 grid((unsigned)(rows / MC_BM));
     hipStream_t s = (hipStream_t)stream;
-    static DevOnce attr;      
+    static DevOnce attr;
     if (attr.needed()) {
-        DISPU_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_chain_kernel<256, 128, 256, 64>),
+        DISPU_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_chain_kernel<256, 128, 256, 64, 128>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)MC_LDS_BYTES));
-        DISPU_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_chain_kernel<256, 256, 256, 64>),
+        DISPU_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_chain_kernel<256, 256, 256, 64, 128>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)MC_LDS_BYTES));
+        DISPU_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_chain_kernel<256, 128, 256, 64, 64>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)MC_LDS_BYTES));
+        DISPU_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_chain_kernel<256, 256, 256, 64, 64>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)MC_LDS_BYTES));
         attr.done();
     }
-    if (K0 == 256 && N1 == 128 && N2 == 256 && N3 == 64)
-        hipLaunchKernelGGL((mlp_chain_kernel<256, 128, 256, 64>), grid, dim3(512), MC_LDS_BYTES, s, a);
-    else if (K0 == 256 && N1 == 256 && N2 == 256 && N3 == 64)
-        hipLaunchKernelGGL((mlp_chain_kernel<256, 256, 256, 64>), grid, dim3(512), MC_LDS_BYTES, s, a);
-    else
-        return (int)hipErrorInvalidValue;
+    // 128-row workgroups once they fill the chip (>= 256 of them); below that (the training step's 8 patches = 8192 rows) 64-row
+    // workgroups: twice as many, each streaming the same weights for half the rows.  Same arithmetic, bit-identical results.
+    const bool small = (rows % MC_BM) != 0 || rows / MC_BM < 192;
+    const bool coarse = (K0 == 256 && N1 == 128 && N2 == 256 && N3 == 64), fine = (K0 == 256 && N1 == 256 && N2 == 256 && N3 == 64);
+    if (!coarse && !fine) return (int)hipErrorInvalidValue;
+    if (small) {
+        const dim3 grid((unsigned)(rows / 64));
+        if (coarse) hipLaunchKernelGGL((mlp_chain_kernel<256, 128, 256, 64, 64>), grid, dim3(512), MC_LDS_BYTES, s, a);
+        else hipLaunchKernelGGL((mlp_chain_kernel<256, 256, 256, 64, 64>), grid, dim3(512), MC_LDS_BYTES, s, a);
+    } else {
+        const dim3 grid((unsigned)(rows / MC_BM));
+        if (coarse) hipLaunchKernelGGL((mlp_chain_kernel<256, 128, 256, 64, 128>), grid, dim3(512), MC_LDS_BYTES, s, a);
+        else hipLaunchKernelGGL((mlp_chain_kernel<256, 256, 256, 64, 128>), grid, dim3(512), MC_LDS_BYTES, s, a);
+    }
     return (int)hipGetLastError();
 }

@@ -180,7 +180,6 @@ __global__ __launch_bounds__(256) void ps_wnet_grad_apply_kernel(long rows, int 
                                                                   const float* __restrict__ sums, const float* __restrict__ dwv,
                                                                   float* __restrict__ dWw, float* __restrict__ dbw, float* __restrict__ dxyz) {
     __shared__ float red[4][256];
-    __shared__ float pi[WN_K][3];
     const int s = threadIdx.x >> 4, t = threadIdx.x & 15;
     const float mu = stats[t], is = stats[2 * WN_T + t], sc = scale[t], sh = shift[t];
     const float inv_n = 1.0f / (float)(rows * WN_K);
@@ -201,17 +200,11 @@ __global__ __launch_bounds__(256) void ps_wnet_grad_apply_kernel(long rows, int 
         float o0 = dwl * w0, o1 = dwl * w1, o2 = dwl * w2;
 #pragma unroll
         for (int m = 8; m > 0; m >>= 1) { o0 += __shfl_xor(o0, m, 16); o1 += __shfl_xor(o1, m, 16); o2 += __shfl_xor(o2, m, 16); }
-        if (t == 0) {
-            unsafeAtomicAdd(dxyz + j * 3 + 0, o0); unsafeAtomicAdd(dxyz + j * 3 + 1, o1); unsafeAtomicAdd(dxyz + j * 3 + 2, o2);
-            pi[s][0] = o0; pi[s][1] = o1; pi[s][2] = o2;
-        }
-        __syncthreads();
-        if (threadIdx.x < 3) {
-            float v = 0.f;
-            for (int q = 0; q < WN_K; ++q) v += pi[q][threadIdx.x];
-            unsafeAtomicAdd(dxyz + i * 3 + threadIdx.x, -v);
-        }
-        __syncthreads();
+        if (t == 0) { unsafeAtomicAdd(dxyz + j * 3 + 0, o0); unsafeAtomicAdd(dxyz + j * 3 + 1, o1); unsafeAtomicAdd(dxyz + j * 3 + 2, o2); }
+        // the point's own share: the 4 pairs of this wave are combined first (one atomic per wave and coordinate, not per pair)
+        o0 += __shfl_xor(o0, 16, 64); o1 += __shfl_xor(o1, 16, 64); o2 += __shfl_xor(o2, 16, 64);
+        o0 += __shfl_xor(o0, 32, 64); o1 += __shfl_xor(o1, 32, 64); o2 += __shfl_xor(o2, 32, 64);
+        if ((threadIdx.x & 63) == 0) { unsafeAtomicAdd(dxyz + i * 3 + 0, -o0); unsafeAtomicAdd(dxyz + i * 3 + 1, -o1); unsafeAtomicAdd(dxyz + i * 3 + 2, -o2); }
     }
     red[0][threadIdx.x] = a0; red[1][threadIdx.x] = a1; red[2][threadIdx.x] = a2; red[3][threadIdx.x] = ab;
     __syncthreads();
@@ -280,20 +273,38 @@ __global__ __launch_bounds__(1024) void knn_invert_kernel(int n, int k, const in
 }
 
 // ---- conv0 per source point, backward (h0 = relu(G[j] - A[i]), csrc/mlp_misc.hip:ps_prep) ---------------------------------------
-// dz0 [(i,s), c] (c = 128, already masked by h0 > 0) ->  dG[p] = sum over the in-edges of p (pairs (i,s) with idx[i,s] = p) of
-// dz0[(i,s)],  dAneg[p] = -sum_s dz0[(p,s)].  32 lanes per point, one float4 of the 512-byte rows each; the in-edge rows are
-// fetched 4 at a time.  No atomics: a point's sums are formed in a fixed order.
-__global__ __launch_bounds__(256) void ps_conv0_gather_grad_kernel(long rows, int n_per_cloud, int k, const int* __restrict__ off,
-                                                                    const int* __restrict__ inv, const float* __restrict__ dz0, long ldz,
-                                                                    float* __restrict__ dG, long ldg, float* __restrict__ dAneg, long lda) {
+// dh0 [(i,s), c] (c = 128; the gradient w.r.t. h0, NOT yet multiplied by relu') ->  dz0 = dh0 * (G[j] - A[i] > 0), then
+// dG[p] = sum over the in-edges of p (pairs (i,s) with idx[i,s] = p) of dz0[(i,s)],  dAneg[p] = -sum_s dz0[(p,s)].
+// The ReLU decision is re-derived from G and A (two [B*M, 128] matrices that live in L2; the same fp32 subtraction the forward
+// made) instead of from a stored h0, and instead of a masked epilogue on the [B*M*16, 128] GEMM that produces dh0.
+// 32 lanes per point, one float4 of the 512-byte rows each; the in-edge rows are fetched 4 at a time.  No atomics: a point's
+// sums are formed in a fixed order (the inverted lists are sorted).  Gm == NULL: dh0 is taken as already masked.
+__device__ __forceinline__ float4 c0_masked(float4 v, float4 g, float4 a) {
+    return make_float4((g.x - a.x > 0.f) ? v.x : 0.f, (g.y - a.y > 0.f) ? v.y : 0.f, (g.z - a.z > 0.f) ? v.z : 0.f, (g.w - a.w > 0.f) ? v.w : 0.f);
+}
+__global__ __launch_bounds__(256) void ps_conv0_gather_grad_kernel(long rows, int n_per_cloud, int k, const int* __restrict__ idx,
+                                                                    const int* __restrict__ off, const int* __restrict__ inv,
+                                                                    const float* __restrict__ dz0, long ldz, const float* __restrict__ Gm,
+                                                                    long ldgm, const float* __restrict__ Am, long ldam, float* __restrict__ dG,
+                                                                    long ldg, float* __restrict__ dAneg, long lda) {
     const int sub = threadIdx.x & 31;
     const long p = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 5;
     if (p >= rows) return;
-    const long cloud = p / n_per_cloud, pl = p - cloud * n_per_cloud;
+    const long cloud = p / n_per_cloud, pl = p - cloud * n_per_cloud, base = cloud * n_per_cloud;
     const float* __restrict__ zc = dz0 + (size_t)cloud * n_per_cloud * k * ldz;        // this cloud's pair rows
+    const bool msk = Gm != nullptr;
+    float4 gp = make_float4(0.f, 0.f, 0.f, 0.f), ap = gp;
+    if (msk) {
+        gp = *reinterpret_cast<const float4*>(Gm + p * ldgm + sub * 4);
+        ap = *reinterpret_cast<const float4*>(Am + p * ldam + sub * 4);
+    }
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int s = 0; s < k; ++s) {
-        const float4 v = *reinterpret_cast<const float4*>(zc + (size_t)(pl * k + s) * ldz + sub * 4);
+        float4 v = *reinterpret_cast<const float4*>(zc + (size_t)(pl * k + s) * ldz + sub * 4);
+        if (msk) {
+            const long j = base + idx[p * k + s];
+            v = c0_masked(v, *reinterpret_cast<const float4*>(Gm + j * ldgm + sub * 4), ap);
+        }
         a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
     }
     *reinterpret_cast<float4*>(dAneg + p * lda + sub * 4) = make_float4(-a.x, -a.y, -a.z, -a.w);
@@ -304,17 +315,25 @@ __global__ __launch_bounds__(256) void ps_conv0_gather_grad_kernel(long rows, in
     int e = lo;
     for (; e + 4 <= hi; e += 4) {
         const int e0 = iv[e], e1 = iv[e + 1], e2 = iv[e + 2], e3 = iv[e + 3];
-        const float4 v0 = *reinterpret_cast<const float4*>(zc + (size_t)e0 * ldz + sub * 4);
-        const float4 v1 = *reinterpret_cast<const float4*>(zc + (size_t)e1 * ldz + sub * 4);
-        const float4 v2 = *reinterpret_cast<const float4*>(zc + (size_t)e2 * ldz + sub * 4);
-        const float4 v3 = *reinterpret_cast<const float4*>(zc + (size_t)e3 * ldz + sub * 4);
+        float4 v0 = *reinterpret_cast<const float4*>(zc + (size_t)e0 * ldz + sub * 4);
+        float4 v1 = *reinterpret_cast<const float4*>(zc + (size_t)e1 * ldz + sub * 4);
+        float4 v2 = *reinterpret_cast<const float4*>(zc + (size_t)e2 * ldz + sub * 4);
+        float4 v3 = *reinterpret_cast<const float4*>(zc + (size_t)e3 * ldz + sub * 4);
+        if (msk) {
+            v0 = c0_masked(v0, gp, *reinterpret_cast<const float4*>(Am + (base + e0 / k) * ldam + sub * 4));
+            v1 = c0_masked(v1, gp, *reinterpret_cast<const float4*>(Am + (base + e1 / k) * ldam + sub * 4));
+            v2 = c0_masked(v2, gp, *reinterpret_cast<const float4*>(Am + (base + e2 / k) * ldam + sub * 4));
+            v3 = c0_masked(v3, gp, *reinterpret_cast<const float4*>(Am + (base + e3 / k) * ldam + sub * 4));
+        }
         g.x += v0.x; g.y += v0.y; g.z += v0.z; g.w += v0.w;
         g.x += v1.x; g.y += v1.y; g.z += v1.z; g.w += v1.w;
         g.x += v2.x; g.y += v2.y; g.z += v2.z; g.w += v2.w;
         g.x += v3.x; g.y += v3.y; g.z += v3.z; g.w += v3.w;
     }
     for (; e < hi; ++e) {
-        const float4 v = *reinterpret_cast<const float4*>(zc + (size_t)iv[e] * ldz + sub * 4);
+        const int ee = iv[e];
+        float4 v = *reinterpret_cast<const float4*>(zc + (size_t)ee * ldz + sub * 4);
+        if (msk) v = c0_masked(v, gp, *reinterpret_cast<const float4*>(Am + (base + ee / k) * ldam + sub * 4));
         g.x += v.x; g.y += v.y; g.z += v.z; g.w += v.w;
     }
     *reinterpret_cast<float4*>(dG + p * ldg + sub * 4) = g;
@@ -376,7 +395,7 @@ __global__ __launch_bounds__(256) void ps_prep_grad_kernel(long rows, const floa
 __global__ __launch_bounds__(256) void ps_skip_max_grad_kernel(long rows, int n_per_cloud, const int* __restrict__ idx, const float* __restrict__ xyz,
                                                                 const float* __restrict__ feat, long ldf, const float* __restrict__ gmax, long ldm,
                                                                 const float* __restrict__ dgmax, long ldd, float* __restrict__ dxyz,
-                                                                float* __restrict__ dfeat, long lddf) {
+                                                                float* __restrict__ dfeat, long lddf, int feat_is_relu) {
     const int sub = threadIdx.x & 31;
     const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 5;
     if (i >= rows) return;
@@ -402,7 +421,13 @@ __global__ __launch_bounds__(256) void ps_skip_max_grad_kernel(long rows, int n_
     for (int s = 0; s < 16; ++s) {
         cnt[0] += v[s].x == mf[0]; cnt[1] += v[s].y == mf[1]; cnt[2] += v[s].z == mf[2]; cnt[3] += v[s].w == mf[3];
     }
-    const float sh[4] = {gf[0] / (float)cnt[0], gf[1] / (float)cnt[1], gf[2] / (float)cnt[2], gf[3] / (float)cnt[3]};
+    float sh[4] = {gf[0] / (float)cnt[0], gf[1] / (float)cnt[1], gf[2] / (float)cnt[2], gf[3] / (float)cnt[3]};
+    // feat_is_relu: feat is a ReLU output whose relu_grad is applied to dfeat afterwards.  A maximum of 0 means every one of the 16
+    // candidates is a ReLU zero (the common case: a 16-way tie) and its share lands on entries that mask kills -- not sent at all.
+    if (feat_is_relu) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) sh[c] = (mf[c] > 0.f) ? sh[c] : 0.f;
+    }
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
         float* d = dfeat + jj[s] * lddf + sub * 4;
@@ -457,6 +482,82 @@ __global__ __launch_bounds__(256) void ps_point_matmul_grad_relu_kernel(long row
             dwv[(i * K + s) * T + t] = a;
         }
         __syncthreads();
+    }
+}
+
+
+// ---- pu_loss glue (DisPU/model.py:75-87, Common/loss_utils.py:45-64,271-298) ---------------------------------------------------
+// Round 2 evaluated CD = mean_b[(mean_k dist_gt + mean_j dist_pred) / radius_b] and its constant per-row gradients with ~15 tiny
+// tensor ops per Chamfer term (row means, adds, fills, memsets: 5 - 10 us of launch gap each; the loss took 0.46 ms of a 3 ms step).
+// chamfer_value_kernel: ONE workgroup walks the clouds in order -> value[0] = sum_b (mean d_gt[b] + mean d_pred[b]) / radius[b] / B.
+__global__ __launch_bounds__(1024) void chamfer_value_kernel(int b, int n_gt, int n_pred, const float* __restrict__ d_gt,
+                                                              const float* __restrict__ d_pred, const float* __restrict__ radius,
+                                                              float* __restrict__ value) {
+    __shared__ float red[2][16];
+    float total = 0.f;
+    for (int c = 0; c < b; ++c) {
+        float s1 = 0.f, s2 = 0.f;
+        for (int i = threadIdx.x; i < n_gt; i += 1024) s1 += d_gt[(size_t)c * n_gt + i];
+        for (int i = threadIdx.x; i < n_pred; i += 1024) s2 += d_pred[(size_t)c * n_pred + i];
+        s1 = wave_sum_f32(s1);
+        s2 = wave_sum_f32(s2);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s1; red[1][threadIdx.x >> 6] = s2; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float a = 0.f, bb = 0.f;
+            for (int w = 0; w < 16; ++w) { a += red[0][w]; bb += red[1][w]; }
+            total += (a / (float)n_gt + bb / (float)n_pred) / radius[c];
+        }
+    }
+    if (threadIdx.x == 0) value[0] = total / (float)b;
+}
+
+// d(coef * CD)/d pred: nn_distance's gradient (tf_nndistance.py:31-37, tf_nndistance_g.cu:132-157) with the constant upstream
+// gradients coef / (radius_b n B) of the two row means folded in; pred only (gt is data).  blockIdx.z = 0: every gt point pulls its
+// nearest pred point; 1: every pred point is pulled towards its nearest gt point.  dpred must be zero-filled (atomics).
+__global__ void chamfer_grad_kernel(int bcount, int n_gt, int n_pred, const float* __restrict__ gt, const float* __restrict__ pred,
+                                    const int* __restrict__ i_gt, const int* __restrict__ i_pred, const float* __restrict__ radius,
+                                    float coef, float* __restrict__ dpred) {
+    const int cloud = blockIdx.y;
+    const bool from_gt = blockIdx.z == 0;
+    const int nf = from_gt ? n_gt : n_pred;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= nf) return;
+    const float* g0 = gt + (size_t)cloud * n_gt * 3;
+    const float* p0 = pred + (size_t)cloud * n_pred * 3;
+    float* dp = dpred + (size_t)cloud * n_pred * 3;
+    const float inv_r = 1.0f / radius[cloud];
+    const float g = (inv_r * (coef / ((float)nf * (float)bcount))) * 2;
+    if (from_gt) {
+        const int j2 = i_gt[(size_t)cloud * n_gt + j];
+#pragma unroll
+        for (int l = 0; l < 3; ++l) unsafeAtomicAdd(dp + j2 * 3 + l, -(g * (g0[j * 3 + l] - p0[j2 * 3 + l])));
+    } else {
+        const int j2 = i_pred[(size_t)cloud * n_pred + j];
+#pragma unroll
+        for (int l = 0; l < 3; ++l) unsafeAtomicAdd(dp + j * 3 + l, g * (p0[j * 3 + l] - g0[j2 * 3 + l]));
+    }
+}
+
+// out[0] = 1000 cd_coarse, out[1] = 1000 cd_fine, out[2] = repulsion_w * mean(rep) / 4 (loss_utils.py:296-297: mean over
+// [B, M, 4] of the hinge terms; rep[i] holds the sum over the 4 neighbours), out[3] = pu_loss = out[0] + wf out[1] + out[2]
+// (model.py:87), out[4] = wf.  One workgroup, fixed order.
+__global__ __launch_bounds__(1024) void pu_loss_finalize_kernel(const float* __restrict__ cd, const float* __restrict__ rep, long nrep, float wf,
+                                                                 float rep_w, float* __restrict__ out) {
+    __shared__ float red[16];
+    float s = 0.f;
+    if (rep)
+        for (long i = threadIdx.x; i < nrep; i += 1024) s += rep[i];
+    s = wave_sum_f32(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float a = 0.f;
+        for (int w = 0; w < 16; ++w) a += red[w];
+        const float r = rep ? rep_w * (a / ((float)nrep * 4.0f)) : 0.f;
+        const float c = 1000.0f * cd[0], f = 1000.0f * cd[1];
+        out[0] = c; out[1] = f; out[2] = r; out[3] = (c + wf * f) + r; out[4] = wf;
     }
 }
 
@@ -518,12 +619,15 @@ DISPU_EXPORT int dispu_knn_invert(int b, int n, int k, const int* idx, int* off,
     return (int)hipGetLastError();
 }
 
-DISPU_EXPORT int dispu_ps_conv0_gather_grad(long rows, int n_per_cloud, int k, int c, const int* off, const int* inv, const float* dz0,
-                                            long ldz, float* dG, long ldg, float* dAneg, long lda, void* stream) {
-    if (rows < 0 || c != 128 || n_per_cloud <= 0 || rows % n_per_cloud != 0 || ((ldz | ldg | lda) & 3)) return (int)hipErrorInvalidValue;
+DISPU_EXPORT int dispu_ps_conv0_gather_grad(long rows, int n_per_cloud, int k, int c, const int* idx, const int* off, const int* inv,
+                                            const float* dh0, long ldz, const float* Gm, long ldgm, const float* Am, long ldam, float* dG,
+                                            long ldg, float* dAneg, long lda, void* stream) {
+    if (rows < 0 || c != 128 || n_per_cloud <= 0 || rows % n_per_cloud != 0 || ((ldz | ldg | lda | ldgm | ldam) & 3) || ((Gm == nullptr) != (Am == nullptr)) ||
+        (Gm && !idx))
+        return (int)hipErrorInvalidValue;
     if (rows == 0) return 0;
     hipLaunchKernelGGL(ps_conv0_gather_grad_kernel, dim3((unsigned)((rows * 32 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, rows,
-                       n_per_cloud, k, off, inv, dz0, ldz, dG, ldg, dAneg, lda);
+                       n_per_cloud, k, idx, off, inv, dh0, ldz, Gm, ldgm, Am, ldam, dG, ldg, dAneg, lda);
     return (int)hipGetLastError();
 }
 
@@ -538,11 +642,11 @@ DISPU_EXPORT int dispu_ps_prep_grad(long rows, int co, const float* xyz, const f
 
 DISPU_EXPORT int dispu_ps_skip_max_grad(long rows, int n_per_cloud, int k, int cf, const int* idx, const float* xyz, const float* feat,
                                         long ldf, const float* gmax, long ldm, const float* dgmax, long ldd, float* dxyz, float* dfeat,
-                                        long lddf, void* stream) {
+                                        long lddf, int feat_is_relu, void* stream) {
     if (rows < 0 || k != 16 || cf != 128 || n_per_cloud <= 0 || (ldf & 3)) return (int)hipErrorInvalidValue;
     if (rows == 0) return 0;
     hipLaunchKernelGGL(ps_skip_max_grad_kernel, dim3((unsigned)((rows * 32 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, rows, n_per_cloud,
-                       idx, xyz, feat, ldf, gmax, ldm, dgmax, ldd, dxyz, dfeat, lddf);
+                       idx, xyz, feat, ldf, gmax, ldm, dgmax, ldd, dxyz, dfeat, lddf, feat_is_relu);
     return (int)hipGetLastError();
 }
 
@@ -553,5 +657,30 @@ DISPU_EXPORT int dispu_ps_point_matmul_grad_relu(long rows, int k, int c, int t_
     const int nb = (int)(rows < 16384 ? rows : 16384);
     hipLaunchKernelGGL(ps_point_matmul_grad_relu_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, rows, X2, ldx2, wv, dout, ldo, dX2,
                        lddx2, dwv);
+    return (int)hipGetLastError();
+}
+
+// Chamfer term of pu_loss: value[0] = CD(gt, pred) (loss_utils.py:45-64, un-scaled) from nn_distance's outputs, and
+// dpred = d(coef * CD)/d pred (zero-filled here, then accumulated).  radius [b]: the per-cloud normaliser.
+DISPU_EXPORT int dispu_chamfer_loss_grad(int b, int n_gt, const float* gt, int n_pred, const float* pred, const float* d_gt, const int* i_gt,
+                                         const float* d_pred, const int* i_pred, const float* radius, float coef, float* value, float* dpred,
+                                         void* stream) {
+    if (b <= 0 || n_gt <= 0 || n_pred <= 0 || !gt || !pred || !d_gt || !i_gt || !d_pred || !i_pred || !radius || !value || !dpred)
+        return (int)hipErrorInvalidValue;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(chamfer_value_kernel, dim3(1), dim3(1024), 0, s, b, n_gt, n_pred, d_gt, d_pred, radius, value);
+    DISPU_CHECK_LAUNCH();
+    DISPU_TRY(hipMemsetAsync(dpred, 0, sizeof(float) * (size_t)b * n_pred * 3, s));
+    const int mx = n_gt > n_pred ? n_gt : n_pred;
+    hipLaunchKernelGGL(chamfer_grad_kernel, dim3((mx + 255) / 256, b, 2), dim3(256), 0, s, b, n_gt, n_pred, gt, pred, i_gt, i_pred, radius, coef,
+                       dpred);
+    return (int)hipGetLastError();
+}
+
+// out[5] = 1000 CD_coarse | 1000 CD_fine | repulsion term | pu_loss | weight_fine  (model.py:75-87); cd[2] = the two un-scaled
+// Chamfer values, rep [nrep] = per-point hinge sums of dispu_repulsion (NULL: no repulsion term).
+DISPU_EXPORT int dispu_pu_loss_finalize(const float* cd, const float* rep, long nrep, float wf, float rep_w, float* out, void* stream) {
+    if (!cd || !out || (rep && nrep <= 0)) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(pu_loss_finalize_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, cd, rep, nrep, wf, rep_w, out);
     return (int)hipGetLastError();
 }

@@ -89,6 +89,7 @@ class Trainer(object):
         self._scratch = {}                    # per stream: scratch of the split reductions / column sums
         self._bn_scratch = None
         self._stash_ready = False
+        self._graphs = {}
         # weight-gradient products (dW = X^T dZ) are off the backward chain: only Adam reads them.  They run on a second
         # HIP stream next to the dX products that ARE the chain (both read dZ; at 8 patches neither fills 256 CUs alone).
         self.overlap_dw = os.environ.get("DISPU_TRAIN_OVERLAP", "1") != "0"
@@ -171,7 +172,7 @@ class Trainer(object):
             cd=[dict(d_gt=E(B, M), i_gt=E(B, M, dtype=i32), d_pred=E(B, M), i_pred=E(B, M, dtype=i32), g_gt=E(B, M), g_pred=E(B, M),
                      dgt_unused=E(B, M, 3), rowmean=E(B), rowmax=E(B)) for _ in range(2)],      # one set per Chamfer term
             ball=E(B, M, 20, dtype=i32), ball_cnt=E(B, M, dtype=i32), rep=E(B, M), rowmean=E(B), rowmax=E(B),
-            zeros=Z(1))
+            loss_vals=Z(8), r07=torch.full((B,), 0.07, dtype=f32, device=dev), zeros=Z(1))
         # grid code of duplicate_up: row (cloud*up + r)*N + i carries grid[r]
         ws["gcode"].view(B, self.up_ratio, N, 2).copy_(self.grid.view(1, self.up_ratio, 1, 2).expand(B, self.up_ratio, N, 2))
         self._ws[key] = ws
@@ -200,6 +201,16 @@ class Trainer(object):
         self._side.wait_event(self._fork_ev)
         self._side_busy = True
         return ctypes.c_void_p(self._side.cuda_stream)
+
+    def _fork_point(self):
+        """an event at the current position of the main stream, for a dW product queued later (see _lin_bwd)."""
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.device)
+            self._fork_ev = torch.cuda.Event()
+            self._join_ev = torch.cuda.Event()
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        return ev
 
     def _join(self):
         """the current stream waits for every dW product queued so far (before a buffer they read is overwritten, before Adam)."""
@@ -251,14 +262,19 @@ class Trainer(object):
         _lib.check(self._dl(1, M, K, N, _p(X, xoff), X.stride(0), 0, _p(W, woff), W.stride(0), 0, 0, _p(b), act,
                                   _p(Y, yoff), Y.stride(0), 0, None, 0, 0, None, 0, 0, self.st), "dispu_linear")
 
-    def _tn(self, batch, M, K, N, X, xoff, ldx, sx, Zt, zoff, ldz, sz, out, ooff, ldo, so, accumulate, dbias=None, side=False):
+    def _tn(self, batch, M, K, N, X, xoff, ldx, sx, Zt, zoff, ldz, sz, out, ooff, ldo, so, accumulate, dbias=None, side=False, after=None):
         """out (+)= X^T . Zt.  side=True: on the second stream (the caller guarantees nothing overwrites X / Zt before _join)."""
         L = _lib.lib()
         side = side and self.overlap_dw
         bf = self.bf16 and K > 4 and N > 4
         need = (L.dispu_linear_tn_bf16_scratch_floats if bf else L.dispu_linear_tn_scratch_floats)(batch, M, K, N)
         sc = self._scratch_floats(need, side)
-        st = self._fork() if side else self.st
+        if side and after is not None:
+            self._side.wait_event(after)
+            self._side_busy = True
+            st = ctypes.c_void_p(self._side.cuda_stream)
+        else:
+            st = self._fork() if side else self.st
         fn = L.dispu_linear_tn_bf16 if bf else L.dispu_linear_tn
         _lib.check(fn(batch, M, K, N, _p(X, xoff), ldx, sx, _p(Zt, zoff), ldz, sz, _p(out, ooff), ldo, so, accumulate, _p(dbias), _p(sc),
                       sc.numel(), st), "dispu_linear_tn_bf16" if bf else "dispu_linear_tn")
@@ -298,9 +314,12 @@ class Trainer(object):
         dW = self.G[wname + "/weights"] if dW is None else dW
         if db is None and bias:
             db = self.G[wname + "/biases"]
-        self._tn(1, M, K, N, X, xoff, X.stride(0), 0, dY, dyoff, dY.stride(0), 0, dW, woff, dW.stride(0), 0, 1, dbias=db, side=True)
+        # the dX product IS the backward chain: it is queued first; the dW product (read by Adam only) follows on the second stream,
+        # ordered after dZ by an event recorded BEFORE the dX launch (dX never writes what the dW product reads)
+        ev = self._fork_point() if (self.overlap_dw and dX is not None) else None
         if dX is not None:
             self._dx(M, N, K, dY, dyoff, W, woff, dX, dxoff, acc_dx, mask)
+        self._tn(1, M, K, N, X, xoff, X.stride(0), 0, dY, dyoff, dY.stride(0), 0, dW, woff, dW.stride(0), 0, 1, dbias=db, side=True, after=ev)
 
     # ----------------------------------------------------------------------------------------------- forward ----
     def forward(self, inputs):
@@ -437,23 +456,18 @@ class Trainer(object):
         self._stash_ready = True
 
     # -------------------------------------------------------------------------------------------------- loss ----
-    def _chamfer(self, pred, gt, inv_r, coef, dpred, slot):
-        """1000-scaled-by-caller Chamfer value and d(coef * CD)/d pred written into dpred (loss_utils.py:45-64 with
-        nn_distance(gt, pred), gradient tf_nndistance.py:31-37)."""
+    def _chamfer(self, pred, gt, radius, coef, dpred, slot):
+        """one Chamfer term (loss_utils.py:45-64 with nn_distance(gt, pred)): its un-scaled value into loss_vals[slot] and
+        d(coef * CD)/d pred into dpred -- three launches (nn_distance, value, gradient) + one memset."""
         L = _lib.lib()
-        ws = self._workspace(*self._shape)["cd"][slot]
+        full = self._workspace(*self._shape)
+        ws = full["cd"][slot]
         B, n_gt, n_pred = gt.shape[0], gt.shape[1], pred.shape[1]
         _lib.check(L.dispu_nn_distance(B, n_gt, _p(gt), n_pred, _p(pred), _p(ws["d_gt"]), _p(ws["i_gt"]), _p(ws["d_pred"]),
                                        _p(ws["i_pred"]), _lib.ARITH_CONTRACT, self.st), "nn_distance")
-        _lib.check(L.dispu_row_mean_max(B, n_gt, _p(ws["d_gt"]), _p(ws["rowmean"]), _p(ws["rowmax"]), self.st), "row_mean")
-        fwd = ws["rowmean"].clone()
-        _lib.check(L.dispu_row_mean_max(B, n_pred, _p(ws["d_pred"]), _p(ws["rowmean"]), _p(ws["rowmax"]), self.st), "row_mean")
-        value = ((fwd + ws["rowmean"]) * inv_r).sum() / B
-        _lib.check(L.dispu_fill_rows(B, n_gt, _p(inv_r), coef / (n_gt * B), _p(ws["g_gt"]), self.st), "fill_rows")
-        _lib.check(L.dispu_fill_rows(B, n_pred, _p(inv_r), coef / (n_pred * B), _p(ws["g_pred"]), self.st), "fill_rows")
-        _lib.check(L.dispu_nn_distance_grad(B, n_gt, _p(gt), n_pred, _p(pred), _p(ws["g_gt"]), _p(ws["i_gt"]), _p(ws["g_pred"]),
-                                            _p(ws["i_pred"]), _p(ws["dgt_unused"]), _p(dpred), self.st), "nn_distance_grad")
-        return value
+        _lib.check(L.dispu_chamfer_loss_grad(B, n_gt, _p(gt), n_pred, _p(pred), _p(ws["d_gt"]), _p(ws["i_gt"]), _p(ws["d_pred"]),
+                                             _p(ws["i_pred"]), _p(radius), coef, _p(full["loss_vals"], slot), _p(dpred), self.st),
+                   "chamfer_loss_grad")
 
     def _check_targets(self, gt, radius, B, M):
         """gt [B, 4N, 3] / radius [B] float32 on the device: the loss workspace (d_gt, i_gt, g_gt, ...) is sized [B, 4N]
@@ -472,31 +486,27 @@ class Trainer(object):
         M = N * self.up_ratio
         ws = self._workspace(B, N)
         gt, radius = self._check_targets(gt, radius, B, M)
-        inv_r = (1.0 / radius).contiguous()
         wf = weight_fine(self.epoch)
         with self._branch(2):                                   # off the chain: needed by the local cell's backward only
             self._recompute_pair_tensors()
         with self._branch(0):                                   # the coarse term next to the fine term and the repulsion term
-            cd_c = 1000.0 * self._chamfer(ws["coarse"], gt, inv_r, 1000.0, ws["dcoarse"], 0)
-        cd_f = 1000.0 * self._chamfer(ws["fine"], gt, inv_r, 1000.0 * wf, ws["dfine"], 1)
-        terms = {"dis_coarse_cd": cd_c, "dis_fine_cd": cd_f, "weight_fine": wf}
-        rep = torch.zeros((), dtype=torch.float32, device=self.device)
+            self._chamfer(ws["coarse"], gt, radius, 1000.0, ws["dcoarse"], 0)
+        self._chamfer(ws["fine"], gt, radius, 1000.0 * wf, ws["dfine"], 1)
+        rep = None
         if self.opts.use_repulse:
             fine = ws["fine"]
-            r07 = torch.full((B,), 0.07, dtype=torch.float32, device=self.device)
-            _lib.check(L.dispu_query_ball(B, M, M, _p(r07), 20, _p(fine), _p(fine), _p(ws["ball"]), _p(ws["ball_cnt"]),
+            _lib.check(L.dispu_query_ball(B, M, M, _p(ws["r07"]), 20, _p(fine), _p(fine), _p(ws["ball"]), _p(ws["ball_cnt"]),
                                           _lib.ARITH_CONTRACT, self.st), "query_ball")   # as loss_utils.get_repulsion_loss
             _lib.check(L.dispu_repulsion(B * M, M, 20, 0, 0.001, _p(fine), _p(ws["ball"]), _p(ws["rep"]), self.st), "repulsion")
-            _lib.check(L.dispu_row_mean_max(B, M, _p(ws["rep"]), _p(ws["rowmean"]), _p(ws["rowmax"]), self.st), "row_mean")
-            rep = self.opts.repulsion_w * ws["rowmean"].sum() / (B * 4.0)
             _lib.check(L.dispu_repulsion_grad(B * M, M, 20, 0.001, self.opts.repulsion_w / (B * M * 4.0), _p(fine), _p(ws["ball"]),
                                               _p(ws["dfine"]), self.st), "repulsion_grad")
+            rep = ws["rep"]
         self._merge(0)
-        if self.overlap_dw:
-            cd_c.record_stream(torch.cuda.current_stream(self.device))    # allocated on the branch stream, read from here on
-        terms["repulsion_loss"] = rep
-        terms["pu_loss"] = cd_c + wf * cd_f + rep
-        return terms
+        out = ws["loss_vals"]
+        _lib.check(L.dispu_pu_loss_finalize(_p(out), _p(rep) if rep is not None else None, B * M, wf, float(self.opts.repulsion_w),
+                                            _p(out, 2), self.st), "pu_loss_finalize")
+        vals = out[2:6].clone()                                 # device scalars that survive the next step
+        return {"dis_coarse_cd": vals[0], "dis_fine_cd": vals[1], "repulsion_loss": vals[2], "pu_loss": vals[3], "weight_fine": wf}
 
     # ---------------------------------------------------------------------------------------------- backward ----
     def backward(self):
@@ -527,6 +537,8 @@ class Trainer(object):
         _lib.check(L.dispu_mask3(rm, 256, _p(ws["dsum"]), 256, _p(ws["aft"]), 256, _p(ws["skip"]), 256, _p(ws["nl"]), 256, _p(ws["daft"]),
                                  _p(ws["dskip"]), _p(ws["dnl"]), 256, self.st), "mask3")
 
+        # local cell first: the host needs ~0.1 ms to queue the two branches below, the chain must not sit idle meanwhile
+        self._lin_bwd(ws["hp"], 0, 2048, ps + "after_conv", 256, ws["daft"], 0, ws["dhp"])
         # non-local cell: reads dnl, writes datt / dS / dkv / dq / dup128 -- nothing the local cell or the skip branch touches, so
         # it runs as a branch next to them; merged before anything else accumulates into dup128
         dup128 = ws["dup128"]
@@ -549,8 +561,6 @@ class Trainer(object):
         # skip branch (a second branch): 134 -> 256 backward; its max gradient is scattered after the merges below
         with self._branch(1):
             self._lin_bwd(ws["gmax"], 0, 134, ps + "skip", 256, ws["dskip"], 0, ws["dgmax"])
-        # local cell
-        self._lin_bwd(ws["hp"], 0, 2048, ps + "after_conv", 256, ws["daft"], 0, ws["dhp"])
         self._merge(2)                                   # h0 / h1 / wv / the inverted graph are in place
         _lib.check(L.dispu_ps_point_matmul_grad_relu(rm, k, 128, 16, _p(ws["h1"]), 128, _p(ws["wv"]), _p(ws["dhp"]), 2048, _p(ws["dz1"]),
                                                      128, _p(ws["dwv"]), self.st), "point_matmul_grad")
@@ -559,10 +569,11 @@ class Trainer(object):
                                         _p(ws["bn_shift"]), _p(P[BN + "gamma"]), _p(ws["dwv"]), _p(G[ps + "weight_net/wconv0/weights"]),
                                         _p(G[ps + "weight_net/wconv0/biases"]), _p(G[BN + "gamma"]), _p(G[BN + "beta"]), _p(dcoarse),
                                         _p(ws["bn_sums"]), _p(self._bn_scratch), self._bn_scratch.numel() * 8, self.st), "ps_wnet_grad")
-        self._lin_bwd(ws["h0"], 0, 128, ps + "conv1", 128, ws["dz1"], 0, ws["dz0"], mask=(ws["h0"], 0, 128))
-        # conv0 in its per-source-point form: dz0 -> dG (gather through the inverted graph), -dA; then [B*M, 128] products
-        _lib.check(L.dispu_ps_conv0_gather_grad(rm, M, k, 128, _p(ws["inv_off"]), _p(ws["inv"]), _p(ws["dz0"]), 128, _p(ws["dG"]), 128,
-                                                _p(ws["dAneg"]), 128, self.st), "conv0_gather_grad")
+        self._lin_bwd(ws["h0"], 0, 128, ps + "conv1", 128, ws["dz1"], 0, ws["dz0"])          # dz0 holds dh0: conv0's relu' rides in the gather
+        # conv0 in its per-source-point form: dh0 * (G[j] - A[i] > 0) -> dG (gather through the inverted graph), -dA; then [B*M, 128] products
+        _lib.check(L.dispu_ps_conv0_gather_grad(rm, M, k, 128, _p(ws["psidx"]), _p(ws["inv_off"]), _p(ws["inv"]), _p(ws["dz0"]), 128,
+                                                _p(ws["gm"]), 128, _p(ws["am"]), 128, _p(ws["dG"]), 128, _p(ws["dAneg"]), 128, self.st),
+                   "conv0_gather_grad")
         w0, dw0 = P[ps + "conv0/weights"], G[ps + "conv0/weights"]
         self._merge(0)                                   # dup128 holds the non-local cell's part from here on
         self._lin_bwd(ws["up128"], 0, 128, None, 128, ws["dG"], 0, dup128, 0, acc_dx=True, W=w0, dW=dw0, woff=6 * 128, bias=False,
@@ -571,7 +582,7 @@ class Trainer(object):
                    "ps_prep_grad")
         self._merge(1)
         _lib.check(L.dispu_ps_skip_max_grad(rm, M, k, 128, _p(ws["psidx"]), _p(coarse), _p(ws["up128"]), 128, _p(ws["gmax"]), 144,
-                                            _p(ws["dgmax"]), 136, _p(dcoarse), _p(dup128), 128, self.st), "ps_skip_max_grad")
+                                            _p(ws["dgmax"]), 136, _p(dcoarse), _p(dup128), 128, 1, self.st), "ps_skip_max_grad")
 
         # coarse regressor
         cs = "generator/coarse_coordinate_regressor/"
@@ -636,6 +647,44 @@ class Trainer(object):
         lr_t = lr * math.sqrt(1.0 - b2 ** self.adam_t) / (1.0 - b1 ** self.adam_t)
         _lib.check(_lib.lib().dispu_adam(self.flat_p.numel(), _p(self.flat_p), _p(self.flat_g), _p(self.flat_m), _p(self.flat_v),
                                          lr_t, b1, b2, 1e-8, 1.0 / world, _lib.stream_ptr(self.device)), "dispu_adam")
+
+    def train_step_graphed(self, inputs, gt, radius):
+        """train_step with forward + loss + backward replayed from ONE hipGraph (the ~200 launches of 5 - 50 us each are queued by
+        the HIP runtime instead of by Python: at 8 patches per GPU the eager step is partly launch-bound).  The graph is captured on
+        first use for this (B, N) and re-captured when weight_fine changes (epochs 10 / 20 / 30: the only scalar baked into its
+        kernel arguments); the gradient all-reduce and Adam (bias-corrected learning rate changes every step) stay eager."""
+        B, N = inputs.shape[0], inputs.shape[1]
+        self._check_targets(gt, radius, B, N * self.up_ratio)
+        key = (B, N, weight_fine(self.epoch), self.opts.use_repulse)
+        g = self._graphs.get(key)
+        if g is None:
+            st = dict(x=inputs.clone(), gt=gt.clone(), radius=radius.clone())
+            for _ in range(2):                                   # warm-up: every workspace / scratch buffer exists before the capture
+                self.zero_grad()
+                self.forward(st["x"])
+                self.loss_backward(st["gt"], st["radius"])
+                self.backward()
+            torch.cuda.synchronize(self.device)
+            graph = torch.cuda.CUDAGraph()
+            cap = torch.cuda.Stream(device=self.device)
+            cap.wait_stream(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(cap):
+                with torch.cuda.graph(graph, stream=cap):
+                    self.zero_grad()
+                    self.forward(st["x"])
+                    st["terms"] = self.loss_backward(st["gt"], st["radius"])
+                    self.backward()
+            torch.cuda.current_stream(self.device).wait_stream(cap)
+            st["graph"] = graph
+            g = self._graphs[key] = st
+        g["x"].copy_(inputs)
+        g["gt"].copy_(gt)
+        g["radius"].copy_(radius)
+        g["graph"].replay()
+        world = self.all_reduce_grads()
+        self.adam(world)
+        self.global_step += 1
+        return g["terms"]
 
     def train_step(self, inputs, gt, radius):
         """one iteration of the loop body of Model.train (model.py:215-232) -> loss terms (device scalars)."""

@@ -414,18 +414,31 @@ int dispu_ps_wnet_grad(long rows, int n_per_cloud, int k, int t_n, const int* id
 /* the k-NN graph idx [b, n, k] (cloud-local ids) inverted per cloud: off [b, n+1], inv [b, n*k] = the pair ids i*k + s with
  * idx[i,s] == j in off[j] .. off[j+1], ascending.  n <= 4096. */
 int dispu_knn_invert(int b, int n, int k, const int* idx, int* off, int* inv, void* stream);
-/* conv0 per source point (h0 = relu(G[j] - A[i]), dispu_ps_prep) backward: dG[p] = sum of dz0 over the in-edges of p (a
- * deterministic gather through the inverted graph), dAneg[p] = -sum_s dz0[(p,s)].  c == 128. */
-int dispu_ps_conv0_gather_grad(long rows, int n_per_cloud, int k, int c, const int* off, const int* inv, const float* dz0, long ldz,
-                               float* dG, long ldg, float* dAneg, long lda, void* stream);
+/* conv0 per source point (h0 = relu(G[j] - A[i]), dispu_ps_prep) backward from dh0 [rows*k, 128], the gradient w.r.t. h0:
+ * dz0 = dh0 * (G[j] - A[i] > 0) (the ReLU decision re-derived from G / A; Gm == Am == NULL: dh0 is taken as already masked), then
+ * dG[p] = sum of dz0 over the in-edges of p (a deterministic gather through the inverted graph), dAneg[p] = -sum_s dz0[(p,s)]. */
+int dispu_ps_conv0_gather_grad(long rows, int n_per_cloud, int k, int c, const int* idx, const int* off, const int* inv, const float* dh0,
+                               long ldz, const float* Gm, long ldgm, const float* Am, long ldam, float* dG, long ldg, float* dAneg, long lda,
+                               void* stream);
 /* the xyz side of dispu_ps_prep backward: dxyz += dG.(Wc+Wr)^T + dAneg.Wc^T (atomics); dW0[0:3] += xyz^T (dG + dAneg),
  * dW0[3:6] += xyz^T dG (atomics).  W0 [134, 128] (rows 0:3 = Wc, 3:6 = Wr). */
 int dispu_ps_prep_grad(long rows, int co, const float* xyz, const float* W0, const float* dG, long ldg, const float* dAneg, long lda,
                        float* dxyz, float* dW0, void* stream);
 /* gradient of dispu_ps_skip_max (max over the 16 neighbours of [xyz_j - xyz_i | xyz_j | feat_j], ops.py:1049) without the grouped
- * tensor: shared evenly by the entries equal to the maximum, accumulated (atomics) into dxyz [rows,3] and dfeat [rows, cf]. */
+ * tensor: shared evenly by the entries equal to the maximum, accumulated (atomics) into dxyz [rows,3] and dfeat [rows, cf].
+ * feat_is_relu != 0: feat is a ReLU output whose relu_grad the caller applies to dfeat afterwards; shares that would land on its
+ * zeros (a maximum of 0 = a 16-way tie of ReLU zeros) are then not sent at all -- same dfeat after the mask, 10x fewer atomics. */
 int dispu_ps_skip_max_grad(long rows, int n_per_cloud, int k, int cf, const int* idx, const float* xyz, const float* feat, long ldf,
-                           const float* gmax, long ldm, const float* dgmax, long ldd, float* dxyz, float* dfeat, long lddf, void* stream);
+                           const float* gmax, long ldm, const float* dgmax, long ldd, float* dxyz, float* dfeat, long lddf,
+                           int feat_is_relu, void* stream);
+/* one Chamfer term of pu_loss from dispu_nn_distance's outputs (loss_utils.py:45-64; gradient tf_nndistance.py:31-37): value[0] =
+ * mean_b[(mean d_gt + mean d_pred) / radius_b]; dpred [b, n_pred, 3] = d(coef * CD)/d pred (zero-filled, then accumulated). */
+int dispu_chamfer_loss_grad(int b, int n_gt, const float* gt, int n_pred, const float* pred, const float* d_gt, const int* i_gt,
+                            const float* d_pred, const int* i_pred, const float* radius, float coef, float* value, float* dpred,
+                            void* stream);
+/* out[5] = 1000 CD_coarse | 1000 CD_fine | repulsion_w * mean(rep) / 4 | pu_loss (model.py:87) | weight_fine; cd[2] = the two
+ * values of dispu_chamfer_loss_grad, rep [nrep] = dispu_repulsion's per-point sums (NULL: no repulsion term). */
+int dispu_pu_loss_finalize(const float* cd, const float* rep, long nrep, float wf, float rep_w, float* out, void* stream);
 /* dispu_ps_point_matmul_grad with conv1's ReLU gradient folded in: dX2 is zero where X2 <= 0. */
 int dispu_ps_point_matmul_grad_relu(long rows, int k, int c, int t_n, const float* X2, long ldx2, const float* wv, const float* dout,
                                     long ldo, float* dX2, long lddx2, float* dwv, void* stream);

@@ -192,7 +192,8 @@ def test_conv0_per_source_point_backward(dev, L):
     res = []
     for _ in range(2):
         dG, dA = torch.empty((rows, c), dtype=torch.float32, device=dev), torch.empty((rows, c), dtype=torch.float32, device=dev)
-        L.check(lib.dispu_ps_conv0_gather_grad(rows, n, k, c, p(off), p(inv), p(tz), c, p(dG), c, p(dA), c, st), "conv0_gather_grad")
+        L.check(lib.dispu_ps_conv0_gather_grad(rows, n, k, c, p(di), p(off), p(inv), p(tz), c, None, 0, None, 0, p(dG), c, p(dA), c, st),
+                "conv0_gather_grad")
         res.append((N_(dG).copy(), N_(dA).copy()))
         _KEEP.extend([dG, dA])
     assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
@@ -202,6 +203,19 @@ def test_conv0_per_source_point_backward(dev, L):
         np.add.at(refG[b], idx[b].reshape(-1), z[b].reshape(-1, c))
     close(res[0][0].reshape(B, n, c), refG, 1e-5, "dG")
     close(res[0][1].reshape(B, n, c), -z.sum(2), 1e-5, "dAneg")
+    # with the ReLU decision of h0 = relu(G[j] - A[i]) re-derived inside the kernel
+    Gm, Am = rng.standard_normal((rows, c)).astype(np.float32), rng.standard_normal((rows, c)).astype(np.float32)
+    dGm, dAm = torch.empty((rows, c), dtype=torch.float32, device=dev), torch.empty((rows, c), dtype=torch.float32, device=dev)
+    L.check(lib.dispu_ps_conv0_gather_grad(rows, n, k, c, p(di), p(off), p(inv), p(tz), c, p(dv(Gm, dev)), c, p(dv(Am, dev)), c, p(dGm), c, p(dAm), c, st),
+            "conv0_gather_grad(masked)")
+    gj = np.stack([Gm.reshape(B, n, c)[b][idx[b]] for b in range(B)])                     # [B, n, k, c]
+    keep = (gj - Am.reshape(B, n, 1, c)) > 0
+    zm = z * keep
+    refGm = np.zeros((B, n, c))
+    for b in range(B):
+        np.add.at(refGm[b], idx[b].reshape(-1), zm[b].reshape(-1, c))
+    close(N_(dGm).reshape(B, n, c), refGm, 1e-5, "dG (masked)")
+    close(N_(dAm).reshape(B, n, c), -zm.sum(2), 1e-5, "dAneg (masked)")
     # xyz side: autograd of sum(dz0 * (G[j] - A[i])) w.r.t. xyz and W0[0:6], feature term excluded
     xt = torch.tensor(xyz, dtype=F64, requires_grad=True)
     wt = torch.tensor(W0[:6], dtype=F64, requires_grad=True)
@@ -243,10 +257,24 @@ def test_skip_max_grad(dev, L):
     ref.backward(torch.tensor(g[:, :134].reshape(B, n, 134), dtype=F64))
     dxyz = torch.zeros((rows, 3), dtype=torch.float32, device=dev)
     dfeat = torch.zeros((rows, cf), dtype=torch.float32, device=dev)
-    L.check(lib.dispu_ps_skip_max_grad(rows, n, k, cf, p(di), p(dx), p(df), cf, p(gmax), 144, p(dv(g, dev)), 136, p(dxyz), p(dfeat), cf, st),
+    L.check(lib.dispu_ps_skip_max_grad(rows, n, k, cf, p(di), p(dx), p(df), cf, p(gmax), 144, p(dv(g, dev)), 136, p(dxyz), p(dfeat), cf, 0, st),
             "skip_max_grad")
     close(N_(dfeat).reshape(B, n, cf), ft.grad.numpy(), 1e-5, "dfeat")
     close(N_(dxyz).reshape(B, n, 3), xt.grad.numpy(), 1e-5, "dxyz")
+    # feat_is_relu: ReLU features (half of them zeros, so many maxima are 16-way ties at 0); equal to the full gradient after relu_grad
+    featr = np.maximum(feat, 0).astype(np.float32)
+    featr[:, :, :8] = 0.0
+    dfr = dv(featr, dev)
+    L.check(lib.dispu_ps_skip_max(rows, n, k, cf, p(di), p(dx), p(dfr), cf, p(gmax), 144, st), "skip_max")
+    outs = []
+    for flag in (0, 1):
+        dxyz2 = torch.zeros((rows, 3), dtype=torch.float32, device=dev)
+        dfeat2 = torch.zeros((rows, cf), dtype=torch.float32, device=dev)
+        L.check(lib.dispu_ps_skip_max_grad(rows, n, k, cf, p(di), p(dx), p(dfr), cf, p(gmax), 144, p(dv(g, dev)), 136, p(dxyz2), p(dfeat2), cf, flag, st),
+                "skip_max_grad")
+        outs.append((N_(dfeat2) * (featr.reshape(rows, cf) > 0), N_(dxyz2)))
+    close(outs[1][0], outs[0][0].astype(np.float64), 1e-5, "dfeat after relu_grad")
+    close(outs[1][1], outs[0][1].astype(np.float64), 1e-5, "dxyz")
 
 
 def test_point_matmul_grad_relu(dev, L):
