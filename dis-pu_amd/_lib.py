@@ -119,6 +119,9 @@ SIGNATURES = {
     "dispu_ps_prep_grad": (_i, [_l, _i, _vp, _vp, _vp, _l, _vp, _l, _vp, _vp, _vp]),
     "dispu_ps_skip_max_grad": (_i, [_l, _i, _i, _i, _vp, _vp, _vp, _l, _vp, _l, _vp, _l, _vp, _vp, _l, _i, _vp]),
     "dispu_ps_point_matmul_grad_relu": (_i, [_l, _i, _i, _i, _vp, _l, _vp, _vp, _l, _vp, _l, _vp, _vp]),
+    "dispu_edge_dense_conv_grad_scratch_floats": (_l, [_i, _i]),
+    "dispu_edge_dense_conv_grad": (_i, [_i, _i, _i, _vp, _l, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _l, _vp, _l, _vp, _vp, _vp, _vp, _vp,
+                                        _vp, _vp, _l, _vp]),
     "dispu_chamfer_loss_grad": (_i, [_i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, C.c_float, _vp, _vp, _vp]),
     "dispu_pu_loss_finalize": (_i, [_vp, _vp, _l, C.c_float, C.c_float, _vp, _vp]),
     "dispu_augment": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

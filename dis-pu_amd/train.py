@@ -93,6 +93,9 @@ class Trainer(object):
         # weight-gradient products (dW = X^T dZ) are off the backward chain: only Adam reads them.  They run on a second
         # HIP stream next to the dX products that ARE the chain (both read dZ; at 8 patches neither fills 256 CUs alone).
         self.overlap_dw = os.environ.get("DISPU_TRAIN_OVERLAP", "1") != "0"
+        # dense blocks: forward = the fused inference kernel, backward = one recomputing kernel per block (csrc/edge_bwd.hip);
+        # 0 = round 2's path through materialised edge tensors (A/B tests)
+        self.fused_dense = os.environ.get("DISPU_TRAIN_FUSED_DENSE", "1") != "0"
         self._aux = []
         self._cur = "main"
         self._side = None
@@ -153,8 +156,6 @@ class Trainer(object):
             prep=[None, None] + [E(rn, 48) for _ in range(2, DENSE_BLOCKS + 1)],
             dprep=[None, None] + [E(rn, 48) for _ in range(2, DENSE_BLOCKS + 1)],      # per block: the dW products on the second stream read them
             kidx=[None] + [E(rn, k + 1, dtype=i32) for _ in range(DENSE_BLOCKS)],
-            edge=[None, E(rn * k, 72 + 48)] + [E(rn * k, 72 + 96) for _ in range(2, DENSE_BLOCKS + 1)],
-            dedge=[None, E(rn * k, 72 + 48)] + [E(rn * k, 72 + 96) for _ in range(2, DENSE_BLOCKS + 1)],
             h256=E(rn, 256), dh256=E(rn, 256), gcode=E(rm, 2),
             up256=E(rm, 256), dup256=E(rm, 256), up128=E(rm, 128), dup128=E(rm, 128),
             c256=E(rm, 256), dc256=E(rm, 256), c64=E(rm, 64), dc64=E(rm, 64), coarse=E(B, M, 3), dcoarse=E(B, M, 3),
@@ -177,6 +178,17 @@ class Trainer(object):
         ws["gcode"].view(B, self.up_ratio, N, 2).copy_(self.grid.view(1, self.up_ratio, 1, 2).expand(B, self.up_ratio, N, 2))
         self._ws[key] = ws
         return ws
+
+    def _edge_buffers(self, B, N):
+        """edge tensors [B*N*16, 72 + 2C] and their gradients, one pair per dense block: only the UNFUSED dense-block path
+        (DISPU_TRAIN_FUSED_DENSE=0, kept for A/B tests) materialises them."""
+        key = ("edge", B, N)
+        if key not in self._ws:
+            rows = B * N * K_NEIGH
+            mk = lambda: [None, torch.empty((rows, 72 + 48), dtype=torch.float32, device=self.device)] + \
+                [torch.empty((rows, 72 + 96), dtype=torch.float32, device=self.device) for _ in range(2, DENSE_BLOCKS + 1)]
+            self._ws[key] = (mk(), mk())
+        return self._ws[key]
 
     def _scratch_floats(self, n, side=False):
         """scratch of the launches queued on ONE stream (they run in order, so they can share it): the dW stream's, or the
@@ -350,17 +362,26 @@ class Trainer(object):
                 self._lin(feat, col, 480 - col, fe + "layer%d_prep" % d, 1, ws["prep"][d], 0, 48)
                 F, foff, C = ws["prep"][d], 0, 48
             ldf = F.stride(0)
-            kidx, Eb = ws["kidx"][d], ws["edge"][d]
+            kidx = ws["kidx"][d]
             _lib.check(L.dispu_knn_feat_strided(B, N, N, C, k + 1, _p(F, foff), ldf, _p(F, foff), ldf, None, _p(kidx), self.st), "knn_feat")
-            _lib.check(L.dispu_edge_feature(rn, N, k, C, _p(F, foff), ldf, _p(kidx), k + 1, 1, _p(Eb, 72), Eb.stride(0), self.st), "edge_feature")
             sc = fe + "layer%d" % d
-            self._lin(Eb, 72, 2 * C, sc + "/l0", 1, Eb, 48, 24)
-            self._lin(Eb, 48, 24 + C, sc + "/l1", 1, Eb, 24, 24)
-            self._lin(Eb, 24, 48 + C, sc + "/l2", 0, Eb, 0, 24)
             width = 3 * GROWTH + C
             in_col = col
             col -= width
-            _lib.check(L.dispu_max_k(rn, k, width, _p(Eb), Eb.stride(0), _p(feat, col), 480, self.st), "max_k")
+            if self.fused_dense:
+                # the inference kernel (csrc/edge.hip): edge features, three chained convs and the max in one launch; nothing is kept
+                # for the backward pass, which recomputes the block on chip (csrc/edge_bwd.hip)
+                _lib.check(L.dispu_edge_dense_conv(rn, N, C, _p(F, foff), ldf, _p(kidx), k + 1, 1, _p(P[sc + "/l0/weights"]),
+                                                   _p(P[sc + "/l0/biases"]), _p(P[sc + "/l1/weights"]), _p(P[sc + "/l1/biases"]),
+                                                   _p(P[sc + "/l2/weights"]), _p(P[sc + "/l2/biases"]), _p(feat, col), 480, self.st),
+                           "edge_dense_conv")
+            else:
+                Eb = self._edge_buffers(B, N)[0][d]
+                _lib.check(L.dispu_edge_feature(rn, N, k, C, _p(F, foff), ldf, _p(kidx), k + 1, 1, _p(Eb, 72), Eb.stride(0), self.st), "edge_feature")
+                self._lin(Eb, 72, 2 * C, sc + "/l0", 1, Eb, 48, 24)
+                self._lin(Eb, 48, 24 + C, sc + "/l1", 1, Eb, 24, 24)
+                self._lin(Eb, 24, 48 + C, sc + "/l2", 0, Eb, 0, 24)
+                _lib.check(L.dispu_max_k(rn, k, width, _p(Eb), Eb.stride(0), _p(feat, col), 480, self.st), "max_k")
             self._blocks.append((d, C, col, in_col, width))
         assert col == 0
 
@@ -603,22 +624,33 @@ class Trainer(object):
         # the chain moves on, no join inside the loop)
         fe = "generator/feature_extraction_coarse/"
         for (d, C, col, in_col, width) in reversed(self._blocks):
-            Eb, dE = ws["edge"][d], ws["dedge"][d]
-            lde = dE.stride(0)
-            # max gradient into the pooled columns [0, width), zeros into the neighbour half of the edge feature behind them
-            _lib.check(L.dispu_max_k_grad_tail(rn, k, width, C, _p(Eb), Eb.stride(0), _p(feat, col), 480, _p(dfeat, col), 480, _p(dE), lde, self.st),
-                       "max_k_grad")
             sc = fe + "layer%d" % d
-            self._lin_bwd(Eb, 24, 48 + C, sc + "/l2", 24, dE, 0, dE, 24, acc_dx=True, mask=(Eb, 24, 24))     # columns 24:48 = l1: relu'
-            self._lin_bwd(Eb, 48, 24 + C, sc + "/l1", 24, dE, 24, dE, 48, acc_dx=True, mask=(Eb, 48, 24))    # columns 48:72 = l0: relu'
-            self._lin_bwd(Eb, 72, 2 * C, sc + "/l0", 24, dE, 48, dE, 72, acc_dx=True)
             if d == 1:
-                dF, dfoff = dfeat, 456
+                dF, dfoff, F, foff = dfeat, 456, feat, 456
             else:
-                dF, dfoff = ws["dprep"][d], 0
+                dF, dfoff, F, foff = ws["dprep"][d], 0, ws["prep"][d], 0
                 dF.zero_()
-            _lib.check(L.dispu_edge_feature_grad(rn, N, k, C, _p(dE, 72), lde, _p(ws["kidx"][d]), k + 1, 1, _p(dF, dfoff), dF.stride(0), self.st),
-                       "edge_feature_grad")
+            if self.fused_dense:
+                need = L.dispu_edge_dense_conv_grad_scratch_floats(rn, C)
+                scr = self._scratch_floats(need)
+                _lib.check(L.dispu_edge_dense_conv_grad(rn, N, C, _p(F, foff), F.stride(0), _p(ws["kidx"][d]), k + 1, 1,
+                                                        _p(P[sc + "/l0/weights"]), _p(P[sc + "/l0/biases"]), _p(P[sc + "/l1/weights"]),
+                                                        _p(P[sc + "/l1/biases"]), _p(P[sc + "/l2/weights"]), _p(P[sc + "/l2/biases"]),
+                                                        _p(dfeat, col), 480, _p(dF, dfoff), dF.stride(0),
+                                                        _p(G[sc + "/l0/weights"]), _p(G[sc + "/l0/biases"]), _p(G[sc + "/l1/weights"]),
+                                                        _p(G[sc + "/l1/biases"]), _p(G[sc + "/l2/weights"]), _p(G[sc + "/l2/biases"]),
+                                                        _p(scr), scr.numel(), self.st), "edge_dense_conv_grad")
+            else:
+                Eb, dE = self._edge_buffers(B, N)[0][d], self._edge_buffers(B, N)[1][d]
+                lde = dE.stride(0)
+                # max gradient into the pooled columns [0, width), zeros into the neighbour half of the edge feature behind them
+                _lib.check(L.dispu_max_k_grad_tail(rn, k, width, C, _p(Eb), Eb.stride(0), _p(feat, col), 480, _p(dfeat, col), 480, _p(dE), lde, self.st),
+                           "max_k_grad")
+                self._lin_bwd(Eb, 24, 48 + C, sc + "/l2", 24, dE, 0, dE, 24, acc_dx=True, mask=(Eb, 24, 24))     # columns 24:48 = l1: relu'
+                self._lin_bwd(Eb, 48, 24 + C, sc + "/l1", 24, dE, 24, dE, 48, acc_dx=True, mask=(Eb, 48, 24))    # columns 48:72 = l0: relu'
+                self._lin_bwd(Eb, 72, 2 * C, sc + "/l0", 24, dE, 48, dE, 72, acc_dx=True)
+                _lib.check(L.dispu_edge_feature_grad(rn, N, k, C, _p(dE, 72), lde, _p(ws["kidx"][d]), k + 1, 1, _p(dF, dfoff), dF.stride(0), self.st),
+                           "edge_feature_grad")
             if d > 1:
                 self._act_bias_grad(rn, 48, dF, 0, ws["prep"][d], 0, 1, dF, 0, None)        # prep = relu(.): its mask (dF came from atomics)
                 self._lin_bwd(feat, in_col, 480 - in_col, fe + "layer%d_prep" % d, 48, dF, 0, dfeat, in_col, acc_dx=True)

@@ -431,6 +431,15 @@ int dispu_ps_prep_grad(long rows, int co, const float* xyz, const float* W0, con
 int dispu_ps_skip_max_grad(long rows, int n_per_cloud, int k, int cf, const int* idx, const float* xyz, const float* feat, long ldf,
                            const float* gmax, long ldm, const float* dgmax, long ldd, float* dxyz, float* dfeat, long lddf,
                            int feat_is_relu, void* stream);
+/* Backward of dispu_edge_dense_conv in one launch (+ a fixed-order reduction of the per-workgroup weight-gradient partials): the
+ * forward values are recomputed on chip from F / idx / the weights (bit-identical to the forward kernel's), nothing of the edge
+ * tensor is stored.  dOut [npoints, 72 + C] = gradient of Y; dF [npoints, C] accumulates (atomics); dW* / db* accumulate.
+ * scratch: dispu_edge_dense_conv_grad_scratch_floats(npoints, C) floats. */
+long dispu_edge_dense_conv_grad_scratch_floats(int npoints, int C);
+int dispu_edge_dense_conv_grad(int npoints, int n_per_cloud, int C, const float* F, long ldf, const int* idx, int ldi, int ioff,
+                               const float* W0, const float* b0, const float* W1, const float* b1, const float* W2, const float* b2,
+                               const float* dOut, long lddo, float* dF, long lddf, float* dW0, float* db0, float* dW1, float* db1,
+                               float* dW2, float* db2, float* scratch, long scratch_floats, void* stream);
 /* one Chamfer term of pu_loss from dispu_nn_distance's outputs (loss_utils.py:45-64; gradient tf_nndistance.py:31-37): value[0] =
  * mean_b[(mean d_gt + mean d_pred) / radius_b]; dpred [b, n_pred, 3] = d(coef * CD)/d pred (zero-filled, then accumulated). */
 int dispu_chamfer_loss_grad(int b, int n_gt, const float* gt, int n_pred, const float* pred, const float* d_gt, const int* i_gt,

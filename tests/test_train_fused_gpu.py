@@ -323,3 +323,48 @@ def test_mlp_chain_stash_equals_separate_launches(dev, L, shape, mode):
     L.check(lib.dispu_linear_small_n(rows, N3, 3, p(r3), N3, p(tw[3]), p(tb[3]), mode, p(tr) if mode else None, 3, p(ro), 3, st), "head")
     for a, b, name in ((y1, r1, "Y1"), (y2, r2, "Y2"), (y3, r3, "Y3"), (z, rz, "Z"), (out, ro, "out")):
         assert torch.equal(a, b), name
+
+
+@pytest.mark.parametrize("C,B,n", [(24, 2, 256), (48, 2, 256), (48, 1, 100), (24, 3, 36)])
+def test_edge_dense_conv_grad(dev, L, C, B, n):
+    """dense_conv + get_edge_feature backward in one launch (csrc/edge_bwd.hip: forward recomputed on chip) against float64 autograd
+    of oracle/train_oracle.py:dense_conv; duplicate neighbours make exact arg-max ties (shared evenly); n * B not a multiple of the
+    8-point tile exercises the ragged last tile."""
+    rng = np.random.default_rng(C + n)
+    k = 16
+    F = rng.standard_normal((B, n, C)).astype(np.float32)
+    idx = rng.integers(0, n, (B, n, k + 1)).astype(np.int32)                  # column 0 = "self" (dropped: ioff = 1), as knn_feat returns
+    idx[:, ::5, 7] = idx[:, ::5, 3]
+    scope = "s"
+    shapes = {"/l0": (2 * C, 24), "/l1": (24 + C, 24), "/l2": (48 + C, 24)}
+    P = {}
+    for name, (a, b) in shapes.items():
+        P[scope + name + "/weights"] = (rng.standard_normal((a, b)) / np.sqrt(a)).astype(np.float32)
+        P[scope + name + "/biases"] = (rng.standard_normal(b) * 0.1).astype(np.float32)
+    Pt = {kk: torch.tensor(v, dtype=F64, requires_grad=True) for kk, v in P.items()}
+    ft = torch.tensor(F, dtype=F64, requires_grad=True)
+    out = T.dense_conv(Pt, scope, ft, torch.tensor(idx[:, :, 1:].astype(np.int64)))
+    rows = B * n
+    lib, st = L.lib(), L.stream_ptr(dev)
+    tF, ti = dv(F.reshape(rows, C), dev), dv(idx.reshape(rows, k + 1), dev, torch.int32)
+    tp = {kk: dv(v, dev) for kk, v in P.items()}
+    # forward of the device kernel == oracle forward (same arithmetic as the recompute inside the backward kernel)
+    Y = torch.empty((rows, 72 + C), dtype=torch.float32, device=dev)
+    L.check(lib.dispu_edge_dense_conv(rows, n, C, p(tF), C, p(ti), k + 1, 1, p(tp["s/l0/weights"]), p(tp["s/l0/biases"]), p(tp["s/l1/weights"]),
+                                      p(tp["s/l1/biases"]), p(tp["s/l2/weights"]), p(tp["s/l2/biases"]), p(Y), 72 + C, st), "edge_dense_conv")
+    close(N_(Y).reshape(B, n, 72 + C), out.detach().numpy(), 1e-5, "forward")
+    g = rng.standard_normal((rows, 72 + C)).astype(np.float32)
+    out.backward(torch.tensor(g.reshape(B, n, 72 + C), dtype=F64))
+    dF = torch.zeros((rows, C), dtype=torch.float32, device=dev)
+    dW = {kk: torch.zeros(v.shape, dtype=torch.float32, device=dev) for kk, v in P.items()}
+    need = lib.dispu_edge_dense_conv_grad_scratch_floats(rows, C)
+    sc = torch.empty(max(need, 1), dtype=torch.float32, device=dev)
+    for rep in range(2):                                                      # accumulating entry: the second call doubles everything
+        L.check(lib.dispu_edge_dense_conv_grad(rows, n, C, p(tF), C, p(ti), k + 1, 1, p(tp["s/l0/weights"]), p(tp["s/l0/biases"]),
+                                               p(tp["s/l1/weights"]), p(tp["s/l1/biases"]), p(tp["s/l2/weights"]), p(tp["s/l2/biases"]),
+                                               p(dv(g, dev)), 72 + C, p(dF), C, p(dW["s/l0/weights"]), p(dW["s/l0/biases"]), p(dW["s/l1/weights"]),
+                                               p(dW["s/l1/biases"]), p(dW["s/l2/weights"]), p(dW["s/l2/biases"]), p(sc), need, st),
+                "edge_dense_conv_grad")
+        close(N_(dF).reshape(B, n, C), (rep + 1) * ft.grad.numpy(), 2e-5, "dF")
+        for kk in P:
+            close(N_(dW[kk]), (rep + 1) * Pt[kk].grad.numpy(), 2e-5, kk)
