@@ -122,6 +122,8 @@ SIGNATURES = {
     "dispu_edge_dense_conv_grad_scratch_floats": (_l, [_i, _i]),
     "dispu_edge_dense_conv_grad": (_i, [_i, _i, _i, _vp, _l, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _l, _vp, _l, _vp, _vp, _vp, _vp, _vp,
                                         _vp, _vp, _l, _vp]),
+    "dispu_repulsion_loss_grad": (_i, [_l, _i, _i, C.c_float, C.c_float, _vp, _vp, _vp, _vp, _vp]),
+    "dispu_transpose_batched": (_i, [_i, _vp, _vp, _vp, _vp]),
     "dispu_chamfer_loss_grad": (_i, [_i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, C.c_float, _vp, _vp, _vp]),
     "dispu_pu_loss_finalize": (_i, [_vp, _vp, _l, C.c_float, C.c_float, _vp, _vp]),
     "dispu_augment": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

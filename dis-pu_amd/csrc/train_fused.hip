@@ -179,39 +179,62 @@ __global__ __launch_bounds__(256) void ps_wnet_grad_apply_kernel(long rows, int 
                                                                   const float* __restrict__ shift, const float* __restrict__ gamma,
                                                                   const float* __restrict__ sums, const float* __restrict__ dwv,
                                                                   float* __restrict__ dWw, float* __restrict__ dbw, float* __restrict__ dxyz) {
+    constexpr int PTS = 8;                         // points per pass: their index / coordinate / dwv loads are all issued before the first use
     __shared__ float red[4][256];
     const int s = threadIdx.x >> 4, t = threadIdx.x & 15;
     const float mu = stats[t], is = stats[2 * WN_T + t], sc = scale[t], sh = shift[t];
     const float inv_n = 1.0f / (float)(rows * WN_K);
     const float m1 = sums[t] * inv_n, m2 = sums[WN_T + t] * inv_n, gi = gamma[t] * is;
-    const float w0 = Ww[0 * WN_T + t], w1 = Ww[1 * WN_T + t], w2 = Ww[2 * WN_T + t];
+    const float w0 = Ww[0 * WN_T + t], w1 = Ww[1 * WN_T + t], w2 = Ww[2 * WN_T + t], bt = bw[t];
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, ab = 0.f;
-    for (long i = blockIdx.x; i < rows; i += gridDim.x) {
-        const long j = (i / n_per_cloud) * n_per_cloud + idx[i * WN_K + s];
-        float dx, dy, dz;
-        const float wl = wn_wl(xyz, i, j, Ww, bw, t, dx, dy, dz);
-        const float wv = wl * sc + sh;
-        const float u = (wv > 0.f) ? dwv[(i * WN_K + s) * WN_T + t] : 0.f;
-        const float xh = (wl - mu) * is;
-        const float dwl = gi * ((u - m1) - xh * m2);
-        a0 = __builtin_fmaf(dx, dwl, a0); a1 = __builtin_fmaf(dy, dwl, a1); a2 = __builtin_fmaf(dz, dwl, a2);
-        ab += dwl;
-        // d offset: sum over the 16 channels (= the 16 lanes of a DPP row)
-        float o0 = dwl * w0, o1 = dwl * w1, o2 = dwl * w2;
+    for (long i0 = (long)blockIdx.x * PTS; i0 < rows; i0 += (long)gridDim.x * PTS) {
+        long ii[PTS], jj[PTS];
+        float g[PTS], ox[PTS], oy[PTS], oz[PTS];
 #pragma unroll
-        for (int m = 8; m > 0; m >>= 1) { o0 += __shfl_xor(o0, m, 16); o1 += __shfl_xor(o1, m, 16); o2 += __shfl_xor(o2, m, 16); }
-        if (t == 0) { unsafeAtomicAdd(dxyz + j * 3 + 0, o0); unsafeAtomicAdd(dxyz + j * 3 + 1, o1); unsafeAtomicAdd(dxyz + j * 3 + 2, o2); }
-        // the point's own share: the 4 pairs of this wave are combined first (one atomic per wave and coordinate, not per pair)
-        o0 += __shfl_xor(o0, 16, 64); o1 += __shfl_xor(o1, 16, 64); o2 += __shfl_xor(o2, 16, 64);
-        o0 += __shfl_xor(o0, 32, 64); o1 += __shfl_xor(o1, 32, 64); o2 += __shfl_xor(o2, 32, 64);
-        if ((threadIdx.x & 63) == 0) { unsafeAtomicAdd(dxyz + i * 3 + 0, -o0); unsafeAtomicAdd(dxyz + i * 3 + 1, -o1); unsafeAtomicAdd(dxyz + i * 3 + 2, -o2); }
+        for (int u = 0; u < PTS; ++u) {
+            ii[u] = min(i0 + u, rows - 1);
+            jj[u] = (ii[u] / n_per_cloud) * n_per_cloud + idx[ii[u] * WN_K + s];
+            g[u] = dwv[(ii[u] * WN_K + s) * WN_T + t];
+        }
+#pragma unroll
+        for (int u = 0; u < PTS; ++u) {
+            ox[u] = xyz[jj[u] * 3 + 0] - xyz[ii[u] * 3 + 0];
+            oy[u] = xyz[jj[u] * 3 + 1] - xyz[ii[u] * 3 + 1];
+            oz[u] = xyz[jj[u] * 3 + 2] - xyz[ii[u] * 3 + 2];
+        }
+#pragma unroll
+        for (int u = 0; u < PTS; ++u) {
+            const bool live = i0 + u < rows;
+            float acc = 0.f;                                             // wn_wl's chain
+            acc = __builtin_fmaf(ox[u], w0, acc);
+            acc = __builtin_fmaf(oy[u], w1, acc);
+            acc = __builtin_fmaf(oz[u], w2, acc);
+            const float wl = acc + bt;
+            const float wv = wl * sc + sh;
+            const float uu = (wv > 0.f) ? g[u] : 0.f;
+            const float xh = (wl - mu) * is;
+            const float dwl = live ? gi * ((uu - m1) - xh * m2) : 0.f;
+            a0 = __builtin_fmaf(ox[u], dwl, a0); a1 = __builtin_fmaf(oy[u], dwl, a1); a2 = __builtin_fmaf(oz[u], dwl, a2);
+            ab += dwl;
+            // d offset: sum over the 16 channels (= the 16 lanes of a DPP row)
+            float o0 = dwl * w0, o1 = dwl * w1, o2 = dwl * w2;
+#pragma unroll
+            for (int m = 8; m > 0; m >>= 1) { o0 += __shfl_xor(o0, m, 16); o1 += __shfl_xor(o1, m, 16); o2 += __shfl_xor(o2, m, 16); }
+            if (t == 0 && live) { unsafeAtomicAdd(dxyz + jj[u] * 3 + 0, o0); unsafeAtomicAdd(dxyz + jj[u] * 3 + 1, o1); unsafeAtomicAdd(dxyz + jj[u] * 3 + 2, o2); }
+            // the point's own share: the 4 pairs of this wave are combined first (one atomic per wave and coordinate, not per pair)
+            o0 += __shfl_xor(o0, 16, 64); o1 += __shfl_xor(o1, 16, 64); o2 += __shfl_xor(o2, 16, 64);
+            o0 += __shfl_xor(o0, 32, 64); o1 += __shfl_xor(o1, 32, 64); o2 += __shfl_xor(o2, 32, 64);
+            if ((threadIdx.x & 63) == 0 && live) {
+                unsafeAtomicAdd(dxyz + ii[u] * 3 + 0, -o0); unsafeAtomicAdd(dxyz + ii[u] * 3 + 1, -o1); unsafeAtomicAdd(dxyz + ii[u] * 3 + 2, -o2);
+            }
+        }
     }
     red[0][threadIdx.x] = a0; red[1][threadIdx.x] = a1; red[2][threadIdx.x] = a2; red[3][threadIdx.x] = ab;
     __syncthreads();
     if (threadIdx.x < 64) {
         const int which = threadIdx.x >> 4, tt = threadIdx.x & 15;
         float v = 0.f;
-        for (int g = 0; g < WN_K; ++g) v += red[which][g * WN_T + tt];
+        for (int gq = 0; gq < WN_K; ++gq) v += red[which][gq * WN_T + tt];
         if (which < 3) unsafeAtomicAdd(dWw + which * WN_T + tt, v);
         else if (dbw) unsafeAtomicAdd(dbw + tt, v);
     }
@@ -561,6 +584,85 @@ __global__ __launch_bounds__(1024) void pu_loss_finalize_kernel(const float* __r
     }
 }
 
+// get_repulsion_loss (loss_utils.py:271-298) value AND gradient in one pass: per point the 20 ball neighbours' squared distances,
+// the 2nd..5th smallest (stable, like top_k), out[i] = sum max(0, h - d), dpred += scale * d/d pred (both points of a pair, atomics).
+// NS neighbour ids and 3 NS coordinates are requested before the first is used (the one-thread-per-point kernels of round 2 walked
+// them as a dependent chain: 42 us for 8192 points); 64-thread workgroups spread the points over the CUs.
+template <int NS>
+__global__ __launch_bounds__(64) void repulsion_loss_grad_kernel(long rows, int n_per_cloud, float h, float scale, const float* __restrict__ pred,
+                                                                  const int* __restrict__ idx, float* __restrict__ out, float* __restrict__ dpred) {
+    const long i = (long)blockIdx.x * 64 + threadIdx.x;
+    if (i >= rows) return;
+    const long base = (i / n_per_cloud) * n_per_cloud;
+    const float px = pred[i * 3], py = pred[i * 3 + 1], pz = pred[i * 3 + 2];
+    int id[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) id[s] = idx[i * NS + s];
+    float dx[NS], dy[NS], dz[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const long j = base + id[s];
+        dx[s] = pred[j * 3] - px; dy[s] = pred[j * 3 + 1] - py; dz[s] = pred[j * 3 + 2] - pz;
+    }
+    float b[5] = {__builtin_inff(), __builtin_inff(), __builtin_inff(), __builtin_inff(), __builtin_inff()};
+    int bs[5] = {-1, -1, -1, -1, -1};
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const float d = (dx[s] * dx[s] + dy[s] * dy[s]) + dz[s] * dz[s];
+        if (d < b[4]) {                     // stable insertion: strict '<' keeps the earlier slot first on ties
+            b[4] = d; bs[4] = s;
+#pragma unroll
+            for (int t = 4; t > 0; --t)
+                if (b[t] < b[t - 1]) {
+                    const float tmp = b[t]; b[t] = b[t - 1]; b[t - 1] = tmp;
+                    const int ts = bs[t]; bs[t] = bs[t - 1]; bs[t - 1] = ts;
+                }
+        }
+    }
+    float acc = 0.f, gx = 0.f, gy = 0.f, gz = 0.f;
+#pragma unroll
+    for (int t = 1; t < 5; ++t) {
+        acc += fmaxf(0.0f, h - b[t]);
+        if (bs[t] < 0 || !(h - b[t] > 0.f)) continue;
+        float ex = 0.f, ey = 0.f, ez = 0.f;
+        int jl = 0;
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+            if (s == bs[t]) { ex = dx[s]; ey = dy[s]; ez = dz[s]; jl = id[s]; }
+        const long j = base + jl;
+        const float cx = 2.f * scale * ex, cy = 2.f * scale * ey, cz = 2.f * scale * ez;
+        unsafeAtomicAdd(dpred + j * 3 + 0, -cx);
+        unsafeAtomicAdd(dpred + j * 3 + 1, -cy);
+        unsafeAtomicAdd(dpred + j * 3 + 2, -cz);
+        gx += cx; gy += cy; gz += cz;
+    }
+    out[i] = acc;
+    unsafeAtomicAdd(dpred + i * 3 + 0, gx);
+    unsafeAtomicAdd(dpred + i * 3 + 1, gy);
+    unsafeAtomicAdd(dpred + i * 3 + 2, gz);
+}
+
+// ---- W^T copies of the weight matrices (one launch per step): the dX = dZ . W^T products of the backward pass then read their
+// B operand with k contiguous, i.e. take the untransposed (DMA / float4-staged) path of the forward GEMM instead of the transb path.
+// desc[m] = {source offset, K, N} (floats / rows / columns of W [K][N] inside `src`); dst gets W^T [N][K] at the same offset.
+__global__ __launch_bounds__(256) void transpose_batched_kernel(const int* __restrict__ desc, const float* __restrict__ src, float* __restrict__ dst) {
+    __shared__ float tile[32][33];
+    const int off = desc[blockIdx.y * 3 + 0], K = desc[blockIdx.y * 3 + 1], N = desc[blockIdx.y * 3 + 2];
+    const int tn = (N + 31) / 32, tk = (K + 31) / 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int tI = blockIdx.x; tI < tn * tk; tI += gridDim.x) {
+        const int k0 = (tI / tn) * 32, n0 = (tI % tn) * 32;
+        __syncthreads();
+#pragma unroll
+        for (int r = ty; r < 32; r += 8)
+            if (k0 + r < K && n0 + tx < N) tile[r][tx] = src[off + (size_t)(k0 + r) * N + n0 + tx];
+        __syncthreads();
+#pragma unroll
+        for (int r = ty; r < 32; r += 8)
+            if (n0 + r < N && k0 + tx < K) dst[off + (size_t)(n0 + r) * K + k0 + tx] = tile[tx][r];
+    }
+}
+
 static int wn_blocks(long rows) { return (int)(rows < 1024 ? rows : 1024); }
 
 }  // namespace dispu
@@ -607,7 +709,8 @@ DISPU_EXPORT int dispu_ps_wnet_grad(long rows, int n_per_cloud, int k, int t_n, 
     DISPU_CHECK_LAUNCH();
     hipLaunchKernelGGL(ps_wnet_grad_finalize_kernel, dim3(WN_T), dim3(64), 0, s, nb, (const double*)scratch, sums, dgamma, dbeta);
     DISPU_CHECK_LAUNCH();
-    hipLaunchKernelGGL(ps_wnet_grad_apply_kernel, dim3(nb), dim3(256), 0, s, rows, n_per_cloud, idx, xyz, Ww, bw, stats, scale, shift, gamma,
+    const int nba = (int)((rows + 7) / 8 < 2048 ? (rows + 7) / 8 : 2048);
+    hipLaunchKernelGGL(ps_wnet_grad_apply_kernel, dim3(nba), dim3(256), 0, s, rows, n_per_cloud, idx, xyz, Ww, bw, stats, scale, shift, gamma,
                        sums, dwv, dWw, dbw, dxyz);
     return (int)hipGetLastError();
 }
@@ -682,5 +785,23 @@ DISPU_EXPORT int dispu_chamfer_loss_grad(int b, int n_gt, const float* gt, int n
 DISPU_EXPORT int dispu_pu_loss_finalize(const float* cd, const float* rep, long nrep, float wf, float rep_w, float* out, void* stream) {
     if (!cd || !out || (rep && nrep <= 0)) return (int)hipErrorInvalidValue;
     hipLaunchKernelGGL(pu_loss_finalize_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, cd, rep, nrep, wf, rep_w, out);
+    return (int)hipGetLastError();
+}
+
+// get_repulsion_loss value + gradient (dispu_repulsion + dispu_repulsion_grad in one launch): out [rows], dpred accumulates.
+DISPU_EXPORT int dispu_repulsion_loss_grad(long rows, int n_per_cloud, int ns, float h, float scale, const float* pred, const int* idx,
+                                           float* out, float* dpred, void* stream) {
+    if (rows < 0 || n_per_cloud <= 0 || ns != 20 || !pred || !idx || !out || !dpred) return (int)hipErrorInvalidValue;
+    if (rows == 0) return 0;
+    hipLaunchKernelGGL(repulsion_loss_grad_kernel<20>, dim3((unsigned)((rows + 63) / 64)), dim3(64), 0, (hipStream_t)stream, rows, n_per_cloud, h,
+                       scale, pred, idx, out, dpred);
+    return (int)hipGetLastError();
+}
+
+// dst[off .. off + K*N) = transpose of src[off ..] viewed as [K][N], for every {off, K, N} triple of desc [count][3] (device ints).
+DISPU_EXPORT int dispu_transpose_batched(int count, const int* desc, const float* src, float* dst, void* stream) {
+    if (count < 0 || !desc || !src || !dst) return (int)hipErrorInvalidValue;
+    if (count == 0) return 0;
+    hipLaunchKernelGGL(transpose_batched_kernel, dim3(64, count), dim3(256), 0, (hipStream_t)stream, desc, src, dst);
     return (int)hipGetLastError();
 }

@@ -96,12 +96,14 @@ class Trainer(object):
         # dense blocks: forward = the fused inference kernel, backward = one recomputing kernel per block (csrc/edge_bwd.hip);
         # 0 = round 2's path through materialised edge tensors (A/B tests)
         self.fused_dense = os.environ.get("DISPU_TRAIN_FUSED_DENSE", "1") != "0"
+        self.use_wt = os.environ.get("DISPU_TRAIN_WT", "1") != "0"          # dX products through per-step W^T copies (A/B switch)
         self._aux = []
         self._cur = "main"
-        self._side = None
+        self._sides = []
+        self._side_rr = -1
         self._fork_ev = None
         self._join_ev = None
-        self._side_busy = False
+        self._side_busy = []
         self.P = None
         if params is not None:
             self.load_params(params)
@@ -126,6 +128,16 @@ class Trainer(object):
             self.P[k] = self.flat_p[o:o + s].view(shp)
             self.G[k] = self.flat_g[o:o + s].view(shp)
             self.P[k].copy_(torch.from_numpy(np.ascontiguousarray(params[k], np.float32)))
+        # W^T copies for the dX products (refreshed once per step by ONE launch, csrc/train_fused.hip:transpose_batched_kernel):
+        # every 2-D weight whose transposed rows stay 16-byte aligned (K % 4 == 0)
+        self.flat_pT = torch.zeros_like(self.flat_p)
+        self.PT, desc = OrderedDict(), []
+        for k, o, s in zip(names, offs, sizes):
+            shp = np.asarray(params[k]).shape
+            if k.endswith("/weights") and len(shp) == 2 and shp[0] % 4 == 0 and shp[1] % 4 == 0 and shp[0] >= 16:
+                self.PT[k] = self.flat_pT[o:o + s].view(shp[1], shp[0])
+                desc += [o, shp[0], shp[1]]
+        self._t_desc = torch.tensor(desc, dtype=torch.int32, device=dev)
         self.moving_mean = torch.from_numpy(np.ascontiguousarray(params[BN + "moving_mean"], np.float32)).to(dev)
         self.moving_var = torch.from_numpy(np.ascontiguousarray(params[BN + "moving_variance"], np.float32)).to(dev)
         self.grid = torch.from_numpy(gen_grid(self.up_ratio)).to(dev)
@@ -190,10 +202,10 @@ class Trainer(object):
             self._ws[key] = (mk(), mk())
         return self._ws[key]
 
-    def _scratch_floats(self, n, side=False):
-        """scratch of the launches queued on ONE stream (they run in order, so they can share it): the dW stream's, or the
+    def _scratch_floats(self, n, key=None):
+        """scratch of the launches queued on ONE stream (they run in order, so they can share it): a dW stream's (key "dw<i>"), or the
         current stream's (main or a branch)."""
-        key = "dw" if side else self._cur
+        key = key if key else self._cur
         cur = self._scratch.get(key)
         if cur is None or cur.numel() < n:
             if cur is not None:
@@ -201,35 +213,45 @@ class Trainer(object):
             cur = self._scratch[key] = torch.empty(max(int(n), 1 << 20), dtype=torch.float32, device=self.device)
         return cur
 
-    # ---- second stream for the weight-gradient products
-    def _fork(self):
-        """-> stream pointer for a dW product that may start once everything queued on the main stream so far is done."""
-        if self._side is None:
-            self._side = torch.cuda.Stream(device=self.device)
+    # ---- side stream(s) for the weight-gradient products (DISPU_TRAIN_DW_STREAMS of them, used round-robin; each has its own scratch)
+    def _side_next(self):
+        if not self._sides:
+            n = max(1, int(os.environ.get("DISPU_TRAIN_DW_STREAMS", "2")))
+            self._sides = [torch.cuda.Stream(device=self.device) for _ in range(n)]
             self._fork_ev = torch.cuda.Event()
-            self._join_ev = torch.cuda.Event()
+            self._join_evs = [torch.cuda.Event() for _ in range(n)]
+            self._side_busy = [False] * n
+        self._side_rr = (self._side_rr + 1) % len(self._sides)
+        return self._side_rr
+
+    def _fork(self):
+        """-> (stream pointer, scratch key) for a dW product that may start once everything queued on the main stream so far is done."""
+        i = self._side_next()
         main = torch.cuda.current_stream(self.device)
         self._fork_ev.record(main)
-        self._side.wait_event(self._fork_ev)
-        self._side_busy = True
-        return ctypes.c_void_p(self._side.cuda_stream)
+        self._sides[i].wait_event(self._fork_ev)
+        self._side_busy[i] = True
+        return ctypes.c_void_p(self._sides[i].cuda_stream), "dw%d" % i
 
     def _fork_point(self):
         """an event at the current position of the main stream, for a dW product queued later (see _lin_bwd)."""
-        if self._side is None:
-            self._side = torch.cuda.Stream(device=self.device)
-            self._fork_ev = torch.cuda.Event()
-            self._join_ev = torch.cuda.Event()
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(self.device))
         return ev
 
+    def _fork_after(self, ev):
+        i = self._side_next()
+        self._sides[i].wait_event(ev)
+        self._side_busy[i] = True
+        return ctypes.c_void_p(self._sides[i].cuda_stream), "dw%d" % i
+
     def _join(self):
         """the current stream waits for every dW product queued so far (before a buffer they read is overwritten, before Adam)."""
-        if self._side_busy:
-            self._join_ev.record(self._side)
-            torch.cuda.current_stream(self.device).wait_event(self._join_ev)
-            self._side_busy = False
+        for i, busy in enumerate(self._side_busy if self._sides else []):
+            if busy:
+                self._join_evs[i].record(self._sides[i])
+                torch.cuda.current_stream(self.device).wait_event(self._join_evs[i])
+                self._side_busy[i] = False
 
     @contextlib.contextmanager
     def _branch(self, i):
@@ -280,13 +302,11 @@ class Trainer(object):
         side = side and self.overlap_dw
         bf = self.bf16 and K > 4 and N > 4
         need = (L.dispu_linear_tn_bf16_scratch_floats if bf else L.dispu_linear_tn_scratch_floats)(batch, M, K, N)
-        sc = self._scratch_floats(need, side)
-        if side and after is not None:
-            self._side.wait_event(after)
-            self._side_busy = True
-            st = ctypes.c_void_p(self._side.cuda_stream)
+        if side:
+            st, key = self._fork_after(after) if after is not None else self._fork()
         else:
-            st = self._fork() if side else self.st
+            st, key = self.st, None
+        sc = self._scratch_floats(need, key)
         fn = L.dispu_linear_tn_bf16 if bf else L.dispu_linear_tn
         _lib.check(fn(batch, M, K, N, _p(X, xoff), ldx, sx, _p(Zt, zoff), ldz, sz, _p(out, ooff), ldo, so, accumulate, _p(dbias), _p(sc),
                       sc.numel(), st), "dispu_linear_tn_bf16" if bf else "dispu_linear_tn")
@@ -300,21 +320,26 @@ class Trainer(object):
                                          dZ.stride(0) if dZ is not None else 0, _p(dbias), 1, _p(sc), sc.numel(), self.st),
                    "dispu_act_bias_grad")
 
-    def _dx(self, M, N, K, dY, dyoff, W, woff, dX, dxoff, acc, mask=None):
+    def _dx(self, M, N, K, dY, dyoff, W, woff, dX, dxoff, acc, mask=None, WT=None):
         """dX[:, dxoff:dxoff+K] (+)= dY[:, dyoff:dyoff+N] . W^T, then zeroed where mask <= 0: mask = (tensor, column offset, columns) is the
-        ReLU output that fed this layer -- the relu_grad of the layer below rides in the GEMM epilogue (no separate pass over dX)."""
+        ReLU output that fed this layer -- the relu_grad of the layer below rides in the GEMM epilogue (no separate pass over dX).
+        WT: the step's transposed copy of W ([N, K] row-major): the product then runs untransposed (the forward GEMM's fast path)."""
         L = _lib.lib()
         bf = self.bf16 and K > 4 and N > 4
         r1 = _p(dX, dxoff) if acc else None
         ldr = dX.stride(0) if acc else 0
+        if WT is not None:
+            wp, ldw, tb = _p(WT), WT.stride(0), 0
+        else:
+            wp, ldw, tb = _p(W, woff), W.stride(0), 1
         if mask is None:
             fn = L.dispu_linear_bf16 if bf else L.dispu_linear
-            _lib.check(fn(1, M, N, K, _p(dY, dyoff), dY.stride(0), 0, _p(W, woff), W.stride(0), 0, 1, None, 0, _p(dX, dxoff), dX.stride(0), 0,
+            _lib.check(fn(1, M, N, K, _p(dY, dyoff), dY.stride(0), 0, wp, ldw, 0, tb, None, 0, _p(dX, dxoff), dX.stride(0), 0,
                           r1, ldr, 0, None, 0, 0, self.st), "dispu_linear(dX)")
         else:
             mt, moff, mcols = mask
             fn = L.dispu_linear_bf16_masked if bf else L.dispu_linear_masked
-            _lib.check(fn(1, M, N, K, _p(dY, dyoff), dY.stride(0), 0, _p(W, woff), W.stride(0), 0, 1, None, 0, _p(dX, dxoff), dX.stride(0), 0,
+            _lib.check(fn(1, M, N, K, _p(dY, dyoff), dY.stride(0), 0, wp, ldw, 0, tb, None, 0, _p(dX, dxoff), dX.stride(0), 0,
                           r1, ldr, 0, _p(mt, moff), mt.stride(0), int(mcols), self.st), "dispu_linear_masked(dX)")
 
     def _lin_bwd(self, X, xoff, K, wname, N, dY, dyoff, dX=None, dxoff=0, acc_dx=False, M=None, bias=True, W=None, dW=None, woff=0,
@@ -330,7 +355,8 @@ class Trainer(object):
         # ordered after dZ by an event recorded BEFORE the dX launch (dX never writes what the dW product reads)
         ev = self._fork_point() if (self.overlap_dw and dX is not None) else None
         if dX is not None:
-            self._dx(M, N, K, dY, dyoff, W, woff, dX, dxoff, acc_dx, mask)
+            WT = self.PT.get(wname + "/weights") if (wname is not None and woff == 0 and self.use_wt and K == W.shape[0]) else None
+            self._dx(M, N, K, dY, dyoff, W, woff, dX, dxoff, acc_dx, mask, WT)
         self._tn(1, M, K, N, X, xoff, X.stride(0), 0, dY, dyoff, dY.stride(0), 0, dW, woff, dW.stride(0), 0, 1, dbias=db, side=True, after=ev)
 
     # ----------------------------------------------------------------------------------------------- forward ----
@@ -460,6 +486,9 @@ class Trainer(object):
         if self._stash_ready:
             return
         L = _lib.lib()
+        if self.use_wt and self._t_desc.numel():
+            _lib.check(L.dispu_transpose_batched(self._t_desc.numel() // 3, _p(self._t_desc), _p(self.flat_p), _p(self.flat_pT), self.st),
+                       "transpose_batched")
         B, N = self._shape
         M, k = N * self.up_ratio, K_NEIGH
         rm = B * M
@@ -512,15 +541,19 @@ class Trainer(object):
             self._recompute_pair_tensors()
         with self._branch(0):                                   # the coarse term next to the fine term and the repulsion term
             self._chamfer(ws["coarse"], gt, radius, 1000.0, ws["dcoarse"], 0)
-        self._chamfer(ws["fine"], gt, radius, 1000.0 * wf, ws["dfine"], 1)
+        # fine term: nn_distance, then value + gradient (which zero-fills dfine); the repulsion term's ball query runs next to it and
+        # adds its gradient once the Chamfer gradient is in place
         rep = None
         if self.opts.use_repulse:
             fine = ws["fine"]
-            _lib.check(L.dispu_query_ball(B, M, M, _p(ws["r07"]), 20, _p(fine), _p(fine), _p(ws["ball"]), _p(ws["ball_cnt"]),
-                                          _lib.ARITH_CONTRACT, self.st), "query_ball")   # as loss_utils.get_repulsion_loss
-            _lib.check(L.dispu_repulsion(B * M, M, 20, 0, 0.001, _p(fine), _p(ws["ball"]), _p(ws["rep"]), self.st), "repulsion")
-            _lib.check(L.dispu_repulsion_grad(B * M, M, 20, 0.001, self.opts.repulsion_w / (B * M * 4.0), _p(fine), _p(ws["ball"]),
-                                              _p(ws["dfine"]), self.st), "repulsion_grad")
+            with self._branch(1):
+                _lib.check(L.dispu_query_ball(B, M, M, _p(ws["r07"]), 20, _p(fine), _p(fine), _p(ws["ball"]), _p(ws["ball_cnt"]),
+                                              _lib.ARITH_CONTRACT, self.st), "query_ball")   # as loss_utils.get_repulsion_loss
+        self._chamfer(ws["fine"], gt, radius, 1000.0 * wf, ws["dfine"], 1)
+        if self.opts.use_repulse:
+            self._merge(1)
+            _lib.check(L.dispu_repulsion_loss_grad(B * M, M, 20, 0.001, self.opts.repulsion_w / (B * M * 4.0), _p(fine), _p(ws["ball"]),
+                                                   _p(ws["rep"]), _p(ws["dfine"]), self.st), "repulsion_loss_grad")
             rep = ws["rep"]
         self._merge(0)
         out = ws["loss_vals"]

@@ -448,6 +448,13 @@ int dispu_chamfer_loss_grad(int b, int n_gt, const float* gt, int n_pred, const 
 /* out[5] = 1000 CD_coarse | 1000 CD_fine | repulsion_w * mean(rep) / 4 | pu_loss (model.py:87) | weight_fine; cd[2] = the two
  * values of dispu_chamfer_loss_grad, rep [nrep] = dispu_repulsion's per-point sums (NULL: no repulsion term). */
 int dispu_pu_loss_finalize(const float* cd, const float* rep, long nrep, float wf, float rep_w, float* out, void* stream);
+/* get_repulsion_loss (loss_utils.py:271-298) value and gradient in one launch (= dispu_repulsion + dispu_repulsion_grad): out [rows]
+ * per-point hinge sums, dpred [rows, 3] accumulates scale * d loss / d pred (atomics).  ns == 20. */
+int dispu_repulsion_loss_grad(long rows, int n_per_cloud, int ns, float h, float scale, const float* pred, const int* idx, float* out,
+                              float* dpred, void* stream);
+/* dst[off ..] = W^T [N][K] for every weight matrix W [K][N] at src[off ..]; desc [count][3] = {off, K, N} (device int32).  The training
+ * step's dX = dZ . W^T products read W^T untransposed (the forward GEMM's fast path). */
+int dispu_transpose_batched(int count, const int* desc, const float* src, float* dst, void* stream);
 /* dispu_ps_point_matmul_grad with conv1's ReLU gradient folded in: dX2 is zero where X2 <= 0. */
 int dispu_ps_point_matmul_grad_relu(long rows, int k, int c, int t_n, const float* X2, long ldx2, const float* wv, const float* dout,
                                     long ldo, float* dX2, long lddx2, float* dwv, void* stream);

@@ -399,7 +399,7 @@ def test_weight_gradients_on_second_stream(dev, dtype, B):
 
     tr_o, g_o = passes(True)
     tr_s, g_s = passes(False)
-    assert tr_o._side is not None and tr_s._side is None
+    assert tr_o._sides and not tr_s._sides
     # bf16 products: an fp32 ulp of atomics noise upstream can flip an operand's bf16 rounding (2^-9 relative) downstream
     tol = 1e-5 if dtype == "f32" else 1e-3
     for k in g_o[0]:

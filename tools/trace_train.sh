@@ -6,7 +6,7 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-rocprofv3 --kernel-trace --output-format csv -d $OUT/raw -o prof -- python $GRAFT_REPO_ROOT/tools/train_bench.py --batch $B --steps 4 --warmup 2 --dtype $DT > $OUT/bench_profiled.json 2> $OUT/rocprof.log || true
+rocprofv3 --kernel-trace --output-format csv -d $OUT/raw -o prof -- python $GRAFT_REPO_ROOT/tools/train_bench.py --batch $B --steps 4 --warmup 2 --dtype $DT $4 > $OUT/bench_profiled.json 2> $OUT/rocprof.log || true
 cd $GRAFT_REPO_ROOT
 F=$(find $OUT/raw -name "*kernel_trace.csv" | head -1)
 python tools/trace_timeline.py $F > $OUT/timeline.txt
