@@ -124,6 +124,11 @@ SIGNATURES = {
                                         _vp, _vp, _l, _vp]),
     "dispu_repulsion_loss_grad": (_i, [_l, _i, _i, C.c_float, C.c_float, _vp, _vp, _vp, _vp, _vp]),
     "dispu_transpose_batched": (_i, [_i, _vp, _vp, _vp, _vp]),
+    "dispu_linear_bf16s": (_i, [_i, _i, _i, _i, _vp, _l, _l, _vp, _l, _l, _i, _vp, _i, _vp, _l, _l, _vp, _l, _l, _i, _vp]),
+    "dispu_linear_tn_bf16s": (_i, [_i, _i, _i, _i, _vp, _l, _l, _vp, _l, _l, _vp, _l, _l, _i, _vp, _vp, _l, _i, _vp]),
+    "dispu_ps_gather_sub_relu_bf16": (_i, [_l, _i, _i, _i, _vp, _vp, _l, _vp, _l, _vp, _l, _vp]),
+    "dispu_ps_point_matmul_grad_relu_s": (_i, [_l, _i, _i, _i, _vp, _l, _vp, _vp, _l, _vp, _l, _vp, _i, _vp]),
+    "dispu_ps_conv0_gather_grad_s": (_i, [_l, _i, _i, _i, _vp, _vp, _vp, _vp, _l, _i, _vp, _l, _vp, _l, _vp, _l, _vp, _l, _vp]),
     "dispu_chamfer_loss_grad": (_i, [_i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, C.c_float, _vp, _vp, _vp]),
     "dispu_pu_loss_finalize": (_i, [_vp, _vp, _l, C.c_float, C.c_float, _vp, _vp]),
     "dispu_augment": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

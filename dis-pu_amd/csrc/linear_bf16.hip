@@ -41,6 +41,8 @@ struct GbArgs {
     float* part;
     float* colsum; int colsum_acc;     // TN only: column sums of B (fp32, un-rounded) = the bias gradient; NULL = not wanted
     const float* Mk; long ldm; int mcols;   // optional ReLU-gradient mask, applied last (dispu_linear_bf16_masked)
+    int a_bf16, b_bf16, c_bf16;             // operand / output tensors STORED as bf16 (2-byte elements behind the float* pointers;
+                                            // strides stay in elements): the training step's bf16 activation storage
 };
 
 // four consecutive elements along the operand's contiguous direction, zero beyond `valid`
@@ -61,8 +63,46 @@ __device__ __forceinline__ float4 gb_load4(const float* p, int valid) {
 //          stores, conflict-free at an 80-byte row pitch (transposing float4 loads needed 2-byte stores with 8-way conflicts).
 template <int ROWS, int BK> struct GbRegs { float v[ROWS * BK / 256]; };
 
+__device__ __forceinline__ float gb_bf16_to_f32(unsigned short h) { return __uint_as_float(((unsigned)h) << 16); }
+
+// four consecutive bf16 elements (8 bytes), zero beyond `valid`
+__device__ __forceinline__ float4 gb_load4_bf16(const unsigned short* p, int valid) {
+    if (valid >= 4 && (((uintptr_t)p) & 7) == 0) {
+        const uint2 w = *reinterpret_cast<const uint2*>(p);
+        return make_float4(__uint_as_float(w.x << 16), __uint_as_float(w.x & 0xFFFF0000u), __uint_as_float(w.y << 16), __uint_as_float(w.y & 0xFFFF0000u));
+    }
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (valid > 0) v.x = gb_bf16_to_f32(p[0]);
+    if (valid > 1) v.y = gb_bf16_to_f32(p[1]);
+    if (valid > 2) v.z = gb_bf16_to_f32(p[2]);
+    if (valid > 3) v.w = gb_bf16_to_f32(p[3]);
+    return v;
+}
+
 template <int ROWS, int BK, bool KFAST>
-__device__ __forceinline__ void gb_fetch(GbRegs<ROWS, BK>& reg, const float* base, long s_o, long s_k, int o0, int olim, int k0, int klim, int tid) {
+__device__ __forceinline__ void gb_fetch(GbRegs<ROWS, BK>& reg, const float* base, long s_o, long s_k, int o0, int olim, int k0, int klim, int tid,
+                                         int src_bf16) {
+    if (src_bf16) {                                            // wave-uniform: the tensor is stored as bf16 (exact in the float registers)
+        const unsigned short* hb = reinterpret_cast<const unsigned short*>(base);
+        if constexpr (KFAST) {
+            constexpr int Q = BK / 4;
+#pragma unroll
+            for (int u = 0; u < ROWS * Q / 256; ++u) {
+                const int s = tid + 256 * u;
+                const int o = o0 + s / Q, k = k0 + (s % Q) * 4;
+                const float4 t = (o < olim) ? gb_load4_bf16(hb + (long)o * s_o + k, klim - k) : make_float4(0.f, 0.f, 0.f, 0.f);
+                reg.v[4 * u + 0] = t.x; reg.v[4 * u + 1] = t.y; reg.v[4 * u + 2] = t.z; reg.v[4 * u + 3] = t.w;
+            }
+        } else {
+            constexpr int KP = ROWS * BK / 256;
+            const int o = o0 + (tid % ROWS), kb = k0 + (tid / ROWS) * KP;
+            const bool ok = o < olim;
+            const unsigned short* p = hb + (long)kb * s_k + o;
+#pragma unroll
+            for (int u = 0; u < KP; ++u) reg.v[u] = (ok && kb + u < klim) ? gb_bf16_to_f32(p[(long)u * s_k]) : 0.f;
+        }
+        return;
+    }
     if constexpr (KFAST) {
         constexpr int Q = BK / 4;                              // float4 per row
 #pragma unroll
@@ -125,8 +165,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GbArgs a) {
     const int m0 = (blockIdx.x / tiles_n) * BM, n0 = (blockIdx.x % tiles_n) * BN;
     const int z = blockIdx.z, split = blockIdx.y;
     const int kbeg = split * a.k_per_split, kend = min(a.K, kbeg + a.k_per_split);
-    const float* __restrict__ Ab = a.A + (long)z * a.a_z;
-    const float* __restrict__ Bb = a.B + (long)z * a.b_z;
+    const float* __restrict__ Ab = a.a_bf16 ? reinterpret_cast<const float*>(reinterpret_cast<const unsigned short*>(a.A) + (long)z * a.a_z) : a.A + (long)z * a.a_z;
+    const float* __restrict__ Bb = a.b_bf16 ? reinterpret_cast<const float*>(reinterpret_cast<const unsigned short*>(a.B) + (long)z * a.b_z) : a.B + (long)z * a.b_z;
 
     f32x16v acc[TI][TJ];
 #pragma unroll
@@ -142,8 +182,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GbArgs a) {
     const bool want_cs = !B_KFAST && a.colsum != nullptr && m0 == 0;
     const int nslab = (kend - kbeg + GB_BK - 1) / GB_BK;
     if (nslab > 0) {
-        gb_fetch<BM, BK, A_KFAST>(ra, Ab, a.a_o, a.a_k, m0, a.M, kbeg, kend, tid);
-        gb_fetch<BN, BK, B_KFAST>(rb, Bb, a.b_o, a.b_k, n0, a.N, kbeg, kend, tid);
+        gb_fetch<BM, BK, A_KFAST>(ra, Ab, a.a_o, a.a_k, m0, a.M, kbeg, kend, tid, a.a_bf16);
+        gb_fetch<BN, BK, B_KFAST>(rb, Bb, a.b_o, a.b_k, n0, a.N, kbeg, kend, tid, a.b_bf16);
         gb_stage<BM, BK, A_KFAST>(ra, lds, tid);
         gb_stage<BN, BK, B_KFAST>(rb, lds + BM * GB_PITCH, tid);
         if constexpr (!B_KFAST)
@@ -157,8 +197,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GbArgs a) {
         const __bf16* As = lds + (t & 1) * STAGE;
         const __bf16* Bs = As + BM * GB_PITCH;
         if (t + 1 < nslab) {                                   // next slab's global loads fly under this slab's MFMAs
-            gb_fetch<BM, BK, A_KFAST>(ra, Ab, a.a_o, a.a_k, m0, a.M, kbeg + (t + 1) * GB_BK, kend, tid);
-            gb_fetch<BN, BK, B_KFAST>(rb, Bb, a.b_o, a.b_k, n0, a.N, kbeg + (t + 1) * GB_BK, kend, tid);
+            gb_fetch<BM, BK, A_KFAST>(ra, Ab, a.a_o, a.a_k, m0, a.M, kbeg + (t + 1) * GB_BK, kend, tid, a.a_bf16);
+            gb_fetch<BN, BK, B_KFAST>(rb, Bb, a.b_o, a.b_k, n0, a.N, kbeg + (t + 1) * GB_BK, kend, tid, a.b_bf16);
         }
 #pragma unroll
         for (int ks = 0; ks < GB_BK / 16; ++ks) {
@@ -238,7 +278,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GbArgs a) {
                 if (R1) v += R1[(long)row * a.ldr1 + col];
                 if (R2) v += R2[(long)row * a.ldr2 + col];
                 if (a.Mk && col < a.mcols) v = (a.Mk[(long)row * a.ldm + col] > 0.f) ? v : 0.f;
-                C[(long)row * a.ldc + col] = v;
+                if (a.c_bf16) reinterpret_cast<__bf16*>(a.C)[(long)z * a.c_z + (long)row * a.ldc + col] = (__bf16)v;
+                else C[(long)row * a.ldc + col] = v;
             }
         }
 }
@@ -315,6 +356,20 @@ DISPU_EXPORT int dispu_linear_bf16(int batch, int M, int K, int N, const float* 
     return transb ? gb_launch<true, true>(a, batch, (hipStream_t)stream) : gb_launch<true, false>(a, batch, (hipStream_t)stream);
 }
 
+// dispu_linear_bf16 with bf16-STORED tensors: storage bit 0: X holds bf16 elements, bit 2: Y is written as bf16 (W, bias, R1 stay
+// fp32; R1 must be NULL when Y is bf16).  ldx / ldy / sx / sy count elements.
+DISPU_EXPORT int dispu_linear_bf16s(int batch, int M, int K, int N, const void* X, long ldx, long sx, const float* W, long ldw, long sw,
+                                    int transb, const float* bias, int act, void* Y, long ldy, long sy, const float* R1, long ldr1, long sr1,
+                                    int storage, void* stream) {
+    if (batch < 0 || M < 0 || K < 0 || N < 0 || !X || !W || !Y || (act != 0 && act != 1) || ((storage & 4) && R1)) return (int)hipErrorInvalidValue;
+    if (batch == 0 || M == 0 || N == 0) return 0;
+    int per = ((K + GB_KALIGN - 1) / GB_KALIGN) * GB_KALIGN;
+    if (per == 0) per = GB_KALIGN;
+    GbArgs a{M, N, K, (const float*)X, ldx, 1, sx, W, transb ? ldw : 1, transb ? 1 : ldw, sw, (float*)Y, ldy, sy, bias, act, R1, ldr1, sr1, nullptr, 0, 0,
+             1, per, nullptr, nullptr, 0, nullptr, 0, 0, (storage & 1) ? 1 : 0, 0, (storage & 4) ? 1 : 0};
+    return transb ? gb_launch<true, true>(a, batch, (hipStream_t)stream) : gb_launch<true, false>(a, batch, (hipStream_t)stream);
+}
+
 // dispu_linear_masked (include/dispu_hip.h) with bf16 products: Y = mask(R1 + act(X . W + bias)), Y = 0 where Mk <= 0 (columns < mcols).
 DISPU_EXPORT int dispu_linear_bf16_masked(int batch, int M, int K, int N, const float* X, long ldx, long sx, const float* W, long ldw,
                                           long sw, int transb, const float* bias, int act, float* Y, long ldy, long sy, const float* R1,
@@ -337,9 +392,24 @@ DISPU_EXPORT long dispu_linear_tn_bf16_scratch_floats(int batch, int M, int K, i
 
 // out[z] (+)= X[z]^T . Z[z]   (X [M, K], Z [M, N], out [K, N]); bf16 products, fp32 sums, deterministic split reduction.
 // dbias (optional, batch == 1): (+)= column sums of Z, accumulated in fp32 from the UN-rounded values inside the same kernel.
+DISPU_EXPORT int dispu_linear_tn_bf16s(int batch, int M, int K, int N, const void* X, long ldx, long sx, const void* Z, long ldz, long sz,
+                                       float* out, long ldo, long so, int accumulate, float* dbias, float* scratch, long scratch_floats,
+                                       int storage, void* stream);
+
 DISPU_EXPORT int dispu_linear_tn_bf16(int batch, int M, int K, int N, const float* X, long ldx, long sx, const float* Z, long ldz,
                                       long sz, float* out, long ldo, long so, int accumulate, float* dbias, float* scratch,
                                       long scratch_floats, void* stream) {
+    return dispu_linear_tn_bf16s(batch, M, K, N, X, ldx, sx, Z, ldz, sz, out, ldo, so, accumulate, dbias, scratch, scratch_floats, 0, stream);
+}
+
+// dispu_linear_tn_bf16 with bf16-STORED operands: storage bit 0: X holds bf16 elements, bit 1: Z does (the bias gradient is then the
+// sum of the stored, i.e. rounded, values).
+DISPU_EXPORT int dispu_linear_tn_bf16s(int batch, int M, int K, int N, const void* Xv, long ldx, long sx, const void* Zv, long ldz, long sz,
+                                       float* out, long ldo, long so, int accumulate, float* dbias, float* scratch, long scratch_floats,
+                                       int storage, void* stream) {
+    const float* X = (const float*)Xv;
+    const float* Z = (const float*)Zv;
+    const int xa = (storage & 1) ? 1 : 0, zb = (storage & 2) ? 1 : 0;
     if (batch < 0 || M < 0 || K < 0 || N < 0 || !out || (dbias && batch != 1)) return (int)hipErrorInvalidValue;
     if (batch == 0 || K == 0 || N == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
@@ -354,13 +424,13 @@ DISPU_EXPORT int dispu_linear_tn_bf16(int batch, int M, int K, int N, const floa
     tn_bf16_plan(batch, M, K, N, splits, per);
     if (splits == 1) {       // one workgroup per output tile walks the whole contraction; accumulate = out as its own residual
         GbArgs a{K, N, M, X, 1, ldx, sx, Z, 1, ldz, sz, out, ldo, so, nullptr, 0, accumulate ? out : nullptr, ldo, so, nullptr, 0, 0, 1,
-                 per, nullptr, dbias, accumulate};
+                 per, nullptr, dbias, accumulate, nullptr, 0, 0, xa, zb, 0};
         return gb_launch<false, false>(a, batch, s);
     }
     const long rows_p = dbias ? (long)K + 1 : (long)K;
     if (!scratch || scratch_floats < (long)batch * splits * rows_p * N) return (int)hipErrorInvalidValue;
     GbArgs a{K, N, M, X, 1, ldx, sx, Z, 1, ldz, sz, out, ldo, so, nullptr, 0, nullptr, 0, 0, nullptr, 0, 0, splits, per, scratch, dbias,
-             accumulate};
+             accumulate, nullptr, 0, 0, xa, zb, 0};
     const int rc = gb_launch<false, false>(a, batch, s);
     if (rc != 0) return rc;
     const long total = rows_p * N;

@@ -22,6 +22,23 @@ static inline int tf_grid(size_t total, int block) {
     return (int)(g > 16384 ? 16384 : (g < 1 ? 1 : g));
 }
 
+// bf16 activation storage (Trainer(dtype="bf16")): the [B*M*16, 128] pair tensors and dF' are kept as bf16 in HBM
+__device__ __forceinline__ float4 tf_ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float4 tf_ld4(const __bf16* p) {
+    const uint2 w = *reinterpret_cast<const uint2*>(p);
+    return make_float4(__uint_as_float(w.x << 16), __uint_as_float(w.x & 0xFFFF0000u), __uint_as_float(w.y << 16), __uint_as_float(w.y & 0xFFFF0000u));
+}
+__device__ __forceinline__ float tf_ld1(const float* p) { return *p; }
+__device__ __forceinline__ float tf_ld1(const __bf16* p) { return (float)*p; }
+__device__ __forceinline__ void tf_st1(float* p, float v) { *p = v; }
+__device__ __forceinline__ void tf_st1(__bf16* p, float v) { *p = (__bf16)v; }
+typedef __bf16 tf_bf16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void tf_st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ void tf_st4(__bf16* p, float4 v) {
+    tf_bf16x4 h = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+    *reinterpret_cast<tf_bf16x4*>(p) = h;
+}
+
 __device__ __forceinline__ double tf_wave_sum(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -305,16 +322,17 @@ __global__ __launch_bounds__(1024) void knn_invert_kernel(int n, int k, const in
 __device__ __forceinline__ float4 c0_masked(float4 v, float4 g, float4 a) {
     return make_float4((g.x - a.x > 0.f) ? v.x : 0.f, (g.y - a.y > 0.f) ? v.y : 0.f, (g.z - a.z > 0.f) ? v.z : 0.f, (g.w - a.w > 0.f) ? v.w : 0.f);
 }
+template <class TZ>
 __global__ __launch_bounds__(256) void ps_conv0_gather_grad_kernel(long rows, int n_per_cloud, int k, const int* __restrict__ idx,
                                                                     const int* __restrict__ off, const int* __restrict__ inv,
-                                                                    const float* __restrict__ dz0, long ldz, const float* __restrict__ Gm,
+                                                                    const TZ* __restrict__ dz0, long ldz, const float* __restrict__ Gm,
                                                                     long ldgm, const float* __restrict__ Am, long ldam, float* __restrict__ dG,
                                                                     long ldg, float* __restrict__ dAneg, long lda) {
     const int sub = threadIdx.x & 31;
     const long p = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 5;
     if (p >= rows) return;
     const long cloud = p / n_per_cloud, pl = p - cloud * n_per_cloud, base = cloud * n_per_cloud;
-    const float* __restrict__ zc = dz0 + (size_t)cloud * n_per_cloud * k * ldz;        // this cloud's pair rows
+    const TZ* __restrict__ zc = dz0 + (size_t)cloud * n_per_cloud * k * ldz;           // this cloud's pair rows
     const bool msk = Gm != nullptr;
     float4 gp = make_float4(0.f, 0.f, 0.f, 0.f), ap = gp;
     if (msk) {
@@ -323,7 +341,7 @@ __global__ __launch_bounds__(256) void ps_conv0_gather_grad_kernel(long rows, in
     }
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int s = 0; s < k; ++s) {
-        float4 v = *reinterpret_cast<const float4*>(zc + (size_t)(pl * k + s) * ldz + sub * 4);
+        float4 v = tf_ld4(zc + (size_t)(pl * k + s) * ldz + sub * 4);
         if (msk) {
             const long j = base + idx[p * k + s];
             v = c0_masked(v, *reinterpret_cast<const float4*>(Gm + j * ldgm + sub * 4), ap);
@@ -338,10 +356,10 @@ __global__ __launch_bounds__(256) void ps_conv0_gather_grad_kernel(long rows, in
     int e = lo;
     for (; e + 4 <= hi; e += 4) {
         const int e0 = iv[e], e1 = iv[e + 1], e2 = iv[e + 2], e3 = iv[e + 3];
-        float4 v0 = *reinterpret_cast<const float4*>(zc + (size_t)e0 * ldz + sub * 4);
-        float4 v1 = *reinterpret_cast<const float4*>(zc + (size_t)e1 * ldz + sub * 4);
-        float4 v2 = *reinterpret_cast<const float4*>(zc + (size_t)e2 * ldz + sub * 4);
-        float4 v3 = *reinterpret_cast<const float4*>(zc + (size_t)e3 * ldz + sub * 4);
+        float4 v0 = tf_ld4(zc + (size_t)e0 * ldz + sub * 4);
+        float4 v1 = tf_ld4(zc + (size_t)e1 * ldz + sub * 4);
+        float4 v2 = tf_ld4(zc + (size_t)e2 * ldz + sub * 4);
+        float4 v3 = tf_ld4(zc + (size_t)e3 * ldz + sub * 4);
         if (msk) {
             v0 = c0_masked(v0, gp, *reinterpret_cast<const float4*>(Am + (base + e0 / k) * ldam + sub * 4));
             v1 = c0_masked(v1, gp, *reinterpret_cast<const float4*>(Am + (base + e1 / k) * ldam + sub * 4));
@@ -355,7 +373,7 @@ __global__ __launch_bounds__(256) void ps_conv0_gather_grad_kernel(long rows, in
     }
     for (; e < hi; ++e) {
         const int ee = iv[e];
-        float4 v = *reinterpret_cast<const float4*>(zc + (size_t)ee * ldz + sub * 4);
+        float4 v = tf_ld4(zc + (size_t)ee * ldz + sub * 4);
         if (msk) v = c0_masked(v, gp, *reinterpret_cast<const float4*>(Am + (base + ee / k) * ldam + sub * 4));
         g.x += v.x; g.y += v.y; g.z += v.z; g.w += v.w;
     }
@@ -478,17 +496,18 @@ __global__ __launch_bounds__(256) void ps_skip_max_grad_kernel(long rows, int n_
 
 // ---- feature x weight product backward with the ReLU of conv1 folded in (csrc/train_ops.hip:ps_point_matmul_grad_kernel) -------
 // dz1[(i,s), c] = (h1 > 0) * sum_t dout[i, c*16 + t] wv[(i,s), t];  dwv[(i,s), t] = sum_c h1[(i,s), c] dout[i, c*16 + t]
-__global__ __launch_bounds__(256) void ps_point_matmul_grad_relu_kernel(long rows, const float* __restrict__ X2, long ldx2,
-                                                                         const float* __restrict__ wv, const float* __restrict__ dout,
-                                                                         long ldo, float* __restrict__ dX2, long lddx2,
+template <class TS>
+__global__ __launch_bounds__(256) void ps_point_matmul_grad_relu_kernel(long rows, const TS* __restrict__ X2, long ldx2,
+                                                                         const float* __restrict__ wv, const TS* __restrict__ dout,
+                                                                         long ldo, TS* __restrict__ dX2, long lddx2,
                                                                          float* __restrict__ dwv) {
     constexpr int K = 16, T = 16, C = 128;
     __shared__ float s_do[C * (T + 1)];
     __shared__ float s_x[K][C + 1];
     __shared__ float s_w[K][T + 1];
     for (long i = blockIdx.x; i < rows; i += gridDim.x) {
-        for (int e = threadIdx.x; e < C * T; e += 256) s_do[(e >> 4) * (T + 1) + (e & 15)] = dout[i * ldo + e];
-        for (int e = threadIdx.x; e < K * C; e += 256) s_x[e / C][e % C] = X2[(i * K + e / C) * ldx2 + e % C];
+        for (int e = threadIdx.x; e < C * T; e += 256) s_do[(e >> 4) * (T + 1) + (e & 15)] = tf_ld1(dout + i * ldo + e);
+        for (int e = threadIdx.x; e < K * C; e += 256) s_x[e / C][e % C] = tf_ld1(X2 + (i * K + e / C) * ldx2 + e % C);
         s_w[threadIdx.x >> 4][threadIdx.x & 15] = wv[(i * K) * T + threadIdx.x];
         __syncthreads();
         for (int e = threadIdx.x; e < K * C; e += 256) {
@@ -496,7 +515,7 @@ __global__ __launch_bounds__(256) void ps_point_matmul_grad_relu_kernel(long row
             float a = 0.f;
 #pragma unroll
             for (int t = 0; t < T; ++t) a = __builtin_fmaf(s_do[c * (T + 1) + t], s_w[s][t], a);
-            dX2[(i * K + s) * lddx2 + c] = (s_x[s][c] > 0.f) ? a : 0.f;
+            tf_st1(dX2 + (i * K + s) * lddx2 + c, (s_x[s][c] > 0.f) ? a : 0.f);
         }
         {
             const int s = threadIdx.x >> 4, t = threadIdx.x & 15;
@@ -663,6 +682,21 @@ __global__ __launch_bounds__(256) void transpose_batched_kernel(const int* __res
     }
 }
 
+// h0[(i,s), c] = relu(G[cloud, idx[i,s], c] - A[i, c]) written as bf16 (csrc/mlp_misc.hip:ps_gather_sub_relu_kernel, bf16 storage)
+__global__ void ps_gather_sub_relu_bf16_kernel(long rows, int n_per_cloud, int k, int c4n, const int* __restrict__ idx, const float* __restrict__ Gm,
+                                               long ldg, const float* __restrict__ A, long lda, __bf16* __restrict__ X1, long ldx1) {
+    const long total = rows * k * c4n;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(e % c4n);
+        const long pr = e / c4n;
+        const long i = pr / k;
+        const long j = (i / n_per_cloud) * n_per_cloud + idx[pr];
+        const float4 g = *reinterpret_cast<const float4*>(Gm + j * ldg + c4 * 4);
+        const float4 a = *reinterpret_cast<const float4*>(A + i * lda + c4 * 4);
+        tf_st4(X1 + pr * ldx1 + c4 * 4, make_float4(fmaxf(g.x - a.x, 0.f), fmaxf(g.y - a.y, 0.f), fmaxf(g.z - a.z, 0.f), fmaxf(g.w - a.w, 0.f)));
+    }
+}
+
 static int wn_blocks(long rows) { return (int)(rows < 1024 ? rows : 1024); }
 
 }  // namespace dispu
@@ -722,15 +756,31 @@ DISPU_EXPORT int dispu_knn_invert(int b, int n, int k, const int* idx, int* off,
     return (int)hipGetLastError();
 }
 
+DISPU_EXPORT int dispu_ps_conv0_gather_grad_s(long rows, int n_per_cloud, int k, int c, const int* idx, const int* off, const int* inv,
+                                              const void* dh0, long ldz, int dh0_bf16, const float* Gm, long ldgm, const float* Am, long ldam,
+                                              float* dG, long ldg, float* dAneg, long lda, void* stream);
+
 DISPU_EXPORT int dispu_ps_conv0_gather_grad(long rows, int n_per_cloud, int k, int c, const int* idx, const int* off, const int* inv,
                                             const float* dh0, long ldz, const float* Gm, long ldgm, const float* Am, long ldam, float* dG,
                                             long ldg, float* dAneg, long lda, void* stream) {
+    return dispu_ps_conv0_gather_grad_s(rows, n_per_cloud, k, c, idx, off, inv, dh0, ldz, 0, Gm, ldgm, Am, ldam, dG, ldg, dAneg, lda, stream);
+}
+
+// the same with dh0 optionally STORED as bf16 (dh0_bf16 != 0; ldz in elements)
+DISPU_EXPORT int dispu_ps_conv0_gather_grad_s(long rows, int n_per_cloud, int k, int c, const int* idx, const int* off, const int* inv,
+                                              const void* dh0, long ldz, int dh0_bf16, const float* Gm, long ldgm, const float* Am, long ldam,
+                                              float* dG, long ldg, float* dAneg, long lda, void* stream) {
     if (rows < 0 || c != 128 || n_per_cloud <= 0 || rows % n_per_cloud != 0 || ((ldz | ldg | lda | ldgm | ldam) & 3) || ((Gm == nullptr) != (Am == nullptr)) ||
         (Gm && !idx))
         return (int)hipErrorInvalidValue;
     if (rows == 0) return 0;
-    hipLaunchKernelGGL(ps_conv0_gather_grad_kernel, dim3((unsigned)((rows * 32 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, rows,
-                       n_per_cloud, k, idx, off, inv, dh0, ldz, Gm, ldgm, Am, ldam, dG, ldg, dAneg, lda);
+    const dim3 grid((unsigned)((rows * 32 + 255) / 256));
+    if (dh0_bf16)
+        hipLaunchKernelGGL(ps_conv0_gather_grad_kernel<__bf16>, grid, dim3(256), 0, (hipStream_t)stream, rows, n_per_cloud, k, idx, off, inv,
+                           (const __bf16*)dh0, ldz, Gm, ldgm, Am, ldam, dG, ldg, dAneg, lda);
+    else
+        hipLaunchKernelGGL(ps_conv0_gather_grad_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, rows, n_per_cloud, k, idx, off, inv,
+                           (const float*)dh0, ldz, Gm, ldgm, Am, ldam, dG, ldg, dAneg, lda);
     return (int)hipGetLastError();
 }
 
@@ -753,13 +803,39 @@ DISPU_EXPORT int dispu_ps_skip_max_grad(long rows, int n_per_cloud, int k, int c
     return (int)hipGetLastError();
 }
 
+DISPU_EXPORT int dispu_ps_point_matmul_grad_relu_s(long rows, int k, int c, int t_n, const void* X2, long ldx2, const float* wv,
+                                                   const void* dout, long ldo, void* dX2, long lddx2, float* dwv, int bf16_storage,
+                                                   void* stream);
+
 DISPU_EXPORT int dispu_ps_point_matmul_grad_relu(long rows, int k, int c, int t_n, const float* X2, long ldx2, const float* wv,
                                                  const float* dout, long ldo, float* dX2, long lddx2, float* dwv, void* stream) {
+    return dispu_ps_point_matmul_grad_relu_s(rows, k, c, t_n, X2, ldx2, wv, dout, ldo, dX2, lddx2, dwv, 0, stream);
+}
+
+// the same with X2, dout and dX2 STORED as bf16 when bf16_storage != 0 (wv / dwv stay fp32; strides in elements)
+DISPU_EXPORT int dispu_ps_point_matmul_grad_relu_s(long rows, int k, int c, int t_n, const void* X2, long ldx2, const float* wv,
+                                                   const void* dout, long ldo, void* dX2, long lddx2, float* dwv, int bf16_storage,
+                                                   void* stream) {
     if (rows < 0 || k != 16 || c != 128 || t_n != 16) return (int)hipErrorInvalidValue;
     if (rows == 0) return 0;
     const int nb = (int)(rows < 16384 ? rows : 16384);
-    hipLaunchKernelGGL(ps_point_matmul_grad_relu_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, rows, X2, ldx2, wv, dout, ldo, dX2,
-                       lddx2, dwv);
+    if (bf16_storage)
+        hipLaunchKernelGGL(ps_point_matmul_grad_relu_kernel<__bf16>, dim3(nb), dim3(256), 0, (hipStream_t)stream, rows, (const __bf16*)X2, ldx2, wv,
+                           (const __bf16*)dout, ldo, (__bf16*)dX2, lddx2, dwv);
+    else
+        hipLaunchKernelGGL(ps_point_matmul_grad_relu_kernel<float>, dim3(nb), dim3(256), 0, (hipStream_t)stream, rows, (const float*)X2, ldx2, wv,
+                           (const float*)dout, ldo, (float*)dX2, lddx2, dwv);
+    return (int)hipGetLastError();
+}
+
+// dispu_ps_gather_sub_relu writing bf16 (bf16 activation storage of the training step)
+DISPU_EXPORT int dispu_ps_gather_sub_relu_bf16(long rows, int n_per_cloud, int k, int c, const int* idx, const float* G, long ldg,
+                                               const float* A, long lda, void* X1, long ldx1, void* stream) {
+    if (rows < 0 || c <= 0 || (c & 3) || ((ldg | lda | ldx1) & 3)) return (int)hipErrorInvalidValue;
+    if (rows == 0) return 0;
+    const size_t total = (size_t)rows * k * (c / 4);
+    hipLaunchKernelGGL(ps_gather_sub_relu_bf16_kernel, dim3(tf_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, rows, n_per_cloud, k, c / 4,
+                       idx, G, ldg, A, lda, (__bf16*)X1, ldx1);
     return (int)hipGetLastError();
 }
 

@@ -96,7 +96,9 @@ class Trainer(object):
         # dense blocks: forward = the fused inference kernel, backward = one recomputing kernel per block (csrc/edge_bwd.hip);
         # 0 = round 2's path through materialised edge tensors (A/B tests)
         self.fused_dense = os.environ.get("DISPU_TRAIN_FUSED_DENSE", "1") != "0"
-        self.use_wt = os.environ.get("DISPU_TRAIN_WT", "1") != "0"          # dX products through per-step W^T copies (A/B switch)
+        self.use_wt = os.environ.get("DISPU_TRAIN_WT", "1") != "0"
+        # dtype "bf16": the big activation / gradient tensors of the local cell are STORED as bf16 (0: fp32 storage, bf16 products only)
+        self.bf16_storage = os.environ.get("DISPU_TRAIN_BF16_STORAGE", "1") != "0"          # dX products through per-step W^T copies (A/B switch)
         self._aux = []
         self._cur = "main"
         self._sides = []
@@ -163,6 +165,7 @@ class Trainer(object):
         rn, rm, k = B * N, B * M, K_NEIGH
         E = lambda *shape, dtype=f32: torch.empty(shape, dtype=dtype, device=dev)
         Z = lambda *shape: torch.zeros(shape, dtype=f32, device=dev)
+        pt = torch.bfloat16 if (self.bf16 and self.bf16_storage) else f32      # storage type of the pair tensors / dF'
         ws = dict(
             feat=E(rn, 480), dfeat=E(rn, 480),
             prep=[None, None] + [E(rn, 48) for _ in range(2, DENSE_BLOCKS + 1)],
@@ -175,9 +178,11 @@ class Trainer(object):
             gmax=Z(rm, 144), dgmax=E(rm, 136), skip=E(rm, 256), dskip=E(rm, 256),
             # local cell: conv0 per source point (G, A), the pair tensors h0 / h1 / wv are RECOMPUTED for the backward pass
             gm=E(rm, 128), am=E(rm, 128), dG=E(rm, 128), dAneg=E(rm, 128),
-            h0=E(rm * k, 128), h1=E(rm * k, 128), dz1=E(rm * k, 128), dz0=E(rm * k, 128), wv=E(rm * k, 16), dwv=E(rm * k, 16),
+            # (dtype "bf16": stored as bf16 -- the GEMMs that read them round their operands to bf16 anyway)
+            h0=E(rm * k, 128, dtype=pt), h1=E(rm * k, 128, dtype=pt), dz1=E(rm * k, 128, dtype=pt), dz0=E(rm * k, 128, dtype=pt),
+            wv=E(rm * k, 16), dwv=E(rm * k, 16),
             bn_stats=E(48), bn_scale=E(16), bn_shift=E(16), bn_sums=E(32),
-            hp=E(rm, 2048), dhp=E(rm, 2048), aft=E(rm, 256), daft=E(rm, 256),
+            hp=E(rm, 2048), dhp=E(rm, 2048, dtype=pt), aft=E(rm, 256), daft=E(rm, 256),
             kv=E(rm, 128), dkv=E(rm, 128), q=E(rm, 64), dq=E(rm, 64), S=E(B, M, M), dS=E(B, M, M), att=E(rm, 64), datt=E(rm, 64),
             nl=E(rm, 256), dnl=E(rm, 256), sum=E(rm, 256), dsum=E(rm, 256), agg=E(rm, 256), dagg=E(rm, 256),
             f256=E(rm, 256), df256=E(rm, 256), f64=E(rm, 64), df64=E(rm, 64), z=E(rm, 3), dz=E(rm, 3), fine=E(B, M, 3), dfine=E(B, M, 3),
@@ -293,6 +298,12 @@ class Trainer(object):
         M = X.shape[0] if M is None else M
         W = self.P[wname + "/weights"] if W is None else W
         b = self.P[wname + "/biases"] if bias else None
+        sto = (1 if X.dtype == torch.bfloat16 else 0) | (4 if Y.dtype == torch.bfloat16 else 0)
+        if sto:
+            assert xoff == 0 and yoff == 0
+            _lib.check(L.dispu_linear_bf16s(1, M, K, N, _p(X), X.stride(0), 0, _p(W, woff), W.stride(0), 0, 0, _p(b), act, _p(Y), Y.stride(0), 0,
+                                            None, 0, 0, sto, self.st), "dispu_linear_bf16s")
+            return
         _lib.check(self._dl(1, M, K, N, _p(X, xoff), X.stride(0), 0, _p(W, woff), W.stride(0), 0, 0, _p(b), act,
                                   _p(Y, yoff), Y.stride(0), 0, None, 0, 0, None, 0, 0, self.st), "dispu_linear")
 
@@ -307,6 +318,12 @@ class Trainer(object):
         else:
             st, key = self.st, None
         sc = self._scratch_floats(need, key)
+        sto = (1 if X.dtype == torch.bfloat16 else 0) | (2 if Zt.dtype == torch.bfloat16 else 0)
+        if sto:
+            assert bf and xoff == 0 and zoff == 0
+            _lib.check(L.dispu_linear_tn_bf16s(batch, M, K, N, _p(X), ldx, sx, _p(Zt), ldz, sz, _p(out, ooff), ldo, so, accumulate, _p(dbias), _p(sc),
+                                               sc.numel(), sto, st), "dispu_linear_tn_bf16s")
+            return
         fn = L.dispu_linear_tn_bf16 if bf else L.dispu_linear_tn
         _lib.check(fn(batch, M, K, N, _p(X, xoff), ldx, sx, _p(Zt, zoff), ldz, sz, _p(out, ooff), ldo, so, accumulate, _p(dbias), _p(sc),
                       sc.numel(), st), "dispu_linear_tn_bf16" if bf else "dispu_linear_tn")
@@ -332,6 +349,12 @@ class Trainer(object):
             wp, ldw, tb = _p(WT), WT.stride(0), 0
         else:
             wp, ldw, tb = _p(W, woff), W.stride(0), 1
+        sto = (1 if dY.dtype == torch.bfloat16 else 0) | (4 if dX.dtype == torch.bfloat16 else 0)
+        if sto:
+            assert bf and mask is None and not acc and dyoff == 0 and dxoff == 0
+            _lib.check(L.dispu_linear_bf16s(1, M, N, K, _p(dY), dY.stride(0), 0, wp, ldw, 0, tb, None, 0, _p(dX), dX.stride(0), 0, None, 0, 0,
+                                            sto, self.st), "dispu_linear_bf16s(dX)")
+            return
         if mask is None:
             fn = L.dispu_linear_bf16 if bf else L.dispu_linear
             _lib.check(fn(1, M, N, K, _p(dY, dyoff), dY.stride(0), 0, wp, ldw, 0, tb, None, 0, _p(dX, dxoff), dX.stride(0), 0,
@@ -497,8 +520,12 @@ class Trainer(object):
         ps = "refine/PointShuffle/"
         coarse = ws["coarse"].view(rm, 3)
         _lib.check(L.dispu_knn_invert(B, M, k, _p(ws["psidx"]), _p(ws["inv_off"]), _p(ws["inv"]), self.st), "knn_invert")
-        _lib.check(L.dispu_ps_gather_sub_relu(rm, M, k, 128, _p(ws["psidx"]), _p(ws["gm"]), 128, _p(ws["am"]), 128, _p(ws["h0"]), 128, self.st),
-                   "gather_sub_relu")
+        if ws["h0"].dtype == torch.bfloat16:
+            _lib.check(L.dispu_ps_gather_sub_relu_bf16(rm, M, k, 128, _p(ws["psidx"]), _p(ws["gm"]), 128, _p(ws["am"]), 128, _p(ws["h0"]), 128,
+                                                       self.st), "gather_sub_relu_bf16")
+        else:
+            _lib.check(L.dispu_ps_gather_sub_relu(rm, M, k, 128, _p(ws["psidx"]), _p(ws["gm"]), 128, _p(ws["am"]), 128, _p(ws["h0"]), 128, self.st),
+                       "gather_sub_relu")
         self._lin(ws["h0"], 0, 128, ps + "conv1", 1, ws["h1"], 0, 128)
         _lib.check(L.dispu_ps_weight_net(rm, M, k, 16, _p(ws["psidx"]), _p(coarse), _p(P[ps + "weight_net/wconv0/weights"]),
                                          _p(P[ps + "weight_net/wconv0/biases"]), _p(ws["bn_scale"]), _p(ws["bn_shift"]), _p(ws["wv"]), self.st),
@@ -616,8 +643,9 @@ class Trainer(object):
         with self._branch(1):
             self._lin_bwd(ws["gmax"], 0, 134, ps + "skip", 256, ws["dskip"], 0, ws["dgmax"])
         self._merge(2)                                   # h0 / h1 / wv / the inverted graph are in place
-        _lib.check(L.dispu_ps_point_matmul_grad_relu(rm, k, 128, 16, _p(ws["h1"]), 128, _p(ws["wv"]), _p(ws["dhp"]), 2048, _p(ws["dz1"]),
-                                                     128, _p(ws["dwv"]), self.st), "point_matmul_grad")
+        _lib.check(L.dispu_ps_point_matmul_grad_relu_s(rm, k, 128, 16, _p(ws["h1"]), 128, _p(ws["wv"]), _p(ws["dhp"]), 2048, _p(ws["dz1"]),
+                                                       128, _p(ws["dwv"]), 1 if ws["h1"].dtype == torch.bfloat16 else 0, self.st),
+                   "point_matmul_grad")
         ww, bw = P[ps + "weight_net/wconv0/weights"], P[ps + "weight_net/wconv0/biases"]
         _lib.check(L.dispu_ps_wnet_grad(rm, M, k, 16, _p(ws["psidx"]), _p(coarse), _p(ww), _p(bw), _p(ws["bn_stats"]), _p(ws["bn_scale"]),
                                         _p(ws["bn_shift"]), _p(P[BN + "gamma"]), _p(ws["dwv"]), _p(G[ps + "weight_net/wconv0/weights"]),
@@ -625,9 +653,9 @@ class Trainer(object):
                                         _p(ws["bn_sums"]), _p(self._bn_scratch), self._bn_scratch.numel() * 8, self.st), "ps_wnet_grad")
         self._lin_bwd(ws["h0"], 0, 128, ps + "conv1", 128, ws["dz1"], 0, ws["dz0"])          # dz0 holds dh0: conv0's relu' rides in the gather
         # conv0 in its per-source-point form: dh0 * (G[j] - A[i] > 0) -> dG (gather through the inverted graph), -dA; then [B*M, 128] products
-        _lib.check(L.dispu_ps_conv0_gather_grad(rm, M, k, 128, _p(ws["psidx"]), _p(ws["inv_off"]), _p(ws["inv"]), _p(ws["dz0"]), 128,
-                                                _p(ws["gm"]), 128, _p(ws["am"]), 128, _p(ws["dG"]), 128, _p(ws["dAneg"]), 128, self.st),
-                   "conv0_gather_grad")
+        _lib.check(L.dispu_ps_conv0_gather_grad_s(rm, M, k, 128, _p(ws["psidx"]), _p(ws["inv_off"]), _p(ws["inv"]), _p(ws["dz0"]), 128,
+                                                  1 if ws["dz0"].dtype == torch.bfloat16 else 0, _p(ws["gm"]), 128, _p(ws["am"]), 128,
+                                                  _p(ws["dG"]), 128, _p(ws["dAneg"]), 128, self.st), "conv0_gather_grad")
         w0, dw0 = P[ps + "conv0/weights"], G[ps + "conv0/weights"]
         self._merge(0)                                   # dup128 holds the non-local cell's part from here on
         self._lin_bwd(ws["up128"], 0, 128, None, 128, ws["dG"], 0, dup128, 0, acc_dx=True, W=w0, dW=dw0, woff=6 * 128, bias=False,

@@ -455,6 +455,22 @@ int dispu_repulsion_loss_grad(long rows, int n_per_cloud, int ns, float h, float
 /* dst[off ..] = W^T [N][K] for every weight matrix W [K][N] at src[off ..]; desc [count][3] = {off, K, N} (device int32).  The training
  * step's dX = dZ . W^T products read W^T untransposed (the forward GEMM's fast path). */
 int dispu_transpose_batched(int count, const int* desc, const float* src, float* dst, void* stream);
+/* bf16 ACTIVATION STORAGE of the training step (Trainer(dtype="bf16"), BASELINE configs[4]): the [B*M*16, 128] pair tensors of
+ * the PointShuffle2 local cell (h0, h1, their gradients) and the gradient of F' [B*M, 2048] live in HBM as bf16; the entries below
+ * take such tensors behind `void*` (strides in ELEMENTS).  storage bits of the GEMMs: 1 = X is bf16, 2 = Z is bf16 (tn only),
+ * 4 = Y is written as bf16. */
+int dispu_linear_bf16s(int batch, int M, int K, int N, const void* X, long ldx, long sx, const float* W, long ldw, long sw, int transb,
+                       const float* bias, int act, void* Y, long ldy, long sy, const float* R1, long ldr1, long sr1, int storage,
+                       void* stream);
+int dispu_linear_tn_bf16s(int batch, int M, int K, int N, const void* X, long ldx, long sx, const void* Z, long ldz, long sz, float* out,
+                          long ldo, long so, int accumulate, float* dbias, float* scratch, long scratch_floats, int storage, void* stream);
+int dispu_ps_gather_sub_relu_bf16(long rows, int n_per_cloud, int k, int c, const int* idx, const float* G, long ldg, const float* A,
+                                  long lda, void* X1, long ldx1, void* stream);
+int dispu_ps_point_matmul_grad_relu_s(long rows, int k, int c, int t_n, const void* X2, long ldx2, const float* wv, const void* dout,
+                                      long ldo, void* dX2, long lddx2, float* dwv, int bf16_storage, void* stream);
+int dispu_ps_conv0_gather_grad_s(long rows, int n_per_cloud, int k, int c, const int* idx, const int* off, const int* inv, const void* dh0,
+                                 long ldz, int dh0_bf16, const float* Gm, long ldgm, const float* Am, long ldam, float* dG, long ldg,
+                                 float* dAneg, long lda, void* stream);
 /* dispu_ps_point_matmul_grad with conv1's ReLU gradient folded in: dX2 is zero where X2 <= 0. */
 int dispu_ps_point_matmul_grad_relu(long rows, int k, int c, int t_n, const float* X2, long ldx2, const float* wv, const float* dout,
                                     long ldo, float* dX2, long lddx2, float* dwv, void* stream);

@@ -152,3 +152,95 @@ def test_bf16_training_decreases_the_loss(steps, dev):
         hist[dt] = [float(tr.train_step(tx, tg, r)["pu_loss"]) for _ in range(10)]
     assert hist["bf16"][-1] < 0.9 * hist["bf16"][0], hist["bf16"]
     assert abs(hist["bf16"][-1] - hist["f32"][-1]) <= 0.15 * hist["f32"][-1], (hist["f32"][-1], hist["bf16"][-1])
+
+
+# ---------------------------------------------------------------------------- round 3: bf16 activation STORAGE ----
+@pytest.mark.parametrize("M,K,N,transb,xb,yb", [(4096, 128, 128, 0, 1, 1), (8192, 256, 2048, 1, 0, 1), (1000, 128, 128, 1, 1, 1), (2048, 128, 64, 0, 1, 0),
+                                                (777, 100, 52, 0, 1, 1)])
+def test_linear_bf16_with_bf16_stored_tensors(dev, M, K, N, transb, xb, yb):
+    """dispu_linear_bf16s: X read from / Y written to bf16 tensors.  A bf16-stored X is exactly what the fp32-storage kernel rounds its
+    operand to, so the product equals dispu_linear_bf16 on the widened tensor bit for bit; a bf16 Y is that result rounded once."""
+    from dispu_amd import _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(M + K)
+    x = rng.standard_normal((M, K)).astype(np.float32)
+    w = (rng.standard_normal((N, K) if transb else (K, N)) * 0.1).astype(np.float32)
+    bias = (rng.standard_normal(N) * 0.1).astype(np.float32)
+    p = lambda t: _lib.C.c_void_p(t.data_ptr()) if t is not None else None
+    tx32 = dv(x, dev)
+    txb = tx32.bfloat16()
+    txw = txb.float().contiguous()
+    tw, tb = dv(w, dev), dv(bias, dev)
+    ref = torch.empty((M, N), device=dev)
+    _lib.check(L.dispu_linear_bf16(1, M, K, N, p(txw if xb else tx32), K, 0, p(tw), K if transb else N, 0, transb, p(tb), 1, p(ref), N, 0,
+                                   None, 0, 0, None, 0, 0, _lib.stream_ptr(dev)), "dispu_linear_bf16")
+    y = torch.empty((M, N), dtype=torch.bfloat16 if yb else torch.float32, device=dev)
+    _lib.check(L.dispu_linear_bf16s(1, M, K, N, p(txb if xb else tx32), K, 0, p(tw), K if transb else N, 0, transb, p(tb), 1, p(y), N, 0, None, 0, 0,
+                                    (1 if xb else 0) | (4 if yb else 0), _lib.stream_ptr(dev)), "dispu_linear_bf16s")
+    want = ref.bfloat16() if yb else ref
+    assert torch.equal(y, want)
+
+
+@pytest.mark.parametrize("M,K,N,xb,zb", [(131072, 128, 128, 1, 1), (8192, 2048, 256, 0, 0), (5000, 128, 128, 1, 0), (3000, 100, 24, 0, 1)])
+def test_linear_tn_bf16_with_bf16_stored_operands(dev, M, K, N, xb, zb):
+    from dispu_amd import _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(M + N)
+    x = rng.standard_normal((M, K)).astype(np.float32)
+    z = rng.standard_normal((M, N)).astype(np.float32)
+    p = lambda t: _lib.C.c_void_p(t.data_ptr()) if t is not None else None
+    tx, tz = dv(x, dev), dv(z, dev)
+    txb, tzb = tx.bfloat16(), tz.bfloat16()
+    txw, tzw = txb.float().contiguous(), tzb.float().contiguous()          # widened copies (kept alive: the launches are asynchronous)
+    need = L.dispu_linear_tn_bf16_scratch_floats(1, M, K, N)
+    sc = torch.empty(max(need, 1), device=dev)
+    outs = []
+    for stored in (False, True):
+        out, db = torch.zeros((K, N), device=dev), torch.zeros(N, device=dev)
+        if stored:
+            _lib.check(L.dispu_linear_tn_bf16s(1, M, K, N, p(txb if xb else tx), K, 0, p(tzb if zb else tz), N, 0, p(out), N, 0, 0, p(db), p(sc), need,
+                                               (1 if xb else 0) | (2 if zb else 0), _lib.stream_ptr(dev)), "tn_bf16s")
+        else:
+            _lib.check(L.dispu_linear_tn_bf16(1, M, K, N, p(txw if xb else tx), K, 0, p(tzw if zb else tz), N, 0,
+                                              p(out), N, 0, 0, p(db), p(sc), need, _lib.stream_ptr(dev)), "tn_bf16")
+        outs.append((out, db))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
+def test_pair_tensor_kernels_with_bf16_storage(dev):
+    """gather_sub_relu / point_matmul_grad_relu / conv0_gather_grad on bf16-stored pair tensors == the fp32-storage kernels on the
+    widened tensors (outputs rounded once where they are stored as bf16)."""
+    from dispu_amd import _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(5)
+    B, n, k, c = 2, 256, 16, 128
+    rows = B * n
+    p = lambda t: _lib.C.c_void_p(t.data_ptr()) if t is not None else None
+    st = _lib.stream_ptr(dev)
+    idx = torch.from_numpy(rng.integers(0, n, (rows, k)).astype(np.int32)).to(dev)
+    G, A = dv(rng.standard_normal((rows, c)), dev), dv(rng.standard_normal((rows, c)), dev)
+    h32 = torch.empty((rows * k, c), device=dev)
+    hb = torch.empty((rows * k, c), dtype=torch.bfloat16, device=dev)
+    _lib.check(L.dispu_ps_gather_sub_relu(rows, n, k, c, p(idx), p(G), c, p(A), c, p(h32), c, st), "gather")
+    _lib.check(L.dispu_ps_gather_sub_relu_bf16(rows, n, k, c, p(idx), p(G), c, p(A), c, p(hb), c, st), "gather_bf16")
+    assert torch.equal(hb, h32.bfloat16())
+    # point_matmul_grad_relu
+    h1b = torch.relu(dv(rng.standard_normal((rows * k, c)), dev)).bfloat16()
+    dob = dv(rng.standard_normal((rows, c * 16)), dev).bfloat16()
+    wv = dv(rng.standard_normal((rows * k, 16)), dev)
+    dz_b = torch.empty((rows * k, c), dtype=torch.bfloat16, device=dev)
+    dz_f, dwv_b, dwv_f = torch.empty((rows * k, c), device=dev), torch.empty((rows * k, 16), device=dev), torch.empty((rows * k, 16), device=dev)
+    _lib.check(L.dispu_ps_point_matmul_grad_relu_s(rows, k, c, 16, p(h1b), c, p(wv), p(dob), c * 16, p(dz_b), c, p(dwv_b), 1, st), "pmg bf16")
+    h1f, dof = h1b.float().contiguous(), dob.float().contiguous()
+    _lib.check(L.dispu_ps_point_matmul_grad_relu_s(rows, k, c, 16, p(h1f), c, p(wv), p(dof), c * 16, p(dz_f), c, p(dwv_f), 0, st), "pmg f32")
+    assert torch.equal(dz_b, dz_f.bfloat16()) and torch.equal(dwv_b, dwv_f)
+    # conv0 gather
+    off = torch.empty((B, n + 1), dtype=torch.int32, device=dev)
+    inv = torch.empty((B, n * k), dtype=torch.int32, device=dev)
+    _lib.check(L.dispu_knn_invert(B, n, k, p(idx), p(off), p(inv), st), "invert")
+    res = []
+    for t, flag in ((dz_b, 1), (dz_b.float().contiguous(), 0)):
+        dG, dA = torch.empty((rows, c), device=dev), torch.empty((rows, c), device=dev)
+        _lib.check(L.dispu_ps_conv0_gather_grad_s(rows, n, k, c, p(idx), p(off), p(inv), p(t), c, flag, p(G), c, p(A), c, p(dG), c, p(dA), c, st), "gather grad")
+        res.append((dG, dA))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
