@@ -119,6 +119,42 @@ def cpu_baseline(target_seconds=14.0, with_ops=True):
     return out
 
 
+def train_step_table(dev, steps=10, warmup=3):
+    """Side table `roofline.train_step` (BASELINE configs[4]'s per-GPU share: 8 patches per GPU, full train step = training-mode forward,
+    pu_loss, backward, gradient all-reduce (a no-op on one rank), Adam): ms per step eager and hipGraph-replayed, fp32 and bf16, plus the
+    B = 32 step; `mfma_frac` prices 3 x the forward's executed flops against the fp32 MFMA peak (a lower bound on the work: the backward
+    recomputes the dense blocks and conv1)."""
+    import torch
+    from dispu_amd import synth
+    from dispu_amd.params import init_params
+    from dispu_amd.train import Trainer
+    P = init_params(1234)
+    out = {}
+    for dtype, B, graphed in (("f32", 8, False), ("f32", 8, True), ("bf16", 8, False), ("bf16", 8, True), ("f32", 32, True)):
+        tr = Trainer(params=P, device=dev, dtype=dtype)
+        x, gt = synth.patch_with_gt(B, NPOINT, NPOINT * UP, seed=5000)
+        x, gt = torch.from_numpy(x).to(dev), torch.from_numpy(gt).to(dev)
+        radius = torch.ones(B, device=dev)
+        fn = tr.train_step_graphed if graphed else tr.train_step
+        for _ in range(warmup):
+            fn(x, gt, radius)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn(x, gt, radius)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / steps * 1e3
+        flops = 3.0 * 2.0 * step_macs_per_patch() * B
+        out["%s_b%d_%s" % (dtype, B, "hipgraph" if graphed else "eager")] = {
+            "ms_per_step": round(ms, 4), "patches_per_s": round(B / ms * 1e3, 1),
+            "mfma_frac": round(flops / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4)}
+        del tr
+        torch.cuda.empty_cache()
+    out["note"] = ("full train step (forward in training mode + pu_loss + backward + Adam) on one GPU; mfma_frac = 3 x forward flops / time / "
+                   "%.1f TFLOP/s fp32 MFMA peak; bf16 = bf16 products AND bf16 storage of the local cell's pair tensors" % FP32_MFMA_PEAK_TFLOPS)
+    return out
+
+
 def pmc_traffic(kern):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes of this same command
     (tools/pmc_traffic.sh -> profiles/pmc_traffic_latest.json): (2 * FETCH_SIZE + WRITE_SIZE) * 1024, the gfx950
@@ -310,6 +346,10 @@ def main():
             except Exception as e:                             # noqa: BLE001 -- the headline line must survive a failing side table
                 roof["ops"] = None
                 roof["ops_error"] = "%s: %s" % (type(e).__name__, e)
+            try:
+                roof["train_step"] = train_step_table(dev)
+            except Exception as e:                             # noqa: BLE001
+                roof["train_step"] = {"error": "%s: %s" % (type(e).__name__, e)}
             roof["ops_peaks"] = {"hbm_B_per_s": ops_bench.HBM_PEAK, "valu_lane_ops_per_s": ops_bench.VALU_PEAK,
                                  "exp_per_s": ops_bench.EXP_PEAK, "valu_datasheet": ops_bench.VALU_PEAK_DATASHEET,
                                  "exp_datasheet": ops_bench.EXP_PEAK_DATASHEET,

@@ -18,6 +18,8 @@
 // 22 launches per call (init, 10 column passes, 1 + 9 row passes, assembly) instead of 31.
 #include "common.h"
 
+#include <cstdlib>
+
 namespace dispu {
 
 constexpr int AM_ROWS = 256;   // points per workgroup, one lane each
@@ -81,6 +83,38 @@ __device__ __forceinline__ float am_exp_level(float d2, float level) {
     else return __builtin_amdgcn_exp2f(d2 * (level * AM_LOG2E));   // level * AM_LOG2E is loop-invariant (hoisted)
 }
 
+// COH: the persistent kernel's workgroups exchange the scratch vectors while the kernel runs, across XCDs (separate L2s).  Fencing
+// them with agent-scope release / acquire costs an L2 write-back + invalidate per workgroup and stage (measured: ~12 us per stage,
+// the persistent form was SLOWER than 22 launches).  Instead every access to the exchanged arrays is itself an agent-scope atomic
+// (relaxed): global_load / global_store ... sc1, coherent at the device's memory side without touching the rest of the cache.
+template <bool COH>
+__device__ __forceinline__ float am_ld(const float* p) {
+    if constexpr (COH) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else return *p;
+}
+template <bool COH>
+__device__ __forceinline__ void am_st(float* p, float v) {
+    if constexpr (COH) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
+
+// init + p[0] + p[stride] + ... + p[(nc-1) stride], added in ascending order (the pinned association), with the loads issued eight
+// at a time: as a loop of dependent "load, add" steps the nc partials were a chain of nc memory round trips (uncached ones in the
+// persistent kernel).  first_is_init: the sum starts AS p[0] (no leading addition), like the reference's `tot = p[0]; tot += p[c]`.
+template <bool COH>
+__device__ __forceinline__ float am_sum_partials(const float* p, size_t stride, int nc, float init, bool first_is_init) {
+    float tot = init;
+    for (int c0 = 0; c0 < nc; c0 += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = (c0 + u < nc) ? am_ld<COH>(p + (size_t)(c0 + u) * stride) : 0.f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (c0 + u < nc) tot = (first_is_init && c0 + u == 0) ? v[u] : tot + v[u];
+    }
+    return tot;
+}
+
 __global__ void am_init_kernel(int n, int m, float multiL, float multiR, float* __restrict__ temp) {
     const AmView v = am_view(temp, blockIdx.y, n, m);
     for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) v.remL[e] = multiL;
@@ -89,10 +123,10 @@ __global__ void am_init_kernel(int n, int m, float multiL, float multiR, float* 
 
 // pass 2 of level t for one partner l, from the column partials:  (tf_approxmatch_g.cu:100-107)
 //   sumr = (sum_k e ratioL[k]) * remainR[l];  ratioR = min(remainR/(sumr+1e-9), 1) * remainR;  remainR' = max(0, remainR - sumr)
+template <bool COH = false>
 __device__ __forceinline__ void am_finish_col(const AmView& v, int m, int nc2, int t, int l, float& ratr, float& remn) {
-    const float rr = v.remR[(size_t)t * m + l];
-    float tot = v.p2[l];
-    for (int c = 1; c < nc2; ++c) tot += v.p2[(size_t)c * m + l];
+    const float rr = am_ld<COH>(&v.remR[(size_t)t * m + l]);
+    const float tot = am_sum_partials<COH>(v.p2 + l, (size_t)m, nc2, 0.f, true);
     const float sumr = tot * rr;
     const float consumption = fminf(rr / (sumr + 1e-9f), 1.0f);
     ratr = consumption * rr;
@@ -103,13 +137,10 @@ __device__ __forceinline__ void am_finish_col(const AmView& v, int m, int nc2, i
 // one (256 points of cloud 1) x (AM_CH points of cloud 2) tile.  FIRST: only pass 1 of level 0.
 // ratioR_t / remainR_{t+1} of the partners are finished here from pass 2's partials (every workgroup of a chunk computes the
 // same values; the rb == 0 one stores them for the later kernels).
-template <bool FIRST, bool FMA, bool PINNED>
-__global__ __launch_bounds__(AM_ROWS) void am_row_kernel(int n, int m, int t, float level3, float level1,
-                                                          const float* __restrict__ xyz1, const float* __restrict__ xyz2,
-                                                          float* __restrict__ temp) {
-    __shared__ float4 tile[AM_CH];
-    __shared__ float tilew[AM_CH];
-    const int cloud = blockIdx.z, c = blockIdx.y, rb = blockIdx.x, tid = threadIdx.x;
+template <bool FIRST, bool FMA, bool PINNED, bool COH = false>
+__device__ __forceinline__ void am_row_body(int cloud, int rb, int c, float4* tile, float* tilew, int n, int m, int t, float level3, float level1,
+                                            const float* __restrict__ xyz1, const float* __restrict__ xyz2, float* __restrict__ temp) {
+    const int tid = threadIdx.x;
     const AmView v = am_view(temp, cloud, n, m);
     const int nc2 = am_chunks(n);
     const float* __restrict__ p1 = xyz1 + (size_t)cloud * n * 3;
@@ -119,10 +150,10 @@ __global__ __launch_bounds__(AM_ROWS) void am_row_kernel(int n, int m, int t, fl
         const int l = l0 + tid;
         float wr = 0.f, w1;
         if constexpr (FIRST) {
-            w1 = v.remR[l];
+            w1 = am_ld<COH>(&v.remR[l]);
         } else {
-            am_finish_col(v, m, nc2, t, l, wr, w1);
-            if (rb == 0) { v.ratR[(size_t)t * m + l] = wr; v.remR[(size_t)(t + 1) * m + l] = w1; }
+            am_finish_col<COH>(v, m, nc2, t, l, wr, w1);
+            if (rb == 0) { am_st<COH>(&v.ratR[(size_t)t * m + l], wr); am_st<COH>(&v.remR[(size_t)(t + 1) * m + l], w1); }
         }
         tile[tid] = make_float4(p2[l * 3 + 0], p2[l * 3 + 1], p2[l * 3 + 2], wr);
         tilew[tid] = w1;
@@ -133,7 +164,7 @@ __global__ __launch_bounds__(AM_ROWS) void am_row_kernel(int n, int m, int t, fl
     float x1 = 0.f, y1 = 0.f, z1 = 0.f, rl = 0.f;
     if (active) {
         x1 = p1[k * 3 + 0]; y1 = p1[k * 3 + 1]; z1 = p1[k * 3 + 2];
-        if constexpr (!FIRST) rl = v.ratL[(size_t)t * n + k];
+        if constexpr (!FIRST) rl = am_ld<COH>(&v.ratL[(size_t)t * n + k]);
     }
     float s3 = 0.f, s1 = 0.f;
 #pragma unroll 4
@@ -149,19 +180,27 @@ __global__ __launch_bounds__(AM_ROWS) void am_row_kernel(int n, int m, int t, fl
         else s1 = s1 + e1 * tilew[i];
     }
     if (active) {
-        if constexpr (!FIRST) v.p3[(size_t)c * n + k] = s3;
-        v.p1[(size_t)c * n + k] = s1;
+        if constexpr (!FIRST) am_st<COH>(&v.p3[(size_t)c * n + k], s3);
+        am_st<COH>(&v.p1[(size_t)c * n + k], s1);
     }
+}
+
+template <bool FIRST, bool FMA, bool PINNED>
+__global__ __launch_bounds__(AM_ROWS) void am_row_kernel(int n, int m, int t, float level3, float level1,
+                                                          const float* __restrict__ xyz1, const float* __restrict__ xyz2,
+                                                          float* __restrict__ temp) {
+    __shared__ float4 tile[AM_CH];
+    __shared__ float tilew[AM_CH];
+    am_row_body<FIRST, FMA, PINNED>(blockIdx.z, blockIdx.x, blockIdx.y, tile, tilew, n, m, t, level3, level1, xyz1, xyz2, temp);
 }
 
 // Column kernel: pass 2 of level t over one (256 points of cloud 2) x (AM_CH points of cloud 1) tile.
 // remainL_t / ratioL_t of the partners are finished here from the row partials (:56-57, :158-159):
 //   remainL_t = max(0, remainL_{t-1} - sum_l w);  ratioL_t = remainL_t / (1e-9 + sum_l e remainR[l])
-template <bool FMA, bool PINNED>
-__global__ __launch_bounds__(AM_ROWS) void am_col_kernel(int n, int m, int t, float level, const float* __restrict__ xyz1,
-                                                          const float* __restrict__ xyz2, float* __restrict__ temp) {
-    __shared__ float4 tile[AM_CH];
-    const int cloud = blockIdx.z, c2 = blockIdx.y, cb = blockIdx.x, tid = threadIdx.x;
+template <bool FMA, bool PINNED, bool COH = false>
+__device__ __forceinline__ void am_col_body(int cloud, int cb, int c2, float4* tile, int n, int m, int t, float level, const float* __restrict__ xyz1,
+                                            const float* __restrict__ xyz2, float* __restrict__ temp) {
+    const int tid = threadIdx.x;
     const AmView v = am_view(temp, cloud, n, m);
     const int nc1 = am_chunks(m);
     const float* __restrict__ p1 = xyz1 + (size_t)cloud * n * 3;
@@ -171,18 +210,16 @@ __global__ __launch_bounds__(AM_ROWS) void am_col_kernel(int n, int m, int t, fl
         const int k = k0 + tid;
         float reml;
         if (t == 0) {
-            reml = v.remL[k];
+            reml = am_ld<COH>(&v.remL[k]);
         } else {
-            float tot = v.p3[k];
-            for (int c = 1; c < nc1; ++c) tot += v.p3[(size_t)c * n + k];
-            reml = fmaxf(0.0f, v.remL[(size_t)(t - 1) * n + k] - tot);
+            const float tot = am_sum_partials<COH>(v.p3 + k, (size_t)n, nc1, 0.f, true);
+            reml = fmaxf(0.0f, am_ld<COH>(&v.remL[(size_t)(t - 1) * n + k]) - tot);
         }
-        float suml = 1e-9f;
-        for (int c = 0; c < nc1; ++c) suml += v.p1[(size_t)c * n + k];
+        const float suml = am_sum_partials<COH>(v.p1 + k, (size_t)n, nc1, 1e-9f, false);
         const float ratl = reml / suml;
         if (cb == 0) {
-            if (t > 0) v.remL[(size_t)t * n + k] = reml;
-            v.ratL[(size_t)t * n + k] = ratl;
+            if (t > 0) am_st<COH>(&v.remL[(size_t)t * n + k], reml);
+            am_st<COH>(&v.ratL[(size_t)t * n + k], ratl);
         }
         tile[tid] = make_float4(p1[k * 3 + 0], p1[k * 3 + 1], p1[k * 3 + 2], ratl);
     }
@@ -200,19 +237,24 @@ __global__ __launch_bounds__(AM_ROWS) void am_col_kernel(int n, int m, int t, fl
         if constexpr (FMA) s = __builtin_fmaf(e, q.w, s);
         else s = s + e * q.w;
     }
-    if (active) v.p2[(size_t)c2 * m + l] = s;
+    if (active) am_st<COH>(&v.p2[(size_t)c2 * m + l], s);
+}
+
+template <bool FMA, bool PINNED>
+__global__ __launch_bounds__(AM_ROWS) void am_col_kernel(int n, int m, int t, float level, const float* __restrict__ xyz1,
+                                                          const float* __restrict__ xyz2, float* __restrict__ temp) {
+    __shared__ float4 tile[AM_CH];
+    am_col_body<FMA, PINNED>(blockIdx.z, blockIdx.x, blockIdx.y, tile, n, m, t, level, xyz1, xyz2, temp);
 }
 
 // match[l][k] = sum_t (exp(level_t d2) ratioL_t[k]) ratioR_t[l], t ascending from 0 (the reference's `match += w` per level
 // on a zeroed buffer, :16,152).  ratioR of the last level is finished here from pass 2's partials.
 struct AmPartner { float x, y, z, pad; float r[AM_LEVELS]; float pad2[2]; };   // 64 bytes
 
-template <bool FMA, bool PINNED>
-__global__ __launch_bounds__(AM_ROWS) void am_assemble_kernel(int n, int m, AmLevels lv, const float* __restrict__ xyz1,
-                                                               const float* __restrict__ xyz2, float* __restrict__ temp,
-                                                               float* __restrict__ match) {
-    __shared__ AmPartner tile[AM_ACH];
-    const int cloud = blockIdx.z, c = blockIdx.y, rb = blockIdx.x, tid = threadIdx.x;
+template <bool FMA, bool PINNED, bool COH = false>
+__device__ __forceinline__ void am_assemble_body(int cloud, int rb, int c, AmPartner* tile, int n, int m, const AmLevels& lv, const float* __restrict__ xyz1,
+                                                 const float* __restrict__ xyz2, float* __restrict__ temp, float* __restrict__ match) {
+    const int tid = threadIdx.x;
     const AmView v = am_view(temp, cloud, n, m);
     const float* __restrict__ p1 = xyz1 + (size_t)cloud * n * 3;
     const float* __restrict__ p2 = xyz2 + (size_t)cloud * m * 3;
@@ -222,9 +264,9 @@ __global__ __launch_bounds__(AM_ROWS) void am_assemble_kernel(int n, int m, AmLe
         AmPartner q;
         q.x = p2[l * 3 + 0]; q.y = p2[l * 3 + 1]; q.z = p2[l * 3 + 2]; q.pad = 0.f; q.pad2[0] = q.pad2[1] = 0.f;
 #pragma unroll
-        for (int t = 0; t < AM_LEVELS - 1; ++t) q.r[t] = v.ratR[(size_t)t * m + l];
+        for (int t = 0; t < AM_LEVELS - 1; ++t) q.r[t] = am_ld<COH>(&v.ratR[(size_t)t * m + l]);
         float remn;
-        am_finish_col(v, m, am_chunks(n), AM_LEVELS - 1, l, q.r[AM_LEVELS - 1], remn);
+        am_finish_col<COH>(v, m, am_chunks(n), AM_LEVELS - 1, l, q.r[AM_LEVELS - 1], remn);
         tile[tid] = q;
     }
     __syncthreads();
@@ -233,7 +275,7 @@ __global__ __launch_bounds__(AM_ROWS) void am_assemble_kernel(int n, int m, AmLe
     const float x1 = p1[k * 3 + 0], y1 = p1[k * 3 + 1], z1 = p1[k * 3 + 2];
     float rl[AM_LEVELS];
 #pragma unroll
-    for (int t = 0; t < AM_LEVELS; ++t) rl[t] = v.ratL[(size_t)t * n + k];
+    for (int t = 0; t < AM_LEVELS; ++t) rl[t] = am_ld<COH>(&v.ratL[(size_t)t * n + k]);
     float* __restrict__ mt = match + (size_t)cloud * n * m + (size_t)l0 * n + k;
     for (int i = 0; i < len; ++i) {
         const AmPartner& q = tile[i];
@@ -242,6 +284,87 @@ __global__ __launch_bounds__(AM_ROWS) void am_assemble_kernel(int n, int m, AmLe
 #pragma unroll
         for (int t = 1; t < AM_LEVELS; ++t) acc += am_exp_level<PINNED>(d2, lv.v[t]) * rl[t] * q.r[t];
         __builtin_nontemporal_store(acc, mt + (size_t)i * n);
+    }
+}
+
+template <bool FMA, bool PINNED>
+__global__ __launch_bounds__(AM_ROWS) void am_assemble_kernel(int n, int m, AmLevels lv, const float* __restrict__ xyz1,
+                                                               const float* __restrict__ xyz2, float* __restrict__ temp,
+                                                               float* __restrict__ match) {
+    __shared__ AmPartner tile[AM_ACH];
+    am_assemble_body<FMA, PINNED>(blockIdx.z, blockIdx.x, blockIdx.y, tile, n, m, lv, xyz1, xyz2, temp, match);
+}
+
+// ---- the whole auction of SMALL batches in ONE persistent launch (OPT-IN: DISPU_AM_PERSISTENT=1; measured SLOWER, kept as the
+// documented negative result of round 3 and as a tested alternative) ------------------------------------------------------------------
+// 22 launches of a few microseconds each are launch-latency-bound when b * n * m is small ((4, 1024^2): 167 us = 22 x 7.6 us).
+// Measured on MI355X: the persistent form needs 11 us per stage -- (4, 1024^2) 247 us, (32, 1024^2) 723 us against 167 / 368 us for
+// the launches: an in-kernel barrier across XCDs (uncached agent-scope exchange of the partial sums + the counter round trip) costs
+// MORE than a kernel boundary inside a hipGraph (~4 us).  With release / acquire fences instead of per-access atomics: 281 - 333 us.
+// The same 22 stages run inside one kernel: cloud `c` is served by `wpc` workgroups (all co-resident: the grid
+// never exceeds one workgroup per CU) that walk the stage's (row block, chunk) tiles round-robin -- the SAME tiles, bodies and
+// fixed-order combines as the separate kernels, so the results are bit-identical -- and meet at a per-cloud barrier between stages:
+// an agent-scope release increment of a counter in scratch, acquire-polled by one lane (tools/micro/xwg_sync.hip: 0.8 - 1.3 us per
+// exchange).  Spins are bounded; a timeout raises `fail` (results are then invalid, the launch still ends).
+__device__ __forceinline__ bool am_cloud_barrier(unsigned* ctr, unsigned target, int* fail) {
+    __shared__ int ok_s;
+    // every exchanged store of this stage is an agent-scope atomic store (am_st<true>): once the wave's vmcnt reaches 0 they have
+    // been performed at the device's coherence point; no cache-wide release / acquire is needed (or wanted: see am_ld)
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int spins = 0;
+        bool ok = false;
+        while (!(ok = __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) && ++spins < (1 << 22)) __builtin_amdgcn_s_sleep(2);
+        if (!ok) *fail = 1;
+        ok_s = ok ? 1 : 0;
+    }
+    __syncthreads();
+    return ok_s != 0;
+}
+
+template <bool FMA, bool PINNED>
+__global__ __launch_bounds__(AM_ROWS) void am_persistent_kernel(int n, int m, int wpc, AmLevels lv, float multiL, float multiR,
+                                                                 const float* __restrict__ xyz1, const float* __restrict__ xyz2,
+                                                                 float* __restrict__ temp, float* __restrict__ match, unsigned* __restrict__ ctr,
+                                                                 int* __restrict__ fail) {
+    __shared__ AmPartner atile[AM_ACH];                  // 4 KB; the row / column bodies use its front as their float4 tile
+    __shared__ float tilew[AM_CH];
+    float4* tile = reinterpret_cast<float4*>(atile);
+    const int cloud = blockIdx.x / wpc, w = blockIdx.x % wpc, tid = threadIdx.x;
+    unsigned* my = ctr + cloud;
+    unsigned stage = 0;
+    const int nrb = (n + AM_ROWS - 1) / AM_ROWS, ncb = (m + AM_ROWS - 1) / AM_ROWS, nc1 = am_chunks(m), nc2 = am_chunks(n);
+    {   // init (am_init_kernel)
+        const AmView v = am_view(temp, cloud, n, m);
+        for (int e = w * AM_ROWS + tid; e < n; e += wpc * AM_ROWS) am_st<true>(&v.remL[e], multiL);
+        for (int e = w * AM_ROWS + tid; e < m; e += wpc * AM_ROWS) am_st<true>(&v.remR[e], multiR);
+    }
+    if (!am_cloud_barrier(my, ++stage * wpc, fail)) return;
+    for (int vb = w; vb < nrb * nc1; vb += wpc) {        // pass 1 of level 0
+        am_row_body<true, FMA, PINNED, true>(cloud, vb % nrb, vb / nrb, tile, tilew, n, m, 0, 0.f, lv.v[0], xyz1, xyz2, temp);
+        __syncthreads();
+    }
+    if (!am_cloud_barrier(my, ++stage * wpc, fail)) return;
+    for (int t = 0; t < AM_LEVELS; ++t) {
+        for (int vb = w; vb < ncb * nc2; vb += wpc) {
+            am_col_body<FMA, PINNED, true>(cloud, vb % ncb, vb / ncb, tile, n, m, t, lv.v[t], xyz1, xyz2, temp);
+            __syncthreads();
+        }
+        if (!am_cloud_barrier(my, ++stage * wpc, fail)) return;
+        if (t + 1 < AM_LEVELS) {
+            for (int vb = w; vb < nrb * nc1; vb += wpc) {
+                am_row_body<false, FMA, PINNED, true>(cloud, vb % nrb, vb / nrb, tile, tilew, n, m, t, lv.v[t], lv.v[t + 1], xyz1, xyz2, temp);
+                __syncthreads();
+            }
+            if (!am_cloud_barrier(my, ++stage * wpc, fail)) return;
+        }
+    }
+    const int nac = (m + AM_ACH - 1) / AM_ACH;
+    for (int vb = w; vb < nrb * nac; vb += wpc) {
+        am_assemble_body<FMA, PINNED, true>(cloud, vb % nrb, vb / nrb, atile, n, m, lv, xyz1, xyz2, temp, match);
+        __syncthreads();
     }
 }
 
@@ -433,6 +556,11 @@ __global__ __launch_bounds__(256) void match_grad2_kernel(int n, int m, const fl
     if (lane == 0) { float* g = grad + ((size_t)cloud * m + l) * 3; g[0] = gx; g[1] = gy; g[2] = gz; }
 }
 
+static int am_persistent_mode() {       // DISPU_AM_PERSISTENT=1: the one-launch form for small batches (opt-in, see am_persistent_kernel)
+    const char* e = getenv("DISPU_AM_PERSISTENT");      // read per call: tests flip it inside one process
+    return e ? atoi(e) : 0;
+}
+
 template <bool FMA, bool PINNED>
 static int run_approx_match(int b, int n, int m, const float* xyz1, const float* xyz2, float* match, float* temp,
                             hipStream_t s) {
@@ -450,6 +578,21 @@ static int run_approx_match(int b, int n, int m, const float* xyz1, const float*
     }
     const dim3 blk(AM_ROWS);
     const dim3 grow((n + AM_ROWS - 1) / AM_ROWS, am_chunks(m), b), gcol((m + AM_ROWS - 1) / AM_ROWS, am_chunks(n), b);
+    // small batches: all 22 stages in one persistent launch (see am_persistent_kernel).  Used when a stage has at most 512 tiles
+    // in total (the separate launches would then leave most CUs idle and pay 22 launch latencies) and every cloud gets >= 2 workgroups.
+    const long tiles_r = (long)grow.x * grow.y, tiles_c = (long)gcol.x * gcol.y;
+    const long most = tiles_r > tiles_c ? tiles_r : tiles_c;
+    int wpc = b <= 128 ? 256 / b : 0;
+    if (wpc > most) wpc = (int)most;
+    const int mode = am_persistent_mode();
+    if (wpc >= 2 && mode == 1 && most * b <= 4096) {
+        unsigned* ctr = reinterpret_cast<unsigned*>(temp + (size_t)b * am_cloud_floats(n, m));
+        int* fail = reinterpret_cast<int*>(ctr + b);
+        DISPU_TRY(hipMemsetAsync(ctr, 0, sizeof(unsigned) * ((size_t)b + 1), s));
+        hipLaunchKernelGGL((am_persistent_kernel<FMA, PINNED>), dim3(b * wpc), blk, 0, s, n, m, wpc, lv, multiL, multiR, xyz1, xyz2, temp, match, ctr,
+                           fail);
+        return (int)hipGetLastError();
+    }
     hipLaunchKernelGGL(am_init_kernel, dim3(8, b), dim3(256), 0, s, n, m, multiL, multiR, temp);
     hipLaunchKernelGGL((am_row_kernel<true, FMA, PINNED>), grow, blk, 0, s, n, m, 0, 0.f, lv.v[0], xyz1, xyz2, temp);
     for (int t = 0; t < AM_LEVELS; ++t) {
@@ -468,7 +611,7 @@ using namespace dispu;
 
 DISPU_EXPORT size_t dispu_approx_match_scratch_bytes(int b, int n, int m) {
     if (b <= 0 || n <= 0 || m <= 0) return 0;
-    return sizeof(float) * (size_t)b * am_cloud_floats(n, m);
+    return sizeof(float) * (size_t)b * am_cloud_floats(n, m) + sizeof(unsigned) * ((size_t)b + 1);   // + per-cloud stage counters, fail flag
 }
 
 DISPU_EXPORT int dispu_approx_match(int b, int n, int m, const float* xyz1, const float* xyz2, float* match,

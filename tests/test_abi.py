@@ -44,7 +44,7 @@ def test_library_loads_and_binding_is_complete(built_lib):
     assert lib.dispu_version() == 3
     assert lib.dispu_fps_scratch_bytes(2, 1000, 10) == 0
     assert lib.dispu_fps_scratch_bytes(2, 30000, 10) == 2 * 30000 * 4
-    assert lib.dispu_approx_match_scratch_bytes(3, 10, 20) == 3 * (20 * 30 + 2 * 10 + 20) * 4   # ratio vectors + chunk partials
+    assert lib.dispu_approx_match_scratch_bytes(3, 10, 20) == 3 * (20 * 30 + 2 * 10 + 20) * 4 + 4 * 4   # ratio vectors + chunk partials + stage counters
     assert lib.dispu_match_cost_scratch_bytes(2, 300, 200) == 2 * 2 * 13 * 4              # 16-partner tiles at this size
     assert lib.dispu_match_cost_grad_scratch_bytes(2, 300, 200) == 2 * 13 * 300 * 3 * 4
     assert isinstance(lib.dispu_error_string(1), bytes)

@@ -10,7 +10,7 @@ import dispu_amd.tf_approxmatch as A          # noqa: E402
 from ops_bench import _timeit                  # noqa: E402
 
 dev = torch.device("cuda:0")
-for (b, n) in [(4, 1024), (32, 1024), (1, 4096), (32, 4096)]:
+for (b, n) in [(4, 1024), (8, 1024), (16, 1024), (32, 1024), (1, 4096), (32, 4096)]:
     x1, x2 = torch.rand(b, n, 3, device=dev), torch.rand(b, n, 3, device=dev)
     t = _timeit(lambda: A.approx_match(x1, x2), reps=5, warm=2)
     mt = A.approx_match(x1, x2)
