@@ -317,10 +317,10 @@ __global__ __launch_bounds__(FW_BS) void fps_wave_kernel(int n, int m, const flo
 // compares the reference's tie keys of every (lane, group) candidate.  Sorted positions are written to `out` during the loop
 // and replaced by the original indices at the end (the position -> index table is read from global memory: it is needed for the
 // rare ties and the final pass only, which frees 96 KB of LDS for the coordinates of 8 of the 24 slots).
-template <int P, int PL, bool FMA>
+template <int P, int PL, bool FMA, int G = 4>
 __global__ __launch_bounds__(FW_BS) void fps_wave4_kernel(int n, int m, const float* __restrict__ xyz, const int* __restrict__ perm,
                                                           int* __restrict__ out) {
-    constexpr int G = 4, PG = P / G, PR = P - PL;
+    constexpr int PG = P / G, PR = P - PL;                // G = 4 (default) or 8 skip groups per wave (round 3: measured)
     static_assert(P % G == 0, "groups must tile the slots");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* slot = reinterpret_cast<float*>(smem);                             // [2][FW_W][8]: distance key, position, x, y, z
@@ -374,7 +374,7 @@ __global__ __launch_bounds__(FW_BS) void fps_wave4_kernel(int n, int m, const fl
         const float ey = fmaxf(fmaxf(bly - y1, y1 - bhy), 0.f);
         const float ez = fmaxf(fmaxf(blz - z1, z1 - bhz), 0.f);
         const float lb = __builtin_fmaf(ez, ez, __builtin_fmaf(ey, ey, ex * ex));
-        const unsigned act = (unsigned)__ballot(lane < G && lb * 0.99999f <= wtd) & 0xFu;      // wave-uniform group mask
+        const unsigned act = (unsigned)__ballot(lane < G && lb * 0.99999f <= wtd) & ((1u << G) - 1u);      // wave-uniform group mask
         FPSW_TICK(1)
         if (act) {
             FPSW_PROF_ACTIVE
@@ -490,23 +490,23 @@ __global__ __launch_bounds__(FW_BS) void fps_wave4_kernel(int n, int m, const fl
     if (tid == 0) o[0] = 0;                               // sample 0 is point 0 (tf_sampling_g.cu:122-124)
 }
 
-template <int P, int PL>
+template <int P, int PL, int G = 4>
 static int launch_fps_wave4(int b, int n, int m, const float* xyz, int* perm, int* out, int arith, hipStream_t s) {
     const size_t sort_bytes = (size_t)n * 4 + 4096 * 4 + 2048 * 4;
     const size_t bytes = 2 * FW_W * 8 * 4 + (size_t)PL * 3 * FW_BS * 4;
-    static DevOnce attr;      
+    static DevOnce attr;
     if (attr.needed()) {
         DISPU_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fps_wavesort_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 24576 * 4 + 4096 * 4 + 2048 * 4));
-        DISPU_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fps_wave4_kernel<P, PL, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-        DISPU_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fps_wave4_kernel<P, PL, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+        DISPU_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fps_wave4_kernel<P, PL, true, G>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+        DISPU_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fps_wave4_kernel<P, PL, false, G>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
         attr.done();
     }
-    hipLaunchKernelGGL(fps_wavesort_kernel, dim3(b), dim3(1024), sort_bytes, s, n, 64 * (P / 4), xyz, perm);
+    hipLaunchKernelGGL(fps_wavesort_kernel, dim3(b), dim3(1024), sort_bytes, s, n, 64 * (P / G), xyz, perm);
     DISPU_CHECK_LAUNCH();
     if ((arith & DISPU_ARITH_CONTRACT))
-        hipLaunchKernelGGL((fps_wave4_kernel<P, PL, true>), dim3(b), dim3(FW_BS), bytes, s, n, m, xyz, perm, out);
+        hipLaunchKernelGGL((fps_wave4_kernel<P, PL, true, G>), dim3(b), dim3(FW_BS), bytes, s, n, m, xyz, perm, out);
     else
-        hipLaunchKernelGGL((fps_wave4_kernel<P, PL, false>), dim3(b), dim3(FW_BS), bytes, s, n, m, xyz, perm, out);
+        hipLaunchKernelGGL((fps_wave4_kernel<P, PL, false, G>), dim3(b), dim3(FW_BS), bytes, s, n, m, xyz, perm, out);
     return (int)hipGetLastError();
 }
 
@@ -541,6 +541,11 @@ int fps_wave_dispatch(int b, int n, int m, const float* xyz, void* temp, int* ou
     if (whole_waves) {
         if (n <= FW_BS * 16) return launch_fps_wave<16, 0>(b, n, m, xyz, perm, out, arith, s);
         return launch_fps_wave<24, 4>(b, n, m, xyz, perm, out, arith, s);
+    }
+    static const bool eight = [] { const char* e = getenv("DISPU_FPS_GROUPS8"); return e && e[0] == '1'; }();     // A/B: 8 skip groups per wave
+    if (eight) {
+        if (n <= FW_BS * 16) return launch_fps_wave4<16, 0, 8>(b, n, m, xyz, perm, out, arith, s);
+        return launch_fps_wave4<24, 8, 8>(b, n, m, xyz, perm, out, arith, s);
     }
     if (n <= FW_BS * 16) return launch_fps_wave4<16, 0>(b, n, m, xyz, perm, out, arith, s);
     return launch_fps_wave4<24, 8>(b, n, m, xyz, perm, out, arith, s);
