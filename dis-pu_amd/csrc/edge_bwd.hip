@@ -42,24 +42,69 @@ template <int C>
 struct EbLds {
     static constexpr int K0 = 2 * C, K1 = EB_G + C, K2 = 2 * EB_G + C;
     static constexpr int WY = 2 * EB_G + 2 * C, LY = WY + 1;                       // [l1 | l0 | F_p | F_j - F_p], odd pitch
-    static constexpr int FLOATS = EB_ROWS * LY + 3 * EB_ROWS * EB_LZ + (K0 + K1 + K2) * EB_LW + EB_ROWS;
+    static constexpr int FLOATS = EB_ROWS * LY + 3 * EB_ROWS * EB_LZ + (K0 + K1 + K2) * EB_LW + EB_ROWS + 32 * EB_LW + 64;   // + slack: operand
+                                                                                   // reads of lanes whose results are discarded run past the arrays
     static constexpr size_t BYTES = (size_t)FLOATS * sizeof(float);
 };
 
-// D[32 rows][32 cols] += A[32 rows][K] . B[K][32 cols]; lane (i = lane & 31, h = lane >> 5): A element (i, 2s + h) from a_row
-// (already offset to the lane's row), B element (2s + h, i) through `bsel(k)`.
-template <int KSTEPS, class BF>
-__device__ __forceinline__ void eb_rowprod(eb_f32x16& acc, const float* a_row, int h, BF bsel) {
-#pragma unroll 4
-    for (int s = 0; s < KSTEPS; ++s) {
-        const int k = 2 * s + h;
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_row[k], bsel(k), acc, 0, 0, 0);
+// D[32 x 32] += A[32 x 2 KSTEPS] . B[2 KSTEPS x 32], both operands read from LDS: step s uses the dwords at byte addresses
+// a0 + s * SA and b0 + s * SB (the lane's A and B elements of k = 2s + h).  Hand-scheduled: a ring of R = 6 (or 4) operand pairs, the slot an
+// MFMA has just consumed is refilled with the operands of R steps later, and the wait in front of an MFMA lets the 2 R - 2 younger reads
+// stay in flight (s_waitcnt lgkmcnt(10)).  The compiler's own version of this loop waited for all but the two newest reads, i.e. gave
+// every ds_read one MFMA (64 cycles) to land: ~185 cycles per step (tools/micro/edge_bwd_stamps.py).  No lane predicates: lanes whose
+// operand lies outside the product (channels >= 24, k beyond the layer) read whatever follows in LDS and only feed accumulator rows /
+// columns that are never written out.
+__device__ __forceinline__ unsigned eb_lds_addr(const float* p) {
+    return (unsigned)(size_t)(const __attribute__((address_space(3))) float*)p;
+}
+__device__ __forceinline__ void eb_dsread(float& dst, unsigned addr) { asm volatile("ds_read_b32 %0, %1" : "=v"(dst) : "v"(addr) : "memory"); }
+template <int N> __device__ __forceinline__ void eb_wait() { asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"(N) : "memory"); }
+
+template <int KSTEPS, int SA, int SB, int R = (KSTEPS % 6 == 0 ? 6 : 4)>
+__device__ __forceinline__ void eb_prod(eb_f32x16& acc, unsigned a0, unsigned b0) {
+    static_assert(KSTEPS % R == 0 && KSTEPS >= 2 * R && 2 * R <= 14, "operand ring");      // lgkmcnt counts to 15
+    float ra[R], rb[R];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                  // nothing of the surrounding code is in flight: the counts below are exact
+#pragma unroll
+    for (int u = 0; u < R; ++u) { eb_dsread(ra[u], a0 + u * SA); eb_dsread(rb[u], b0 + u * SB); }
+    unsigned pa = a0 + R * SA, pb = b0 + R * SB;
+#pragma unroll 1
+    for (int s0 = 0; s0 < KSTEPS - R; s0 += R) {
+#pragma unroll
+        for (int u = 0; u < R; ++u) {
+            eb_wait<2 * R - 2>();
+            mfma_acc(acc, ra[u], rb[u]);
+            eb_dsread(ra[u], pa + u * SA);
+            eb_dsread(rb[u], pb + u * SB);
+        }
+        pa += R * SA; pb += R * SB;
     }
+#pragma unroll
+    for (int u = 0; u < R; ++u) {                                       // drain: 2 (R - 1 - u) younger reads may still be in flight
+        if (u == 0) eb_wait<2 * R - 2>();
+        else if (u == 1) eb_wait<(2 * R - 4 > 0 ? 2 * R - 4 : 0)>();
+        else if (u == 2) eb_wait<(2 * R - 6 > 0 ? 2 * R - 6 : 0)>();
+        else if (u == 3) eb_wait<(2 * R - 8 > 0 ? 2 * R - 8 : 0)>();
+        else if (u == 4) eb_wait<(2 * R - 10 > 0 ? 2 * R - 10 : 0)>();
+        else eb_wait<0>();
+        mfma_acc(acc, ra[u], rb[u]);
+    }
+    mfma_acc_settle();
 }
 
+#ifdef EB_STAMPS
+#define EB_T(i) do { __builtin_amdgcn_sched_barrier(0); if (threadIdx.x == 0 && blockIdx.x == 1) eb_st[i] = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define EB_T(i)
+#endif
 template <int C>
 __global__ __launch_bounds__(256) void edge_bwd_kernel(EdgeBwdArgs a) {
     using Ld = EbLds<C>;
+#ifdef EB_STAMPS
+    unsigned long long eb_st[16];
+    for (int q = 0; q < 16; ++q) eb_st[q] = 0;
+#endif
+    EB_T(0);
     constexpr int K0 = Ld::K0, K1 = Ld::K1, K2 = Ld::K2, LY = Ld::LY, LZ = EB_LZ, LW = EB_LW, G = EB_G;
     constexpr int L1c = 0, L0c = G, FPc = 2 * G, DFc = 2 * G + C;                  // column offsets inside Y
     extern __shared__ __attribute__((aligned(16))) float eb_lds[];
@@ -98,6 +143,7 @@ __global__ __launch_bounds__(256) void edge_bwd_kernel(EdgeBwdArgs a) {
         fill(Wl2, a.W2, std::integral_constant<int, K2>{});
     }
     const float bias0 = i < G ? a.b0[i] : 0.f, bias1 = i < G ? a.b1[i] : 0.f, bias2 = i < G ? a.b2[i] : 0.f;
+    EB_T(1);
 
     eb_f32x16 gw2, gw1, gw0;                                                       // weight-gradient tiles of waves 0..2 (k rows 32w ..)
 #pragma unroll
@@ -140,12 +186,13 @@ __global__ __launch_bounds__(256) void edge_bwd_kernel(EdgeBwdArgs a) {
             }
         }
         __syncthreads();
+        EB_T(2);
         // ---- 2.-4. forward recompute: the k order of csrc/edge.hip (y0 = [F_p, F_j - F_p]; y1 = [l0, F_p]; y2 = [l1, l0, F_p])
         {
             eb_f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-            eb_rowprod<K0 / 2>(acc, Y + (R0 + i) * LY + FPc, h, [&](int k) { return i < G ? Wl0[k * LW + i] : 0.f; });
+            eb_prod<K0 / 2, 8, 2 * LW * 4>(acc, eb_lds_addr(Y + (R0 + i) * LY + FPc + h), eb_lds_addr(Wl0 + h * LW + i));
             if (i < G) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) Y[(R0 + (r & 3) + 8 * (r >> 2) + 4 * h) * LY + L0c + i] = fmaxf(acc[r] + bias0, 0.f);
@@ -156,7 +203,7 @@ __global__ __launch_bounds__(256) void edge_bwd_kernel(EdgeBwdArgs a) {
             eb_f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-            eb_rowprod<K1 / 2>(acc, Y + (R0 + i) * LY + L0c, h, [&](int k) { return i < G ? Wl1[k * LW + i] : 0.f; });
+            eb_prod<K1 / 2, 8, 2 * LW * 4>(acc, eb_lds_addr(Y + (R0 + i) * LY + L0c + h), eb_lds_addr(Wl1 + h * LW + i));
             if (i < G) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) Y[(R0 + (r & 3) + 8 * (r >> 2) + 4 * h) * LY + L1c + i] = fmaxf(acc[r] + bias1, 0.f);
@@ -167,13 +214,14 @@ __global__ __launch_bounds__(256) void edge_bwd_kernel(EdgeBwdArgs a) {
             eb_f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-            eb_rowprod<K2 / 2>(acc, Y + (R0 + i) * LY + L1c, h, [&](int k) { return i < G ? Wl2[k * LW + i] : 0.f; });
+            eb_prod<K2 / 2, 8, 2 * LW * 4>(acc, eb_lds_addr(Y + (R0 + i) * LY + L1c + h), eb_lds_addr(Wl2 + h * LW + i));
             if (i < G) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) Z2[(R0 + (r & 3) + 8 * (r >> 2) + 4 * h) * LZ + i] = acc[r] + bias2;
             }
         }
         __syncthreads();
+        EB_T(3);
         // ---- 5. gradient of the max over the 16 neighbours: (point, channel) items; ties share evenly.  Writes dz2 (over l2),
         //         and the max part of da1 / da0 into Z1 / Z0
         for (int it = tid; it < 8 * 72; it += 256) {
@@ -201,6 +249,7 @@ __global__ __launch_bounds__(256) void edge_bwd_kernel(EdgeBwdArgs a) {
             if (p < a.npoints) unsafeAtomicAdd(a.dF + (size_t)p * a.lddf + c, a.dOut[(size_t)p * a.lddo + 3 * G + c]);
         }
         __syncthreads();
+        EB_T(4);
 
         // a 32 x 32 tile of d(layer input): column n (this lane) of rows R0 .. R0 + 31.  centre(): the F_p part -- the lane's 8 rows
         // of each of the wave's two points are summed, the two row halves (lanes i, i + 32) combined, one atomic per (point, channel).
@@ -219,7 +268,7 @@ __global__ __launch_bounds__(256) void edge_bwd_kernel(EdgeBwdArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
             const int n = nt * 32 + i;
-            eb_rowprod<G / 2>(acc, Z2 + (R0 + i) * LZ, h, [&](int k) { return n < K2 ? Wl2[n * LW + k] : 0.f; });
+            eb_prod<G / 2, 8, 8>(acc, eb_lds_addr(Z2 + (R0 + i) * LZ + h), eb_lds_addr(Wl2 + n * LW + h));
             if (n < G) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) Z1[(R0 + (r & 3) + 8 * (r >> 2) + 4 * h) * LZ + n] += acc[r];
@@ -241,7 +290,7 @@ __global__ __launch_bounds__(256) void edge_bwd_kernel(EdgeBwdArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
             const int n = nt * 32 + i;
-            eb_rowprod<G / 2>(acc, Z1 + (R0 + i) * LZ, h, [&](int k) { return n < K1 ? Wl1[n * LW + k] : 0.f; });
+            eb_prod<G / 2, 8, 8>(acc, eb_lds_addr(Z1 + (R0 + i) * LZ + h), eb_lds_addr(Wl1 + n * LW + h));
             if (n < G) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) Z0[(R0 + (r & 3) + 8 * (r >> 2) + 4 * h) * LZ + n] += acc[r];
@@ -254,13 +303,14 @@ __global__ __launch_bounds__(256) void edge_bwd_kernel(EdgeBwdArgs a) {
             if (!(Y[row * LY + L0c + c] > 0.f)) Z0[row * LZ + c] = 0.f;
         }
         __syncthreads();
+        EB_T(5);
         // ---- 8. dy0 = dz0 . W0^T over [F_p | F_j - F_p]: the second half goes to the neighbour (+) and to the centre (-)
         for (int nt = 0; nt * 32 < K0; ++nt) {
             eb_f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
             const int n = nt * 32 + i;
-            eb_rowprod<G / 2>(acc, Z0 + (R0 + i) * LZ, h, [&](int k) { return n < K0 ? Wl0[n * LW + k] : 0.f; });
+            eb_prod<G / 2, 8, 8>(acc, eb_lds_addr(Z0 + (R0 + i) * LZ + h), eb_lds_addr(Wl0 + n * LW + h));
             centre(acc, n < C ? n : n - C, n < C ? 1.f : -1.f, n < K0);
             if (n >= C && n < K0) {
 #pragma unroll
@@ -270,32 +320,25 @@ __global__ __launch_bounds__(256) void edge_bwd_kernel(EdgeBwdArgs a) {
                 }
             }
         }
+        EB_T(6);
         // ---- 9. weight gradients: dW_l[k][n] += sum_rows y_l[row][k] dz_l[row][n]  (contraction over the 128 rows; lane = k for the A
         //         operand, lane = n for the B operand, both read one LDS row per step); wave w < 3 owns k rows 32w .. 32w + 31
         if (wave < 3) {
             const int k = wave * 32 + i;
-            if (wave * 32 < K2)
-#pragma unroll 4
-                for (int s = 0; s < EB_ROWS / 2; ++s) {
-                    const int row = 2 * s + h;
-                    gw2 = __builtin_amdgcn_mfma_f32_32x32x2f32(k < K2 ? Y[row * LY + L1c + k] : 0.f, i < G ? Z2[row * LZ + i] : 0.f, gw2, 0, 0, 0);
-                }
-            if (wave * 32 < K1)
-#pragma unroll 4
-                for (int s = 0; s < EB_ROWS / 2; ++s) {
-                    const int row = 2 * s + h;
-                    gw1 = __builtin_amdgcn_mfma_f32_32x32x2f32(k < K1 ? Y[row * LY + L0c + k] : 0.f, i < G ? Z1[row * LZ + i] : 0.f, gw1, 0, 0, 0);
-                }
-            if (wave * 32 < K0)
-#pragma unroll 4
-                for (int s = 0; s < EB_ROWS / 2; ++s) {
-                    const int row = 2 * s + h;
-                    gw0 = __builtin_amdgcn_mfma_f32_32x32x2f32(k < K0 ? Y[row * LY + FPc + k] : 0.f, i < G ? Z0[row * LZ + i] : 0.f, gw0, 0, 0, 0);
-                }
+            if (wave * 32 < K2) eb_prod<EB_ROWS / 2, 2 * LY * 4, 2 * LZ * 4>(gw2, eb_lds_addr(Y + h * LY + L1c + k), eb_lds_addr(Z2 + h * LZ + i));
+            if (wave * 32 < K1) eb_prod<EB_ROWS / 2, 2 * LY * 4, 2 * LZ * 4>(gw1, eb_lds_addr(Y + h * LY + L0c + k), eb_lds_addr(Z1 + h * LZ + i));
+            if (wave * 32 < K0) eb_prod<EB_ROWS / 2, 2 * LY * 4, 2 * LZ * 4>(gw0, eb_lds_addr(Y + h * LY + FPc + k), eb_lds_addr(Z0 + h * LZ + i));
         } else if (i < G) {
             for (int row = h * 64; row < h * 64 + 64; ++row) { gb2 += Z2[row * LZ + i]; gb1 += Z1[row * LZ + i]; gb0 += Z0[row * LZ + i]; }
         }
     }
+    EB_T(7);
+#ifdef EB_STAMPS
+    if (threadIdx.x == 0 && blockIdx.x == 1) {
+        unsigned long long* dbg = reinterpret_cast<unsigned long long*>(a.part + (size_t)gridDim.x * eb_part_floats(C));
+        for (int q = 0; q < 8; ++q) dbg[q] = eb_st[q];
+    }
+#endif
     // ---- the workgroup's partial: [W2 rows | W1 rows | W0 rows] x 24, then b2 | b1 | b0
     float* part = a.part + (size_t)blockIdx.x * eb_part_floats(C);
     if (wave < 3) {
@@ -353,7 +396,7 @@ using namespace dispu;
 
 DISPU_EXPORT long dispu_edge_dense_conv_grad_scratch_floats(int npoints, int C) {
     if (npoints <= 0 || !(C == 24 || C == 48)) return 0;
-    return (long)eb_grid(npoints) * eb_part_floats(C);
+    return (long)eb_grid(npoints) * eb_part_floats(C) + 32;              // + room for the EB_STAMPS debug record
 }
 
 // Backward of dispu_edge_dense_conv (same F / idx / weights): dOut [npoints, 72 + C] -> dF [npoints, C] accumulates (atomics;
