@@ -109,7 +109,10 @@ __device__ __forceinline__ void chain_layer(float* act, const float* wst, int g0
     __syncthreads();                                              // the next layer's input is complete
 }
 
-template <int K0, int N1, int N2, int N3, int BM>
+// STASH: also write the second / third layer's outputs and the head's pre-activation (training forward).  A template flag, not a
+// run-time test: with the pointers as run-time arguments the inference launches lost 3 - 4 us each to the extra branches / address
+// arithmetic in every layer's store loop.
+template <int K0, int N1, int N2, int N3, int BM, bool STASH = false>
 __global__ __launch_bounds__(512) void mlp_chain_kernel(ChainArgs a) {
     constexpr int MC_LDA = BM + 1, XU = BM / 32;                  // XU: float4 loads per loader thread and 32-column input chunk
     static_assert(K0 <= MC_KMAX && N1 <= MC_KMAX && N2 <= MC_KMAX && N3 == 64, "chain shape outside the LDS plan");
@@ -222,8 +225,8 @@ __global__ __launch_bounds__(512) void mlp_chain_kernel(ChainArgs a) {
 #endif
     __syncthreads();
     chain_layer<K0, N1, BM>(act, wst, 0, a.b1, a.Y1, a.ldy1, row0, wm, wn, fi, fk MC_WAIT_ARG);
-    chain_layer<N1, N2, BM>(act, wst, S1, a.b2, a.Y2, a.ldy2, row0, wm, wn, fi, fk MC_WAIT_ARG);
-    chain_layer<N2, N3, BM>(act, wst, S1 + S2, a.b3, a.Y3, a.ldy3, row0, wm, wn, fi, fk MC_WAIT_ARG);
+    chain_layer<N1, N2, BM>(act, wst, S1, a.b2, STASH ? a.Y2 : nullptr, a.ldy2, row0, wm, wn, fi, fk MC_WAIT_ARG);
+    chain_layer<N2, N3, BM>(act, wst, S1 + S2, a.b3, STASH ? a.Y3 : nullptr, a.ldy3, row0, wm, wn, fi, fk MC_WAIT_ARG);
 #ifdef MC_CLOCK
     if (blockIdx.x == 7 && threadIdx.x == 0) { mc_clock_ticks[0] = __builtin_readcyclecounter() - mc_t0; mc_clock_ticks[1] = G; mc_clock_ticks[2] = mc_wait_local; }
 #endif
@@ -243,7 +246,7 @@ __global__ __launch_bounds__(512) void mlp_chain_kernel(ChainArgs a) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             float w = v[c];
-            if (a.Z) a.Z[gr * a.ldz + c] = w;
+            if constexpr (STASH) { if (a.Z) a.Z[gr * a.ldz + c] = w; }
             if (a.mode == 1) w = a.R[gr * a.ldr + c] + (1.0f / (1.0f + expf(-w)) - 0.5f);
             a.out[gr * a.ldo + c] = w;
         }
@@ -278,31 +281,25 @@ DISPU_EXPORT int dispu_mlp_chain_stash(long rows, int K0, int N1, int N2, int N3
     if (rows == 0) return 0;
     ChainArgs a{rows, X, ldx, W1, b1, W2, b2, W3, b3, W4, b4, Y1, ldy1, Y2, ldy2, Y3, ldy3, Z, ldz, R, ldr, out, ldo, mode};
     hipStream_t s = (hipStream_t)stream;
-    static DevOnce attr;
-    if (attr.needed()) {
-        DISPU_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_chain_kernel<256, 128, 256, 64, 128>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)MC_LDS_BYTES));
-        DISPU_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_chain_kernel<256, 256, 256, 64, 128>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)MC_LDS_BYTES));
-        DISPU_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_chain_kernel<256, 128, 256, 64, 64>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)MC_LDS_BYTES));
-        DISPU_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_chain_kernel<256, 256, 256, 64, 64>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)MC_LDS_BYTES));
-        attr.done();
-    }
-    // 128-row workgroups once they fill the chip (>= 256 of them); below that (the training step's 8 patches = 8192 rows) 64-row
+    const bool stash = Y2 || Y3 || Z;
+    // 128-row workgroups once they fill the chip (>= 192 of them); below that (the training step's 8 patches = 8192 rows) 64-row
     // workgroups: twice as many, each streaming the same weights for half the rows.  Same arithmetic, bit-identical results.
     const bool small = (rows % MC_BM) != 0 || rows / MC_BM < 192;
     const bool coarse = (K0 == 256 && N1 == 128 && N2 == 256 && N3 == 64), fine = (K0 == 256 && N1 == 256 && N2 == 256 && N3 == 64);
     if (!coarse && !fine) return (int)hipErrorInvalidValue;
-    if (small) {
-        const dim3 grid((unsigned)(rows / 64));
-        if (coarse) hipLaunchKernelGGL((mlp_chain_kernel<256, 128, 256, 64, 64>), grid, dim3(512), MC_LDS_BYTES, s, a);
-        else hipLaunchKernelGGL((mlp_chain_kernel<256, 256, 256, 64, 64>), grid, dim3(512), MC_LDS_BYTES, s, a);
-    } else {
-        const dim3 grid((unsigned)(rows / MC_BM));
-        if (coarse) hipLaunchKernelGGL((mlp_chain_kernel<256, 128, 256, 64, 128>), grid, dim3(512), MC_LDS_BYTES, s, a);
-        else hipLaunchKernelGGL((mlp_chain_kernel<256, 256, 256, 64, 128>), grid, dim3(512), MC_LDS_BYTES, s, a);
-    }
-    return (int)hipGetLastError();
+    const dim3 grid((unsigned)(rows / (small ? 64 : MC_BM)));
+    auto launch = [&](auto kern) -> int {
+        static DevOnce once;                                   // per instantiation of this generic lambda, per device
+        if (once.needed()) {
+            DISPU_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)MC_LDS_BYTES));
+            once.done();
+        }
+        hipLaunchKernelGGL(kern, grid, dim3(512), MC_LDS_BYTES, s, a);
+        return (int)hipGetLastError();
+    };
+#define MC_PICK(K0_, N1_) \
+    (small ? (stash ? launch(mlp_chain_kernel<K0_, N1_, 256, 64, 64, true>) : launch(mlp_chain_kernel<K0_, N1_, 256, 64, 64, false>)) \
+           : (stash ? launch(mlp_chain_kernel<K0_, N1_, 256, 64, 128, true>) : launch(mlp_chain_kernel<K0_, N1_, 256, 64, 128, false>)))
+    return coarse ? MC_PICK(256, 128) : MC_PICK(256, 256);
+#undef MC_PICK
 }

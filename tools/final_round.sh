@@ -2,7 +2,7 @@
 # Run on the GPU box (through gpurun): the end-of-round evidence in one call -- the GPU test suite, smoke(), the bench with its
 # rocprofv3 kernel statistics and PMC passes, the per-op table, the other BASELINE configurations, the train and FPS benches.
 # Usage: tools/final_round.sh [tag]   -> gpurun_out/<tag>/..., gpurun_out/<tag>_pmc/pmc_summary.json  (copy what is kept to profiles/)
-TAG=${1:-r02_f}
+TAG=${1:-r03_a}
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/$TAG
 timeout 2400 python -m pytest tests -m gpu -q -x 2>&1 | tail -5 > gpurun_out/$TAG/pytest_gpu.txt
@@ -13,6 +13,10 @@ bash tools/pmc_traffic.sh ${TAG}_pmc > gpurun_out/$TAG/pmc.log 2>&1; tail -c 600
 timeout 900 python tools/ops_bench.py > gpurun_out/$TAG/ops_microbench.json 2> gpurun_out/$TAG/ops.log; tail -c 300 gpurun_out/$TAG/ops_microbench.json
 timeout 600 python tools/config_bench.py > gpurun_out/$TAG/configs.json 2>> gpurun_out/$TAG/ops.log
 timeout 300 python tools/train_bench.py > gpurun_out/$TAG/train_b8_bench.json 2>> gpurun_out/$TAG/ops.log
+timeout 300 python tools/train_bench.py --graph > gpurun_out/$TAG/train_b8_graph_bench.json 2>> gpurun_out/$TAG/ops.log
+timeout 300 python tools/train_bench.py --dtype bf16 --graph > gpurun_out/$TAG/train_b8_bf16_graph_bench.json 2>> gpurun_out/$TAG/ops.log
+bash tools/prof_train.sh ${TAG}_train 8 > gpurun_out/$TAG/prof_train.log 2>&1
+timeout 300 python tools/emd_bench.py > gpurun_out/$TAG/emd_bench.txt 2>> gpurun_out/$TAG/ops.log
 timeout 300 python tools/train_bench.py --dtype bf16 > gpurun_out/$TAG/train_b8_bf16_bench.json 2>> gpurun_out/$TAG/ops.log
 timeout 300 python tools/fps_bench.py > gpurun_out/$TAG/fps_bench.txt 2>> gpurun_out/$TAG/ops.log
 echo done
