@@ -2,7 +2,7 @@
 # Run on the GPU box (through gpurun): the end-of-round evidence in one call -- the GPU test suite, smoke(), the bench with its
 # rocprofv3 kernel statistics and PMC passes, the per-op table, the other BASELINE configurations, the train and FPS benches.
 # Usage: tools/final_round.sh [tag]   -> gpurun_out/<tag>/..., gpurun_out/<tag>_pmc/pmc_summary.json  (copy what is kept to profiles/)
-TAG=${1:-r03_a}
+TAG=${1:-r03_d}
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/$TAG
 timeout 2400 python -m pytest tests -m gpu -q -x 2>&1 | tail -5 > gpurun_out/$TAG/pytest_gpu.txt
@@ -15,8 +15,10 @@ timeout 600 python tools/config_bench.py > gpurun_out/$TAG/configs.json 2>> gpur
 timeout 300 python tools/train_bench.py > gpurun_out/$TAG/train_b8_bench.json 2>> gpurun_out/$TAG/ops.log
 timeout 300 python tools/train_bench.py --graph > gpurun_out/$TAG/train_b8_graph_bench.json 2>> gpurun_out/$TAG/ops.log
 timeout 300 python tools/train_bench.py --dtype bf16 --graph > gpurun_out/$TAG/train_b8_bf16_graph_bench.json 2>> gpurun_out/$TAG/ops.log
+timeout 300 python tools/train_bench.py --batch 32 > gpurun_out/$TAG/train_b32_bench.json 2>> gpurun_out/$TAG/ops.log
 bash tools/prof_train.sh ${TAG}_train 8 > gpurun_out/$TAG/prof_train.log 2>&1
 timeout 300 python tools/emd_bench.py > gpurun_out/$TAG/emd_bench.txt 2>> gpurun_out/$TAG/ops.log
 timeout 300 python tools/train_bench.py --dtype bf16 > gpurun_out/$TAG/train_b8_bf16_bench.json 2>> gpurun_out/$TAG/ops.log
 timeout 300 python tools/fps_bench.py > gpurun_out/$TAG/fps_bench.txt 2>> gpurun_out/$TAG/ops.log
+bash tools/trace_train.sh ${TAG}_trace 8 f32 --graph > gpurun_out/$TAG/trace.log 2>&1
 echo done
