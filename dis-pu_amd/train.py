@@ -105,6 +105,7 @@ class Trainer(object):
         self._side_rr = -1
         self._fork_ev = None
         self._join_ev = None
+        self._sched = int(os.environ.get("DISPU_TRAIN_SCHED", "7"))
         self._side_busy = []
         self.P = None
         if params is not None:
@@ -259,8 +260,9 @@ class Trainer(object):
                 self._side_busy[i] = False
 
     @contextlib.contextmanager
-    def _branch(self, i):
-        """Launches inside run on auxiliary stream i, after everything queued on the current stream so far; `_merge(i)` makes
+    def _branch(self, i, after=None):
+        """Launches inside run on auxiliary stream i, after everything queued on the current stream so far (or after the event
+        `after`, recorded earlier on it); `_merge(i)` makes
         the current stream wait for them.  At 8 patches per GPU a chain of 10 us kernels leaves most of the 256 CUs idle:
         independent sub-graphs (non-local cell | skip + local cell; the two Chamfer terms) run side by side."""
         if not self.overlap_dw:
@@ -268,9 +270,11 @@ class Trainer(object):
             return
         while len(self._aux) <= i:
             self._aux.append((torch.cuda.Stream(device=self.device), torch.cuda.Event(), torch.cuda.Event()))
-        aux, ev_fork, _ = self._aux[i]
-        ev_fork.record(torch.cuda.current_stream(self.device))
-        aux.wait_event(ev_fork)
+        aux, ev_fork, ev_done = self._aux[i]
+        if after is None:
+            ev_fork.record(torch.cuda.current_stream(self.device))
+            after = ev_fork
+        aux.wait_event(after)
         old_st, old_cur = self.st, self._cur
         with torch.cuda.stream(aux):
             self.st, self._cur = ctypes.c_void_p(aux.cuda_stream), "aux%d" % i
@@ -278,11 +282,17 @@ class Trainer(object):
                 yield
             finally:
                 self.st, self._cur = old_st, old_cur
+                # recorded HERE, not in _merge: streams share hardware queues (GPU_MAX_HW_QUEUES = 4), and a marker queued at merge
+                # time lands behind whatever the other streams of that queue were given in between (measured: the local cell's
+                # backward started 0.33 ms late, behind dW products it does not depend on)
+                if self._sched & 1:
+                    ev_done.record(aux)
 
     def _merge(self, i):
         if self.overlap_dw and i < len(self._aux):
             aux, _, ev_done = self._aux[i]
-            ev_done.record(aux)
+            if not (self._sched & 1):
+                ev_done.record(aux)
             torch.cuda.current_stream(self.device).wait_event(ev_done)
 
     # ----------------------------------------------------------------------------------------------- helpers ----
@@ -608,6 +618,8 @@ class Trainer(object):
             with self._branch(2):
                 self._recompute_pair_tensors()
 
+        if self._sched & 2:
+            self._merge(2)                               # h0 / h1 / wv / the inverted graph: done by the time the loss is (see _branch)
         # fine = coarse + sigmoid(z) - 0.5
         _lib.check(L.dispu_sigmoid_offset_grad(rm * 3, _p(ws["z"]), _p(dfine), _p(ws["dz"]), _p(dcoarse), self.st), "sigmoid_grad")
         self._lin_bwd(ws["f64"], 0, 64, fs + "fc_layer2", 3, ws["dz"], 0, ws["df64"], mask=(ws["f64"], 0, 64))
@@ -618,12 +630,14 @@ class Trainer(object):
         _lib.check(L.dispu_mask3(rm, 256, _p(ws["dsum"]), 256, _p(ws["aft"]), 256, _p(ws["skip"]), 256, _p(ws["nl"]), 256, _p(ws["daft"]),
                                  _p(ws["dskip"]), _p(ws["dnl"]), 256, self.st), "mask3")
 
-        # local cell first: the host needs ~0.1 ms to queue the two branches below, the chain must not sit idle meanwhile
+        # local cell first: the host needs ~0.1 ms to queue the two branches below, the chain must not sit idle meanwhile; the
+        # branches themselves only need the mask3 outputs, so they are ordered after THIS point of the stream, not after the product
+        ev_br = self._fork_point() if (self.overlap_dw and self._sched & 4) else None
         self._lin_bwd(ws["hp"], 0, 2048, ps + "after_conv", 256, ws["daft"], 0, ws["dhp"])
         # non-local cell: reads dnl, writes datt / dS / dkv / dq / dup128 -- nothing the local cell or the skip branch touches, so
         # it runs as a branch next to them; merged before anything else accumulates into dup128
         dup128 = ws["dup128"]
-        with self._branch(0):
+        with self._branch(0, ev_br):
             self._lin_bwd(ws["att"], 0, 64, ps + "PointShuffle/conv_back_project", 256, ws["dnl"], 0, ws["datt"])
             S, dS, kv, dkv, q = ws["S"], ws["dS"], ws["kv"], ws["dkv"], ws["q"]
             # dP = dO . V^T
@@ -640,9 +654,10 @@ class Trainer(object):
             self._lin_bwd(ws["up128"], 0, 128, ps + "PointShuffle/conv_kv", 128, dkv, 0, dup128)
             self._lin_bwd(ws["up128"], 0, 128, ps + "PointShuffle/conv_query", 64, ws["dq"], 0, dup128, 0, acc_dx=True)
         # skip branch (a second branch): 134 -> 256 backward; its max gradient is scattered after the merges below
-        with self._branch(1):
+        with self._branch(1, ev_br):
             self._lin_bwd(ws["gmax"], 0, 134, ps + "skip", 256, ws["dskip"], 0, ws["dgmax"])
-        self._merge(2)                                   # h0 / h1 / wv / the inverted graph are in place
+        if not (self._sched & 2):
+            self._merge(2)                               # h0 / h1 / wv / the inverted graph are in place
         _lib.check(L.dispu_ps_point_matmul_grad_relu_s(rm, k, 128, 16, _p(ws["h1"]), 128, _p(ws["wv"]), _p(ws["dhp"]), 2048, _p(ws["dz1"]),
                                                        128, _p(ws["dwv"]), 1 if ws["h1"].dtype == torch.bfloat16 else 0, self.st),
                    "point_matmul_grad")
