@@ -73,11 +73,20 @@ ROCPROF_NAME = {"ps_local": "dispu::ps_local_ws_kernel", "mlp_chain[coarse]": "d
                 "knn_xyz": "dispu::knn_xyz_wave_kernel", "skip_max": "dispu::ps_skip_max16_kernel"}
 
 
+def rocprof_name(kern):
+    """launch label -> the kernel name rocprofv3 reports for it"""
+    if kern.startswith("linear<"):
+        return "dispu::linear_mfma_kernel" + kern[len("linear"):]
+    if kern.startswith("linear_skinny<"):
+        return "dispu::linear_skinny_kernel" + kern[len("linear_skinny"):]
+    return ROCPROF_NAME.get(kern, kern)
+
+
 def launch_flops(name, B):
     """ALGORITHMIC flops of one launch of the MFMA kernels of the step, by launch label (shapes: SURVEY.md Appendix A,
     Common/ops.py:1012-1087, :302-346, :1089-1110, :1856-1915).  None: not an MFMA kernel (k-NN selection, gathers, heads)."""
     n, m, k = NPOINT, NPOINT * UP, 16
-    if name.startswith("linear<"):
+    if name.startswith("linear<") or name.startswith("linear_skinny<"):
         return linear_flops(name)
     if name == "ps_local":                       # conv1 128 -> 128 over 16 neighbours, weight net 3 -> 16, feature x weight 16 x 16 x 128
         return 2.0 * B * m * k * (128 * 128 + 3 * 16 + 16 * 128)
@@ -293,7 +302,7 @@ def main():
         edge_c = [24, 48, 48, 48]                                           # dense block d reads C = 24 / 48 / 48 / 48 channels
         edge_seen = 0
         for name, (t, c) in acc.items():
-            kern = name.split("[")[0] if name.startswith("linear<") else name
+            kern = name.split("[")[0] if name.startswith(("linear<", "linear_skinny<")) else name
             g = by_kernel.setdefault(kern, [0.0, 0, 0.0, True])
             g[0] += t / reps
             g[1] += c / reps
@@ -307,7 +316,7 @@ def main():
         t_all = sum(g[0] for g in by_kernel.values())
         # dominant kernel = the launch label with the most time per step, whatever it is (round-2 code filtered on `linear<`)
         kern, (t_k, n_k, fl_k, is_mfma) = max(by_kernel.items(), key=lambda kv: kv[1][0])
-        kname = ("dispu::linear_mfma_kernel" + kern[len("linear"):]) if kern.startswith("linear<") else ROCPROF_NAME.get(kern, kern)
+        kname = rocprof_name(kern)
         achieved = fl_k / t_k / 1e12 if is_mfma else None
         traffic, traffic_src = pmc_traffic(kern) if kern.startswith("linear<") else (None, None)
         roof = {"bound": "mfma" if is_mfma else "valu", "kernel": kname,
@@ -318,7 +327,7 @@ def main():
                                            sorted(by_kernel.items(), key=lambda kv: -kv[1][0])[:8]}}
         # the decomposition of step_frac: every launch label of the step with its time, algorithmic flops and MFMA fraction
         roof["kernels"] = [
-            {"kernel": ("dispu::linear_mfma_kernel" + k[len("linear"):]) if k.startswith("linear<") else ROCPROF_NAME.get(k, k),
+            {"kernel": rocprof_name(k),
              "launches_per_step": round(v[1]), "us_per_step": round(v[0] * 1e6, 2), "avg_launch_us": round(v[0] / max(v[1], 1) * 1e6, 2),
              "gflop_per_step": round(v[2] / 1e9, 3) if v[3] else None,
              "mfma_frac": round(v[2] / v[0] / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4) if v[3] else None}

@@ -198,6 +198,13 @@ class Generator(object):
             epi = 0 if (R1 is None and R2 is None) else 4       # epilogue variant: 0 bias/act, 4 with residual inputs
             name = "linear<%d, %d, 2, 2, %d, %s, %s, %d>[%dx%dx%d]" % (bm, bn, bk, "true" if transb else "false",
                                                                       "true" if edge else "false", epi, M * batch, K, N)
+            # latency-bound shapes leave the tiled kernel (csrc/linear_skinny.hip:linear_skinny_dispatch; same conditions)
+            tiles64 = ((M + 63) // 64) * ((N + 63) // 64)
+            if (batch == 1 and R2 is None and 4 <= K <= 384 and K % 4 == 0 and ldx % 4 == 0 and (X.data_ptr() + 4 * xoff) % 16 == 0
+                    and not (transb and (ldw % 4 or (W.data_ptr() + 4 * woff) % 16))
+                    and ((N <= 64 and tiles64 < 256) or N <= 32 or (K <= 32 and N <= 128))):
+                name = "linear_skinny<%d, %s>[%dx%dx%d]" % (2 if K <= 32 else 8 if K <= 128 else 16 if K <= 256 else 24,
+                                                           "true" if transb else "false", M, K, N)
         self._call(name, L.dispu_linear, batch, M, K, N,
                    p(X, xoff), ldx, sx, p(W, woff), ldw, sw, transb, p(bias), act, p(Y, yoff), ldy, sy, p(R1),
                    R1.stride(0) if R1 is not None else 0, 0, p(R2), R2.stride(0) if R2 is not None else 0, 0, st)

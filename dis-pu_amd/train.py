@@ -105,7 +105,8 @@ class Trainer(object):
         self._side_rr = -1
         self._fork_ev = None
         self._join_ev = None
-        self._sched = int(os.environ.get("DISPU_TRAIN_SCHED", "7"))
+        self._sched = int(os.environ.get("DISPU_TRAIN_SCHED", "1"))
+
         self._side_busy = []
         self.P = None
         if params is not None:

@@ -1,13 +1,13 @@
+# A/B of the training step's stream schedule (run on the GPU box):  DISPU_TRAIN_SCHED / DISPU_TRAIN_PRIO variants, eager and hipGraph
 cd $GRAFT_REPO_ROOT
-for s in 0 1 3 7; do
-  for g in "" "--graph"; do
-    echo "SCHED=$s $g f32: $(DISPU_TRAIN_SCHED=$s timeout 300 python tools/train_bench.py $g 2>/dev/null | python -c 'import json,sys; d=json.loads(sys.stdin.read()); print(round(d["ms_per_step"],4), d["forward_ms"], d["loss_ms"], d["backward_ms"])')"
-  done
-  echo "SCHED=$s --graph bf16: $(DISPU_TRAIN_SCHED=$s timeout 300 python tools/train_bench.py --graph --dtype bf16 2>/dev/null | python -c 'import json,sys; d=json.loads(sys.stdin.read()); print(round(d["ms_per_step"],4))')"
+run() { python tools/train_bench.py "$@" 2>/dev/null | python -c 'import json,sys; d=json.loads(sys.stdin.read()); print(round(d["ms_per_step"],4), d["forward_ms"], d["loss_ms"], d["backward_ms"])'; }
+for p in 0 1 2 3; do
+  echo "PRIO=$p eager f32: $(DISPU_TRAIN_PRIO=$p run)"
+  echo "PRIO=$p graph f32: $(DISPU_TRAIN_PRIO=$p run --graph)"
+  echo "PRIO=$p graph bf16: $(DISPU_TRAIN_PRIO=$p run --graph --dtype bf16)"
+  echo "PRIO=$p eager bf16: $(DISPU_TRAIN_PRIO=$p run --dtype bf16)"
 done
-echo "SCHED=7 HWQ=8 graph: $(GPU_MAX_HW_QUEUES=8 DISPU_TRAIN_SCHED=7 timeout 300 python tools/train_bench.py --graph 2>/dev/null | python -c 'import json,sys; d=json.loads(sys.stdin.read()); print(round(d["ms_per_step"],4))')"
-echo "SCHED=7 HWQ=8 eager: $(GPU_MAX_HW_QUEUES=8 DISPU_TRAIN_SCHED=7 timeout 300 python tools/train_bench.py 2>/dev/null | python -c 'import json,sys; d=json.loads(sys.stdin.read()); print(round(d["ms_per_step"],4))')"
-echo "SCHED=7 b32 graph: $(DISPU_TRAIN_SCHED=7 timeout 300 python tools/train_bench.py --graph --batch 32 2>/dev/null | python -c 'import json,sys; d=json.loads(sys.stdin.read()); print(round(d["ms_per_step"],4))')"
-echo "SCHED=0 b32 graph: $(DISPU_TRAIN_SCHED=0 timeout 300 python tools/train_bench.py --graph --batch 32 2>/dev/null | python -c 'import json,sys; d=json.loads(sys.stdin.read()); print(round(d["ms_per_step"],4))')"
-timeout 600 python -m pytest tests/test_train_gpu.py tests/test_train_bf16_gpu.py -m gpu -x -q 2>&1 | tail -3
-bash tools/trace_train.sh r03_trace_h 8 f32 --graph > /dev/null 2>&1
+echo "PRIO=3 b32 eager: $(DISPU_TRAIN_PRIO=3 run --batch 32)"
+echo "PRIO=0 b32 eager: $(DISPU_TRAIN_PRIO=0 run --batch 32)"
+echo "PRIO=3 b32 graph: $(DISPU_TRAIN_PRIO=3 run --batch 32 --graph)"
+DISPU_TRAIN_PRIO=3 timeout 600 python -m pytest tests/test_train_gpu.py tests/test_train_bf16_gpu.py -m gpu -x -q 2>&1 | tail -3
