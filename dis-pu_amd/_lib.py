@@ -110,6 +110,8 @@ SIGNATURES = {
     "dispu_linear_bf16_masked": (_i, [_i, _i, _i, _i, _vp, _l, _l, _vp, _l, _l, _i, _vp, _i, _vp, _l, _l, _vp, _l, _l, _vp, _l, _i, _vp]),
     "dispu_mlp_chain_stash": (_i, [_l, _i, _i, _i, _i, _vp, _l, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _l, _vp, _l, _vp, _l, _vp, _l,
                                    _i, _vp, _l, _vp, _l, _vp]),
+    "dispu_mlp_chain_grad": (_i, [_l, _i, _i, _i, _vp, _l, _vp, _vp, _vp, _vp, _vp, _l, _vp, _l, _vp, _l, _vp, _l, _vp, _l, _vp, _l, _vp, _l, _vp, _l,
+                                  _vp, _vp, _vp, _l, _vp, _vp, _vp, _l, _vp]),
     "dispu_mask3": (_i, [_l, _i, _vp, _l, _vp, _l, _vp, _l, _vp, _l, _vp, _vp, _vp, _l, _vp]),
     "dispu_ps_wnet_scratch_bytes": (_l, [_l]),
     "dispu_ps_wnet_bn_stats": (_i, [_l, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, C.c_float, C.c_float, _vp, _vp, _vp, _vp, _vp, _vp, _l, _vp]),
@@ -120,6 +122,8 @@ SIGNATURES = {
     "dispu_ps_skip_max_grad": (_i, [_l, _i, _i, _i, _vp, _vp, _vp, _l, _vp, _l, _vp, _l, _vp, _vp, _l, _i, _vp]),
     "dispu_ps_point_matmul_grad_relu": (_i, [_l, _i, _i, _i, _vp, _l, _vp, _vp, _l, _vp, _l, _vp, _vp]),
     "dispu_edge_dense_conv_grad_scratch_floats": (_l, [_i, _i]),
+    "dispu_edge_dense_conv_grad_partials": (_i, [_i, _i, _i, _vp, _l, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _l, _vp, _l, _vp, _l, _vp]),
+    "dispu_edge_dense_conv_grad_reduce": (_i, [_i, _i, _vp, _l, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "dispu_edge_dense_conv_grad": (_i, [_i, _i, _i, _vp, _l, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _l, _vp, _l, _vp, _vp, _vp, _vp, _vp,
                                         _vp, _vp, _l, _vp]),
     "dispu_repulsion_loss_grad": (_i, [_l, _i, _i, C.c_float, C.c_float, _vp, _vp, _vp, _vp, _vp]),

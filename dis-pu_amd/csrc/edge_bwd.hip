@@ -401,11 +401,13 @@ DISPU_EXPORT long dispu_edge_dense_conv_grad_scratch_floats(int npoints, int C) 
 
 // Backward of dispu_edge_dense_conv (same F / idx / weights): dOut [npoints, 72 + C] -> dF [npoints, C] accumulates (atomics;
 // zero-fill it or let it hold the gradient that arrived through other paths), dW* / db* accumulate (+=, deterministic).
-DISPU_EXPORT int dispu_edge_dense_conv_grad(int npoints, int n_per_cloud, int C, const float* F, long ldf, const int* idx, int ldi, int ioff,
-                                            const float* W0, const float* b0, const float* W1, const float* b1, const float* W2,
-                                            const float* b2, const float* dOut, long lddo, float* dF, long lddf, float* dW0, float* db0,
-                                            float* dW1, float* db1, float* dW2, float* db2, float* scratch, long scratch_floats,
-                                            void* stream) {
+// Two halves, so that a caller can keep the second one off its critical path (another stream, ordered after the first by an event):
+// _partials runs the block's backward and leaves the weight gradients as per-workgroup partial sums in `scratch`; _reduce adds them,
+// in a fixed order, to dW* / db*.  dispu_edge_dense_conv_grad = both on one stream.
+DISPU_EXPORT int dispu_edge_dense_conv_grad_partials(int npoints, int n_per_cloud, int C, const float* F, long ldf, const int* idx, int ldi,
+                                                     int ioff, const float* W0, const float* b0, const float* W1, const float* b1,
+                                                     const float* W2, const float* b2, const float* dOut, long lddo, float* dF, long lddf,
+                                                     float* scratch, long scratch_floats, void* stream) {
     if (npoints < 0 || n_per_cloud <= 0 || !(C == 24 || C == 48) || (ldf & 3) || (((uintptr_t)F) & 15) || !scratch ||
         scratch_floats < dispu_edge_dense_conv_grad_scratch_floats(npoints, C))
         return (int)hipErrorInvalidValue;
@@ -423,8 +425,27 @@ DISPU_EXPORT int dispu_edge_dense_conv_grad(int npoints, int n_per_cloud, int C,
     }
     if (C == 24) hipLaunchKernelGGL(edge_bwd_kernel<24>, dim3(grid), dim3(256), EbLds<24>::BYTES, s, a);
     else hipLaunchKernelGGL(edge_bwd_kernel<48>, dim3(grid), dim3(256), EbLds<48>::BYTES, s, a);
-    DISPU_CHECK_LAUNCH();
-    const int total = eb_part_floats(C);
-    hipLaunchKernelGGL(edge_bwd_reduce_kernel, dim3((total + 3) / 4), dim3(256), 0, s, C, grid, scratch, dW2, dW1, dW0, db2, db1, db0);
     return (int)hipGetLastError();
+}
+
+DISPU_EXPORT int dispu_edge_dense_conv_grad_reduce(int npoints, int C, const float* scratch, long scratch_floats, float* dW0, float* db0,
+                                                   float* dW1, float* db1, float* dW2, float* db2, void* stream) {
+    if (npoints < 0 || !(C == 24 || C == 48) || !scratch || scratch_floats < dispu_edge_dense_conv_grad_scratch_floats(npoints, C))
+        return (int)hipErrorInvalidValue;
+    if (npoints == 0) return 0;
+    const int total = eb_part_floats(C);
+    hipLaunchKernelGGL(edge_bwd_reduce_kernel, dim3((total + 3) / 4), dim3(256), 0, (hipStream_t)stream, C, eb_grid(npoints), scratch, dW2, dW1,
+                       dW0, db2, db1, db0);
+    return (int)hipGetLastError();
+}
+
+DISPU_EXPORT int dispu_edge_dense_conv_grad(int npoints, int n_per_cloud, int C, const float* F, long ldf, const int* idx, int ldi, int ioff,
+                                            const float* W0, const float* b0, const float* W1, const float* b1, const float* W2,
+                                            const float* b2, const float* dOut, long lddo, float* dF, long lddf, float* dW0, float* db0,
+                                            float* dW1, float* db1, float* dW2, float* db2, float* scratch, long scratch_floats,
+                                            void* stream) {
+    const int rc = dispu_edge_dense_conv_grad_partials(npoints, n_per_cloud, C, F, ldf, idx, ldi, ioff, W0, b0, W1, b1, W2, b2, dOut, lddo, dF,
+                                                       lddf, scratch, scratch_floats, stream);
+    if (rc != 0 || npoints == 0) return rc;
+    return dispu_edge_dense_conv_grad_reduce(npoints, C, scratch, scratch_floats, dW0, db0, dW1, db1, dW2, db2, stream);
 }

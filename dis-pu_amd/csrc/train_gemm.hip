@@ -240,6 +240,68 @@ __global__ __launch_bounds__(512) void tn_reduce_kernel(int batch, int K, int N,
     }
 }
 
+// The same sum four outputs per lane (N % 4 == 0, 16-byte aligned rows): a workgroup = 32 float4 columns x 8 split groups, every lane
+// keeps up to eight 16-byte loads in flight.  Same association as tn_reduce_kernel (group g: splits g, g + 8, ... alternating between
+// two running sums; groups added in order), so both kernels give the same bits.  The scalar kernel moved the 67 MB of partials of
+// the 2048 x 256 gradient at 2 TB/s (33 us); this one is bandwidth-bound.
+__global__ __launch_bounds__(256) void tn_reduce4_kernel(int batch, int K, int N, int splits, const float* __restrict__ part,
+                                                         float* __restrict__ out, long ldo, long so, int accumulate,
+                                                         float* __restrict__ dbias) {
+    __shared__ float4 red[8][32];
+    const size_t kn1 = (size_t)(K + 1) * N, q1 = kn1 / 4;
+    const int lane = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    const size_t chunks = (q1 + 31) / 32;
+    for (size_t blk = blockIdx.x; blk < chunks * batch; blk += gridDim.x) {
+        const size_t z = blk / chunks, q = (blk - z * chunks) * 32 + lane;
+        float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
+        if (q < q1) {
+            const float4* p = reinterpret_cast<const float4*>(part + z * splits * kn1) + q;
+            for (int s = grp; s < splits; s += 64) {
+                float4 b[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) b[j] = (s + 8 * j < splits) ? p[(size_t)(s + 8 * j) * q1] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int j = 0; j < 8; j += 2) {
+                    if (s + 8 * j < splits) { v0.x += b[j].x; v0.y += b[j].y; v0.z += b[j].z; v0.w += b[j].w; }
+                    if (s + 8 * (j + 1) < splits) { v1.x += b[j + 1].x; v1.y += b[j + 1].y; v1.z += b[j + 1].z; v1.w += b[j + 1].w; }
+                }
+            }
+        }
+        red[grp][lane] = make_float4(v0.x + v1.x, v0.y + v1.y, v0.z + v1.z, v0.w + v1.w);
+        __syncthreads();
+        if (grp == 0 && q < q1) {
+            float4 t = red[0][lane];
+#pragma unroll
+            for (int g = 1; g < 8; ++g) { t.x += red[g][lane].x; t.y += red[g][lane].y; t.z += red[g][lane].z; t.w += red[g][lane].w; }
+            const size_t r = q * 4;
+            const int k = (int)(r / N), n = (int)(r - (size_t)k * N);
+            if (k < K) {
+                float4* o = reinterpret_cast<float4*>(out + z * so + (size_t)k * ldo + n);
+                if (accumulate) { const float4 c = *o; t.x = c.x + t.x; t.y = c.y + t.y; t.z = c.z + t.z; t.w = c.w + t.w; }
+                *o = t;
+            } else if (dbias) {
+                if (batch == 1) { dbias[n] += t.x; dbias[n + 1] += t.y; dbias[n + 2] += t.z; dbias[n + 3] += t.w; }
+                else { unsafeAtomicAdd(dbias + n, t.x); unsafeAtomicAdd(dbias + n + 1, t.y); unsafeAtomicAdd(dbias + n + 2, t.z); unsafeAtomicAdd(dbias + n + 3, t.w); }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+static void launch_tn_reduce(int batch, int K, int N, int splits, const float* part, float* out, long ldo, long so, int accumulate,
+                             float* dbias, hipStream_t s) {
+    const bool vec = (N % 4 == 0) && (ldo % 4 == 0) && (so % 4 == 0) && ((((uintptr_t)part) | ((uintptr_t)out)) & 15) == 0;
+    if (vec) {
+        const size_t chunks = ((((size_t)(K + 1) * N) / 4 + 31) / 32) * batch;
+        hipLaunchKernelGGL(tn_reduce4_kernel, dim3((unsigned)(chunks > 16384 ? 16384 : chunks)), dim3(256), 0, s, batch, K, N, splits, part, out,
+                           ldo, so, accumulate, dbias);
+    } else {
+        const size_t chunks = (((size_t)(K + 1) * N + 63) / 64) * batch;
+        hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)(chunks > 8192 ? 8192 : chunks)), dim3(512), 0, s, batch, K, N, splits, part, out, ldo,
+                           so, accumulate, dbias);
+    }
+}
+
 // ---- narrow outputs (N <= 64, K <= 256: the edge-conv layers' [96 x 24]-sized weight gradients over 10^4 .. 10^5 rows) --------
 // The tiled kernel above gives such a product ONE 128 x 64 block tile that is < 30 % full and as many workgroups as it has
 // M-splits, each paying a full LDS pipeline for a few KB of output (18 us + the reduction for 16 MB of operands).  Here a
@@ -319,12 +381,29 @@ static int tn_narrow_chunks(int batch, int M, int K, int N, int& rows) {
     return (M + rows - 1) / rows;
 }
 
+static int tn_env(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return (e && *e) ? atoi(e) : dflt;
+}
+
 static void tn_plan(int batch, int M, int K, int N, int& tk, int& tnn, int& splits, int& rows) {
-    tk = (K > 64) ? 2 : 1;
-    tnn = (N > 128) ? 4 : (N > 64) ? 2 : 1;
+    static const int want_wgs = tn_env("DISPU_TN_WGS", 768), min_slabs = tn_env("DISPU_TN_MIN_SLABS", 16), force_tnn = tn_env("DISPU_TN_TNN", 0);
+    static const int fill = tn_env("DISPU_TN_FILL", 256);
+    const int max_splits = (M + min_slabs * TN_SLAB - 1) / (min_slabs * TN_SLAB);  // at least 16 slabs (256 rows) per split
+    // the largest block tile whose (tiles x possible M-splits) still fills the chip: with M = 8192 rows (8 training patches) a
+    // 256 x 256 output as two 128 x 256 tiles gave 64 workgroups on 256 CUs (44 us); as eight 64 x 128 tiles it is 256
+    const int tk_max = (K > 64) ? 2 : 1, tnn_max = (N > 128) ? 4 : (N > 64) ? 2 : 1;
+    const int cand[4][2] = {{2, 4}, {2, 2}, {1, 2}, {1, 1}};
+    tk = 1, tnn = 1;
+    for (int c = 0; c < 4; ++c) {
+        const int ck = cand[c][0] < tk_max ? cand[c][0] : tk_max, cn = cand[c][1] < tnn_max ? cand[c][1] : tnn_max;
+        const long t = (long)((K + 64 * ck - 1) / (64 * ck)) * ((N + 64 * cn - 1) / (64 * cn)) * batch;
+        tk = ck, tnn = cn;
+        if (t * max_splits >= fill) break;
+    }
+    if (force_tnn > 0 && force_tnn < tnn) tnn = force_tnn;
     const int tiles = ((K + 64 * tk - 1) / (64 * tk)) * ((N + 64 * tnn - 1) / (64 * tnn)) * batch;
-    int want = (768 + tiles - 1) / tiles;                         // aim at ~768 workgroups (3 per CU); 512 with 512-row splits measured 9 % slower per step
-    const int max_splits = (M + 16 * TN_SLAB - 1) / (16 * TN_SLAB);  // at least 16 slabs (256 rows) per split
+    int want = (want_wgs + tiles - 1) / tiles;                    // aim at ~768 workgroups (3 per CU); 512 with 512-row splits measured 9 % slower per step
     splits = want < 1 ? 1 : want;
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
@@ -443,9 +522,7 @@ DISPU_EXPORT int dispu_linear_tn(int batch, int M, int K, int N, const float* X,
             hipLaunchKernelGGL(linear_tn_narrow_kernel, dim3(nchunks, (jobs + wpb - 1) / wpb), dim3(64 * wpb), 0, s, M, K, N, nrows, KT, NT,
                                X, ldx, Z, ldz, scratch);
             DISPU_CHECK_LAUNCH();
-            const size_t rchunks = ((size_t)(K + 1) * N + 63) / 64;
-            hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)(rchunks > 8192 ? 8192 : rchunks)), dim3(512), 0, s, 1, K, N, nchunks, scratch,
-                               out, ldo, so, accumulate, dbias);
+            launch_tn_reduce(1, K, N, nchunks, scratch, out, ldo, so, accumulate, dbias, s);
             DISPU_CHECK_LAUNCH();
             return 0;
         }
@@ -458,6 +535,8 @@ DISPU_EXPORT int dispu_linear_tn(int batch, int M, int K, int N, const float* X,
         if (trace) fprintf(stderr, "dispu_linear_tn batch %d M %d K %d N %d tile %dx%d splits %d rows %d partial_MB %.1f\n", batch, M, K, N, 64 * tk, 64 * tnn,
                            splits, rows, (double)batch * splits * (K + 1) * N * 4 / 1e6);
     }
+    // (measured and not kept: every split adding its tile to `out` with float atomics instead of partial tiles + reduction --
+    // 124 vs 111 us for the 2048 x 256 gradient, 69 vs 54 us for 131072 rows x 128 x 128, a few us better only on the small ones)
     const int direct = (splits == 1 && !accumulate && !dbias) ? 1 : 0;
     if (!direct && (scratch == nullptr || scratch_floats < (long)batch * splits * (K + 1) * N)) return (int)hipErrorInvalidValue;
     TnArgs a{M, K, N, X, ldx, sx, Z, ldz, sz, out, ldo, so, scratch, splits, rows, direct, dbias ? 1 : 0};
@@ -474,10 +553,7 @@ DISPU_EXPORT int dispu_linear_tn(int batch, int M, int K, int N, const float* X,
     else rc = launch_tn_e<2, 4>(a, grid, edge, s);
     if (rc != 0) return rc;
     if (!direct) {
-        const size_t chunks = (((size_t)(K + 1) * N + 63) / 64) * batch;
-        const int blocks = (int)(chunks > 8192 ? 8192 : chunks);
-        hipLaunchKernelGGL(tn_reduce_kernel, dim3(blocks), dim3(512), 0, s, batch, K, N, splits, scratch, out, ldo, so, accumulate,
-                           dbias);
+        launch_tn_reduce(batch, K, N, splits, scratch, out, ldo, so, accumulate, dbias, s);
         DISPU_CHECK_LAUNCH();
     }
     return 0;

@@ -106,6 +106,7 @@ class Trainer(object):
         self._fork_ev = None
         self._join_ev = None
         self._sched = int(os.environ.get("DISPU_TRAIN_SCHED", "1"))
+        self.fused_heads_bwd = os.environ.get("DISPU_TRAIN_FUSED_HEADS_BWD", "1") != "0"
 
         self._side_busy = []
         self.P = None
@@ -171,7 +172,9 @@ class Trainer(object):
         ws = dict(
             feat=E(rn, 480), dfeat=E(rn, 480),
             prep=[None, None] + [E(rn, 48) for _ in range(2, DENSE_BLOCKS + 1)],
-            dprep=[None, None] + [E(rn, 48) for _ in range(2, DENSE_BLOCKS + 1)],      # per block: the dW products on the second stream read them
+            # zero-filled once per step, off the chain (atomics accumulate into them): the dense blocks' input gradients (one per block:
+            # the dW products on the side streams read them) and the skip branch's share of d(up128)
+            zeroed=E((DENSE_BLOCKS - 1) * rn * 48 + rm * 128),
             kidx=[None] + [E(rn, k + 1, dtype=i32) for _ in range(DENSE_BLOCKS)],
             h256=E(rn, 256), dh256=E(rn, 256), gcode=E(rm, 2),
             up256=E(rm, 256), dup256=E(rm, 256), up128=E(rm, 128), dup128=E(rm, 128),
@@ -193,6 +196,8 @@ class Trainer(object):
                      dgt_unused=E(B, M, 3), rowmean=E(B), rowmax=E(B)) for _ in range(2)],      # one set per Chamfer term
             ball=E(B, M, 20, dtype=i32), ball_cnt=E(B, M, dtype=i32), rep=E(B, M), rowmean=E(B), rowmax=E(B),
             loss_vals=Z(8), r07=torch.full((B,), 0.07, dtype=f32, device=dev), zeros=Z(1))
+        ws["dprep"] = [None, None] + [ws["zeroed"][i * rn * 48:(i + 1) * rn * 48].view(rn, 48) for i in range(DENSE_BLOCKS - 1)]
+        ws["dup128s"] = ws["zeroed"][(DENSE_BLOCKS - 1) * rn * 48:].view(rm, 128)
         # grid code of duplicate_up: row (cloud*up + r)*N + i carries grid[r]
         ws["gcode"].view(B, self.up_ratio, N, 2).copy_(self.grid.view(1, self.up_ratio, 1, 2).expand(B, self.up_ratio, N, 2))
         self._ws[key] = ws
@@ -466,6 +471,12 @@ class Trainer(object):
         up128 = ws["up128"]
         S = ws["S"]
         with self._branch(0):
+            # what the backward needs and nothing in the forward touches rides on this branch (it has slack; no stream of its own: a
+            # fourth auxiliary stream changed the stream -> hardware-queue mapping and cost 0.1 ms per step)
+            ws["zeroed"].zero_()         # the dense blocks' input gradients, the skip branch's d(up128): accumulated with atomics
+            if (self.use_wt or self.fused_heads_bwd) and self._t_desc.numel():       # W^T copies for the dX products
+                _lib.check(L.dispu_transpose_batched(self._t_desc.numel() // 3, _p(self._t_desc), _p(self.flat_p), _p(self.flat_pT), self.st),
+                           "transpose_batched")
             self._lin(up128, 0, 128, ps + "PointShuffle/conv_kv", 0, ws["kv"], 0, 128)
             self._lin(up128, 0, 128, ps + "PointShuffle/conv_query", 0, ws["q"], 0, 64)
             _lib.check(self._dl(B, M, 64, M, _p(ws["q"]), 64, M * 64, _p(ws["kv"]), 128, M * 128, 1, None, 0, _p(S), M, M * M,
@@ -520,9 +531,6 @@ class Trainer(object):
         if self._stash_ready:
             return
         L = _lib.lib()
-        if self.use_wt and self._t_desc.numel():
-            _lib.check(L.dispu_transpose_batched(self._t_desc.numel() // 3, _p(self._t_desc), _p(self.flat_p), _p(self.flat_pT), self.st),
-                       "transpose_batched")
         B, N = self._shape
         M, k = N * self.up_ratio, K_NEIGH
         rm = B * M
@@ -623,13 +631,29 @@ class Trainer(object):
             self._merge(2)                               # h0 / h1 / wv / the inverted graph: done by the time the loss is (see _branch)
         # fine = coarse + sigmoid(z) - 0.5
         _lib.check(L.dispu_sigmoid_offset_grad(rm * 3, _p(ws["z"]), _p(dfine), _p(ws["dz"]), _p(dcoarse), self.st), "sigmoid_grad")
-        self._lin_bwd(ws["f64"], 0, 64, fs + "fc_layer2", 3, ws["dz"], 0, ws["df64"], mask=(ws["f64"], 0, 64))
-        self._lin_bwd(ws["f256"], 0, 256, fs + "fc_layer1", 64, ws["df64"], 0, ws["df256"], mask=(ws["f256"], 0, 256))
-        self._lin_bwd(ws["agg"], 0, 256, fs + "fc_layer0", 256, ws["df256"], 0, ws["dagg"], mask=(ws["agg"], 0, 256))
-        self._lin_bwd(ws["sum"], 0, 256, ps + "aggregation", 256, ws["dagg"], 0, ws["dsum"])
-        # sum = relu(after) + relu(skip) + relu(nl): the three branch gradients in one pass
-        _lib.check(L.dispu_mask3(rm, 256, _p(ws["dsum"]), 256, _p(ws["aft"]), 256, _p(ws["skip"]), 256, _p(ws["nl"]), 256, _p(ws["daft"]),
-                                 _p(ws["dskip"]), _p(ws["dnl"]), 256, self.st), "mask3")
+        ag = ps + "aggregation"
+        if self.fused_heads_bwd:
+            # fc_layer2 -> fc_layer1 -> fc_layer0 -> aggregation backward and the three branch masks of
+            # sum = relu(after) + relu(skip) + relu(nl) in ONE launch (csrc/mlp_chain_bwd.hip); the four dW products follow on the side streams
+            PT = self.PT
+            _lib.check(L.dispu_mlp_chain_grad(rm, 256, 256, 256, _p(ws["dz"]), 3, _p(P[fs + "fc_layer2/weights"]),
+                                              _p(PT[fs + "fc_layer1/weights"]), _p(PT[fs + "fc_layer0/weights"]), _p(PT[ag + "/weights"]),
+                                              _p(ws["f64"]), 64, _p(ws["f256"]), 256, _p(ws["agg"]), 256, None, 0, None, 0,
+                                              _p(ws["df64"]), 64, _p(ws["df256"]), 256, _p(ws["dagg"]), 256,
+                                              _p(ws["aft"]), _p(ws["skip"]), _p(ws["nl"]), 256, _p(ws["daft"]), _p(ws["dskip"]), _p(ws["dnl"]), 256,
+                                              self.st), "mlp_chain_grad[fine]")
+            self._lin_bwd(ws["f64"], 0, 64, fs + "fc_layer2", 3, ws["dz"], 0)
+            self._lin_bwd(ws["f256"], 0, 256, fs + "fc_layer1", 64, ws["df64"], 0)
+            self._lin_bwd(ws["agg"], 0, 256, fs + "fc_layer0", 256, ws["df256"], 0)
+            self._lin_bwd(ws["sum"], 0, 256, ag, 256, ws["dagg"], 0)
+        else:
+            self._lin_bwd(ws["f64"], 0, 64, fs + "fc_layer2", 3, ws["dz"], 0, ws["df64"], mask=(ws["f64"], 0, 64))
+            self._lin_bwd(ws["f256"], 0, 256, fs + "fc_layer1", 64, ws["df64"], 0, ws["df256"], mask=(ws["f256"], 0, 256))
+            self._lin_bwd(ws["agg"], 0, 256, fs + "fc_layer0", 256, ws["df256"], 0, ws["dagg"], mask=(ws["agg"], 0, 256))
+            self._lin_bwd(ws["sum"], 0, 256, ag, 256, ws["dagg"], 0, ws["dsum"])
+            # sum = relu(after) + relu(skip) + relu(nl): the three branch gradients in one pass
+            _lib.check(L.dispu_mask3(rm, 256, _p(ws["dsum"]), 256, _p(ws["aft"]), 256, _p(ws["skip"]), 256, _p(ws["nl"]), 256, _p(ws["daft"]),
+                                     _p(ws["dskip"]), _p(ws["dnl"]), 256, self.st), "mask3")
 
         # local cell first: the host needs ~0.1 ms to queue the two branches below, the chain must not sit idle meanwhile; the
         # branches themselves only need the mask3 outputs, so they are ordered after THIS point of the stream, not after the product
@@ -655,18 +679,24 @@ class Trainer(object):
             self._lin_bwd(ws["up128"], 0, 128, ps + "PointShuffle/conv_kv", 128, dkv, 0, dup128)
             self._lin_bwd(ws["up128"], 0, 128, ps + "PointShuffle/conv_query", 64, ws["dq"], 0, dup128, 0, acc_dx=True)
         # skip branch (a second branch): 134 -> 256 backward; its max gradient is scattered after the merges below
+        split_skip = self.fused_heads_bwd and self.overlap_dw      # the skip branch's d(up128) in its own buffer, summed in the coarse chain
         with self._branch(1, ev_br):
             self._lin_bwd(ws["gmax"], 0, 134, ps + "skip", 256, ws["dskip"], 0, ws["dgmax"])
+            if split_skip:
+                _lib.check(L.dispu_ps_skip_max_grad(rm, M, k, 128, _p(ws["psidx"]), _p(coarse), _p(ws["up128"]), 128, _p(ws["gmax"]), 144,
+                                                    _p(ws["dgmax"]), 136, _p(dcoarse), _p(ws["dup128s"]), 128, 1, self.st), "ps_skip_max_grad")
         if not (self._sched & 2):
             self._merge(2)                               # h0 / h1 / wv / the inverted graph are in place
         _lib.check(L.dispu_ps_point_matmul_grad_relu_s(rm, k, 128, 16, _p(ws["h1"]), 128, _p(ws["wv"]), _p(ws["dhp"]), 2048, _p(ws["dz1"]),
                                                        128, _p(ws["dwv"]), 1 if ws["h1"].dtype == torch.bfloat16 else 0, self.st),
                    "point_matmul_grad")
-        ww, bw = P[ps + "weight_net/wconv0/weights"], P[ps + "weight_net/wconv0/biases"]
-        _lib.check(L.dispu_ps_wnet_grad(rm, M, k, 16, _p(ws["psidx"]), _p(coarse), _p(ww), _p(bw), _p(ws["bn_stats"]), _p(ws["bn_scale"]),
-                                        _p(ws["bn_shift"]), _p(P[BN + "gamma"]), _p(ws["dwv"]), _p(G[ps + "weight_net/wconv0/weights"]),
-                                        _p(G[ps + "weight_net/wconv0/biases"]), _p(G[BN + "gamma"]), _p(G[BN + "beta"]), _p(dcoarse),
-                                        _p(ws["bn_sums"]), _p(self._bn_scratch), self._bn_scratch.numel() * 8, self.st), "ps_wnet_grad")
+        # the weight net's backward (dwv -> BatchNorm -> 3 -> 16 conv -> atomics into dcoarse) next to the conv1 / conv0 gradients
+        with self._branch(2):
+            ww, bw = P[ps + "weight_net/wconv0/weights"], P[ps + "weight_net/wconv0/biases"]
+            _lib.check(L.dispu_ps_wnet_grad(rm, M, k, 16, _p(ws["psidx"]), _p(coarse), _p(ww), _p(bw), _p(ws["bn_stats"]), _p(ws["bn_scale"]),
+                                            _p(ws["bn_shift"]), _p(P[BN + "gamma"]), _p(ws["dwv"]), _p(G[ps + "weight_net/wconv0/weights"]),
+                                            _p(G[ps + "weight_net/wconv0/biases"]), _p(G[BN + "gamma"]), _p(G[BN + "beta"]), _p(dcoarse),
+                                            _p(ws["bn_sums"]), _p(self._bn_scratch), self._bn_scratch.numel() * 8, self.st), "ps_wnet_grad")
         self._lin_bwd(ws["h0"], 0, 128, ps + "conv1", 128, ws["dz1"], 0, ws["dz0"])          # dz0 holds dh0: conv0's relu' rides in the gather
         # conv0 in its per-source-point form: dh0 * (G[j] - A[i] > 0) -> dG (gather through the inverted graph), -dA; then [B*M, 128] products
         _lib.check(L.dispu_ps_conv0_gather_grad_s(rm, M, k, 128, _p(ws["psidx"]), _p(ws["inv_off"]), _p(ws["inv"]), _p(ws["dz0"]), 128,
@@ -679,17 +709,35 @@ class Trainer(object):
         _lib.check(L.dispu_ps_prep_grad(rm, 128, _p(coarse), _p(w0), _p(ws["dG"]), 128, _p(ws["dAneg"]), 128, _p(dcoarse), _p(dw0), self.st),
                    "ps_prep_grad")
         self._merge(1)
-        _lib.check(L.dispu_ps_skip_max_grad(rm, M, k, 128, _p(ws["psidx"]), _p(coarse), _p(ws["up128"]), 128, _p(ws["gmax"]), 144,
-                                            _p(ws["dgmax"]), 136, _p(dcoarse), _p(dup128), 128, 1, self.st), "ps_skip_max_grad")
+        if not split_skip:
+            _lib.check(L.dispu_ps_skip_max_grad(rm, M, k, 128, _p(ws["psidx"]), _p(coarse), _p(ws["up128"]), 128, _p(ws["gmax"]), 144,
+                                                _p(ws["dgmax"]), 136, _p(dcoarse), _p(dup128), 128, 1, self.st), "ps_skip_max_grad")
+        self._merge(2)                                   # the weight net's share of dcoarse
 
         # coarse regressor
         cs = "generator/coarse_coordinate_regressor/"
-        self._lin_bwd(ws["c64"], 0, 64, cs + "fc_layer2", 3, dcoarse, 0, ws["dc64"], mask=(ws["c64"], 0, 64))
-        self._lin_bwd(ws["c256"], 0, 256, cs + "fc_layer1", 64, ws["dc64"], 0, ws["dc256"], mask=(ws["c256"], 0, 256))
-        # the last product that accumulates into dup128 applies conv2's relu' (up128 = relu(conv2))
-        self._lin_bwd(ws["up128"], 0, 128, cs + "fc_layer0", 256, ws["dc256"], 0, dup128, 0, acc_dx=True, mask=(ws["up128"], 0, 128))
-        # duplicate_up
-        self._lin_bwd(ws["up256"], 0, 256, "generator/upshuffle_0/conv2", 128, dup128, 0, ws["dup256"], mask=(ws["up256"], 0, 256))
+        c2 = "generator/upshuffle_0/conv2"
+        if self.fused_heads_bwd:
+            # fc_layer2 -> fc_layer1 -> fc_layer0 (+ everything already accumulated in dup128, then conv2's relu') -> conv2 (duplicate_up's
+            # relu') in one launch
+            PT = self.PT
+            _lib.check(L.dispu_mlp_chain_grad(rm, 256, 128, 256, _p(dcoarse), 3, _p(P[cs + "fc_layer2/weights"]),
+                                              _p(PT[cs + "fc_layer1/weights"]), _p(PT[cs + "fc_layer0/weights"]), _p(PT[c2 + "/weights"]),
+                                              _p(ws["c64"]), 64, _p(ws["c256"]), 256, _p(ws["up128"]), 128, _p(dup128), 128,
+                                              _p(ws["dup128s"]) if split_skip else None, 128, _p(ws["dc64"]), 64, _p(ws["dc256"]), 256, _p(dup128), 128,
+                                              _p(ws["up256"]), None, None, 256, _p(ws["dup256"]), None, None, 256, self.st),
+                       "mlp_chain_grad[coarse]")
+            self._lin_bwd(ws["c64"], 0, 64, cs + "fc_layer2", 3, dcoarse, 0)
+            self._lin_bwd(ws["c256"], 0, 256, cs + "fc_layer1", 64, ws["dc64"], 0)
+            self._lin_bwd(ws["up128"], 0, 128, cs + "fc_layer0", 256, ws["dc256"], 0)
+            self._lin_bwd(ws["up256"], 0, 256, c2, 128, dup128, 0)
+        else:
+            self._lin_bwd(ws["c64"], 0, 64, cs + "fc_layer2", 3, dcoarse, 0, ws["dc64"], mask=(ws["c64"], 0, 64))
+            self._lin_bwd(ws["c256"], 0, 256, cs + "fc_layer1", 64, ws["dc64"], 0, ws["dc256"], mask=(ws["c256"], 0, 256))
+            # the last product that accumulates into dup128 applies conv2's relu' (up128 = relu(conv2))
+            self._lin_bwd(ws["up128"], 0, 128, cs + "fc_layer0", 256, ws["dc256"], 0, dup128, 0, acc_dx=True, mask=(ws["up128"], 0, 128))
+            # duplicate_up
+            self._lin_bwd(ws["up256"], 0, 256, c2, 128, dup128, 0, ws["dup256"], mask=(ws["up256"], 0, 256))
         w1, dw1 = P["generator/upshuffle_0/conv1/weights"], G["generator/upshuffle_0/conv1/weights"]
         self._tn(1, rm, 2, 256, ws["gcode"], 0, 2, 0, ws["dup256"], 0, 256, 0, dw1, 480 * 256, 256, 0, 1,
                  dbias=G["generator/upshuffle_0/conv1/biases"])
@@ -705,18 +753,20 @@ class Trainer(object):
             if d == 1:
                 dF, dfoff, F, foff = dfeat, 456, feat, 456
             else:
-                dF, dfoff, F, foff = ws["dprep"][d], 0, ws["prep"][d], 0
-                dF.zero_()
+                dF, dfoff, F, foff = ws["dprep"][d], 0, ws["prep"][d], 0         # zero-filled in forward(), off the chain
             if self.fused_dense:
+                # the block's backward on the chain; its weight-gradient partials (a scratch buffer per block) are summed on a side stream
                 need = L.dispu_edge_dense_conv_grad_scratch_floats(rn, C)
-                scr = self._scratch_floats(need)
-                _lib.check(L.dispu_edge_dense_conv_grad(rn, N, C, _p(F, foff), F.stride(0), _p(ws["kidx"][d]), k + 1, 1,
-                                                        _p(P[sc + "/l0/weights"]), _p(P[sc + "/l0/biases"]), _p(P[sc + "/l1/weights"]),
-                                                        _p(P[sc + "/l1/biases"]), _p(P[sc + "/l2/weights"]), _p(P[sc + "/l2/biases"]),
-                                                        _p(dfeat, col), 480, _p(dF, dfoff), dF.stride(0),
-                                                        _p(G[sc + "/l0/weights"]), _p(G[sc + "/l0/biases"]), _p(G[sc + "/l1/weights"]),
-                                                        _p(G[sc + "/l1/biases"]), _p(G[sc + "/l2/weights"]), _p(G[sc + "/l2/biases"]),
-                                                        _p(scr), scr.numel(), self.st), "edge_dense_conv_grad")
+                scr = self._scratch_floats(need, "edge%d" % d)
+                _lib.check(L.dispu_edge_dense_conv_grad_partials(rn, N, C, _p(F, foff), F.stride(0), _p(ws["kidx"][d]), k + 1, 1,
+                                                                 _p(P[sc + "/l0/weights"]), _p(P[sc + "/l0/biases"]), _p(P[sc + "/l1/weights"]),
+                                                                 _p(P[sc + "/l1/biases"]), _p(P[sc + "/l2/weights"]), _p(P[sc + "/l2/biases"]),
+                                                                 _p(dfeat, col), 480, _p(dF, dfoff), dF.stride(0), _p(scr), scr.numel(), self.st),
+                           "edge_dense_conv_grad_partials")
+                st_r = self._fork()[0] if self.overlap_dw else self.st
+                _lib.check(L.dispu_edge_dense_conv_grad_reduce(rn, C, _p(scr), scr.numel(), _p(G[sc + "/l0/weights"]), _p(G[sc + "/l0/biases"]),
+                                                               _p(G[sc + "/l1/weights"]), _p(G[sc + "/l1/biases"]), _p(G[sc + "/l2/weights"]),
+                                                               _p(G[sc + "/l2/biases"]), st_r), "edge_dense_conv_grad_reduce")
             else:
                 Eb, dE = self._edge_buffers(B, N)[0][d], self._edge_buffers(B, N)[1][d]
                 lde = dE.stride(0)

@@ -396,6 +396,18 @@ int dispu_mlp_chain_stash(long rows, int K0, int N1, int N2, int N3, const float
                           const float* W2, const float* b2, const float* W3, const float* b3, const float* W4, const float* b4,
                           float* Y1, long ldy1, float* Y2, long ldy2, float* Y3, long ldy3, float* Z, long ldz, int mode,
                           const float* R, long ldr, float* out, long ldo, void* stream);
+/* Backward of dispu_mlp_chain(_stash) in one launch (csrc/mlp_chain_bwd.hip; replaces the four dX products TF autodiff generates for
+ * upshuffle conv2 + coordinate_regressor / aggregation + fine regressor, ops.py:1186-1192, 1089-1108, 1079-1083):
+ *   dY3 = (dZ.W4^T)*[Y3>0] -> D3 [rows,64];  dY2 = (dY3.W3^T)*[Y2>0] -> D2 [rows,N2];  dY1 = (dY2.W2^T + R + R2)*[Y1>0] -> D1 [rows,N1]
+ *   (R, R2 optional gradients that reached Y1 through other consumers, N1 = 128 only; D1 may alias either);  dX = dY1.W1^T -> Da / Db / Dc [rows,K0] through the masks Ma / Mb / Mc (Ma NULL: unmasked; Db, Dc
+ *   optional).  Wt3 / Wt2 / Wt1 are the TRANSPOSED forward weights, row-major [64,N2] / [N2,N1] / [N1,K0]; W4 the forward [64,3].
+ * rows % 64 == 0; (K0,N1,N2) in {(256,128,256), (256,256,256)}; 16-byte aligned pointers.  The weight gradients are separate
+ * dispu_linear_tn products over the stashed activations and D3 / D2 / D1. */
+int dispu_mlp_chain_grad(long rows, int K0, int N1, int N2, const float* dZ, long lddz, const float* W4, const float* Wt3,
+                         const float* Wt2, const float* Wt1, const float* Y3, long ldy3, const float* Y2, long ldy2,
+                         const float* Y1, long ldy1, const float* R, long ldr, const float* R2, long ldr2, float* D3, long ldd3,
+                         float* D2, long ldd2, float* D1, long ldd1, const float* Ma, const float* Mb, const float* Mc, long ldm, float* Da, float* Db,
+                         float* Dc, long ldd0, void* stream);
 /* o_i = dY * (Y_i > 0), i = 1..3: the gradients of sum = relu(after_conv) + relu(skip) + relu(non-local) (ops.py:1072-1075). */
 int dispu_mask3(long rows, int n, const float* dY, long lddy, const float* Y1, long ld1, const float* Y2, long ld2, const float* Y3,
                 long ld3, float* o1, float* o2, float* o3, long ldo, void* stream);
@@ -440,6 +452,15 @@ int dispu_edge_dense_conv_grad(int npoints, int n_per_cloud, int C, const float*
                                const float* W0, const float* b0, const float* W1, const float* b1, const float* W2, const float* b2,
                                const float* dOut, long lddo, float* dF, long lddf, float* dW0, float* db0, float* dW1, float* db1,
                                float* dW2, float* db2, float* scratch, long scratch_floats, void* stream);
+/* the same in two halves (a caller may queue the second on another stream, ordered after the first by an event, to keep the weight
+ * gradients off its critical path): _partials leaves dW* / db* as per-workgroup partial sums in `scratch`, _reduce adds them (fixed
+ * order) to dW* / db*. */
+int dispu_edge_dense_conv_grad_partials(int npoints, int n_per_cloud, int C, const float* F, long ldf, const int* idx, int ldi, int ioff,
+                                        const float* W0, const float* b0, const float* W1, const float* b1, const float* W2,
+                                        const float* b2, const float* dOut, long lddo, float* dF, long lddf, float* scratch,
+                                        long scratch_floats, void* stream);
+int dispu_edge_dense_conv_grad_reduce(int npoints, int C, const float* scratch, long scratch_floats, float* dW0, float* db0, float* dW1,
+                                      float* db1, float* dW2, float* db2, void* stream);
 /* one Chamfer term of pu_loss from dispu_nn_distance's outputs (loss_utils.py:45-64; gradient tf_nndistance.py:31-37): value[0] =
  * mean_b[(mean d_gt + mean d_pred) / radius_b]; dpred [b, n_pred, 3] = d(coef * CD)/d pred (zero-filled, then accumulated). */
 int dispu_chamfer_loss_grad(int b, int n_gt, const float* gt, int n_pred, const float* pred, const float* d_gt, const int* i_gt,

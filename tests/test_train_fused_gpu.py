@@ -325,6 +325,60 @@ def test_mlp_chain_stash_equals_separate_launches(dev, L, shape, mode):
         assert torch.equal(a, b), name
 
 
+@pytest.mark.parametrize("shape,fine,rows", [((256, 128, 256), False, 384), ((256, 256, 256), True, 384), ((256, 128, 256), False, 8192),
+                                             ((256, 256, 256), True, 64)])
+def test_mlp_chain_grad(dev, L, shape, fine, rows):
+    """dispu_mlp_chain_grad (csrc/mlp_chain_bwd.hip): the four dX products of a head chain's backward in one launch against float64
+    autograd of the chain X -> relu(X W1) -> relu(. W2) -> relu(. W3) -> . W4 (ops.py:1186-1192, 1089-1108, 1079-1083).  coarse: the
+    chain input is a ReLU output (one mask) and dY1 accumulates onto an existing gradient (R aliases D1); fine: the chain input is the
+    sum of three ReLU outputs, so dX leaves through three masks (dispu_mask3 folded in)."""
+    rng = np.random.default_rng(rows + sum(shape) + int(fine))
+    K0, N1, N2 = shape
+    Ws = [(rng.standard_normal((a, b)) / np.sqrt(a)).astype(np.float32) for a, b in ((K0, N1), (N1, N2), (N2, 64), (64, 3))]
+    bs = [(rng.standard_normal(b) * 0.1).astype(np.float32) for b in (N1, N2, 64)]
+    if fine:
+        parts = [np.maximum(rng.standard_normal((rows, K0)), 0).astype(np.float32) for _ in range(3)]
+        X = (parts[0] + parts[1] + parts[2]).astype(np.float32)
+    else:
+        parts = [np.maximum(rng.standard_normal((rows, K0)), 0).astype(np.float32)]
+        X = parts[0]
+    dZ = rng.standard_normal((rows, 3)).astype(np.float32)
+    Racc = rng.standard_normal((rows, N1)).astype(np.float32) if not fine else None
+    Racc2 = rng.standard_normal((rows, N1)).astype(np.float32) if (not fine and rows != 8192) else None
+    # float64 reference: activations as the fp32 forward stashes them (the masks), gradients by autograd
+    xt = torch.tensor(X, dtype=F64, requires_grad=True)
+    y1 = torch.relu(xt @ torch.tensor(Ws[0], dtype=F64) + torch.tensor(bs[0], dtype=F64)); y1.retain_grad()
+    y2 = torch.relu(y1 @ torch.tensor(Ws[1], dtype=F64) + torch.tensor(bs[1], dtype=F64)); y2.retain_grad()
+    y3 = torch.relu(y2 @ torch.tensor(Ws[2], dtype=F64) + torch.tensor(bs[2], dtype=F64)); y3.retain_grad()
+    z = y3 @ torch.tensor(Ws[3], dtype=F64)
+    extra = (y1 * torch.tensor(Racc, dtype=F64)).sum() if Racc is not None else 0.0        # other consumers of Y1: gradients R, R2 arrive at Y1
+    if Racc2 is not None:
+        extra = extra + (y1 * torch.tensor(Racc2, dtype=F64)).sum()
+    ((z * torch.tensor(dZ, dtype=F64)).sum() + extra).backward()
+    Y1, Y2, Y3 = (N_(t).astype(np.float32) for t in (y1, y2, y3))
+    # a unit whose float64 pre-activation is within rounding of 0 may be masked differently in fp32: keep the masks float64-exact
+    lib, st = L.lib(), L.stream_ptr(dev)
+    tY1, tY2, tY3, tdz = dv(Y1, dev), dv(Y2, dev), dv(Y3, dev), dv(dZ, dev)
+    tW4 = dv(Ws[3], dev)
+    tWt = [dv(np.ascontiguousarray(w.T), dev) for w in Ws[:3]]
+    E = lambda n: torch.full((rows, n), 7.0, dtype=torch.float32, device=dev)
+    d3, d2 = E(64), E(N2)
+    d1 = dv(Racc, dev) if Racc is not None else E(N1)
+    masks = [dv(m, dev) for m in parts]
+    outs = [E(K0) for _ in parts]
+    pm = lambda i: p(masks[i]) if i < len(masks) else None
+    po = lambda i: p(outs[i]) if i < len(outs) else None
+    L.check(lib.dispu_mlp_chain_grad(rows, K0, N1, N2, p(tdz), 3, p(tW4), p(tWt[2]), p(tWt[1]), p(tWt[0]), p(tY3), 64, p(tY2), N2, p(tY1), N1,
+                                     p(d1) if Racc is not None else None, N1, p(dv(Racc2, dev)) if Racc2 is not None else None, N1, p(d3), 64, p(d2), N2, p(d1), N1, pm(0), pm(1), pm(2), K0,
+                                     po(0), po(1), po(2), K0, st), "mlp_chain_grad")
+    # autograd's .grad of a ReLU OUTPUT is the gradient before that ReLU's own mask; the kernel's D is after it
+    close(N_(d3), y3.grad.numpy() * (Y3 > 0), 1e-5, "dY3")
+    close(N_(d2), y2.grad.numpy() * (Y2 > 0), 1e-5, "dY2")
+    close(N_(d1), y1.grad.numpy() * (Y1 > 0), 1e-5, "dY1")
+    for m, o, name in zip(parts, outs, "abc"):
+        close(N_(o), xt.grad.numpy() * (m > 0), 1e-5, "dX through mask " + name)
+
+
 @pytest.mark.parametrize("C,B,n", [(24, 2, 256), (48, 2, 256), (48, 1, 100), (24, 3, 36)])
 def test_edge_dense_conv_grad(dev, L, C, B, n):
     """dense_conv + get_edge_feature backward in one launch (csrc/edge_bwd.hip: forward recomputed on chip) against float64 autograd
