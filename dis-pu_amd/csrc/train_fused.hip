@@ -496,32 +496,73 @@ __global__ __launch_bounds__(256) void ps_skip_max_grad_kernel(long rows, int n_
 
 // ---- feature x weight product backward with the ReLU of conv1 folded in (csrc/train_ops.hip:ps_point_matmul_grad_kernel) -------
 // dz1[(i,s), c] = (h1 > 0) * sum_t dout[i, c*16 + t] wv[(i,s), t];  dwv[(i,s), t] = sum_c h1[(i,s), c] dout[i, c*16 + t]
+// Round-3 rewrite: the first version kept dout / h1 / wv of a point in LDS and read two LDS words per multiply-add (512 LDS reads per
+// lane and point: 86 us for 8192 points, LDS-issue-bound, 3x its HBM time).  Now
+//   dz1: lane (c, half) holds its dout row [c][0..15] in REGISTERS (four ds_read_b128) and its eight h1 values,
+//        reads wv[s][0..15] as four broadcast ds_read_b128 per s -> 32 LDS reads for 128 multiply-adds, coalesced stores over c;
+//   dwv: lane (s, t-quad, c-quarter) walks 32 channels with one ds_read_b32 (h1) + one ds_read_b128 (dout) per 4 multiply-adds, the four
+//        channel quarters are added through DPP in a fixed order.
 template <class TS>
 __global__ __launch_bounds__(256) void ps_point_matmul_grad_relu_kernel(long rows, const TS* __restrict__ X2, long ldx2,
                                                                          const float* __restrict__ wv, const TS* __restrict__ dout,
                                                                          long ldo, TS* __restrict__ dX2, long lddx2,
                                                                          float* __restrict__ dwv) {
-    constexpr int K = 16, T = 16, C = 128;
-    __shared__ float s_do[C * (T + 1)];
-    __shared__ float s_x[K][C + 1];
-    __shared__ float s_w[K][T + 1];
+    constexpr int K = 16, T = 16, C = 128, LDO = T + 4, LDX = C + 1;
+    __shared__ __attribute__((aligned(16))) float s_do[C * LDO];
+    __shared__ float s_x[K * LDX];
+    __shared__ __attribute__((aligned(16))) float s_w[K * T];
+    const int tid = threadIdx.x;
+    const int c = tid & 127, half = tid >> 7;                    // phase 1 role
+    const int s2 = tid >> 4, tq = (tid >> 2) & 3, cp = tid & 3;  // phase 2 role
     for (long i = blockIdx.x; i < rows; i += gridDim.x) {
-        for (int e = threadIdx.x; e < C * T; e += 256) s_do[(e >> 4) * (T + 1) + (e & 15)] = tf_ld1(dout + i * ldo + e);
-        for (int e = threadIdx.x; e < K * C; e += 256) s_x[e / C][e % C] = tf_ld1(X2 + (i * K + e / C) * ldx2 + e % C);
-        s_w[threadIdx.x >> 4][threadIdx.x & 15] = wv[(i * K) * T + threadIdx.x];
+        // coalesced float4 loads (a lane-per-row read of dout would touch every 64-byte line four times), transposed through LDS
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int idx = tid + u * 256;
+            *reinterpret_cast<float4*>(&s_do[(idx >> 2) * LDO + (idx & 3) * 4]) = tf_ld4(dout + i * ldo + idx * 4);
+            const float4 x = tf_ld4(X2 + (i * K + (idx >> 5)) * ldx2 + (idx & 31) * 4);
+            float* xr = &s_x[(idx >> 5) * LDX + (idx & 31) * 4];
+            xr[0] = x.x; xr[1] = x.y; xr[2] = x.z; xr[3] = x.w;
+        }
+        s_w[tid] = wv[(i * K) * T + tid];
         __syncthreads();
-        for (int e = threadIdx.x; e < K * C; e += 256) {
-            const int s = e / C, c = e - s * C;
+        float4 d[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) d[q] = *reinterpret_cast<const float4*>(&s_do[c * LDO + q * 4]);
+        float hx[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) hx[j] = s_x[(half * 8 + j) * LDX + c];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int s = half * 8 + j;
+            const float4* w4 = reinterpret_cast<const float4*>(&s_w[s * T]);
             float a = 0.f;
 #pragma unroll
-            for (int t = 0; t < T; ++t) a = __builtin_fmaf(s_do[c * (T + 1) + t], s_w[s][t], a);
-            tf_st1(dX2 + (i * K + s) * lddx2 + c, (s_x[s][c] > 0.f) ? a : 0.f);
+            for (int q = 0; q < 4; ++q) {
+                const float4 w = w4[q];
+                a = __builtin_fmaf(d[q].x, w.x, a);
+                a = __builtin_fmaf(d[q].y, w.y, a);
+                a = __builtin_fmaf(d[q].z, w.z, a);
+                a = __builtin_fmaf(d[q].w, w.w, a);
+            }
+            tf_st1(dX2 + (i * K + s) * lddx2 + c, (hx[j] > 0.f) ? a : 0.f);
         }
         {
-            const int s = threadIdx.x >> 4, t = threadIdx.x & 15;
-            float a = 0.f;
-            for (int c = 0; c < C; ++c) a = __builtin_fmaf(s_x[s][c], s_do[c * (T + 1) + t], a);
-            dwv[(i * K + s) * T + t] = a;
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 8
+            for (int j = 0; j < 32; ++j) {
+                const int cc = j * 4 + cp;
+                const float x = s_x[s2 * LDX + cc];
+                const float4 v = *reinterpret_cast<const float4*>(&s_do[cc * LDO + tq * 4]);
+                acc.x = __builtin_fmaf(x, v.x, acc.x);
+                acc.y = __builtin_fmaf(x, v.y, acc.y);
+                acc.z = __builtin_fmaf(x, v.z, acc.z);
+                acc.w = __builtin_fmaf(x, v.w, acc.w);
+            }
+            // (q0 + q1) + (q2 + q3) over the four channel quarters, the same on every lane of the quad
+            acc.x += __shfl_xor(acc.x, 1, 64); acc.y += __shfl_xor(acc.y, 1, 64); acc.z += __shfl_xor(acc.z, 1, 64); acc.w += __shfl_xor(acc.w, 1, 64);
+            acc.x += __shfl_xor(acc.x, 2, 64); acc.y += __shfl_xor(acc.y, 2, 64); acc.z += __shfl_xor(acc.z, 2, 64); acc.w += __shfl_xor(acc.w, 2, 64);
+            if (cp == 0) *reinterpret_cast<float4*>(dwv + (i * K + s2) * T + tq * 4) = acc;
         }
         __syncthreads();
     }
