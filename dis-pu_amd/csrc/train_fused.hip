@@ -340,13 +340,24 @@ __global__ __launch_bounds__(256) void ps_conv0_gather_grad_kernel(long rows, in
         ap = *reinterpret_cast<const float4*>(Am + p * ldam + sub * 4);
     }
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int s = 0; s < k; ++s) {
-        float4 v = tf_ld4(zc + (size_t)(pl * k + s) * ldz + sub * 4);
-        if (msk) {
-            const long j = base + idx[p * k + s];
-            v = c0_masked(v, *reinterpret_cast<const float4*>(Gm + j * ldgm + sub * 4), ap);
+    // the point's own k pair rows, 8 at a time (as a rolled loop with a run-time trip count every row waited for its own loads:
+    // 16 dependent round trips per point); added in ascending s as before
+    const int mine = msk ? idx[p * k + (sub < k ? sub : 0)] : 0;
+    for (int s0 = 0; s0 < k; s0 += 8) {
+        float4 v[8], gj[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int s = (s0 + u < k) ? s0 + u : k - 1;
+            v[u] = tf_ld4(zc + (size_t)(pl * k + s) * ldz + sub * 4);
+            if (msk) gj[u] = *reinterpret_cast<const float4*>(Gm + (base + __shfl(mine, s, 32)) * ldgm + sub * 4);
         }
-        a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (s0 + u < k) {
+                const float4 w = msk ? c0_masked(v[u], gj[u], ap) : v[u];
+                a.x += w.x; a.y += w.y; a.z += w.z; a.w += w.w;
+            }
+        }
     }
     *reinterpret_cast<float4*>(dAneg + p * lda + sub * 4) = make_float4(-a.x, -a.y, -a.z, -a.w);
     const int* __restrict__ o = off + cloud * (n_per_cloud + 1);
@@ -354,6 +365,22 @@ __global__ __launch_bounds__(256) void ps_conv0_gather_grad_kernel(long rows, in
     const int lo = o[pl], hi = o[pl + 1];
     float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
     int e = lo;
+    for (; e + 8 <= hi; e += 8) {                               // eight in-edge rows in flight; summed in list order
+        int ee[8];
+        float4 v[8], am[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) ee[u] = iv[e + u];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            v[u] = tf_ld4(zc + (size_t)ee[u] * ldz + sub * 4);
+            if (msk) am[u] = *reinterpret_cast<const float4*>(Am + (base + ee[u] / k) * ldam + sub * 4);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const float4 w = msk ? c0_masked(v[u], gp, am[u]) : v[u];
+            g.x += w.x; g.y += w.y; g.z += w.z; g.w += w.w;
+        }
+    }
     for (; e + 4 <= hi; e += 4) {
         const int e0 = iv[e], e1 = iv[e + 1], e2 = iv[e + 2], e3 = iv[e + 3];
         float4 v0 = tf_ld4(zc + (size_t)e0 * ldz + sub * 4);
@@ -400,23 +427,41 @@ __global__ __launch_bounds__(256) void ps_prep_grad_kernel(long rows, const floa
     float acc[6][2];
 #pragma unroll
     for (int r = 0; r < 6; ++r) acc[r][0] = acc[r][1] = 0.f;
-    for (long p = (long)blockIdx.x * 4 + wave; p < rows; p += (long)gridDim.x * 4) {
-        const float2 g = *reinterpret_cast<const float2*>(dG + p * ldg + c0);
-        const float2 a = *reinterpret_cast<const float2*>(dAneg + p * lda + c0);
-        const float x[3] = {xyz[p * 3 + 0], xyz[p * 3 + 1], xyz[p * 3 + 2]};
-        const float sx = g.x + a.x, sy = g.y + a.y;
-        float o[3];
+    // four points of the wave per iteration: their loads are requested together (one point at a time the wave walked its 8 points as
+    // 8 dependent round trips); the sums are formed in the same point order as before
+    const long stride = (long)gridDim.x * 4;
+    for (long p0 = (long)blockIdx.x * 4 + wave; p0 < rows; p0 += 4 * stride) {
+        float2 g4[4], a4[4];
+        float x4[4][3];
 #pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            acc[r][0] = __builtin_fmaf(x[r], sx, acc[r][0]); acc[r][1] = __builtin_fmaf(x[r], sy, acc[r][1]);
-            acc[3 + r][0] = __builtin_fmaf(x[r], g.x, acc[3 + r][0]); acc[3 + r][1] = __builtin_fmaf(x[r], g.y, acc[3 + r][1]);
-            // dxyz_r = sum_c dG_c (Wc + Wr)[r][c] + dAneg_c Wc[r][c]
-            float v = g.x * (wc[r][0] + wr[r][0]) + g.y * (wc[r][1] + wr[r][1]);
-            v = __builtin_fmaf(a.x, wc[r][0], v);
-            v = __builtin_fmaf(a.y, wc[r][1], v);
-            o[r] = wave_sum_f32(v);
+        for (int u = 0; u < 4; ++u) {
+            const long p = p0 + u * stride;
+            const bool ok = p < rows;
+            const long q = ok ? p : p0;
+            g4[u] = *reinterpret_cast<const float2*>(dG + q * ldg + c0);
+            a4[u] = *reinterpret_cast<const float2*>(dAneg + q * lda + c0);
+            x4[u][0] = xyz[q * 3 + 0]; x4[u][1] = xyz[q * 3 + 1]; x4[u][2] = xyz[q * 3 + 2];
         }
-        if (lane < 3) unsafeAtomicAdd(dxyz + p * 3 + lane, lane == 0 ? o[0] : lane == 1 ? o[1] : o[2]);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long p = p0 + u * stride;
+            if (p >= rows) break;
+            const float2 g = g4[u], a = a4[u];
+            const float* x = x4[u];
+            const float sx = g.x + a.x, sy = g.y + a.y;
+            float o[3];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                acc[r][0] = __builtin_fmaf(x[r], sx, acc[r][0]); acc[r][1] = __builtin_fmaf(x[r], sy, acc[r][1]);
+                acc[3 + r][0] = __builtin_fmaf(x[r], g.x, acc[3 + r][0]); acc[3 + r][1] = __builtin_fmaf(x[r], g.y, acc[3 + r][1]);
+                // dxyz_r = sum_c dG_c (Wc + Wr)[r][c] + dAneg_c Wc[r][c]
+                float v = g.x * (wc[r][0] + wr[r][0]) + g.y * (wc[r][1] + wr[r][1]);
+                v = __builtin_fmaf(a.x, wc[r][0], v);
+                v = __builtin_fmaf(a.y, wc[r][1], v);
+                o[r] = wave_sum_f32(v);
+            }
+            if (lane < 3) unsafeAtomicAdd(dxyz + p * 3 + lane, lane == 0 ? o[0] : lane == 1 ? o[1] : o[2]);
+        }
     }
 #pragma unroll
     for (int r = 0; r < 6; ++r) { red[wave][r][c0] = acc[r][0]; red[wave][r][c0 + 1] = acc[r][1]; }
