@@ -86,7 +86,7 @@ def launch_flops(name, B):
     """ALGORITHMIC flops of one launch of the MFMA kernels of the step, by launch label (shapes: SURVEY.md Appendix A,
     Common/ops.py:1012-1087, :302-346, :1089-1110, :1856-1915).  None: not an MFMA kernel (k-NN selection, gathers, heads)."""
     n, m, k = NPOINT, NPOINT * UP, 16
-    if name.startswith("linear<") or name.startswith("linear_skinny<"):
+    if name.startswith(("linear<", "linear_skinny<")):
         return linear_flops(name)
     if name == "ps_local":                       # conv1 128 -> 128 over 16 neighbours, weight net 3 -> 16, feature x weight 16 x 16 x 128
         return 2.0 * B * m * k * (128 * 128 + 3 * 16 + 16 * 128)
@@ -128,7 +128,7 @@ def cpu_baseline(target_seconds=14.0, with_ops=True):
     return out
 
 
-def train_step_table(dev, steps=10, warmup=3):
+def train_step_table(dev, steps=20, warmup=4):
     """Side table `roofline.train_step` (BASELINE configs[4]'s per-GPU share: 8 patches per GPU, full train step = training-mode forward,
     pu_loss, backward, gradient all-reduce (a no-op on one rank), Adam): ms per step eager and hipGraph-replayed, fp32 and bf16, plus the
     B = 32 step; `mfma_frac` prices 3 x the forward's executed flops against the fp32 MFMA peak (a lower bound on the work: the backward
@@ -139,7 +139,7 @@ def train_step_table(dev, steps=10, warmup=3):
     from dispu_amd.train import Trainer
     P = init_params(1234)
     out = {}
-    for dtype, B, graphed in (("f32", 8, False), ("f32", 8, True), ("bf16", 8, False), ("bf16", 8, True), ("f32", 32, True)):
+    for dtype, B, graphed in (("f32", 8, False), ("f32", 8, True), ("bf16", 8, False), ("bf16", 8, True), ("f32", 32, False), ("f32", 32, True)):
         tr = Trainer(params=P, device=dev, dtype=dtype)
         x, gt = synth.patch_with_gt(B, NPOINT, NPOINT * UP, seed=5000)
         x, gt = torch.from_numpy(x).to(dev), torch.from_numpy(gt).to(dev)
