@@ -132,35 +132,31 @@ def train_step_table(dev, steps=20, warmup=4):
     """Side table `roofline.train_step` (BASELINE configs[4]'s per-GPU share: 8 patches per GPU, full train step = training-mode forward,
     pu_loss, backward, gradient all-reduce (a no-op on one rank), Adam): ms per step eager and hipGraph-replayed, fp32 and bf16, plus the
     B = 32 step; `mfma_frac` prices 3 x the forward's executed flops against the fp32 MFMA peak (a lower bound on the work: the backward
-    recomputes the dense blocks and conv1)."""
-    import torch
-    from dispu_amd import synth
-    from dispu_amd.params import init_params
-    from dispu_amd.train import Trainer
-    P = init_params(1234)
+    recomputes the dense blocks and conv1).  Every row is tools/train_bench.py in a FRESH process: how HIP maps the step's streams onto
+    its hardware queues depends on how many streams the process created before; inside this process, after the
+    headline / per-op benches, the same step measured 10 - 15 % slower than on its own."""
+    import subprocess
     out = {}
-    for dtype, B, graphed in (("f32", 8, False), ("f32", 8, True), ("bf16", 8, False), ("bf16", 8, True), ("f32", 32, False), ("f32", 32, True)):
-        tr = Trainer(params=P, device=dev, dtype=dtype)
-        x, gt = synth.patch_with_gt(B, NPOINT, NPOINT * UP, seed=5000)
-        x, gt = torch.from_numpy(x).to(dev), torch.from_numpy(gt).to(dev)
-        radius = torch.ones(B, device=dev)
-        fn = tr.train_step_graphed if graphed else tr.train_step
-        for _ in range(warmup):
-            fn(x, gt, radius)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            fn(x, gt, radius)
-        torch.cuda.synchronize()
-        ms = (time.perf_counter() - t0) / steps * 1e3
+    for dtype, B, graphed in (("f32", 8, False), ("f32", 8, True), ("bf16", 8, False), ("bf16", 8, True), ("f32", 32, False)):
+        cmd = [sys.executable, os.path.join(ROOT, "tools", "train_bench.py"), "--batch", str(B), "--steps", str(steps), "--warmup", str(warmup),
+               "--dtype", dtype] + (["--graph"] if graphed else [])
+        env = dict(os.environ)
+        for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+            env.pop(k, None)
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, env=env)
+        key = "%s_b%d_%s" % (dtype, B, "hipgraph" if graphed else "eager")
+        if r.returncode != 0:
+            out[key] = {"error": r.stderr.decode(errors="replace")[-300:]}
+            continue
+        d = json.loads(r.stdout.decode().strip().splitlines()[-1])
+        ms = d["ms_per_step"]
         flops = 3.0 * 2.0 * step_macs_per_patch() * B
-        out["%s_b%d_%s" % (dtype, B, "hipgraph" if graphed else "eager")] = {
-            "ms_per_step": round(ms, 4), "patches_per_s": round(B / ms * 1e3, 1),
-            "mfma_frac": round(flops / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4)}
-        del tr
-        torch.cuda.empty_cache()
-    out["note"] = ("full train step (forward in training mode + pu_loss + backward + Adam) on one GPU; mfma_frac = 3 x forward flops / time / "
-                   "%.1f TFLOP/s fp32 MFMA peak; bf16 = bf16 products AND bf16 storage of the local cell's pair tensors" % FP32_MFMA_PEAK_TFLOPS)
+        out[key] = {"ms_per_step": round(ms, 4), "patches_per_s": round(B / ms * 1e3, 1),
+                    "mfma_frac": round(flops / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
+                    "forward_ms": d.get("forward_ms"), "loss_ms": d.get("loss_ms"), "backward_ms": d.get("backward_ms")}
+    out["note"] = ("full train step (forward in training mode + pu_loss + backward + Adam) on one GPU, each row tools/train_bench.py in its own "
+                   "process; mfma_frac = 3 x forward flops / time / %.1f TFLOP/s fp32 MFMA peak; bf16 = bf16 products AND bf16 storage of the "
+                   "local cell's pair tensors" % FP32_MFMA_PEAK_TFLOPS)
     return out
 
 

@@ -44,6 +44,22 @@ class TrainOpts(_Opts):
     repulsion_w = 1.0
 
 
+# Streams are shared by every Trainer of a process (per device): HIP maps streams onto a few hardware queues in creation order, and
+# which streams end up sharing a queue decides how well the step overlaps -- a second Trainer with streams of
+# its own got a different mapping and a 10 - 15 % slower step (bench.py's side table: 2.2 ms for the bf16 step that takes 1.9 ms in a
+# fresh process).  Trainers of one process run one after the other on the host thread, so sharing is safe: events order the work.
+_STREAM_POOL = {}
+
+
+def _pool_stream(device, kind, i):
+    key = (torch.device(device).index or 0, kind, i)
+    st = _STREAM_POOL.get(key)
+    if st is None:
+        with torch.cuda.device(device):
+            st = _STREAM_POOL[key] = torch.cuda.Stream(device=device)
+    return st
+
+
 def weight_fine(epoch):
     """model.py:52-54 piecewise_constant(epoch, [10, 20, 30], [0.01, 0.1, 0.5, 1.0])."""
     return 0.01 if epoch <= 10 else 0.1 if epoch <= 20 else 0.5 if epoch <= 30 else 1.0
@@ -229,7 +245,7 @@ class Trainer(object):
     def _side_next(self):
         if not self._sides:
             n = max(1, int(os.environ.get("DISPU_TRAIN_DW_STREAMS", "2")))
-            self._sides = [torch.cuda.Stream(device=self.device) for _ in range(n)]
+            self._sides = [_pool_stream(self.device, "dw", j) for j in range(n)]
             self._fork_ev = torch.cuda.Event()
             self._join_evs = [torch.cuda.Event() for _ in range(n)]
             self._side_busy = [False] * n
@@ -275,7 +291,7 @@ class Trainer(object):
             yield
             return
         while len(self._aux) <= i:
-            self._aux.append((torch.cuda.Stream(device=self.device), torch.cuda.Event(), torch.cuda.Event()))
+            self._aux.append((_pool_stream(self.device, "aux", len(self._aux)), torch.cuda.Event(), torch.cuda.Event()))
         aux, ev_fork, ev_done = self._aux[i]
         if after is None:
             ev_fork.record(torch.cuda.current_stream(self.device))

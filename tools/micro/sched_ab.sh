@@ -1,33 +1,6 @@
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_generator_gpu.py tests/test_headline_gpu.py tests/test_train_fused_gpu.py tests/test_train_gpu.py -m gpu -x -q 2>&1 | tail -4
-python - <<'PY'
-import ctypes as C, torch, sys, os
-sys.path.insert(0, os.getcwd())
-from dispu_amd import _lib
-dev=torch.device("cuda:0"); L=_lib.lib(); p=lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
-for (M,N,act,res) in ((131072,128,1,False),(131072,128,0,True),(32768,256,1,False),(32768,384,0,False),(65536,128,0,False)):
-    X=torch.randn(M,128,device=dev); W=torch.randn(128,N,device=dev)/11; b=torch.randn(N,device=dev); R=torch.randn(M,N,device=dev) if res else None
-    outs=[]
-    for env in ("1","0"):
-        Y=torch.empty(M,N,device=dev)
-        def call(st, Y=Y):
-            _lib.check(L.dispu_linear(1,M,128,N,p(X),128,0,p(W),N,0,0,p(b),act,p(Y),N,0,p(R),N if res else 0,0,None,0,0,st),"lin")
-        # the env switch is read once per process: compare against the masked entry with mcols=0?  -> use tile override instead
-        outs.append((Y,call))
-    Y,call=outs[0]
-    call(_lib.stream_ptr(dev)); torch.cuda.synchronize()
-    g=torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g):
-        st=_lib.stream_ptr(dev)
-        for _ in range(10): call(st)
-    g.replay(); torch.cuda.synchronize()
-    e0,e1=torch.cuda.Event(enable_timing=True),torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(5): g.replay()
-    e1.record(); torch.cuda.synchronize()
-    us=e0.elapsed_time(e1)*1e3/50
-    ref=torch.relu(X.double()@W.double()+b.double()) if act else X.double()@W.double()+b.double()
-    if res: ref=ref+R.double()
-    err=float((Y.double()-ref).abs().max()/ref.abs().max())
-    print("M %d N %d act %d res %d: %.1f us %.1f TFLOP/s err %.2e"%(M,N,act,res,us,2.0*M*128*N/us/1e6,err))
-PY
+T0=$(date +%s)
+python bench.py > gpurun_out/bench_sub.json 2> gpurun_out/bench_sub.err
+echo "bench.py wall: $(( $(date +%s) - T0 )) s"
+python -c "
+import json;d=json.load(open('gpurun_out/bench_sub.json'));print(d['value'],d['ms_per_step']);print(json.dumps(d['roofline']['train_step'],indent=0)[:1500])"
