@@ -132,9 +132,8 @@ def train_step_table(dev, steps=20, warmup=4):
     """Side table `roofline.train_step` (BASELINE configs[4]'s per-GPU share: 8 patches per GPU, full train step = training-mode forward,
     pu_loss, backward, gradient all-reduce (a no-op on one rank), Adam): ms per step eager and hipGraph-replayed, fp32 and bf16, plus the
     B = 32 step; `mfma_frac` prices 3 x the forward's executed flops against the fp32 MFMA peak (a lower bound on the work: the backward
-    recomputes the dense blocks and conv1).  Every row is tools/train_bench.py in a FRESH process: how HIP maps the step's streams onto
-    its hardware queues depends on how many streams the process created before; inside this process, after the
-    headline / per-op benches, the same step measured 10 - 15 % slower than on its own."""
+    recomputes the dense blocks and conv1).  Every row is tools/train_bench.py in a FRESH process: inside this one, after the headline /
+    per-op benches and the Trainers of the earlier rows, the same step measured 10 - 15 % slower than on its own (2.2 vs 1.9 ms)."""
     import subprocess
     out = {}
     for dtype, B, graphed in (("f32", 8, False), ("f32", 8, True), ("bf16", 8, False), ("bf16", 8, True), ("f32", 32, False)):

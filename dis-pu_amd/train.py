@@ -44,10 +44,10 @@ class TrainOpts(_Opts):
     repulsion_w = 1.0
 
 
-# Streams are shared by every Trainer of a process (per device): HIP maps streams onto a few hardware queues in creation order, and
-# which streams end up sharing a queue decides how well the step overlaps -- a second Trainer with streams of
-# its own got a different mapping and a 10 - 15 % slower step (bench.py's side table: 2.2 ms for the bf16 step that takes 1.9 ms in a
-# fresh process).  Trainers of one process run one after the other on the host thread, so sharing is safe: events order the work.
+# Streams are shared by every Trainer of a process (per device): HIP maps streams onto a few hardware queues, and a process that
+# builds Trainer after Trainer (bench.py's side table, the test suite) would otherwise keep adding streams to them.  Trainers of one
+# process run one after the other on the host thread, so sharing is safe: events order the work.  (Which of torch's pooled streams
+# the step gets does not matter: skipping 0 - 7 of them first leaves the step at 1.945 ms.)
 _STREAM_POOL = {}
 
 

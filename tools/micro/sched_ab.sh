@@ -1,6 +1,5 @@
 cd $GRAFT_REPO_ROOT
-T0=$(date +%s)
-python bench.py > gpurun_out/bench_sub.json 2> gpurun_out/bench_sub.err
-echo "bench.py wall: $(( $(date +%s) - T0 )) s"
-python -c "
-import json;d=json.load(open('gpurun_out/bench_sub.json'));print(d['value'],d['ms_per_step']);print(json.dumps(d['roofline']['train_step'],indent=0)[:1500])"
+run() { python tools/train_bench.py "$@" 2>/dev/null | python -c 'import json,sys; d=json.loads(sys.stdin.read()); print(round(d["ms_per_step"],4), d["forward_ms"], d["loss_ms"], d["backward_ms"])'; }
+for r in 0 1 2 3 4 5 6 7; do
+  echo "ROT=$r f32: $(DISPU_STREAM_ROT=$r run)   bf16: $(DISPU_STREAM_ROT=$r run --dtype bf16)   b32: $(DISPU_STREAM_ROT=$r run --batch 32)"
+done
