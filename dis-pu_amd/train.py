@@ -123,6 +123,7 @@ class Trainer(object):
         self._join_ev = None
         self._sched = int(os.environ.get("DISPU_TRAIN_SCHED", "1"))
         self.fused_heads_bwd = os.environ.get("DISPU_TRAIN_FUSED_HEADS_BWD", "1") != "0"
+        self.bf16_min_macs = float(os.environ.get("DISPU_TRAIN_BF16_MIN_MACS", "1.5e9"))
 
         self._side_busy = []
         self.P = None
@@ -321,8 +322,14 @@ class Trainer(object):
     def _dl(self, batch, M, K, N, *rest):
         """dispu_linear, or its bf16-product twin when the trainer runs mixed precision (narrow 3-wide layers stay fp32)."""
         L = _lib.lib()
-        fn = L.dispu_linear_bf16 if (self.bf16 and K > 4 and N > 4) else L.dispu_linear
+        fn = L.dispu_linear_bf16 if self._use_bf16(batch, M, K, N) else L.dispu_linear
         return fn(batch, M, K, N, *rest)
+
+    def _use_bf16(self, batch, M, K, N):
+        """bf16 products for this GEMM?  Mixed precision is per product: the narrow 3-wide layers always stay fp32, and so do products
+        below `bf16_min_macs` multiply-adds -- at 8192 rows the K <= 256 products are launch / prologue-bound and the bf16 kernel (fp32
+        operands rounded on their way into LDS) is no faster than the fp32 one, often slower (24 - 29 us vs 15 - 24 us)."""
+        return self.bf16 and K > 4 and N > 4 and float(batch) * M * K * N >= self.bf16_min_macs
 
     def _lin(self, X, xoff, K, wname, act, Y, yoff, N, M=None, bias=True, W=None, woff=0):
         """Y[:, yoff:yoff+N] = act(X[:, xoff:xoff+K] . W + b)"""
@@ -343,14 +350,14 @@ class Trainer(object):
         """out (+)= X^T . Zt.  side=True: on the second stream (the caller guarantees nothing overwrites X / Zt before _join)."""
         L = _lib.lib()
         side = side and self.overlap_dw
-        bf = self.bf16 and K > 4 and N > 4
+        sto = (1 if X.dtype == torch.bfloat16 else 0) | (2 if Zt.dtype == torch.bfloat16 else 0)
+        bf = self._use_bf16(batch, M, K, N) or bool(sto)
         need = (L.dispu_linear_tn_bf16_scratch_floats if bf else L.dispu_linear_tn_scratch_floats)(batch, M, K, N)
         if side:
             st, key = self._fork_after(after) if after is not None else self._fork()
         else:
             st, key = self.st, None
         sc = self._scratch_floats(need, key)
-        sto = (1 if X.dtype == torch.bfloat16 else 0) | (2 if Zt.dtype == torch.bfloat16 else 0)
         if sto:
             assert bf and xoff == 0 and zoff == 0
             _lib.check(L.dispu_linear_tn_bf16s(batch, M, K, N, _p(X), ldx, sx, _p(Zt), ldz, sz, _p(out, ooff), ldo, so, accumulate, _p(dbias), _p(sc),
@@ -374,7 +381,7 @@ class Trainer(object):
         ReLU output that fed this layer -- the relu_grad of the layer below rides in the GEMM epilogue (no separate pass over dX).
         WT: the step's transposed copy of W ([N, K] row-major): the product then runs untransposed (the forward GEMM's fast path)."""
         L = _lib.lib()
-        bf = self.bf16 and K > 4 and N > 4
+        bf = self._use_bf16(1, M, N, K)
         r1 = _p(dX, dxoff) if acc else None
         ldr = dX.stride(0) if acc else 0
         if WT is not None:
@@ -383,7 +390,7 @@ class Trainer(object):
             wp, ldw, tb = _p(W, woff), W.stride(0), 1
         sto = (1 if dY.dtype == torch.bfloat16 else 0) | (4 if dX.dtype == torch.bfloat16 else 0)
         if sto:
-            assert bf and mask is None and not acc and dyoff == 0 and dxoff == 0
+            assert self.bf16 and mask is None and not acc and dyoff == 0 and dxoff == 0
             _lib.check(L.dispu_linear_bf16s(1, M, N, K, _p(dY), dY.stride(0), 0, wp, ldw, 0, tb, None, 0, _p(dX), dX.stride(0), 0, None, 0, 0,
                                             sto, self.st), "dispu_linear_bf16s(dX)")
             return
