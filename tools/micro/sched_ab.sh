@@ -1,6 +1,8 @@
 cd $GRAFT_REPO_ROOT
+GEMM_SHAPES=train python tools/gemm_bench.py 0 2>&1 | grep -v amdgpu.ids
+python tools/gemm_bench.py 0 2>&1 | grep -v amdgpu.ids
 run() { python tools/train_bench.py "$@" 2>/dev/null | python -c 'import json,sys; d=json.loads(sys.stdin.read()); print(round(d["ms_per_step"],4), d["forward_ms"], d["loss_ms"], d["backward_ms"])'; }
-for t in 0 2e8 6e8 1.5e9 3e9 1e12; do
-  echo "MIN_MACS=$t bf16 b8: $(DISPU_TRAIN_BF16_MIN_MACS=$t run --dtype bf16)   b32: $(DISPU_TRAIN_BF16_MIN_MACS=$t run --dtype bf16 --batch 32)"
-done
-DISPU_TRAIN_BF16_MIN_MACS=1.5e9 timeout 600 python -m pytest tests/test_train_bf16_gpu.py tests/test_distributed_gpu.py -m gpu -x -q 2>&1 | tail -3
+echo "f32 b8: $(run)   bf16 b8: $(run --dtype bf16)   f32 b32: $(run --batch 32)"
+timeout 900 python -m pytest tests/test_generator_gpu.py tests/test_headline_gpu.py tests/test_train_gpu.py -m gpu -x -q 2>&1 | tail -3
+python bench.py --no-cpu-baseline --no-ops 2>/dev/null | cut -c1-200
+python tools/config_bench.py 2>/dev/null | head -8
