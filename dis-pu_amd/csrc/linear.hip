@@ -489,7 +489,7 @@ DISPU_EXPORT int dispu_linear_tile(int batch, int M, int N) {
     if (ov > 0) return ov;
     const long mb128 = (long)((M + 127) / 128) * batch;
     if (N >= 256 && N % 256 == 0 && mb128 * (N / 256) >= 256) return 128257;   // 128x256 tile, BK 16: 64x128 per wave
-    if (N > 64 && N % 128 != 0 && N % 64 == 0 && mb128 >= 64) return 128064;   // e.g. N = 320: five full 64-wide tiles beat a half-empty edge tile
+    if (N > 64 && N % 128 != 0 && N % 64 == 0 && mb128 >= 64) return 64064;    // e.g. N = 320: five full 64-wide tiles beat a half-empty edge tile (64 x 64: 34 us, 128 x 64: 41 us at 32768 x 128 x 320)
     // fewer than 512 workgroups of 64 x 128: 64 x 64 tiles (8192 rows x 128 columns: 13.8 -> 8.6 us, 2048 x 480: 22.6 -> 12.7 us)
     const long mb64 = (long)((M + 63) / 64) * batch;
     if (N > 64) return (mb128 * ((N + 127) / 128) >= 256) ? 128128 : (mb64 * ((N + 127) / 128) >= 512 ? 64128 : 64064);
