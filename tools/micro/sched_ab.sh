@@ -1,3 +1,3 @@
 cd $GRAFT_REPO_ROOT
-python bench.py --no-cpu-baseline --no-ops 2>/dev/null | cut -c1-240
-timeout 900 python -m pytest tests/test_generator_gpu.py tests/test_headline_gpu.py -m gpu -x -q 2>&1 | tail -2
+bash tools/prof_train.sh r03_h_train 8 > /dev/null 2>&1
+cat gpurun_out/r03_h_train/bench.json | cut -c1-300
