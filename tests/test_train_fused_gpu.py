@@ -2,6 +2,7 @@
 float64 torch autograd of the forward op each one differentiates -- 1e-5, like tests/test_train_gpu.py.  The reference has no
 native code here (TF1 autodiff, DisPU/model.py:158-178); the forward ops are Common/ops.py:1012-1087 (PointShuffle2)."""
 import ctypes as C
+import ctypes
 
 import numpy as np
 import pytest
@@ -422,3 +423,21 @@ def test_edge_dense_conv_grad(dev, L, C, B, n):
         close(N_(dF).reshape(B, n, C), (rep + 1) * ft.grad.numpy(), 2e-5, "dF")
         for kk in P:
             close(N_(dW[kk]), (rep + 1) * Pt[kk].grad.numpy(), 2e-5, kk)
+    # the two-halves form (weight-gradient sums on another stream in the training step): the same weight gradients, bit for bit
+    dF2 = torch.zeros((rows, C), dtype=torch.float32, device=dev)
+    dW2 = {kk: torch.zeros(v.shape, dtype=torch.float32, device=dev) for kk, v in P.items()}
+    side = torch.cuda.Stream(device=dev)
+    for rep in range(2):
+        L.check(lib.dispu_edge_dense_conv_grad_partials(rows, n, C, p(tF), C, p(ti), k + 1, 1, p(tp["s/l0/weights"]), p(tp["s/l0/biases"]),
+                                                        p(tp["s/l1/weights"]), p(tp["s/l1/biases"]), p(tp["s/l2/weights"]), p(tp["s/l2/biases"]),
+                                                        p(dv(g, dev)), 72 + C, p(dF2), C, p(sc), need, st), "edge_dense_conv_grad_partials")
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(dev))
+        side.wait_event(ev)
+        L.check(lib.dispu_edge_dense_conv_grad_reduce(rows, C, p(sc), need, p(dW2["s/l0/weights"]), p(dW2["s/l0/biases"]), p(dW2["s/l1/weights"]),
+                                                      p(dW2["s/l1/biases"]), p(dW2["s/l2/weights"]), p(dW2["s/l2/biases"]),
+                                                      ctypes.c_void_p(side.cuda_stream)), "edge_dense_conv_grad_reduce")
+        torch.cuda.current_stream(dev).wait_stream(side)                      # the next pass overwrites the partials
+    for kk in P:
+        assert torch.equal(dW2[kk], dW[kk]), kk
+    close(N_(dF2).reshape(B, n, C), 2 * ft.grad.numpy(), 2e-5, "dF (two halves)")
