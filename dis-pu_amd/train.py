@@ -509,25 +509,28 @@ class Trainer(object):
                                       M * 64, None, 0, 0, None, 0, 0, self.st), "att.V")
             self._lin(ws["att"], 0, 64, ps + "PointShuffle/conv_back_project", 1, ws["nl"], 0, 256)
 
-        # PointShuffle2 (ops.py:1012-1087) in the inference path's form: no [B, M, 16, 134] grouped tensor
-        _lib.check(L.dispu_knn_xyz(B, M, M, k, _p(coarse), _p(coarse), _p(ws["psidx"]), None, _lib.ARITH_PLAIN, self.st), "knn_xyz")
-        # skip (a second branch next to the local cell): gather-max straight from xyz / up128, then 134 -> 256
-        with self._branch(1):
-            _lib.check(L.dispu_ps_skip_max(rm, M, k, 128, _p(ws["psidx"]), _p(coarse), _p(up128), 128, _p(ws["gmax"]), 144, self.st), "skip_max")
-            self._lin(ws["gmax"], 0, 134, ps + "skip", 1, ws["skip"], 0, 256)
-        # local cell: conv0 per source point (G = up128.Wf + xyz.(Wc + Wr) + b0, A = xyz.Wc; h0 = relu(G[j] - A[i])), weight_net
-        # BatchNorm on batch statistics straight from the neighbour offsets, then the fused cell (conv1, weight_net, feature x weight)
-        w0 = P[ps + "conv0/weights"]
-        self._lin(up128, 0, 128, None, 0, ws["gm"], 0, 128, bias=False, W=w0, woff=6 * 128)
-        _lib.check(L.dispu_ps_prep(rm, 128, _p(coarse), _p(w0), _p(P[ps + "conv0/biases"]), _p(ws["gm"]), 128, _p(ws["am"]), 128, self.st), "ps_prep")
+        # PointShuffle2 (ops.py:1012-1087) in the inference path's form: no [B, M, 16, 134] grouped tensor.  The k-NN graph and the
+        # weight net's BatchNorm statistics (from the neighbour offsets) on a branch, next to the per-point halves of conv0
+        # (G = up128.Wf + xyz.(Wc + Wr) + b0, A = xyz.Wc; h0 = relu(G[j] - A[i])) that need neither
         ww, bw = P[ps + "weight_net/wconv0/weights"], P[ps + "weight_net/wconv0/biases"]
         nb = L.dispu_ps_wnet_scratch_bytes(rm)
         if self._bn_scratch is None or self._bn_scratch.numel() * 8 < nb:
             self._bn_scratch = torch.empty((nb + 7) // 8, dtype=torch.float64, device=self.device)
-        _lib.check(L.dispu_ps_wnet_bn_stats(rm, M, k, 16, _p(ws["psidx"]), _p(coarse), _p(ww), _p(bw), _p(P[BN + "gamma"]), _p(P[BN + "beta"]),
-                                            BN_EPS, BN_DECAY, _p(ws["bn_stats"]), _p(ws["bn_scale"]), _p(ws["bn_shift"]),
-                                            _p(self.moving_mean), _p(self.moving_var), _p(self._bn_scratch), self._bn_scratch.numel() * 8,
-                                            self.st), "ps_wnet_bn_stats")
+        with self._branch(2):
+            _lib.check(L.dispu_knn_xyz(B, M, M, k, _p(coarse), _p(coarse), _p(ws["psidx"]), None, _lib.ARITH_PLAIN, self.st), "knn_xyz")
+            _lib.check(L.dispu_ps_wnet_bn_stats(rm, M, k, 16, _p(ws["psidx"]), _p(coarse), _p(ww), _p(bw), _p(P[BN + "gamma"]), _p(P[BN + "beta"]),
+                                                BN_EPS, BN_DECAY, _p(ws["bn_stats"]), _p(ws["bn_scale"]), _p(ws["bn_shift"]),
+                                                _p(self.moving_mean), _p(self.moving_var), _p(self._bn_scratch), self._bn_scratch.numel() * 8,
+                                                self.st), "ps_wnet_bn_stats")
+        w0 = P[ps + "conv0/weights"]
+        self._lin(up128, 0, 128, None, 0, ws["gm"], 0, 128, bias=False, W=w0, woff=6 * 128)
+        _lib.check(L.dispu_ps_prep(rm, 128, _p(coarse), _p(w0), _p(P[ps + "conv0/biases"]), _p(ws["gm"]), 128, _p(ws["am"]), 128, self.st), "ps_prep")
+        self._merge(2)
+        # skip (a second branch next to the local cell): gather-max straight from xyz / up128, then 134 -> 256
+        with self._branch(1):
+            _lib.check(L.dispu_ps_skip_max(rm, M, k, 128, _p(ws["psidx"]), _p(coarse), _p(up128), 128, _p(ws["gmax"]), 144, self.st), "skip_max")
+            self._lin(ws["gmax"], 0, 134, ps + "skip", 1, ws["skip"], 0, 256)
+        # the fused cell (conv1, weight_net with the folded BatchNorm, feature x weight)
         _lib.check(L.dispu_ps_local(rm, M, k, 128, _p(ws["psidx"]), _p(coarse), _p(ws["gm"]), 128, _p(ws["am"]),
                                     _p(P[ps + "conv1/weights"]), _p(P[ps + "conv1/biases"]), _p(ww), _p(bw), _p(ws["bn_scale"]),
                                     _p(ws["bn_shift"]), _p(ws["hp"]), self.st), "ps_local")
