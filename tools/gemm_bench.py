@@ -7,7 +7,7 @@ import subprocess
 import sys
 
 TRAIN_SHAPES = [(8192, 256, 256), (8192, 256, 128), (8192, 128, 256), (8192, 64, 256), (8192, 256, 2048), (8192, 128, 128), (8192, 256, 64),
-                (8192, 128, 64), (131072, 128, 128), (2048, 256, 480), (8192, 256, 134)]        # dX / forward products of the 8-patch training step
+                (8192, 128, 64), (131072, 128, 128), (2048, 256, 480), (8192, 256, 134), (8192, 2048, 256), (8192, 134, 256), (2048, 480, 256)]        # dX / forward products of the 8-patch training step
 SHAPES = TRAIN_SHAPES if os.environ.get("GEMM_SHAPES") == "train" else [(32768, 2048, 256), (524288, 128, 128), (32768, 256, 256), (8192, 480, 256), (32768, 256, 128),
           (32768, 128, 256), (32768, 134, 256), (32768, 128, 128), (32768, 64, 256), (32768, 256, 64), (8192, 360, 48),
           (32768, 144, 256), (32768, 128, 320), (8192, 120, 48), (8192, 240, 48)]
