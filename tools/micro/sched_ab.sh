@@ -1,2 +1,2 @@
 cd $GRAFT_REPO_ROOT
-GEMM_SHAPES=train python tools/gemm_bench.py 0 64064 64128 128064 128128 128257 2>&1 | grep "8192x2048x256\|8192x 134x256\|2048x 480x256\|=="
+python tools/micro/c4_graph.py 2>&1 | grep -v amdgpu.ids | tail -5
