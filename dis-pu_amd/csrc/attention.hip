@@ -44,7 +44,15 @@ __global__ __launch_bounds__(512) void flash_attention_kernel(int m, int nk, con
                                                                const float* __restrict__ Wbp, const float* __restrict__ bbp) {
     extern __shared__ __attribute__((aligned(16))) float lds[];       // [2 * FA_STAGE] (+ W [64][256] when BP)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int cloud = blockIdx.y;
+    // XCD-aware (cloud, query block): workgroup ids go round-robin over the 8 XCDs, so the query blocks of ONE cloud (consecutive ids)
+    // landed on all eight and every L2 fetched that cloud's K | V (counter traffic 3x the algorithmic bytes).  With a cloud count that
+    // is a multiple of 8 each XCD gets whole clouds.
+    int cloud = blockIdx.y, qblk = blockIdx.x;
+    if ((gridDim.y & 7u) == 0) {
+        const unsigned lin = blockIdx.x + gridDim.x * blockIdx.y, slot = lin >> 3;
+        cloud = (int)((lin & 7u) * (gridDim.y >> 3) + slot / gridDim.x);
+        qblk = (int)(slot % gridDim.x);
+    }
     const float* __restrict__ kb = K + (size_t)cloud * nk * ldk;
     const float* __restrict__ vb = V + (size_t)cloud * nk * ldv;
     const int ntile = nk / FA_TK;
@@ -101,7 +109,7 @@ __global__ __launch_bounds__(512) void flash_attention_kernel(int m, int nk, con
     }
 
     // ------------------------------------------------------------------------------------------ MFMA waves
-    const int qrow = blockIdx.x * 128 + wave * 32 + (lane & 31);
+    const int qrow = qblk * 128 + wave * 32 + (lane & 31);
     const int kh = lane >> 5, li = lane & 31;
     const bool qok = qrow < m;
     const float* __restrict__ qp = Q + ((size_t)cloud * m + (qok ? qrow : 0)) * ldq;

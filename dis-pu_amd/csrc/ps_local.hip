@@ -242,8 +242,15 @@ __global__ __launch_bounds__(512) void ps_local_ws_kernel(long npoints, int n_pe
     float* cxbuf = abuf + 2 * 1024;                                  // [128 pairs][4]: x_j - x_i
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int np = (int)npoints;
-    const int ng = (np + 7) / 8, gstep = (int)gridDim.x;
-    if ((int)blockIdx.x >= ng) return;
+    // group -> workgroup: workgroup ids go round-robin over the 8 XCDs; with group = id + n * grid every XCD touched every cloud and each
+    // L2 fetched every cloud's G / A rows.  When the counts divide, XCD x (ids = x mod 8) walks ONE contiguous eighth of the groups --
+    // whole clouds -- with its own workgroups striding through it.
+    const int ng_all = (np + 7) / 8;
+    const bool xcd_map = ((gridDim.x & 7u) == 0) && (ng_all % 8 == 0) && ((int)gridDim.x <= ng_all);
+    const int gstep = xcd_map ? (int)(gridDim.x >> 3) : (int)gridDim.x;
+    const int g_first = xcd_map ? (int)(blockIdx.x & 7u) * (ng_all / 8) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    const int ng = xcd_map ? ((int)(blockIdx.x & 7u) + 1) * (ng_all / 8) : ng_all;      // end of this workgroup's range
+    if (g_first >= ng) return;
     constexpr int NTILE = PL_K / PL_BK;                              // 4 slabs of 32
 
     if (wave >= 4) {
@@ -350,7 +357,7 @@ __global__ __launch_bounds__(512) void ps_local_ws_kernel(long npoints, int n_pe
             const int kr = e >> 5, nq = e & 31;
             *reinterpret_cast<float4*>(&wres[kr * PW_LDB + nq * 4]) = *reinterpret_cast<const float4*>(W1 + (size_t)kr * PL_BN + nq * 4);
         }
-        int g = blockIdx.x;
+        int g = g_first;
         rows_of(g, goff);
         load_arow(g);
         store_arow(abuf);
@@ -476,7 +483,7 @@ __global__ __launch_bounds__(512) void ps_local_ws_kernel(long npoints, int n_pe
         const unsigned off = (live && pi < np) ? ((unsigned)pi * 2048u + (unsigned)(ch * 16 + t0)) * 4u : 0xFFFFFFF0u;
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), out_rsrc, (int)off, 0, 0);
     };
-    for (int g = blockIdx.x; g < ng; g += gstep, ++n) {
+    for (int g = g_first; g < ng; g += gstep, ++n) {
         const bool have_prev = n > 0;
         f32x4 acc[4][4];
 #pragma unroll

@@ -329,7 +329,7 @@ __global__ __launch_bounds__(256) void ps_conv0_gather_grad_kernel(long rows, in
                                                                     long ldgm, const float* __restrict__ Am, long ldam, float* __restrict__ dG,
                                                                     long ldg, float* __restrict__ dAneg, long lda) {
     const int sub = threadIdx.x & 31;
-    const long p = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 5;
+    const long p = ((long)xcd_block(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x) >> 5;
     if (p >= rows) return;
     const long cloud = p / n_per_cloud, pl = p - cloud * n_per_cloud, base = cloud * n_per_cloud;
     const TZ* __restrict__ zc = dz0 + (size_t)cloud * n_per_cloud * k * ldz;           // this cloud's pair rows
@@ -483,7 +483,7 @@ __global__ __launch_bounds__(256) void ps_skip_max_grad_kernel(long rows, int n_
                                                                 const float* __restrict__ dgmax, long ldd, float* __restrict__ dxyz,
                                                                 float* __restrict__ dfeat, long lddf, int feat_is_relu) {
     const int sub = threadIdx.x & 31;
-    const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 5;
+    const long i = ((long)xcd_block(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x) >> 5;
     if (i >= rows) return;
     const long base = (i / n_per_cloud) * n_per_cloud;
     const int mine = idx[i * 16 + (sub & 15)];
