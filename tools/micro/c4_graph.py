@@ -1,5 +1,6 @@
 import os, sys, torch, time
-sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tools"))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
 from dispu_amd import synth, upsample as U
 from dispu_amd.generator import Generator
 from dispu_amd.params import init_params
