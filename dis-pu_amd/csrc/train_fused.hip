@@ -85,12 +85,35 @@ __global__ __launch_bounds__(256) void ps_wnet_stats_kernel(long rows, int n_per
     __shared__ double red[2][256];
     const int s = threadIdx.x >> 4, t = threadIdx.x & 15;
     double s1 = 0.0, s2 = 0.0;
-    for (long i = blockIdx.x; i < rows; i += gridDim.x) {
-        const long j = (i / n_per_cloud) * n_per_cloud + idx[i * WN_K + s];
-        float dx, dy, dz;
-        const double v = wn_wl(xyz, i, j, Ww, bw, t, dx, dy, dz);
-        s1 += v;
-        s2 += v * v;
+    // four points per pass, their index / coordinate loads requested together (one point per pass the workgroup walked its points
+    // as a chain of dependent id -> xyz round trips); summed in the same point order
+    const float w0 = Ww[0 * WN_T + t], w1 = Ww[1 * WN_T + t], w2 = Ww[2 * WN_T + t], bt = bw[t];
+    for (long i0 = blockIdx.x; i0 < rows; i0 += 4 * (long)gridDim.x) {
+        long ii[4], jj[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            ii[u] = min(i0 + u * (long)gridDim.x, rows - 1);
+            jj[u] = (ii[u] / n_per_cloud) * n_per_cloud + idx[ii[u] * WN_K + s];
+        }
+        float ox[4], oy[4], oz[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            ox[u] = xyz[jj[u] * 3 + 0] - xyz[ii[u] * 3 + 0];
+            oy[u] = xyz[jj[u] * 3 + 1] - xyz[ii[u] * 3 + 1];
+            oz[u] = xyz[jj[u] * 3 + 2] - xyz[ii[u] * 3 + 2];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (i0 + u * (long)gridDim.x < rows) {
+                float acc = 0.f;                                         // wn_wl's chain
+                acc = __builtin_fmaf(ox[u], w0, acc);
+                acc = __builtin_fmaf(oy[u], w1, acc);
+                acc = __builtin_fmaf(oz[u], w2, acc);
+                const double v = acc + bt;
+                s1 += v;
+                s2 += v * v;
+            }
+        }
     }
     red[0][threadIdx.x] = s1;
     red[1][threadIdx.x] = s2;
@@ -112,9 +135,16 @@ __global__ __launch_bounds__(64) void ps_wnet_stats_finalize_kernel(long count, 
                                                                      float* __restrict__ moving_mean, float* __restrict__ moving_var) {
     const int ch = blockIdx.x;
     double a = 0.0, b = 0.0;
-    for (int p = threadIdx.x; p < nparts; p += 64) {
-        a += part[((size_t)p * 2 + 0) * WN_T + ch];
-        b += part[((size_t)p * 2 + 1) * WN_T + ch];
+    for (int p0 = threadIdx.x; p0 < nparts; p0 += 8 * 64) {      // eight partials per lane requested together (was a chain of round trips)
+        double va[8], vb[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int p = p0 + u * 64;
+            va[u] = p < nparts ? part[((size_t)p * 2 + 0) * WN_T + ch] : 0.0;
+            vb[u] = p < nparts ? part[((size_t)p * 2 + 1) * WN_T + ch] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { a += va[u]; b += vb[u]; }
     }
     a = tf_wave_sum(a);
     b = tf_wave_sum(b);
@@ -147,15 +177,38 @@ __global__ __launch_bounds__(256) void ps_wnet_grad_stats_kernel(long rows, int 
     const int s = threadIdx.x >> 4, t = threadIdx.x & 15;
     const float mu = stats[t], is = stats[2 * WN_T + t], sc = scale[t], sh = shift[t];
     double s1 = 0.0, s2 = 0.0;
-    for (long i = blockIdx.x; i < rows; i += gridDim.x) {
-        const long j = (i / n_per_cloud) * n_per_cloud + idx[i * WN_K + s];
-        float dx, dy, dz;
-        const float wl = wn_wl(xyz, i, j, Ww, bw, t, dx, dy, dz);
-        const float wv = wl * sc + sh;
-        const float u = (wv > 0.f) ? dwv[(i * WN_K + s) * WN_T + t] : 0.f;
-        const float xh = (wl - mu) * is;
-        s1 += (double)u;
-        s2 += (double)u * (double)xh;
+    const float w0 = Ww[0 * WN_T + t], w1 = Ww[1 * WN_T + t], w2 = Ww[2 * WN_T + t], bt = bw[t];
+    for (long i0 = blockIdx.x; i0 < rows; i0 += 4 * (long)gridDim.x) {      // four points per pass (see ps_wnet_stats_kernel)
+        long ii[4], jj[4];
+        float g[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            ii[u] = min(i0 + u * (long)gridDim.x, rows - 1);
+            jj[u] = (ii[u] / n_per_cloud) * n_per_cloud + idx[ii[u] * WN_K + s];
+            g[u] = dwv[(ii[u] * WN_K + s) * WN_T + t];
+        }
+        float ox[4], oy[4], oz[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            ox[u] = xyz[jj[u] * 3 + 0] - xyz[ii[u] * 3 + 0];
+            oy[u] = xyz[jj[u] * 3 + 1] - xyz[ii[u] * 3 + 1];
+            oz[u] = xyz[jj[u] * 3 + 2] - xyz[ii[u] * 3 + 2];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (i0 + u * (long)gridDim.x < rows) {
+                float acc = 0.f;
+                acc = __builtin_fmaf(ox[u], w0, acc);
+                acc = __builtin_fmaf(oy[u], w1, acc);
+                acc = __builtin_fmaf(oz[u], w2, acc);
+                const float wl = acc + bt;
+                const float wv = wl * sc + sh;
+                const float uu = (wv > 0.f) ? g[u] : 0.f;
+                const float xh = (wl - mu) * is;
+                s1 += (double)uu;
+                s2 += (double)uu * (double)xh;
+            }
+        }
     }
     red[0][threadIdx.x] = s1;
     red[1][threadIdx.x] = s2;
@@ -173,9 +226,16 @@ __global__ __launch_bounds__(64) void ps_wnet_grad_finalize_kernel(int nparts, c
                                                                     float* __restrict__ dgamma, float* __restrict__ dbeta) {
     const int ch = blockIdx.x;
     double a = 0.0, b = 0.0;
-    for (int p = threadIdx.x; p < nparts; p += 64) {
-        a += part[((size_t)p * 2 + 0) * WN_T + ch];
-        b += part[((size_t)p * 2 + 1) * WN_T + ch];
+    for (int p0 = threadIdx.x; p0 < nparts; p0 += 8 * 64) {      // eight partials per lane requested together (was a chain of round trips)
+        double va[8], vb[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int p = p0 + u * 64;
+            va[u] = p < nparts ? part[((size_t)p * 2 + 0) * WN_T + ch] : 0.0;
+            vb[u] = p < nparts ? part[((size_t)p * 2 + 1) * WN_T + ch] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { a += va[u]; b += vb[u]; }
     }
     a = tf_wave_sum(a);
     b = tf_wave_sum(b);
