@@ -766,7 +766,7 @@ class Trainer(object):
             self._lin_bwd(ws["up256"], 0, 256, c2, 128, dup128, 0, ws["dup256"], mask=(ws["up256"], 0, 256))
         w1, dw1 = P["generator/upshuffle_0/conv1/weights"], G["generator/upshuffle_0/conv1/weights"]
         self._tn(1, rm, 2, 256, ws["gcode"], 0, 2, 0, ws["dup256"], 0, 256, 0, dw1, 480 * 256, 256, 0, 1,
-                 dbias=G["generator/upshuffle_0/conv1/biases"])
+                 dbias=G["generator/upshuffle_0/conv1/biases"], side=True)     # read by Adam only: off the chain like every other dW
         _lib.check(L.dispu_dup_sum_grad(B, N, 256, self.up_ratio, _p(ws["dup256"]), 256, _p(ws["dh256"]), 256, self.st), "dup_sum_grad")
         feat, dfeat = ws["feat"], ws["dfeat"]
         self._lin_bwd(feat, 0, 480, None, 256, ws["dh256"], 0, dfeat, 0, bias=False, W=w1, dW=dw1)
