@@ -224,6 +224,7 @@ int knn_feat_chunked_dispatch(int b, int n, int m, int c, int k, int ldp, int ld
 
 // 1024 < n <= 8192, k <= 32 (knn_wave.hip): per-chunk wave kernel + merge; needs caller scratch
 size_t knn_xyz_chunked_scratch(int b, int n, int m, int k);
+int knn_xyz_lds_dispatch(int b, int n, int m, int k, const float* s, const float* q, int* idx, float* dist, int arith, hipStream_t st);
 int knn_xyz_chunked_dispatch(int b, int n, int m, int k, const float* s, const float* q, int* idx, float* dist, void* scratch,
                              size_t scratch_bytes, int arith, hipStream_t st);
 // general path (knn_general.hip): any k <= 4096, c <= 4096, any n; mode 0/1 xyz plain/contract, 2 knn_point, 3 knn_point_2
@@ -245,6 +246,8 @@ DISPU_EXPORT int dispu_knn_xyz(int b, int n, int m, int k, const float* support,
     if (!(arith & DISPU_KNN_LANE_PER_QUERY)) {       // fast path: wave-per-query (knn_wave.hip), n <= 1024
         const int rc = knn_xyz_wave_dispatch(b, n, m, k, support, query, idx, dist, arith, st);
         if (rc >= 0) return rc;
+        const int rl = knn_xyz_lds_dispatch(b, n, m, k, support, query, idx, dist, arith, st);     // 1024 < n <= 4096, no scratch needed
+        if (rl >= 0) return rl;
     }
     if (k <= 4) return launch_xyz<4>(b, n, m, k, support, query, idx, dist, arith, st);
     if (k <= 8) return launch_xyz<8>(b, n, m, k, support, query, idx, dist, arith, st);

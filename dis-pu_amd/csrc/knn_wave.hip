@@ -603,6 +603,141 @@ int knn_xyz_wave_dispatch(int b, int n, int m, int k, const float* s, const floa
     return launch_xyz_wave<16>(b, n, m, k, s, q, idx, dist, arith, st);
 }
 
+// ---- 1024 < n <= 4096 (round 3): ONE pass per query over the whole cloud ---------------------------------------------------------
+// The chunked path below runs the n <= 1024 kernel once per 1024-candidate chunk and merges: every chunk pays the selection again
+// (lane minima, 64-lane bitonic sort, 16 ballot compactions, rank: ~240 of its ~490 wave instructions per query) and the merge is a
+// third launch -- 413 us at (32, 4096, 4096, 16).  Here the cloud's coordinates sit in LDS (SoA, 48 KB; candidates past n are +inf), a
+// wave owns a query, every lane evaluates 64 candidates (lane rotation as above), and the threshold / compaction / rank runs ONCE per
+// query; a 64-candidate row without a survivor costs a compare and a scalar branch.  Same keys, same order: (distance, index).
+constexpr int KXL_N = 4096, KXL_R = KXL_N / 64, KXL_CAP = 128;
+
+__device__ __forceinline__ uint32_t kxl_wave_min_u32(uint32_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = min(v, (uint32_t)__shfl_xor((int)v, o, 64));
+    return v;
+}
+
+constexpr int KXL_W = 8;                                                   // waves per workgroup: two workgroups (2 x 57 KB of LDS) give a CU 16 waves
+template <bool FMA>
+__global__ __launch_bounds__(64 * KXL_W, 4) void knn_xyz_lds_kernel(int n, int m, int k, int qpb, const float* __restrict__ support,
+                                                          const float* __restrict__ query, int* __restrict__ idx, float* __restrict__ dist) {
+    extern __shared__ __attribute__((aligned(16))) float kxl_lds[];
+    float* cxs = kxl_lds;
+    float* cys = cxs + KXL_N;
+    float* czs = cys + KXL_N;
+    uint64_t* bufs = reinterpret_cast<uint64_t*>(czs + KXL_N);            // [KXL_W waves][KXL_CAP + 4]
+    const int cloud = blockIdx.y, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const float* __restrict__ s = support + (size_t)cloud * n * 3;
+    const float* __restrict__ q = query + (size_t)cloud * m * 3;
+    // LDS slot (r, l) holds candidate 64 r + ((l + 17 r) & 63): the lane rotation of the n <= 1024 kernel, applied when the cloud is
+    // staged, so that the distance loop reads slot 64 r + lane with an immediate offset (rotating in the loop cost 64 index registers)
+    for (int e = threadIdx.x; e < KXL_N; e += 64 * KXL_W) {
+        const bool ok = e < n;
+        const int r = e >> 6, l = ((e & 63) - 17 * r) & 63;
+        cxs[64 * r + l] = ok ? s[e * 3 + 0] : __builtin_inff();
+        cys[64 * r + l] = ok ? s[e * 3 + 1] : __builtin_inff();
+        czs[64 * r + l] = ok ? s[e * 3 + 2] : __builtin_inff();
+    }
+    __syncthreads();
+    uint64_t* buf = bufs + wave * (KXL_CAP + 4);
+    const int q0 = blockIdx.x * qpb, q1 = min(m, q0 + qpb);
+    for (int qv = q0 + wave; qv < q1; qv += KXL_W) {
+        const int qi = __builtin_amdgcn_readfirstlane(qv);
+        const float qx = q[qi * 3 + 0], qy = q[qi * 3 + 1], qz = q[qi * 3 + 2];
+        uint32_t od[KXL_R];
+        uint32_t dmin = 0xFFFFFFFFu;
+#pragma unroll
+        for (int rb = 0; rb < KXL_R; rb += 8) {
+            __builtin_amdgcn_sched_barrier(0);        // 8 candidates' LDS reads in flight at a time: hoisting all 192 spilled the kernel
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int r = rb + u;
+                od[r] = __float_as_uint(sqdist3<FMA>(qx - cxs[64 * r + lane], qy - cys[64 * r + lane], qz - czs[64 * r + lane]));   // +inf: padding
+                dmin = min(dmin, od[r]);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // k distinct candidates are <= the k-th smallest lane minimum; never admit the padding (+inf)
+        uint32_t T = (uint32_t)__builtin_amdgcn_readlane((int)wave_bitonic_sort_u32(dmin, lane), k - 1);
+        T = min(T, 0x7F7FFFFFu);
+        int cnt = 0;
+#pragma unroll
+        for (int r = 0; r < KXL_R; ++r) {
+            const bool flag = od[r] <= T;
+            const unsigned long long mk = __ballot(flag);
+            if (mk) {                                                     // wave-uniform: most rows have no survivor
+                const int pos = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0u));
+                int lq = lane;
+                asm volatile("" : "+v"(lq));                              // keeps the 64 candidate ids from being hoisted out of the query loop
+                if (flag && cnt + pos < KXL_CAP) (buf + cnt)[pos] = ((uint64_t)od[r] << 32) | (uint32_t)(64 * r + ((lq + 17 * r) & 63));
+                cnt += __popcll(mk);
+            }
+        }
+        const size_t o = ((size_t)cloud * m + qi) * k;
+        if (cnt <= KXL_CAP) {
+            // rank of every survivor among the survivors (keys are distinct): the survivor of rank t < k IS result t
+            if (lane < 4) buf[cnt + lane] = KEY_MAX;                      // the loop reads in fours
+            const uint64_t m0 = (lane < cnt) ? buf[lane] : KEY_MAX;
+            const uint64_t m1 = (lane + 64 < cnt) ? buf[lane + 64] : KEY_MAX;
+            int r0 = 0, r1 = 0;
+            for (int j = 0; j < cnt; j += 4) {
+                const uint64_t a0 = buf[j], a1 = buf[j + 1], a2 = buf[j + 2], a3 = buf[j + 3];
+                r0 += (int)(a0 < m0) + (int)(a1 < m0) + (int)(a2 < m0) + (int)(a3 < m0);
+                r1 += (int)(a0 < m1) + (int)(a1 < m1) + (int)(a2 < m1) + (int)(a3 < m1);
+            }
+            if (lane < cnt && r0 < k) {
+                idx[o + r0] = (int)(uint32_t)m0;
+                if (dist) dist[o + r0] = __uint_as_float((uint32_t)(m0 >> 32));
+            }
+            if (lane + 64 < cnt && r1 < k) {
+                idx[o + r1] = (int)(uint32_t)m1;
+                if (dist) dist[o + r1] = __uint_as_float((uint32_t)(m1 >> 32));
+            }
+        } else {
+            // degenerate clouds (more than 128 candidates within the bound: many equal distances): k rounds of a wave arg-min over the
+            // keys larger than the last one taken -- slow, exact, rare
+            uint64_t last = 0;
+            bool first = true;
+            for (int t = 0; t < k; ++t) {
+                uint64_t best = KEY_MAX;
+#pragma unroll 1
+                for (int r = 0; r < KXL_R; ++r) {                         // distances recomputed (same arithmetic): no register array here
+                    const int p = 64 * r + ((lane + 17 * r) & 63);
+                    const uint32_t w = __float_as_uint(sqdist3<FMA>(qx - cxs[64 * r + lane], qy - cys[64 * r + lane], qz - czs[64 * r + lane]));
+                    const uint64_t key = ((uint64_t)w << 32) | (uint32_t)p;
+                    if (w <= 0x7F7FFFFFu && (first || key > last) && key < best) best = key;
+                }
+                const uint32_t hi = kxl_wave_min_u32((uint32_t)(best >> 32));
+                const uint32_t lo = kxl_wave_min_u32(((uint32_t)(best >> 32) == hi) ? (uint32_t)best : 0xFFFFFFFFu);
+                last = ((uint64_t)hi << 32) | lo;
+                first = false;
+                if (lane == 0) {
+                    idx[o + t] = (int)lo;
+                    if (dist) dist[o + t] = __uint_as_float(hi);
+                }
+            }
+        }
+    }
+}
+
+// -1: shape outside this path
+int knn_xyz_lds_dispatch(int b, int n, int m, int k, const float* s, const float* q, int* idx, float* dist, int arith, hipStream_t st) {
+    static const int off = [] { const char* e = getenv("DISPU_KNN_LDS"); return (e && *e == '0') ? 1 : 0; }();   // A/B: the chunked path
+    if (off || n <= 1024 || n > KXL_N || k > 32) return -1;
+    const size_t bytes = (size_t)3 * KXL_N * sizeof(float) + (size_t)KXL_W * (KXL_CAP + 4) * sizeof(uint64_t);
+    static DevOnce attr;
+    if (attr.needed()) {
+        DISPU_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(knn_xyz_lds_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+        DISPU_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(knn_xyz_lds_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+        attr.done();
+    }
+    const int qpb = 16 * KXL_W;                                           // 16 queries per wave behind one staging of the cloud
+    dim3 grid((m + qpb - 1) / qpb, b);
+    if (arith & DISPU_ARITH_CONTRACT) hipLaunchKernelGGL((knn_xyz_lds_kernel<true>), grid, dim3(64 * KXL_W), bytes, st, n, m, k, qpb, s, q, idx, dist);
+    else hipLaunchKernelGGL((knn_xyz_lds_kernel<false>), grid, dim3(64 * KXL_W), bytes, st, n, m, k, qpb, s, q, idx, dist);
+    return (int)hipGetLastError();
+}
+
 // ---- 1024 < n <= 8192: the cloud is cut into nc balanced chunks of <= 1024 candidates, the wave kernel above finds every
 // chunk's k nearest (exact, ties -> lower index) into caller scratch, and knn_xyz_merge_kernel merges the nc sorted lists by
 // (distance, global index).  Any global k-nearest neighbour is among its chunk's k nearest, so the result equals one scan
@@ -648,6 +783,10 @@ size_t knn_xyz_chunked_scratch(int b, int n, int m, int k) {
 // -1: shape outside this path / scratch too small
 int knn_xyz_chunked_dispatch(int b, int n, int m, int k, const float* s, const float* q, int* idx, float* dist, void* scratch,
                              size_t scratch_bytes, int arith, hipStream_t st) {
+    {
+        const int rl = knn_xyz_lds_dispatch(b, n, m, k, s, q, idx, dist, arith, st);      // 1024 < n <= 4096: one pass, no scratch
+        if (rl >= 0) return rl;
+    }
     const size_t need = knn_xyz_chunked_scratch(b, n, m, k);
     if (need == 0 || !scratch || scratch_bytes < need) return -1;
     const int nc = (n + 1023) / 1024, cs = (n + nc - 1) / nc;

@@ -544,6 +544,27 @@ def test_knn_xyz_chunked_path(ops, dev, b, n, m, k):
     assert np.array_equal(N(i3), oi1) and np.array_equal(N(d3), od1)
 
 
+@pytest.mark.parametrize("n,ndup,k", [(4096, 40, 16), (3000, 100, 16), (2048, 300, 16), (1500, 90, 32), (4096, 4096, 8)])
+def test_knn_xyz_lds_path_degenerate_clouds(ops, dev, n, ndup, k):
+    """1024 < n <= 4096 takes the single-pass kernel with the cloud in LDS (csrc/knn_wave.hip:knn_xyz_lds_kernel): `ndup` coincident
+    points force its three selection paths (<= 64 survivors, <= 128, the k-round arg-min beyond); ties -> lower index; both distance
+    flavours; children of one parent 1024 apart in memory (the second 16x pass's coarse clouds)."""
+    rng = np.random.default_rng(n + ndup)
+    s = rng.random((2, n, 3)).astype(np.float32)
+    where = rng.permutation(n)[:ndup]
+    s[:, where] = s[:, where[:1]]
+    q = np.concatenate([s[:, where[:3]], s[:, :40], rng.random((2, 21, 3)).astype(np.float32)], 1)
+    for contract, arith in ((0, PLAIN), (1, CONTRACT)):
+        i, d = ops["K"].knn_batch(T(s, dev), T(q, dev), k, return_dist=True, arith=arith)
+        oi, od = O.knn_batch(s, q, k, contract=contract, return_dist=True)
+        assert np.array_equal(N(i), oi) and np.array_equal(N(d), od)
+    par = rng.random((1, 1024, 3)).astype(np.float32)
+    c = (par[:, None] + 0.01 * rng.standard_normal((1, 4, 1024, 3)).astype(np.float32)).reshape(1, 4096, 3)
+    i, d = ops["K"].knn_batch(T(c, dev), T(c[:, ::8], dev), 16, return_dist=True)
+    oi, od = O.knn_batch(c, c[:, ::8], 16, return_dist=True)
+    assert np.array_equal(N(i), oi) and np.array_equal(N(d), od)
+
+
 def test_empty_and_ragged_inputs(ops, dev):
     """Edge cases the reference's shape checks admit: empty batches / query sets, single points, k == n, row counts that are not
     a multiple of any tile (the reference tests none of these explicitly; its kernels loop `for (i = blockIdx.x; i < b; ...)`
