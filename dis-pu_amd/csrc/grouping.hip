@@ -65,6 +65,26 @@ __global__ __launch_bounds__(QB_BS) void query_ball_kernel(int n, int m, const f
 // nsample hits are written in index order exactly as the serial scan does, and the wave stops at the block that fills
 // the row.  The lane-per-query kernel above runs b * m / 64 waves that each scan n candidates serially (141 us for the
 // repulsion loss's (8, 1024, 1024, 20)); here all 64 lanes of b * m waves work.
+// hit <=> max(sqrtf(d2), 1e-20f) < radius (tf_grouping_g.cu:20-27), decided WITHOUT the correctly rounded square root for all but the
+// candidates within 4e-6 (relative) of radius^2: sqrt is monotone and correctly rounded, radius^2 is rounded once, so d2 below
+// r2 (1 - 2^-18) is a hit and d2 above r2 (1 + 2^-18) is a miss whatever the roundings; a wave computes the exact form only when one
+// of its lanes falls into that band (or is unordered: NaN coordinates take the reference's path).  The square root with its fix-up
+// was ~2/3 of the instructions of a candidate.
+struct QbBand {
+    float rad, lo, hi;
+    bool always_exact;
+};
+__device__ __forceinline__ QbBand qb_band(float rad) {
+    const float r2 = rad * rad;
+    return QbBand{rad, r2 * (1.0f - 3.8146973e-6f), r2 * (1.0f + 3.8146973e-6f), !(rad > 1e-19f) || !(r2 > 1e-30f) || !(r2 < 1e30f)};
+}
+__device__ __forceinline__ bool qb_hit(const QbBand& b, float d2) {
+    bool hit = d2 < b.lo;
+    const bool band = !(d2 < b.lo) && !(d2 > b.hi);
+    if (b.always_exact || __ballot(band)) hit = fmaxf(sqrtf(d2), 1e-20f) < b.rad;      // wave-uniform branch
+    return hit;
+}
+
 template <int R, bool FMA>
 __global__ __launch_bounds__(256) void query_ball_wave_kernel(int n, int m, int qpb, const float* __restrict__ radius, int nsample,
                                                                const float* __restrict__ xyz1, const float* __restrict__ xyz2,
@@ -73,6 +93,7 @@ __global__ __launch_bounds__(256) void query_ball_wave_kernel(int n, int m, int 
     const float* __restrict__ p1 = xyz1 + (size_t)cloud * n * 3;
     const float* __restrict__ p2 = xyz2 + (size_t)cloud * m * 3;
     const float rad = radius[0];
+    const QbBand band = qb_band(rad);
     float cx[R], cy[R], cz[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
@@ -89,8 +110,7 @@ __global__ __launch_bounds__(256) void query_ball_wave_kernel(int n, int m, int 
         for (int r = 0; r < R; ++r) {
             if (cnt < nsample && 64 * r < n) {
                 const float d2 = sqdist3<FMA>(x2 - cx[r], y2 - cy[r], z2 - cz[r]);
-                const float d = fmaxf(sqrtf(d2), 1e-20f);
-                const bool hit = (d < rad) && (64 * r + lane < n);
+                const bool hit = qb_hit(band, d2) && (64 * r + lane < n);
                 const unsigned long long mk = __ballot(hit);
                 if (mk) {
                     if (cnt == 0) first = 64 * r + (int)__builtin_ctzll(mk);
@@ -122,6 +142,7 @@ __global__ __launch_bounds__(256) void query_ball_wave_chunked_kernel(int n, int
     const float* __restrict__ p1 = xyz1 + (size_t)cloud * n * 3;
     const float* __restrict__ p2 = xyz2 + (size_t)cloud * m * 3;
     const float rad = radius[0];
+    const QbBand band = qb_band(rad);
     const int q0 = blockIdx.x * qpb, q1 = min(m, q0 + qpb);
     if (threadIdx.x < 64) { s_cnt[threadIdx.x] = 0; s_first[threadIdx.x] = 0; }
     __syncthreads();
@@ -142,8 +163,7 @@ __global__ __launch_bounds__(256) void query_ball_wave_chunked_kernel(int n, int
             for (int r = 0; r < R; ++r) {
                 if (cnt < nsample && c0 + 64 * r < n) {
                     const float d2 = sqdist3<FMA>(x2 - cx[r], y2 - cy[r], z2 - cz[r]);
-                    const float d = fmaxf(sqrtf(d2), 1e-20f);
-                    const bool hit = (d < rad) && (c0 + 64 * r + lane < n);
+                    const bool hit = qb_hit(band, d2) && (c0 + 64 * r + lane < n);
                     const unsigned long long mk = __ballot(hit);
                     if (mk) {
                         if (cnt == 0) first = c0 + 64 * r + (int)__builtin_ctzll(mk);

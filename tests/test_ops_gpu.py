@@ -251,6 +251,26 @@ def test_query_ball_index_exact(ops, dev, b, n, m, r, ns, arith):
     assert np.array_equal(N(cnt), oc) and np.array_equal(N(idx), oi)
 
 
+@pytest.mark.parametrize("n,r", [(1024, 0.25), (3000, 0.25), (512, 1e-3), (1024, 3.0)])
+def test_query_ball_candidates_on_the_radius(ops, dev, n, r):
+    """The wave kernels decide `max(sqrtf(d2), 1e-20) < radius` from d2 alone outside a 4e-6 band around radius^2 and take the exact
+    square root inside it (csrc/grouping.hip:qb_hit): candidates placed within a few ulps of the radius, on both sides and exactly on it,
+    must be classified as the reference's expression classifies them (the oracle evaluates it literally); both distance flavours."""
+    rng = np.random.default_rng(n)
+    q = rng.random((2, 40, 3)).astype(np.float32)
+    x = rng.random((2, n, 3)).astype(np.float32) * 4.0 + 10.0            # far away: never hit
+    u = rng.standard_normal((2, 40, 12, 3))
+    u /= np.linalg.norm(u, axis=-1, keepdims=True)
+    scale = np.float64(r) * (1.0 + np.array([-3e-6, -1e-6, -3e-7, -1e-7, -3e-8, 0.0, 0.0, 3e-8, 1e-7, 3e-7, 1e-6, 3e-6]))
+    shell = (q[:, :, None, :].astype(np.float64) + u * scale[None, None, :, None]).astype(np.float32).reshape(2, 480, 3)
+    pos = rng.permutation(n)[:480]
+    x[:, pos] = shell
+    for contract in (0, 1):
+        idx, cnt = ops["G"].query_ball_point(r, 16, T(x, dev), T(q, dev), arith=contract)
+        oi, oc = O.query_ball_point(r, 16, x, q, contract=contract)
+        assert np.array_equal(N(cnt), oc) and np.array_equal(N(idx), oi)
+
+
 def test_query_ball_no_hit_rows_and_radius_tensor(ops, dev):
     x = np.random.default_rng(1).random((2, 50, 3)).astype(np.float32)
     q = x[:, :9] + 100.0
