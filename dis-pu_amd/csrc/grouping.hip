@@ -78,11 +78,22 @@ __device__ __forceinline__ QbBand qb_band(float rad) {
     const float r2 = rad * rad;
     return QbBand{rad, r2 * (1.0f - 3.8146973e-6f), r2 * (1.0f + 3.8146973e-6f), !(rad > 1e-19f) || !(r2 > 1e-30f) || !(r2 < 1e30f)};
 }
-__device__ __forceinline__ bool qb_hit(const QbBand& b, float d2) {
-    bool hit = d2 < b.lo;
-    const bool band = !(d2 < b.lo) && !(d2 > b.hi);
-    if (b.always_exact || __ballot(band)) hit = fmaxf(sqrtf(d2), 1e-20f) < b.rad;      // wave-uniform branch
-    return hit;
+// The hit masks of R 64-candidate blocks at once: R independent compares and ballots, ONE band test for all of them (block by block
+// a query was a chain of scalar branches, each waiting for a vector compare).
+template <int R>
+__device__ __forceinline__ void qb_masks(const QbBand& b, const float (&d2)[R], int base, int lane, int n, unsigned long long (&mk)[R]) {
+    bool hit[R], band = false;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        hit[r] = d2[r] < b.lo;
+        band = band || (!(d2[r] < b.lo) && !(d2[r] > b.hi));
+    }
+    if (b.always_exact || __ballot(band)) {                              // wave-uniform, rare
+#pragma unroll
+        for (int r = 0; r < R; ++r) hit[r] = fmaxf(sqrtf(d2[r]), 1e-20f) < b.rad;
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) mk[r] = __ballot(hit[r] && (base + 64 * r + lane < n));
 }
 
 template <int R, bool FMA>
@@ -106,18 +117,18 @@ __global__ __launch_bounds__(256) void query_ball_wave_kernel(int n, int m, int 
         const float x2 = p2[j * 3 + 0], y2 = p2[j * 3 + 1], z2 = p2[j * 3 + 2];
         int* __restrict__ row = idx + ((size_t)cloud * m + j) * nsample;
         int cnt = 0, first = 0;                                    // wave-uniform
+        float d2[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) d2[r] = sqdist3<FMA>(x2 - cx[r], y2 - cy[r], z2 - cz[r]);
+        unsigned long long mk[R];
+        qb_masks<R>(band, d2, 0, lane, n, mk);
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            if (cnt < nsample && 64 * r < n) {
-                const float d2 = sqdist3<FMA>(x2 - cx[r], y2 - cy[r], z2 - cz[r]);
-                const bool hit = qb_hit(band, d2) && (64 * r + lane < n);
-                const unsigned long long mk = __ballot(hit);
-                if (mk) {
-                    if (cnt == 0) first = 64 * r + (int)__builtin_ctzll(mk);
-                    const int pos = cnt + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0u));
-                    if (hit && pos < nsample) row[pos] = 64 * r + lane;
-                    cnt = min(nsample, cnt + (int)__popcll(mk));
-                }
+            if (mk[r] && cnt < nsample) {                          // scalar values: no vector compare to wait for
+                if (cnt == 0) first = 64 * r + (int)__builtin_ctzll(mk[r]);
+                const int pos = cnt + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mk[r] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk[r], 0u));
+                if (((mk[r] >> lane) & 1ull) && pos < nsample) row[pos] = 64 * r + lane;
+                cnt = min(nsample, cnt + (int)__popcll(mk[r]));
             }
         }
         // first hit replicated into the unused tail; a row without any hit stays untouched
@@ -159,18 +170,18 @@ __global__ __launch_bounds__(256) void query_ball_wave_chunked_kernel(int n, int
             if (cnt >= nsample) continue;
             const float x2 = p2[j * 3 + 0], y2 = p2[j * 3 + 1], z2 = p2[j * 3 + 2];
             int* __restrict__ row = idx + ((size_t)cloud * m + j) * nsample;
+            float d2[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) d2[r] = sqdist3<FMA>(x2 - cx[r], y2 - cy[r], z2 - cz[r]);
+            unsigned long long mk[R];
+            qb_masks<R>(band, d2, c0, lane, n, mk);
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                if (cnt < nsample && c0 + 64 * r < n) {
-                    const float d2 = sqdist3<FMA>(x2 - cx[r], y2 - cy[r], z2 - cz[r]);
-                    const bool hit = qb_hit(band, d2) && (c0 + 64 * r + lane < n);
-                    const unsigned long long mk = __ballot(hit);
-                    if (mk) {
-                        if (cnt == 0) first = c0 + 64 * r + (int)__builtin_ctzll(mk);
-                        const int pos = cnt + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0u));
-                        if (hit && pos < nsample) row[pos] = c0 + 64 * r + lane;
-                        cnt = min(nsample, cnt + (int)__popcll(mk));
-                    }
+                if (mk[r] && cnt < nsample) {
+                    if (cnt == 0) first = c0 + 64 * r + (int)__builtin_ctzll(mk[r]);
+                    const int pos = cnt + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mk[r] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk[r], 0u));
+                    if (((mk[r] >> lane) & 1ull) && pos < nsample) row[pos] = c0 + 64 * r + lane;
+                    cnt = min(nsample, cnt + (int)__popcll(mk[r]));
                 }
             }
             if (lane == 0) { s_cnt[j - q0] = cnt; s_first[j - q0] = first; }
