@@ -82,18 +82,23 @@ __device__ __forceinline__ QbBand qb_band(float rad) {
 // a query was a chain of scalar branches, each waiting for a vector compare).
 template <int R>
 __device__ __forceinline__ void qb_masks(const QbBand& b, const float (&d2)[R], int base, int lane, int n, unsigned long long (&mk)[R]) {
-    bool hit[R], band = false;
+    // every predicate is a vector compare written straight to a scalar mask; the rest is scalar logic (as per-lane bools the masks cost
+    // ~6 vector instructions per block on top of the distance: 450 vector instructions per query, which is what bounded the kernel)
+    unsigned long long band = 0;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-        hit[r] = d2[r] < b.lo;
-        band = band || (!(d2[r] < b.lo) && !(d2[r] > b.hi));
+        mk[r] = __ballot(d2[r] < b.lo);
+        band |= ~mk[r] & __ballot(!(d2[r] > b.hi));                      // includes unordered (NaN) distances
     }
-    if (b.always_exact || __ballot(band)) {                              // wave-uniform, rare
+    if (b.always_exact || band) {                                        // wave-uniform, rare
 #pragma unroll
-        for (int r = 0; r < R; ++r) hit[r] = fmaxf(sqrtf(d2[r]), 1e-20f) < b.rad;
+        for (int r = 0; r < R; ++r) mk[r] = __ballot(fmaxf(sqrtf(d2[r]), 1e-20f) < b.rad);
     }
 #pragma unroll
-    for (int r = 0; r < R; ++r) mk[r] = __ballot(hit[r] && (base + 64 * r + lane < n));
+    for (int r = 0; r < R; ++r) {                                        // candidates past n (clamped loads): masked out, scalar
+        const int left = n - (base + 64 * r);
+        mk[r] &= left >= 64 ? ~0ull : left <= 0 ? 0ull : ((1ull << left) - 1ull);
+    }
 }
 
 template <int R, bool FMA>
