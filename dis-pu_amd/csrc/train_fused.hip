@@ -39,6 +39,18 @@ __device__ __forceinline__ void tf_st4(__bf16* p, float4 v) {
     *reinterpret_cast<tf_bf16x4*>(p) = h;
 }
 
+template <int CTRL>
+__device__ __forceinline__ float tf_dpp(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float tf_row16_sum(float v) {                 // fixed order: ((v + ror8) + ror4) + ror2) + ror1
+    v += tf_dpp<0x128>(v);
+    v += tf_dpp<0x124>(v);
+    v += tf_dpp<0x122>(v);
+    v += tf_dpp<0x121>(v);
+    return v;
+}
+
 __device__ __forceinline__ double tf_wave_sum(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -295,8 +307,9 @@ __global__ __launch_bounds__(256) void ps_wnet_grad_apply_kernel(long rows, int 
             ab += dwl;
             // d offset: sum over the 16 channels (= the 16 lanes of a DPP row)
             float o0 = dwl * w0, o1 = dwl * w1, o2 = dwl * w2;
-#pragma unroll
-            for (int m = 8; m > 0; m >>= 1) { o0 += __shfl_xor(o0, m, 16); o1 += __shfl_xor(o1, m, 16); o2 += __shfl_xor(o2, m, 16); }
+            // row_ror 8 / 4 / 2 / 1: every lane of the 16-lane DPP row ends with the row sum (four VALU-DPP adds per value; as
+            // __shfl_xor butterflies these were twelve ds_bpermute round trips per point)
+            o0 = tf_row16_sum(o0); o1 = tf_row16_sum(o1); o2 = tf_row16_sum(o2);
             if (t == 0 && live) { unsafeAtomicAdd(dxyz + jj[u] * 3 + 0, o0); unsafeAtomicAdd(dxyz + jj[u] * 3 + 1, o1); unsafeAtomicAdd(dxyz + jj[u] * 3 + 2, o2); }
             // the point's own share: the 4 pairs of this wave are combined first (one atomic per wave and coordinate, not per pair)
             o0 += __shfl_xor(o0, 16, 64); o1 += __shfl_xor(o1, 16, 64); o2 += __shfl_xor(o2, 16, 64);
