@@ -365,3 +365,77 @@ def save_generator_params(prefix, params, scope="generator", step=None, epoch=No
     with open(os.path.join(d, "checkpoint"), "w") as f:
         f.write('model_checkpoint_path: "%s"\nall_model_checkpoint_paths: "%s"\n' % (base, base))
     return prefix
+
+
+# ------------------------------------------------------------------------ the reference's two restore sites ----
+def restore_generator(log_dir, device=None, opts=None):
+    """`Model.test` (DisPU/model.py:350-353: Saver().restore(sess, pre_load_checkpoint(log_dir))) -> (restore_epoch, Generator):
+    the latest checkpoint named by `<log_dir>/checkpoint`, loaded into device tensors."""
+    from .generator import Generator
+    epoch, prefix = pre_load_checkpoint(log_dir)
+    if prefix is None:
+        raise FileNotFoundError("no checkpoint state file under %s" % log_dir)
+    return epoch, Generator(opts=opts, params=load_generator_params(prefix), device=device)
+
+
+def restore_train_state(log_dir, trainer):
+    """`Model.train` with opts.restore (DisPU/model.py:190-193): parameters, BN moving statistics, BOTH Adam moments, the
+    bias-correction powers, `epoch` and `global_step` of the latest checkpoint -> `trainer` (device buffers).  Returns the
+    restore epoch the training loop resumes from (Common/model_utils.py:138)."""
+    import math
+    import torch
+    epoch, prefix = pre_load_checkpoint(log_dir)
+    if prefix is None:
+        raise FileNotFoundError("no checkpoint state file under %s" % log_dir)
+    raw = read_bundle(prefix)
+    trainer.load_params(load_generator_params(prefix))
+    missing = []
+    for k in trainer.names:
+        for slot, flat in (("Adam", trainer.flat_m), ("Adam_1", trainer.flat_v)):
+            name = "generator/%s/%s" % (k, slot)
+            if name not in raw:
+                missing.append(name)
+                continue
+            view = trainer.P[k]
+            off = (view.data_ptr() - trainer.flat_p.data_ptr()) // 4
+            flat[off:off + view.numel()].copy_(torch.from_numpy(np.ascontiguousarray(raw[name], np.float32).reshape(-1)))
+    if missing:
+        raise KeyError("checkpoint %s lacks %d Adam slots (a test-graph checkpoint?), e.g. %s" % (prefix, len(missing), missing[:2]))
+    # TF keeps beta^(t+1) after t updates (initial value beta, multiplied after every apply): adam_t = t
+    b1 = float(trainer.opts.beta)
+    p1 = float(raw["beta1_power"])
+    trainer.adam_t = max(0, int(round(math.log(p1) / math.log(b1))) - 1) if 0.0 < p1 < 1.0 else 0
+    trainer.epoch = int(round(float(raw["epoch"]))) if "epoch" in raw else epoch
+    trainer.global_step = int(raw["global_step"]) if "global_step" in raw else 0
+    return epoch
+
+
+def save_train_state(log_dir, trainer, epoch=None):
+    """`self.saver.save(sess, os.path.join(log_dir, 'model'), epoch)` (DisPU/model.py:226) for a Trainer: everything a
+    Saver over the reference's TRAIN graph holds, i.e. save_generator_params + the real Adam moments and powers."""
+    from .params import layer_shapes
+    epoch = trainer.epoch if epoch is None else int(epoch)
+    P = trainer.params()
+    shapes = dict(layer_shapes())
+    out = {}
+    for k, v in P.items():
+        a = np.asarray(v, np.float32)
+        if k.endswith("/weights"):
+            a = a.reshape(shapes[k[:-len("/weights")]])
+        out["generator/" + k] = a
+    for k in trainer.names:
+        view = trainer.P[k]
+        off = (view.data_ptr() - trainer.flat_p.data_ptr()) // 4
+        shp = out["generator/" + k].shape
+        out["generator/%s/Adam" % k] = trainer.flat_m[off:off + view.numel()].cpu().numpy().reshape(shp).copy()
+        out["generator/%s/Adam_1" % k] = trainer.flat_v[off:off + view.numel()].cpu().numpy().reshape(shp).copy()
+    out["beta1_power"] = np.array(float(trainer.opts.beta) ** (trainer.adam_t + 1), np.float32)
+    out["beta2_power"] = np.array(0.999 ** (trainer.adam_t + 1), np.float32)
+    out["epoch"] = np.array(float(epoch), np.float32)
+    out["global_step"] = np.array(int(trainer.global_step), np.int32)
+    os.makedirs(log_dir, exist_ok=True)
+    prefix = os.path.join(log_dir, "model-%d" % epoch)
+    write_bundle(prefix, out)
+    with open(os.path.join(log_dir, "checkpoint"), "w") as f:
+        f.write('model_checkpoint_path: "%s"\nall_model_checkpoint_paths: "%s"\n' % (os.path.basename(prefix), os.path.basename(prefix)))
+    return prefix

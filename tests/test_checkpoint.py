@@ -103,3 +103,103 @@ def test_optimizer_slots_are_ignored_and_missing_variables_reported(tmp_path):
     CK.write_bundle(prefix, T)
     with pytest.raises(KeyError):
         CK.load_generator_params(prefix)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# bytes the product's own writer never emits: tests/tf_bundle_fixture.py restates TensorFlow's C++ table builder
+# (separator keys in the index block, size-estimate block cuts, several shards) without importing checkpoint.py
+# ------------------------------------------------------------------------------------------------------------------
+import tf_bundle_fixture as TFB  # noqa: E402  (tests/ is on sys.path under pytest's rootdir conftest)
+
+
+def test_fixture_crc_and_separators_known_answers():
+    assert TFB.crc32c(b"123456789") == 0xE3069283 and TFB.masked(0) == 0xA282EAD8
+    # 32 zero bytes / 32 0xff bytes: the iSCSI test patterns of RFC 3720 B.4
+    assert TFB.crc32c(bytes(32)) == 0x8A9136AA and TFB.crc32c(b"\xff" * 32) == 0x62A8AB43
+    assert CK.crc32c(bytes(32)) == 0x8A9136AA and CK.crc32c(b"\xff" * 32) == 0x62A8AB43
+    assert TFB.shortest_separator(b"abcdefg", b"abzz") == b"abd"
+    assert TFB.shortest_separator(b"generator/a/biases", b"generator/a/weights") == b"generator/a/c"
+    assert TFB.shortest_separator(b"abc", b"abcd") == b"abc" and TFB.short_successor(b"\xff\xffq") == b"\xff\xffr"
+
+
+@pytest.mark.parametrize("num_shards,block_size", [(1, 262144), (2, 1024), (3, 512)])
+def test_reader_on_independently_assembled_bundle(tmp_path, num_shards, block_size):
+    P = PP.init_params(11)
+    rng = np.random.default_rng(5)
+    for k in P:                                         # nothing at its initial value: biases, BN statistics too
+        P[k] = (P[k] + 0.05 * rng.standard_normal(P[k].shape)).astype(np.float32)
+    P[PP.BN_SCOPE + "moving_variance"] = np.abs(P[PP.BN_SCOPE + "moving_variance"]) + 0.5
+    T = TFB.reference_named_variables(P, PP.layer_shapes(), adam=True, epoch=40.0, global_step=77, adam_t=9, rng=rng)
+    prefix = str(tmp_path / "model-40")
+    facts = TFB.write_tf_style_bundle(prefix, T, num_shards=num_shards, block_size=block_size)
+    TFB.write_checkpoint_state(str(tmp_path), "model-40")
+    assert facts["max_shared"] >= 20                                 # prefix-compressed keys with a long shared part
+    if block_size < 262144:
+        assert facts["data_blocks"] >= 2
+        assert all(b > 0 for b in facts["shard_bytes"])              # every shard really holds tensors
+    else:
+        assert facts["data_blocks"] == 1                             # TF's default block size: the whole index is one block
+    header, entries = CK.read_index(prefix + ".index")
+    assert header[1] == num_shards and set(entries) == set(T)
+    assert {e["shard_id"] for e in entries.values()} == set(range(num_shards))
+    assert entries["epoch"]["shape"] == [] and entries["generator/refine/PointShuffle/after_conv/weights/Adam_1"]["shape"] == [1, 128, 16, 256]
+    raw = CK.read_bundle(prefix)
+    assert list(raw) == sorted(T, key=lambda s: s.encode())
+    for k in T:
+        assert raw[k].dtype == T[k].dtype and raw[k].shape == T[k].shape and np.array_equal(raw[k], T[k]), k
+    assert CK.pre_load_checkpoint(str(tmp_path)) == (40, prefix)
+    Q = CK.load_generator_params(prefix)
+    assert list(Q) == list(P) and all(np.array_equal(Q[k], P[k]) for k in P)
+    # a corrupted byte in the LAST shard is caught
+    last = "%s.data-%05d-of-%05d" % (prefix, num_shards - 1, num_shards)
+    blob = bytearray(open(last, "rb").read())
+    blob[len(blob) // 2] ^= 0x40
+    open(last, "wb").write(bytes(blob))
+    with pytest.raises(ValueError):
+        CK.read_bundle(prefix)
+
+
+def test_product_writer_read_back_by_the_independent_parser(tmp_path):
+    """the other direction: checkpoint.write_bundle's bytes walked by code that shares nothing with it."""
+    import struct as S
+    P = PP.init_params(3)
+    prefix = CK.save_generator_params(str(tmp_path / "model"), P, step=5, adam_slots=True)
+    data = open(prefix + ".index", "rb").read()
+    assert S.unpack("<Q", data[-8:])[0] == TFB.TABLE_MAGIC
+
+    def uv(buf, p):
+        v = s = 0
+        while True:
+            b = buf[p]
+            p += 1
+            v |= (b & 127) << s
+            s += 7
+            if b < 128:
+                return v, p
+
+    def block(off, size):
+        body = data[off:off + size]
+        assert TFB.masked(TFB.crc32c(data[off:off + size + 1])) == S.unpack_from("<I", data, off + size + 1)[0]
+        nrest = S.unpack_from("<I", body, size - 4)[0]
+        end, p, key, out = size - 4 - 4 * nrest, 0, b"", []
+        while p < end:
+            sh, p = uv(body, p)
+            ns, p = uv(body, p)
+            vl, p = uv(body, p)
+            key = key[:sh] + body[p:p + ns]
+            out.append((key, body[p + ns:p + ns + vl]))
+            p += ns + vl
+        return out
+
+    p = len(data) - 48
+    _, p = uv(data, p)
+    _, p = uv(data, p)
+    ioff, p = uv(data, p)
+    isz, p = uv(data, p)
+    keys = []
+    for _, h in block(ioff, isz):
+        o, q = uv(h, 0)
+        z, q = uv(h, q)
+        keys += [k for k, _ in block(o, z)]
+    assert keys == sorted(keys) and keys[0] == b"" and len(keys) > 2 * len(P)
+    assert b"generator/generator/upshuffle_0/conv1/weights/Adam_1" in keys and b"global_step" in keys
