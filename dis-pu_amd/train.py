@@ -431,6 +431,12 @@ class Trainer(object):
         B, N, _ = x.shape
         M, k = N * self.up_ratio, K_NEIGH
         rn, rm = B * N, B * M
+        # shape limits of the fused training kernels, refused here instead of as a bare hipErrorInvalidValue mid-step:
+        # dispu_mlp_chain_stash / dispu_mlp_chain_grad tile 64 rows; dispu_knn_invert sorts one cloud's graph in LDS
+        req(N > K_NEIGH, "a patch needs more than %d points (k-NN graph of the dense blocks), got N = %d" % (K_NEIGH, N))
+        req(rm % 64 == 0, "the fused head chains work on 64-row tiles: B * %d * N must be a multiple of 64, got B = %d, N = %d "
+                          "(pad the batch)" % (self.up_ratio, B, N))
+        req(M <= 4096, "the local cell's backward inverts a cloud's k-NN graph in LDS: %d * N <= 4096, got N = %d" % (self.up_ratio, N))
         ws = self._workspace(B, N)
         L = _lib.lib()
         self.st = _lib.stream_ptr(x.device)
@@ -548,6 +554,7 @@ class Trainer(object):
                                            _p(ws["agg"]), 256, _p(ws["f256"]), 256, _p(ws["f64"]), 64, _p(ws["z"]), 3, 1, _p(coarse), 3,
                                            _p(ws["fine"]), 3, self.st), "mlp_chain[fine]")
         self._stash_ready = False
+        self._fresh = True               # the atomics accumulators (dprep, dup128s) were zero-filled for exactly ONE backward()
         return ws["coarse"], ws["fine"]
 
     def _recompute_pair_tensors(self):
@@ -649,6 +656,11 @@ class Trainer(object):
         dcoarse, dfine = ws["dcoarse"].view(rm, 3), ws["dfine"].view(rm, 3)
         ps = "refine/PointShuffle/"
         fs = "refine/fine_coordinate_regressor/"
+        if not getattr(self, "_fresh", False):
+            # a second backward() on the same forward (new targets / loss weights): the atomics accumulators still hold the previous,
+            # already masked gradients -- clear them again, on this stream, before anything accumulates
+            ws["zeroed"].zero_()
+        self._fresh = False
         if not self._stash_ready:                       # backward() without loss_backward(): rebuild the pair tensors here
             with self._branch(2):
                 self._recompute_pair_tensors()
@@ -844,11 +856,16 @@ class Trainer(object):
         g = self._graphs.get(key)
         if g is None:
             st = dict(x=inputs.clone(), gt=gt.clone(), radius=radius.clone())
-            for _ in range(2):                                   # warm-up: every workspace / scratch buffer exists before the capture
+            # warm-up: every workspace / scratch buffer exists before the capture.  The warm-up forwards must not count as training
+            # steps: the weight net's BatchNorm moving statistics are put back afterwards (the reference updates them once per step)
+            mm, mv = self.moving_mean.clone(), self.moving_var.clone()
+            for _ in range(2):
                 self.zero_grad()
                 self.forward(st["x"])
                 self.loss_backward(st["gt"], st["radius"])
                 self.backward()
+            self.moving_mean.copy_(mm)
+            self.moving_var.copy_(mv)
             torch.cuda.synchronize(self.device)
             graph = torch.cuda.CUDAGraph()
             cap = torch.cuda.Stream(device=self.device)
@@ -869,7 +886,8 @@ class Trainer(object):
         world = self.all_reduce_grads()
         self.adam(world)
         self.global_step += 1
-        return g["terms"]
+        # the captured scalars live in the graph's memory pool and are overwritten by the next replay: hand out copies
+        return {k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in g["terms"].items()}
 
     def train_step(self, inputs, gt, radius):
         """one iteration of the loop body of Model.train (model.py:215-232) -> loss terms (device scalars)."""

@@ -48,3 +48,82 @@ def test_product_initialiser_matches_oracle_inventory():
     assert list(a) == list(b)
     assert all(np.array_equal(a[k], b[k]) for k in a)
     assert PP.num_params(b) == OG.num_params(a) + 32           # + BN gamma / beta
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# two independent readings of the reference graph agree (oracle/generator_check.py: float64 torch LIBRARY primitives,
+# F.conv2d on NHWC->NCHW, torch.topk, F.batch_norm, F.softmax, written straight from Common/ops.py)
+# ----------------------------------------------------------------------------------------------------------------------
+import pytest  # noqa: E402
+
+
+def _near_tie_only(D, mine, theirs, rel=2e-5):
+    """rows where the two rank tables differ: at every rank where they name different candidates, the two candidates must be
+    within `rel` of each other in float64 distance (a legitimate fp32-vs-float64 near-tie, swapped or pushed across the k-th
+    place) -- never a structurally different pick.  Returns the number of differing rows."""
+    B, n = mine.shape[:2]
+    bad = 0
+    for b in range(B):
+        for i in range(n):
+            if np.array_equal(mine[b, i], theirs[b, i]):
+                continue
+            bad += 1
+            row = D[b, i]
+            scale = max(np.abs(row).max() * 1e-3, 1e-12)
+            for ja, jc in zip(mine[b, i].tolist(), theirs[b, i].tolist()):
+                if ja != jc:
+                    assert abs(row[ja] - row[jc]) <= rel * max(scale, abs(row[ja])), \
+                        "selection differs away from a tie: row (%d,%d) candidates %d / %d" % (b, i, ja, jc)
+    return bad
+
+
+@pytest.mark.parametrize("seed,n", [(1, 256), (2, 256), (3, 96)])
+def test_two_independent_readings_agree(seed, n):
+    from dispu_amd import synth
+    from oracle import generator_check as G2
+    P = OG.init_params(seed=100 + seed, bias_scale=0.05, bn_random=True)       # non-zero biases, non-trivial BN statistics
+    x = synth.patches(2, n, seed=seed)
+    tap1 = {}
+    c1, f1 = OG.generator_forward(P, x, tap1)
+    tap2 = {}
+    c2, f2 = G2.forward(P, x, tap=tap2)
+    # (1) the selections, decided independently (fp32 GEMM-order arithmetic there, float64 torch.topk here)
+    flips = 0
+    for d in range(4):
+        D = tap2["fe%d_D" % (d + 1)].numpy()
+        flips += _near_tie_only(D, tap2["fe_idx"][d], tap1["fe_idx%d" % (d + 1)])
+        if flips:
+            break                                   # later blocks see different inputs once a pick differs
+    same_graph = flips == 0
+    if same_graph:
+        flips += _near_tie_only(tap2["ps_D"].numpy(), tap2["ps_idx"], tap1["ps_idx"])
+        same_graph = flips == 0
+    if not same_graph:
+        # a near-tie was broken differently: the comparison of the ARITHMETIC continues on the first reading's tables
+        knn = dict(fe=[tap1["fe_idx%d" % d] for d in (1, 2, 3, 4)], ps=tap1["ps_idx"])
+        c2, f2 = G2.forward(P, x, knn=knn)
+    # (2) the arithmetic: fp32 fmaf chains vs float64 library convolutions
+    ec = np.abs(c1.astype(np.float64) - c2).max()
+    ef = np.abs(f1.astype(np.float64) - f2).max()
+    assert ec <= 2e-6 and ef <= 2e-6, "the two readings differ: coarse %.2e fine %.2e (flips %d)" % (ec, ef, flips)
+
+
+def test_second_reading_is_sensitive():
+    """the agreement above is not vacuous: one swapped concat order / tile order in the SECOND reading moves the output by
+    orders of magnitude more than 2e-6."""
+    from dispu_amd import synth
+    from oracle import generator_check as G2
+    P = OG.init_params(seed=7, bias_scale=0.05, bn_random=True)
+    x = synth.patches(1, 64, seed=4)
+    c, f = G2.forward(P, x)
+    Q = dict(P)
+    w = P["generator/upshuffle_0/conv1/weights"].copy()
+    w[[480, 481]] = w[[481, 480]]                                   # grid code columns swapped
+    Q["generator/upshuffle_0/conv1/weights"] = w
+    c2, _ = G2.forward(Q, x)
+    assert np.abs(c2 - c).max() > 1e-4
+    Q = dict(P)
+    w = P["refine/PointShuffle/after_conv/weights"].reshape(128, 16, 256).transpose(1, 0, 2).reshape(2048, 256).copy()
+    Q["refine/PointShuffle/after_conv/weights"] = w                 # feature-major <-> sample-major flatten
+    _, f2 = G2.forward(Q, x)
+    assert np.abs(f2 - f).max() > 1e-4

@@ -474,3 +474,78 @@ def test_conv2d_training_mode_batch_norm(dev):
     mm, mv = N_(P["s/bn/moving_mean"]).astype(np.float64), N_(P["s/bn/moving_variance"]).astype(np.float64)
     want2 = np.maximum((z - mm) / np.sqrt(mv + 1e-3) * P["s/bn/gamma"] + P["s/bn/beta"], 0).reshape(2, 50, 8, 20)
     assert np.abs(y2 - want2).max() <= 2e-5
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_graphed_steps_equal_eager_steps(dev, dtype):
+    """train_step_graphed (forward + loss + backward replayed from one hipGraph) is the SAME step: after n steps the parameters,
+    both Adam moments, the BatchNorm moving statistics (ONE update per step -- the capture's warm-up passes must not count,
+    the reference updates them once per sess.run, DisPU/model.py:215-232) and every reported loss term equal the eager
+    trainer's, up to the order-free float atomics of the scatter gradients.  Crossing epoch 10 re-captures (weight_fine)."""
+    from dispu_amd import synth
+    from dispu_amd.train import Trainer
+    P = OG.init_params(seed=21, bias_scale=0.05, bn_random=True)
+    B = 4
+    batches = [synth.patch_with_gt(B, 256, 1024, seed=30 + i) for i in range(4)]
+    rs = torch.ones(B, device=dev)
+    e = Trainer(params=P, device=dev, dtype=dtype)
+    g = Trainer(params=P, device=dev, dtype=dtype)
+    e.epoch = g.epoch = 10
+    kept = []
+    for i, (x, gt) in enumerate(batches):
+        if i == 2:
+            e.epoch = g.epoch = 11                   # weight_fine 0.01 -> 0.1: a second capture with its own warm-up
+        xs, gs = dv(x, dev), dv(gt, dev)
+        te = e.train_step(xs, gs, rs)
+        tg = g.train_step_graphed(xs, gs, rs)
+        kept.append((te, tg))
+        torch.cuda.synchronize()
+        # moving statistics: decay 0.95 applied exactly once per step on both sides
+        tol = 1e-5 if dtype == "f32" else 2e-3
+        assert np.allclose(N(g.moving_mean), N(e.moving_mean), rtol=tol, atol=tol * 1e-2), "moving_mean after step %d" % i
+        assert np.allclose(N(g.moving_var), N(e.moving_var), rtol=tol, atol=tol * 1e-2), "moving_variance after step %d" % i
+    assert len(g._graphs) == 2 and g.global_step == e.global_step == 4 and g.adam_t == e.adam_t == 4
+    ptol = 2e-5 if dtype == "f32" else 2e-3          # Adam's first steps move every weight by ~lr whatever the gradient's size
+    assert float((g.flat_p - e.flat_p).abs().max()) <= ptol
+    assert float((g.flat_m - e.flat_m).abs().max()) <= ptol * max(1.0, float(e.flat_m.abs().max()))
+    # the returned terms are the caller's: a later replay must not overwrite them
+    for i, (te, tg) in enumerate(kept):
+        for k in te:
+            a, b = float(te[k]), float(tg[k])
+            assert abs(a - b) <= (1e-4 if dtype == "f32" else 2e-2) * max(1.0, abs(a)), (i, k, a, b)
+    assert float(kept[0][1]["pu_loss"]) != float(kept[3][1]["pu_loss"])
+
+
+def test_forward_refuses_shapes_the_fused_kernels_cannot_take(dev):
+    from dispu_amd import synth
+    from dispu_amd.train import Trainer
+    tr = Trainer(params=OG.init_params(seed=3), device=dev)
+    with pytest.raises(ValueError, match="multiple of 64"):
+        tr.forward(dv(synth.patches(1, 250, seed=1), dev))           # 4 * 250 rows: not a multiple of 64
+    with pytest.raises(ValueError, match="4096"):
+        tr.forward(dv(synth.patches(1, 2048, seed=1), dev))          # 8192-point clouds: beyond the LDS graph inversion
+    with pytest.raises(ValueError):
+        tr.forward(dv(synth.patches(4, 16, seed=1), dev))            # fewer points than neighbours
+
+
+def test_second_backward_on_one_forward(dev):
+    """backward() masks / accumulates into buffers that forward() zero-fills; running it twice on one forward (new loss
+    weights, new targets) must give the second loss's gradients, not the sum with stale ones."""
+    from dispu_amd import synth
+    from dispu_amd.train import Trainer
+    P = OG.init_params(seed=8, bias_scale=0.05)
+    x, gt = synth.patch_with_gt(2, 256, 1024, seed=4)
+    xs, gs, rs = dv(x, dev), dv(gt, dev), torch.ones(2, device=dev)
+    tr = Trainer(params=P, device=dev)
+    tr.zero_grad()
+    tr.forward(xs)
+    tr.loss_backward(gs, rs)
+    tr.backward()
+    torch.cuda.synchronize()
+    first = tr.flat_g.clone()
+    tr.zero_grad()
+    tr.loss_backward(gs, rs)
+    tr.backward()                                                    # no forward in between
+    torch.cuda.synchronize()
+    scale = float(first.abs().max())
+    assert float((tr.flat_g - first).abs().max()) <= 1e-5 * scale
