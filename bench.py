@@ -277,6 +277,25 @@ def main():
         tt = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+    # variance of the figure above: the same K-step loop four more times (20 steps are ~20 ms); `value` / `ms_per_step` stay the FIRST
+    # loop's (the contract's timed region), min / median / max of all five ride along
+    loops = [dt]
+    for _ in range(4):
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        d1 = time.perf_counter() - t1
+        if world > 1:
+            tt = torch.tensor([d1], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            d1 = float(tt.item())
+        loops.append(d1)
 
     # ---- roofline of the dominant kernel: HIP events around every launch, on the launch stream (eager pass)
     roof = None
@@ -342,23 +361,24 @@ def main():
                              "TFLOP/s; step_frac_reference_graph prices the same step at the reference graph's %.3f GFLOP "
                              "per patch (work removed by exact algebra counted as done)"
                              % (step_macs_per_patch() / 1e9, PATCHES_PER_GPU, FP32_MFMA_PEAK_TFLOPS, REFERENCE_FLOPS_PER_PATCH / 1e9))
+        side = {}
         if world == 1 and not args.no_ops:
             sys.path.insert(0, os.path.join(ROOT, "tools"))
             import ops_bench
             try:
-                roof["ops"] = ops_bench.gpu_ops(dev, quick=True)
+                side["ops"] = ops_bench.gpu_ops(dev, quick=True)
             except Exception as e:                             # noqa: BLE001 -- the headline line must survive a failing side table
-                roof["ops"] = None
-                roof["ops_error"] = "%s: %s" % (type(e).__name__, e)
+                side["ops"] = None
+                side["ops_error"] = "%s: %s" % (type(e).__name__, e)
             try:
-                roof["train_step"] = train_step_table(dev)
+                side["train_step"] = train_step_table(dev)
             except Exception as e:                             # noqa: BLE001
-                roof["train_step"] = {"error": "%s: %s" % (type(e).__name__, e)}
-            roof["ops_peaks"] = {"hbm_B_per_s": ops_bench.HBM_PEAK, "valu_lane_ops_per_s": ops_bench.VALU_PEAK,
-                                 "exp_per_s": ops_bench.EXP_PEAK, "valu_datasheet": ops_bench.VALU_PEAK_DATASHEET,
-                                 "exp_datasheet": ops_bench.EXP_PEAK_DATASHEET,
-                                 "note": "VALU / exp peaks are MEASURED issue rates (tools/micro/valu_rate.hip); frac_datasheet prices "
-                                         "the row against the datasheet-derived figure"}
+                side["train_step"] = {"error": "%s: %s" % (type(e).__name__, e)}
+            side["ops_peaks"] = {"hbm_B_per_s": ops_bench.HBM_PEAK, "valu_lane_ops_per_s_datasheet": ops_bench.VALU_PEAK_DATASHEET,
+                                 "exp_per_s_datasheet": ops_bench.EXP_PEAK_DATASHEET, "valu_measured": ops_bench.VALU_PEAK,
+                                 "exp_measured": ops_bench.EXP_PEAK,
+                                 "note": "`frac` of a VALU / exp row is against the DATASHEET figure (256 CU x 4 SIMD x 32 lanes x 2.4 GHz); "
+                                         "frac_measured_peak against the measured issue rate (tools/micro/valu_rate.hip)"}
         pts = world * PATCHES_PER_GPU * NPOINT * UP
         out = {"metric": "upsampled points/sec (256->1024, 4x)", "value": pts * args.steps / dt, "unit": "points/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -372,11 +392,33 @@ def main():
                           "points_out_per_step": pts, "launch": launch, "weights": "xavier-uniform seed 1234, zero bias",
                           "parallelism": "patch-sharded x%d" % world},
                "roofline": roof}
+        srt = sorted(loops)
+        out["ms_per_step_repeats"] = {"n": len(loops), "min": srt[0] / args.steps * 1e3, "median": srt[len(srt) // 2] / args.steps * 1e3,
+                                      "max": srt[-1] / args.steps * 1e3, "note": "the timed K-step loop run 5 times; value / ms_per_step = the first"}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(with_ops=not args.no_ops)
             except Exception as e:                             # noqa: BLE001
                 out["cpu_baseline"] = {"value": None, "unit": "points/s", "cores": 0, "kind": "port", "sample": "failed: %s: %s" % (type(e).__name__, e)}
+        # The ONE JSON line stays small enough for the driver to keep it whole (round 3's ~40 KB line lost its nested tables): scalars + the
+        # top-8 kernels here; the full per-kernel list, the per-op roofline table, the train-step table and the per-op CPU baseline go to a
+        # side file next to the rocprof summaries.
+        side["kernels"] = roof.pop("kernels")
+        side["kernels_note"] = roof.pop("kernels_note")
+        roof["kernels_top8"] = side["kernels"][:8]
+        if "cpu_baseline" in out and "ops" in out["cpu_baseline"]:
+            side["cpu_baseline_ops"] = out["cpu_baseline"].pop("ops")
+        if "train_step" in side and isinstance(side["train_step"], dict):
+            roof["train_step_ms"] = {k: v.get("ms_per_step") for k, v in side["train_step"].items() if isinstance(v, dict)}
+        side["headline"] = {k: out[k] for k in ("value", "ms_per_step", "steps", "warmup", "n_gpus")}
+        for d in (os.path.join(ROOT, "profiles"), os.path.join(ROOT, "gpurun_out")):
+            try:
+                os.makedirs(d, exist_ok=True)
+                with open(os.path.join(d, "bench_side_tables.json"), "w") as f:
+                    json.dump(side, f, indent=1)
+            except OSError:
+                pass
+        roof["side_tables"] = "profiles/bench_side_tables.json (keys: kernels, ops, train_step, ops_peaks, cpu_baseline_ops)"
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

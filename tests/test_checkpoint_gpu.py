@@ -103,8 +103,10 @@ def test_train_state_restore_resumes_the_same_trajectory(tmp_path, dev):
         tb = b.train_step(x, gt, radius)
     torch.cuda.synchronize()
     # the scatter gradients use float atomics (order-free): the two trajectories agree to rounding, not bit for bit
-    pa, pb = N(a.flat_p), N(b.flat_p)
-    assert np.abs(pa - pb).max() <= 2e-5, np.abs(pa - pb).max()
+    # (Adam's update is lr * m / sqrt(v): where a gradient entry is ~0 its atomics noise decides the SIGN of a full lr-sized move,
+    # so single weights may differ by up to 2 steps x lr; everything else agrees to rounding)
+    diff = np.abs(N(a.flat_p) - N(b.flat_p))
+    assert diff.max() <= 2.5e-3 and np.quantile(diff, 0.999) <= 2e-5 and diff.mean() <= 1e-6, (diff.max(), np.quantile(diff, 0.999), diff.mean())
     assert np.allclose(N(a.moving_var), N(b.moving_var), rtol=1e-5, atol=1e-7)
     for k in ta:
         assert abs(float(ta[k]) - float(tb[k])) <= 1e-4 * max(1.0, abs(float(ta[k]))), k

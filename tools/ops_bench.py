@@ -75,8 +75,10 @@ def _row(name, shape, seconds, nbytes, bound, work, note=""):
     peak, unit = PEAK[bound]
     return {"op": name, "shape": list(shape), "us": round(seconds * 1e6, 2), "algorithmic_bytes": int(nbytes),
             "hbm_frac": round(nbytes / seconds / HBM_PEAK, 4), "bound": bound, "work": float(work), "work_unit": unit,
-            "achieved": work / seconds, "peak": peak, "frac": round(work / seconds / peak, 4),
-            "frac_datasheet": round(work / seconds / PEAK_DATASHEET[bound], 4), "note": note}
+            # `frac` prices the row against the DATASHEET peak of its bound (round-3 verdict: the measured VALU issue rate flatters
+            # every VALU row by 1.46x); the measured-rate fraction stays beside it as `frac_measured_peak`
+            "achieved": work / seconds, "peak": PEAK_DATASHEET[bound], "frac": round(work / seconds / PEAK_DATASHEET[bound], 4),
+            "frac_measured_peak": round(work / seconds / peak, 4), "measured_peak": peak, "note": note}
 
 
 def gpu_ops(dev=None, quick=False):
