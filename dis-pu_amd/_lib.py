@@ -8,7 +8,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libdispu_hip.so")
 
-ABI_VERSION = 3       # include/dispu_hip.h: dispu_version()
+ABI_VERSION = 4       # include/dispu_hip.h: dispu_version()
 ARITH_PLAIN = 0
 ARITH_CONTRACT = 1
 ARITH_PINNED_EXP = 2   # OR-able, approx_match only (bit-reproducible exp; parity mode)
@@ -77,6 +77,9 @@ SIGNATURES = {
     "dispu_normalize_patches": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp]),
     "dispu_denormalize_patches": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp]),
     "dispu_attention": (_i, [_i, _i, _i, _i, _vp, _l, _vp, _l, _vp, _l, C.c_float, _vp, _l, _vp]),
+    "dispu_attention_fwd_lse": (_i, [_i, _i, _i, _i, _vp, _l, _vp, _l, _vp, _l, C.c_float, _vp, _l, _vp, _vp]),
+    "dispu_attention_bwd": (_i, [_i, _i, _i, _i, _vp, _l, _vp, _l, _vp, _l, C.c_float, _vp, _l, _vp, _vp, _l, _vp, _l, _vp, _l, _vp, _l,
+                                 _vp, _vp]),
     "dispu_attention_project": (_i, [_i, _i, _i, _i, _vp, _l, _vp, _l, _vp, _l, C.c_float, _vp, _vp, _i, _vp, _l, _vp]),
     "dispu_softmax_rows": (_i, [_l, _i, C.c_float, _vp, _l, _vp]),
     "dispu_linear_bf16": (_i, [_i, _i, _i, _i, _vp, _l, _l, _vp, _l, _l, _i, _vp, _i, _vp, _l, _l, _vp, _l, _l, _vp, _l, _l, _vp]),

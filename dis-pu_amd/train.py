@@ -123,6 +123,9 @@ class Trainer(object):
         self._join_ev = None
         self._sched = int(os.environ.get("DISPU_TRAIN_SCHED", "1"))
         self.fused_heads_bwd = os.environ.get("DISPU_TRAIN_FUSED_HEADS_BWD", "1") != "0"
+        # non-local cell: flash-style attention forward (+ per-row log-sum-exp) and a recomputing backward (csrc/attention_train.hip);
+        # 0 = round 3's path through a materialised [B, M, M] probability tensor (A/B tests, the parity twin)
+        self.flash_attn = os.environ.get("DISPU_TRAIN_FLASH_ATTN", "1") != "0"
         self.bf16_min_macs = float(os.environ.get("DISPU_TRAIN_BF16_MIN_MACS", "1.5e9"))
 
         self._side_busy = []
@@ -205,7 +208,8 @@ class Trainer(object):
             wv=E(rm * k, 16), dwv=E(rm * k, 16),
             bn_stats=E(48), bn_scale=E(16), bn_shift=E(16), bn_sums=E(32),
             hp=E(rm, 2048), dhp=E(rm, 2048, dtype=pt), aft=E(rm, 256), daft=E(rm, 256),
-            kv=E(rm, 128), dkv=E(rm, 128), q=E(rm, 64), dq=E(rm, 64), S=E(B, M, M), dS=E(B, M, M), att=E(rm, 64), datt=E(rm, 64),
+            kv=E(rm, 128), dkv=E(rm, 128), q=E(rm, 64), dq=E(rm, 64), att=E(rm, 64), datt=E(rm, 64), lse=E(rm), dvec=E(rm),
+            S=None if self.flash_attn else E(B, M, M), dS=None if self.flash_attn else E(B, M, M),
             nl=E(rm, 256), dnl=E(rm, 256), sum=E(rm, 256), dsum=E(rm, 256), agg=E(rm, 256), dagg=E(rm, 256),
             f256=E(rm, 256), df256=E(rm, 256), f64=E(rm, 64), df64=E(rm, 64), z=E(rm, 3), dz=E(rm, 3), fine=E(B, M, 3), dfine=E(B, M, 3),
             # loss
@@ -437,6 +441,8 @@ class Trainer(object):
         req(rm % 64 == 0, "the fused head chains work on 64-row tiles: B * %d * N must be a multiple of 64, got B = %d, N = %d "
                           "(pad the batch)" % (self.up_ratio, B, N))
         req(M <= 4096, "the local cell's backward inverts a cloud's k-NN graph in LDS: %d * N <= 4096, got N = %d" % (self.up_ratio, N))
+        req(M % 32 == 0, "the non-local cell's attention kernels work on 32-point tiles: %d * N must be a multiple of 32, got N = %d"
+                         % (self.up_ratio, N))
         ws = self._workspace(B, N)
         L = _lib.lib()
         self.st = _lib.stream_ptr(x.device)
@@ -494,30 +500,11 @@ class Trainer(object):
                                            _p(P[cs + "fc_layer2/weights"]), _p(P[cs + "fc_layer2/biases"]),
                                            _p(ws["up128"]), 128, _p(ws["c256"]), 256, _p(ws["c64"]), 64, None, 0, 0, None, 0,
                                            _p(coarse), 3, self.st), "mlp_chain[coarse]")
-        # non-local cell with materialised attention (kept for the backward).  It reads up128 only: a branch next to the grouping,
-        # the skip and the local cell; merged before add3
         ps = "refine/PointShuffle/"
         up128 = ws["up128"]
-        S = ws["S"]
-        with self._branch(0):
-            # what the backward needs and nothing in the forward touches rides on this branch (it has slack; no stream of its own: a
-            # fourth auxiliary stream changed the stream -> hardware-queue mapping and cost 0.1 ms per step)
-            ws["zeroed"].zero_()         # the dense blocks' input gradients, the skip branch's d(up128): accumulated with atomics
-            if (self.use_wt or self.fused_heads_bwd) and self._t_desc.numel():       # W^T copies for the dX products
-                _lib.check(L.dispu_transpose_batched(self._t_desc.numel() // 3, _p(self._t_desc), _p(self.flat_p), _p(self.flat_pT), self.st),
-                           "transpose_batched")
-            self._lin(up128, 0, 128, ps + "PointShuffle/conv_kv", 0, ws["kv"], 0, 128)
-            self._lin(up128, 0, 128, ps + "PointShuffle/conv_query", 0, ws["q"], 0, 64)
-            _lib.check(self._dl(B, M, 64, M, _p(ws["q"]), 64, M * 64, _p(ws["kv"]), 128, M * 128, 1, None, 0, _p(S), M, M * M,
-                                      None, 0, 0, None, 0, 0, self.st), "scores")
-            _lib.check(L.dispu_softmax_rows(rm, M, 0.125, _p(S), M, self.st), "softmax")
-            _lib.check(self._dl(B, M, M, 64, _p(S), M, M * M, _p(ws["kv"], 64), 128, M * 128, 0, None, 0, _p(ws["att"]), 64,
-                                      M * 64, None, 0, 0, None, 0, 0, self.st), "att.V")
-            self._lin(ws["att"], 0, 64, ps + "PointShuffle/conv_back_project", 1, ws["nl"], 0, 256)
-
-        # PointShuffle2 (ops.py:1012-1087) in the inference path's form: no [B, M, 16, 134] grouped tensor.  The k-NN graph and the
-        # weight net's BatchNorm statistics (from the neighbour offsets) on a branch, next to the per-point halves of conv0
-        # (G = up128.Wf + xyz.(Wc + Wr) + b0, A = xyz.Wc; h0 = relu(G[j] - A[i])) that need neither
+        # The k-NN graph of the coarse cloud heads the step's critical path (knn -> BatchNorm statistics -> fused local cell ->
+        # after_conv -> fine head): its two launches are queued BEFORE the ~8 launches of the non-local branch, which has slack
+        # (round 4: queued after them, the graph waited ~70 us for the host to get there -- tools/trace_timeline.py)
         ww, bw = P[ps + "weight_net/wconv0/weights"], P[ps + "weight_net/wconv0/biases"]
         nb = L.dispu_ps_wnet_scratch_bytes(rm)
         if self._bn_scratch is None or self._bn_scratch.numel() * 8 < nb:
@@ -528,9 +515,36 @@ class Trainer(object):
                                                 BN_EPS, BN_DECAY, _p(ws["bn_stats"]), _p(ws["bn_scale"]), _p(ws["bn_shift"]),
                                                 _p(self.moving_mean), _p(self.moving_var), _p(self._bn_scratch), self._bn_scratch.numel() * 8,
                                                 self.st), "ps_wnet_bn_stats")
+        # PointShuffle2 (ops.py:1012-1087) in the inference path's form: no [B, M, 16, 134] grouped tensor.  The k-NN graph and the
+        # weight net's BatchNorm statistics (from the neighbour offsets) on a branch, next to the per-point halves of conv0
+        # (G = up128.Wf + xyz.(Wc + Wr) + b0, A = xyz.Wc; h0 = relu(G[j] - A[i])) that need neither
         w0 = P[ps + "conv0/weights"]
         self._lin(up128, 0, 128, None, 0, ws["gm"], 0, 128, bias=False, W=w0, woff=6 * 128)
         _lib.check(L.dispu_ps_prep(rm, 128, _p(coarse), _p(w0), _p(P[ps + "conv0/biases"]), _p(ws["gm"]), 128, _p(ws["am"]), 128, self.st), "ps_prep")
+        # non-local cell with materialised attention (kept for the backward).  It reads up128 only: a branch next to the grouping,
+        # the skip and the local cell; merged before add3
+        S = ws["S"]
+        with self._branch(0):
+            # what the backward needs and nothing in the forward touches rides on this branch (it has slack; no stream of its own: a
+            # fourth auxiliary stream changed the stream -> hardware-queue mapping and cost 0.1 ms per step)
+            ws["zeroed"].zero_()         # the dense blocks' input gradients, the skip branch's d(up128): accumulated with atomics
+            if (self.use_wt or self.fused_heads_bwd) and self._t_desc.numel():       # W^T copies for the dX products
+                _lib.check(L.dispu_transpose_batched(self._t_desc.numel() // 3, _p(self._t_desc), _p(self.flat_p), _p(self.flat_pT), self.st),
+                           "transpose_batched")
+            self._lin(up128, 0, 128, ps + "PointShuffle/conv_kv", 0, ws["kv"], 0, 128)
+            self._lin(up128, 0, 128, ps + "PointShuffle/conv_query", 0, ws["q"], 0, 64)
+            if self.flash_attn:
+                # softmax(Q.K^T / 8).V on chip; what the backward needs is att and ONE float per query (csrc/attention_train.hip)
+                _lib.check(L.dispu_attention_fwd_lse(B, M, M, 64, _p(ws["q"]), 64, _p(ws["kv"]), 128, _p(ws["kv"], 64), 128, 0.125,
+                                                     _p(ws["att"]), 64, _p(ws["lse"]), self.st), "attention_fwd_lse")
+            else:
+                _lib.check(self._dl(B, M, 64, M, _p(ws["q"]), 64, M * 64, _p(ws["kv"]), 128, M * 128, 1, None, 0, _p(S), M, M * M,
+                                          None, 0, 0, None, 0, 0, self.st), "scores")
+                _lib.check(L.dispu_softmax_rows(rm, M, 0.125, _p(S), M, self.st), "softmax")
+                _lib.check(self._dl(B, M, M, 64, _p(S), M, M * M, _p(ws["kv"], 64), 128, M * 128, 0, None, 0, _p(ws["att"]), 64,
+                                          M * 64, None, 0, 0, None, 0, 0, self.st), "att.V")
+            self._lin(ws["att"], 0, 64, ps + "PointShuffle/conv_back_project", 1, ws["nl"], 0, 256)
+
         self._merge(2)
         # skip (a second branch next to the local cell): gather-max straight from xyz / up128, then 134 -> 256
         with self._branch(1):
@@ -703,17 +717,23 @@ class Trainer(object):
         with self._branch(0, ev_br):
             self._lin_bwd(ws["att"], 0, 64, ps + "PointShuffle/conv_back_project", 256, ws["dnl"], 0, ws["datt"])
             S, dS, kv, dkv, q = ws["S"], ws["dS"], ws["kv"], ws["dkv"], ws["q"]
-            # dP = dO . V^T
-            _lib.check(self._dl(B, M, 64, M, _p(ws["datt"]), 64, M * 64, _p(kv, 64), 128, M * 128, 1, None, 0, _p(dS), M, M * M,
-                                      None, 0, 0, None, 0, 0, self.st), "dP")
-            # dV = P^T . dO  -> dkv[:, 64:128]
-            self._tn(B, M, M, 64, S, 0, M, M * M, ws["datt"], 0, 64, M * 64, dkv, 64, 128, M * 128, 0)
-            _lib.check(L.dispu_softmax_rows_grad(rm, M, 0.125, _p(S), M, _p(dS), M, self.st), "softmax_grad")
-            # dQ = dS . K
-            _lib.check(self._dl(B, M, M, 64, _p(dS), M, M * M, _p(kv), 128, M * 128, 0, None, 0, _p(ws["dq"]), 64, M * 64,
-                                      None, 0, 0, None, 0, 0, self.st), "dQ")
-            # dK = dS^T . Q -> dkv[:, 0:64]
-            self._tn(B, M, M, 64, dS, 0, M, M * M, q, 0, 64, M * 64, dkv, 0, 128, M * 128, 0)
+            if self.flash_attn:
+                # dQ, dK, dV with the probabilities recomputed tile by tile from Q, K and the forward's log-sum-exp: two launches
+                _lib.check(L.dispu_attention_bwd(B, M, M, 64, _p(q), 64, _p(kv), 128, _p(kv, 64), 128, 0.125, _p(ws["att"]), 64,
+                                                 _p(ws["lse"]), _p(ws["datt"]), 64, _p(ws["dq"]), 64, _p(dkv), 128, _p(dkv, 64), 128,
+                                                 _p(ws["dvec"]), self.st), "attention_bwd")
+            else:
+                # dP = dO . V^T
+                _lib.check(self._dl(B, M, 64, M, _p(ws["datt"]), 64, M * 64, _p(kv, 64), 128, M * 128, 1, None, 0, _p(dS), M, M * M,
+                                          None, 0, 0, None, 0, 0, self.st), "dP")
+                # dV = P^T . dO  -> dkv[:, 64:128]
+                self._tn(B, M, M, 64, S, 0, M, M * M, ws["datt"], 0, 64, M * 64, dkv, 64, 128, M * 128, 0)
+                _lib.check(L.dispu_softmax_rows_grad(rm, M, 0.125, _p(S), M, _p(dS), M, self.st), "softmax_grad")
+                # dQ = dS . K
+                _lib.check(self._dl(B, M, M, 64, _p(dS), M, M * M, _p(kv), 128, M * 128, 0, None, 0, _p(ws["dq"]), 64, M * 64,
+                                          None, 0, 0, None, 0, 0, self.st), "dQ")
+                # dK = dS^T . Q -> dkv[:, 0:64]
+                self._tn(B, M, M, 64, dS, 0, M, M * M, q, 0, 64, M * 64, dkv, 0, 128, M * 128, 0)
             self._lin_bwd(ws["up128"], 0, 128, ps + "PointShuffle/conv_kv", 128, dkv, 0, dup128)
             self._lin_bwd(ws["up128"], 0, 128, ps + "PointShuffle/conv_query", 64, ws["dq"], 0, dup128, 0, acc_dx=True)
         # skip branch (a second branch): 134 -> 256 backward; its max gradient is scattered after the merges below

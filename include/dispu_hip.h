@@ -48,7 +48,7 @@ extern "C" {
  * 3 = round 3: dispu_match_cost / dispu_match_cost_grad are the reference's launcher signatures again (as in version 1, no
  * scratch) and the scratch-taking fast paths are dispu_match_cost_ws / dispu_match_cost_grad_ws; dispu_fps_ws (scratch with an
  * explicit size), dispu_prob_sample, dispu_selection_sort; the fused training kernels.  A symbol never changes signature again:
- * new forms get new names. */
+ * new forms get new names.  4 = round 4: additions only (dispu_attention_fwd_lse / dispu_attention_bwd, ...). */
 int dispu_version(void);
 /* hipGetErrorString for the codes returned below. */
 const char* dispu_error_string(int code);
@@ -256,6 +256,16 @@ int dispu_attention(int b, int m, int nk, int d, const float* Q, long ldq, const
 int dispu_attention_project(int b, int m, int nk, int d, const float* Q, long ldq, const float* K, long ldk, const float* V,
                             long ldv, float scale, const float* W, const float* bias, int n_out, float* Y, long ldy,
                             void* stream);
+/* The cell's attention for the TRAINING step, without the [b, m, nk] probability tensor the reference keeps for its backward pass
+ * (tf.matmul / tf.nn.softmax / tf.matmul of ops.py:326-339 and their TF1 gradients).  Forward: O as dispu_attention, plus
+ * lse2[b*m] = log2 sum_k 2^(scale log2(e) Q.K) per query.  Backward: P is recomputed tile by tile from Q, K and lse2; writes
+ * (overwrites) dQ [b*m, 64], dK / dV [b*nk, 64]; dvec [b*m] floats of scratch (receives rowsum(dO o O)).  Two launches, no float
+ * atomics (run-to-run identical).  d == 64, m % 32 == 0, nk % 32 == 0, every row 16-byte aligned. */
+int dispu_attention_fwd_lse(int b, int m, int nk, int d, const float* Q, long ldq, const float* K, long ldk, const float* V,
+                            long ldv, float scale, float* O, long ldo, float* lse2, void* stream);
+int dispu_attention_bwd(int b, int m, int nk, int d, const float* Q, long ldq, const float* K, long ldk, const float* V, long ldv,
+                        float scale, const float* O, long ldo, const float* lse2, const float* dO, long lddo, float* dQ, long lddq,
+                        float* dK, long lddk, float* dV, long lddv, float* dvec, void* stream);
 /* S <- softmax(S * mul) per row, in place (tf.nn.softmax of PointNonLocalCell, ops.py:338). */
 int dispu_softmax_rows(long rows, int n, float mul, float* S, long lds, void* stream);
 

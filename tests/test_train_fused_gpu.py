@@ -441,3 +441,71 @@ def test_edge_dense_conv_grad(dev, L, C, B, n):
     for kk in P:
         assert torch.equal(dW2[kk], dW[kk]), kk
     close(N_(dF2).reshape(B, n, C), 2 * ft.grad.numpy(), 2e-5, "dF (two halves)")
+
+
+# ---- round 4: the non-local cell's attention without the [B, M, M] tensor (csrc/attention_train.hip) ----------------------------
+@pytest.mark.parametrize("b,m,strided", [(8, 1024, True), (2, 256, False), (1, 96, True), (16, 1024, False), (32, 1024, True), (3, 32, False), (64, 512, False)])
+def test_attention_train_forward_and_backward(dev, L, b, m, strided):
+    """softmax(Q.K^T / 8).V of Common/ops.py:326-339 and its gradients w.r.t. Q, K, V against float64 autograd of the SAME
+    three TF ops (matmul(transpose_b), softmax, matmul).  The backward recomputes the probabilities from Q, K and the forward's
+    per-row log-sum-exp; b / m sweep the three workgroup shapes (1, 2, 4 MFMA waves) and the strided K|V layout of the trainer."""
+    rng = np.random.default_rng(b * 1000 + m)
+    q = rng.standard_normal((b, m, 64)).astype(np.float32) * 1.5
+    kv = rng.standard_normal((b, m, 128)).astype(np.float32) * 1.5
+    do = rng.standard_normal((b, m, 64)).astype(np.float32)
+    tq = torch.tensor(q, dtype=F64, requires_grad=True)
+    tkv = torch.tensor(kv, dtype=F64, requires_grad=True)
+    att = torch.softmax(torch.matmul(tq, tkv[..., :64].transpose(1, 2)) / 8.0, dim=-1)
+    out = torch.matmul(att, tkv[..., 64:])
+    out.backward(torch.tensor(do, dtype=F64))
+    st = L.stream_ptr(dev)
+    Q, dO = dv(q, dev), dv(do, dev)
+    if strided:
+        KV = dv(kv, dev)
+        Kp, Vp, ld = p(KV), p(KV, 64), 128
+        dKV = torch.full((b, m, 128), float("nan"), device=dev)
+        dKp, dVp = p(dKV), p(dKV, 64)
+    else:
+        Kt, Vt = dv(kv[..., :64].copy(), dev), dv(kv[..., 64:].copy(), dev)
+        Kp, Vp, ld = p(Kt), p(Vt), 64
+        dKt, dVt = torch.full((b, m, 64), float("nan"), device=dev), torch.full((b, m, 64), float("nan"), device=dev)
+        dKp, dVp = p(dKt), p(dVt)
+    O = torch.full((b, m, 64), float("nan"), device=dev)
+    lse = torch.full((b, m), float("nan"), device=dev)
+    dQ = torch.full((b, m, 64), float("nan"), device=dev)
+    dvec = torch.empty((b, m), device=dev)
+    L.check(L.lib().dispu_attention_fwd_lse(b, m, m, 64, p(Q), 64, Kp, ld, Vp, ld, 0.125, p(O), 64, p(lse), st), "attention_fwd_lse")
+    L.check(L.lib().dispu_attention_bwd(b, m, m, 64, p(Q), 64, Kp, ld, Vp, ld, 0.125, p(O), 64, p(lse), p(dO), 64, p(dQ), 64,
+                                        dKp, ld, dVp, ld, p(dvec), st), "attention_bwd")
+    torch.cuda.synchronize()
+    close(N_(O), out.detach().numpy(), 1e-5, "O")
+    logits = (torch.matmul(tq, tkv[..., :64].transpose(1, 2)) / 8.0).detach()
+    want_lse = (torch.logsumexp(logits, dim=-1) / np.log(2.0)).numpy()
+    assert np.abs(N_(lse) - want_lse).max() <= 1e-5 * max(1.0, np.abs(want_lse).max())
+    close(N_(dvec), (torch.tensor(do, dtype=F64) * out.detach()).sum(-1).numpy(), 1e-5, "D")
+    close(N_(dQ), tq.grad.numpy(), 1e-5, "dQ")
+    gkv = tkv.grad.numpy()
+    if strided:
+        close(N_(dKV)[..., :64], gkv[..., :64], 1e-5, "dK")
+        close(N_(dKV)[..., 64:], gkv[..., 64:], 1e-5, "dV")
+    else:
+        close(N_(dKt), gkv[..., :64], 1e-5, "dK")
+        close(N_(dVt), gkv[..., 64:], 1e-5, "dV")
+    # deterministic: no float atomics anywhere in the two backward kernels
+    dQ2 = torch.empty_like(dQ)
+    L.check(L.lib().dispu_attention_bwd(b, m, m, 64, p(Q), 64, Kp, ld, Vp, ld, 0.125, p(O), 64, p(lse), p(dO), 64, p(dQ2), 64,
+                                        dKp, ld, dVp, ld, p(dvec), st), "attention_bwd")
+    torch.cuda.synchronize()
+    assert torch.equal(dQ, dQ2)
+
+
+def test_attention_train_refuses_unsupported_shapes(dev, L):
+    t = torch.zeros((1, 64, 64), device=dev)
+    v = torch.zeros(64, device=dev)
+    st = L.stream_ptr(dev)
+    bad = L.lib().dispu_attention_fwd_lse(1, 48, 64, 64, p(t), 64, p(t), 64, p(t), 64, 0.125, p(t), 64, p(v), st)     # m % 32
+    assert bad != 0
+    bad = L.lib().dispu_attention_fwd_lse(1, 64, 64, 32, p(t), 64, p(t), 64, p(t), 64, 0.125, p(t), 64, p(v), st)     # d != 64
+    assert bad != 0
+    bad = L.lib().dispu_attention_fwd_lse(1, 64, 64, 64, p(t), 66, p(t), 64, p(t), 64, 0.125, p(t), 64, p(v), st)     # unaligned rows
+    assert bad != 0

@@ -501,9 +501,12 @@ def test_graphed_steps_equal_eager_steps(dev, dtype):
         kept.append((te, tg))
         torch.cuda.synchronize()
         # moving statistics: decay 0.95 applied exactly once per step on both sides
-        tol = 1e-5 if dtype == "f32" else 2e-3
-        assert np.allclose(N(g.moving_mean), N(e.moving_mean), rtol=tol, atol=tol * 1e-2), "moving_mean after step %d" % i
-        assert np.allclose(N(g.moving_var), N(e.moving_var), rtol=tol, atol=tol * 1e-2), "moving_variance after step %d" % i
+        # (after the first Adam step single weights of the two trainers sit up to 2 lr apart -- see below -- so the batch statistics agree
+        # to ~1e-3, not to rounding; a warm-up pass counted as a step would move them by 5 % of (batch - moving) = O(1e-2))
+        assert np.allclose(N(g.moving_mean), N(e.moving_mean), rtol=2e-3, atol=2e-4), "moving_mean after step %d" % i
+        assert np.allclose(N(g.moving_var), N(e.moving_var), rtol=2e-3, atol=2e-4), "moving_variance after step %d" % i
+        if i == 0:                                    # before any Adam step the two forwards see identical weights: exact to atomics noise
+            assert np.allclose(N(g.moving_mean), N(e.moving_mean), rtol=1e-5, atol=1e-7)
     assert len(g._graphs) == 2 and g.global_step == e.global_step == 4 and g.adam_t == e.adam_t == 4
     # Adam's first steps move every weight by ~lr whatever the gradient's size: where a gradient entry is ~0 the atomics noise
     # decides the SIGN of a full lr-sized move, so single weights may sit up to steps x 2 lr apart; all but a sliver agree to rounding
@@ -553,3 +556,38 @@ def test_second_backward_on_one_forward(dev):
     torch.cuda.synchronize()
     scale = float(first.abs().max())
     assert float((tr.flat_g - first).abs().max()) <= 1e-5 * scale
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_flash_attention_step_equals_materialised_attention_step(dev, dtype):
+    """round 4: the non-local cell through dispu_attention_fwd_lse / dispu_attention_bwd (no [B, M, M] tensor) gives the step the
+    SAME forward values and gradients as round 3's matmul -> softmax -> matmul path and its five backward products."""
+    from dispu_amd import synth
+    from dispu_amd.train import Trainer
+    P = OG.init_params(seed=77, bias_scale=0.05, bn_random=True)
+    B = 4
+    x, gt = synth.patch_with_gt(B, 256, 1024, seed=13)
+    xs, gs, rs = dv(x, dev), dv(gt, dev), torch.ones(B, device=dev)
+    res = {}
+    for flash in (True, False):
+        tr = Trainer(params=P, device=dev, dtype=dtype)
+        tr.flash_attn = flash
+        tr.zero_grad()
+        c, f = tr.forward(xs)
+        ws = tr._ws[(B, 256)]
+        assert (ws["S"] is None) == flash
+        terms = tr.loss_backward(gs, rs)
+        tr.backward()
+        torch.cuda.synchronize()
+        res[flash] = dict(fine=f.clone(), nl=ws["nl"].clone(), att=ws["att"].clone(), dq=ws["dq"].clone(), dkv=ws["dkv"].clone(),
+                          g={k: v.clone() for k, v in tr.G.items()}, loss=float(terms["pu_loss"]))
+    a, b = res[True], res[False]
+    tol = 2e-5 if dtype == "f32" else 5e-3
+    for k in ("att", "nl", "fine", "dq", "dkv"):
+        scale = float(b[k].abs().max()) + 1e-12
+        assert float((a[k] - b[k]).abs().max()) <= tol * scale, k
+    assert abs(a["loss"] - b["loss"]) <= tol * abs(b["loss"])
+    gtol = 1e-4 if dtype == "f32" else 2e-2
+    for k in a["g"]:
+        scale = float(b["g"][k].abs().max()) + 1e-12
+        assert float((a["g"][k] - b["g"][k]).abs().max()) <= gtol * scale + 2e-6, k
