@@ -6,6 +6,9 @@ the moving statistics in `params` (forward only: the hand-written backward exist
 
 torch is used here only to allocate / concatenate / reshape device buffers; every arithmetic step is a HIP kernel
 of libdispu_hip.so."""
+import ctypes
+import os
+
 import torch
 
 from . import _lib, tf_util
@@ -65,9 +68,56 @@ def sample_and_group_all(xyz, points, use_xyz=True):
     return new_xyz, new_points, idx, grouped_xyz
 
 
+def _sa_fused(xyz, new_xyz, points, idx, mlp, scope, params, bn):
+    """group -> centre -> MLP -> max over nsample in ONE launch (csrc/sa_fused.hip): [b, m, ns, C] never reaches HBM."""
+    b, n, _ = xyz.shape
+    m, ns = idx.shape[1], idx.shape[2]
+    dev = xyz.device
+    c = 0 if points is None else points.shape[2]
+    keep, Ws, bs, scs, shs = [], [], [], [], []
+    cin = 3 + c
+    for i, co in enumerate(mlp):
+        sc = scope + "/conv%d" % i
+        W, bias = tf_util._dev(params[sc + "/weights"], dev), tf_util._dev(params[sc + "/biases"], dev)
+        if tuple(W.shape) != (cin, co):
+            raise ValueError("%s/weights has shape %s, expected (%d, %d)" % (sc, tuple(W.shape), cin, co))
+        scale, shift = tf_util.bn_fold(params, sc, dev) if bn else (None, None)
+        keep += [W, bias, scale, shift]
+        Ws.append(_lib.ptr(W)); bs.append(_lib.ptr(bias)); scs.append(_lib.ptr(scale)); shs.append(_lib.ptr(shift))
+        cin = co
+    arr = lambda ps: (ctypes.c_void_p * len(ps))(*[p.value for p in ps])       # NULL entries: no BatchNorm on that layer
+    couts = (ctypes.c_int * len(mlp))(*[int(v) for v in mlp])
+    out = torch.empty((b, m, mlp[-1]), dtype=torch.float32, device=dev)
+    pts = points.contiguous() if points is not None else None
+    _lib.check(_lib.lib().dispu_sa_fused(b, n, m, ns, c, _lib.ptr(xyz.contiguous()), _lib.ptr(new_xyz.contiguous()), _lib.ptr(pts),
+                                         _lib.ptr(idx.contiguous()), len(mlp), arr(Ws), arr(bs), arr(scs), arr(shs), couts, _lib.ptr(out),
+                                         _lib.stream_ptr(dev)), "dispu_sa_fused")
+    return out
+
+
+def _sa_fusable(points, nsample, mlp, mlp2, group_all, is_training, bn, pooling, tnet_spec, use_xyz):
+    if os.environ.get("DISPU_SA_FUSED", "1") == "0" or group_all or mlp2 or pooling != "max" or tnet_spec is not None or not use_xyz:
+        return False
+    if (bn and is_training) or nsample not in (32, 64) or not 1 <= len(mlp) <= 3:
+        return False
+    c = 0 if points is None else points.shape[2]
+    width = max([(3 + c + 1) & ~1] + [(co + 1) & ~1 for co in mlp[:-1]]) | 1
+    return (2 * nsample * width + (nsample // 32) * mlp[-1]) * 4 <= 160 * 1024
+
+
 def pointnet_sa_module(xyz, points, npoint, radius, nsample, mlp, mlp2, group_all, is_training, bn_decay, scope,
                        bn=True, pooling="max", tnet_spec=None, knn=False, use_xyz=True, params=None):
-    """pointnet_util.py:91-149 -> (new_xyz, new_points[b,npoint,mlp[-1] or mlp2[-1]], idx)."""
+    """pointnet_util.py:91-149 -> (new_xyz, new_points[b,npoint,mlp[-1] or mlp2[-1]], idx).
+
+    Max pooling over 32 / 64 samples without mlp2 in inference mode (every call of Common/ops.py:505-550) runs as ONE fused
+    kernel after the sampling / ball query; other configurations compose the single ops (DISPU_SA_FUSED=0 forces that)."""
+    if _sa_fusable(points, nsample, mlp, mlp2, group_all, is_training, bn, pooling, tnet_spec, use_xyz):
+        new_xyz = gather_point(xyz, farthest_point_sample(npoint, xyz))
+        if knn:
+            _, idx = knn_point(nsample, xyz, new_xyz)
+        else:
+            idx, _ = query_ball_point(radius, nsample, xyz, new_xyz)
+        return new_xyz, _sa_fused(xyz, new_xyz, points, idx, mlp, scope, params, bn), idx
     if group_all:
         nsample = xyz.shape[1]
         new_xyz, new_points, idx, grouped_xyz = sample_and_group_all(xyz, points, use_xyz)

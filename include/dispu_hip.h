@@ -282,6 +282,15 @@ int dispu_mlp_chain(long rows, int K0, int N1, int N2, int N3, const float* X, l
  * (Common/pointnet_util.py, gcn_lib/tf_vertex.py, Common/loss_utils.py: chains of generic TF ops in the reference) */
 /* grouped[r,s,:] -= center[r,:]  ("translation normalization", pointnet_util.py:43; loss_utils.py:281). */
 int dispu_group_center(long rows, int ns, int c, float* grouped, const float* center, void* stream);
+/* pointnet_sa_module's hot loop fused (pointnet_util.py:91-149 with pooling 'max', mlp2 None, use_xyz, inference BatchNorm):
+ * out[b,m,cout[nl-1]] = max_s mlp([xyz[idx[b,m,s]] - new_xyz[b,m] | points[idx[b,m,s]]]) -- group_point, the translation
+ * normalisation, nl <= 3 conv2d layers (bias, optional BatchNorm fold scale/shift, ReLU) and the max over nsample in one
+ * launch; the [b,m,ns,C] tensors never reach HBM.  ns in {32, 64}; W[l] [cin_l, cout_l] row-major, cin_0 = 3 + c (c = 0:
+ * points may be NULL), cin_l = cout[l-1]; scale / shift may be NULL (no BatchNorm) or hold NULL entries.  Bit-identical to
+ * dispu_group_point -> dispu_group_center -> dispu_linear_bn x nl -> dispu_pool_nsample(max). */
+int dispu_sa_fused(int b, int n, int m, int ns, int c, const float* xyz, const float* new_xyz, const float* points, const int* idx,
+                   int nl, const float* const* W, const float* const* bias, const float* const* scale, const float* const* shift,
+                   const int* cout, float* out, void* stream);
 /* pooling over nsample of X[rows,ns,c] (pointnet_util.py:121-140): mode 0 max, 1 avg, 2 "min" (= max(-x), as the
  * reference computes it), 3 weighted_avg (needs gxyz[rows,ns,3]), 4 max_and_avg -> [max|avg] (2c outputs),
  * 5 sum (GIN aggregation, gcn_lib/tf_vertex.py:248). */

@@ -108,6 +108,19 @@ def pointnet_fp_module(P, scope, xyz1, xyz2, points1, points2, mlp, bn=True):
     return x[:, :, 0]
 
 
+def hierachy_feature_extractor(P, inputs, npoints=(1024, 384, 128), radius=(0.1, 0.2, 0.4)):
+    """Common/ops.py:505-550 (modules with their default bn=True; scopes layer1..4, fa_layer1..4) -> [B, N, 128]; `tap`-free."""
+    l0_xyz, l0_points = inputs, None
+    l1_xyz, l1_points, _ = pointnet_sa_module(P, "layer1", l0_xyz, l0_points, npoints[0], radius[0], 64, [32, 32, 64], None, False)
+    l2_xyz, l2_points, _ = pointnet_sa_module(P, "layer2", l1_xyz, l1_points, npoints[1], radius[1], 64, [64, 64, 128], None, False)
+    l3_xyz, l3_points, _ = pointnet_sa_module(P, "layer3", l2_xyz, l2_points, npoints[2], radius[2], 64, [128, 128, 256], None, False)
+    l4_xyz, l4_points, _ = pointnet_sa_module(P, "layer4", l3_xyz, l3_points, None, None, None, [256, 256, 512], None, True)
+    l3_points = pointnet_fp_module(P, "fa_layer1", l3_xyz, l4_xyz, l3_points, l4_points, [512, 512])
+    l2_points = pointnet_fp_module(P, "fa_layer2", l2_xyz, l3_xyz, l2_points, l3_points, [512, 256])
+    l1_points = pointnet_fp_module(P, "fa_layer3", l1_xyz, l2_xyz, l1_points, l2_points, [256, 128])
+    return pointnet_fp_module(P, "fa_layer4", l0_xyz, l1_xyz, l0_points, l1_points, [128, 128, 128])
+
+
 def knn_graph(feat, k):
     """tf_edge.py:19-28 + tf_util.py:618-651 (self is kept)."""
     return O.knn_point_2(k, feat, feat)[1][..., 1]

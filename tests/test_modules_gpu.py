@@ -162,3 +162,64 @@ def test_hausdorff_loss_gradient(dev):
             e = np.zeros_like(pred); e[b, i, c] = eps
             num = (OM.hausdorff_loss(pred + e, gt) - OM.hausdorff_loss(pred - e, gt)) / (2 * eps)
             assert abs(num - g[b, i, c]) < 5e-3 * max(1.0, abs(num))
+
+
+# ---- round 4: the set-abstraction hot loop as one kernel (csrc/sa_fused.hip) and Common/ops.py:505-550 at its own shapes ----------
+@pytest.mark.parametrize("c,mlp,ns,bn,knn", [(0, [32, 32, 64], 64, True, False), (64, [64, 64, 128], 64, True, False),
+                                             (128, [128, 128, 256], 64, True, False), (13, [33, 17, 40], 64, False, False),
+                                             (5, [24, 48], 32, True, True), (0, [16], 32, False, False), (260, [64, 64], 64, True, False)])
+def test_sa_fused_equals_unfused_chain(dev, monkeypatch, c, mlp, ns, bn, knn):
+    """pointnet_sa_module through dispu_sa_fused (group -> centre -> MLP -> max in one launch, nothing of size [b, m, ns, C] in HBM)
+    == the composition group_point / group_center / linear_bn x nl / pool_nsample BIT FOR BIT, and the oracle to 1e-5; odd input and
+    hidden widths (67, 131, 33, 17), 32 and 64 samples, with / without BatchNorm, ball query and k-NN grouping."""
+    from dispu_amd import pointnet_util as PU
+    rng = np.random.default_rng(c * 7 + ns)
+    b, n, m = 3, 512, 96
+    xyz = cloud(rng, b, n)
+    pts = rng.standard_normal((b, n, c)).astype(np.float32) if c else None
+    spec, cin = [], 3 + c
+    for i, co in enumerate(mlp):
+        spec.append(("sa/conv%d" % i, cin, co))
+        cin = co
+    P = make_params(rng, spec, bn=bn)
+    tp = T(pts, dev) if c else None
+    calls = []
+    real = PU._sa_fused
+    monkeypatch.setattr(PU, "_sa_fused", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    fx, fp, fi = PU.pointnet_sa_module(T(xyz, dev), tp, m, 0.25, ns, mlp, None, False, False, None, "sa", bn=bn, knn=knn, params=P)
+    assert calls, "the fused kernel was not used"
+    monkeypatch.setenv("DISPU_SA_FUSED", "0")
+    ux, up, ui = PU.pointnet_sa_module(T(xyz, dev), tp, m, 0.25, ns, mlp, None, False, False, None, "sa", bn=bn, knn=knn, params=P)
+    assert len(calls) == 1
+    assert np.array_equal(N(fi), N(ui)) and np.array_equal(N(fx), N(ux))
+    assert N(fp).shape == (b, m, mlp[-1]) and np.array_equal(N(fp), N(up)), "fused != unfused chain (bit-exact expected)"
+    wx, wp, wi = OM.pointnet_sa_module(P, "sa", xyz, pts, m, 0.25, ns, mlp, None, False, bn=bn, knn=knn)
+    assert np.array_equal(N(fi), wi) and np.allclose(N(fp), wp, rtol=1e-5, atol=1e-5)
+
+
+def test_hierachy_feature_extractor_at_reference_shapes(dev, monkeypatch):
+    """Common/ops.py:505-550 assembled from the modules at the shapes the reference names: B = 4 clouds of 1024 points, levels of
+    1024 / 384 / 128 centres with 64 samples and radii .1 / .2 / .4, MLPs up to 512 wide, group-all, four FP levels -- against
+    oracle/modules.py.  The sampled levels run fused; the unfused composition gives the same bits."""
+    from dispu_amd import ops as DO
+    rng = np.random.default_rng(11)
+    P = make_params(rng, DO.hierachy_feature_extractor_variables(), bn=True)
+    x = cloud(rng, 4, 1024)
+    want = OM.hierachy_feature_extractor(P, x)
+    got = DO.hierachy_feature_extractor(T(x, dev), False, params=P)
+    assert N(got).shape == (4, 1024, 128)
+    scale = np.abs(want).max()
+    assert np.abs(N(got) - want).max() <= 1e-5 * max(scale, 1.0), np.abs(N(got) - want).max()
+    monkeypatch.setenv("DISPU_SA_FUSED", "0")
+    unf = DO.hierachy_feature_extractor(T(x, dev), False, params=P)
+    assert np.array_equal(N(unf), N(got))
+    # the variable inventory is the checkpoint's: 21 conv layers with their BatchNorm quartets
+    assert len(DO.hierachy_feature_extractor_variables()) == 21 and sum(k.endswith("/weights") for k in P) == 21
+
+
+def test_sa_fused_refuses_bad_arguments(dev):
+    from dispu_amd import _lib
+    z = torch.zeros(64, device=dev)
+    bad = _lib.lib().dispu_sa_fused(1, 8, 1, 48, 0, _lib.ptr(z), _lib.ptr(z), None, _lib.ptr(z), 1, None, None, None, None, None, _lib.ptr(z),
+                                    _lib.stream_ptr(dev))
+    assert bad != 0

@@ -29,8 +29,9 @@ VALU_PEAK = 54.0e12            # measured v_fma_f32 lane-results/s (tools/micro/
 EXP_PEAK = 14.4e12             # measured v_exp_f32 results/s
 VALU_PEAK_DATASHEET = 78.6e12  # 157.3 TFLOP/s fp32 vector / 2
 EXP_PEAK_DATASHEET = VALU_PEAK_DATASHEET / 4
-PEAK = {"hbm": (HBM_PEAK, "B/s"), "valu": (VALU_PEAK, "lane-op/s"), "exp": (EXP_PEAK, "exp/s")}
-PEAK_DATASHEET = {"hbm": HBM_PEAK, "valu": VALU_PEAK_DATASHEET, "exp": EXP_PEAK_DATASHEET}
+MFMA_F32_PEAK = 157.3e12       # dense fp32 MFMA peak (MI355X_MICROARCH.md)
+PEAK = {"hbm": (HBM_PEAK, "B/s"), "valu": (VALU_PEAK, "lane-op/s"), "exp": (EXP_PEAK, "exp/s"), "mfma": (MFMA_F32_PEAK, "flop/s")}
+PEAK_DATASHEET = {"hbm": HBM_PEAK, "valu": VALU_PEAK_DATASHEET, "exp": EXP_PEAK_DATASHEET, "mfma": MFMA_F32_PEAK}
 
 
 def _timeit(fn, reps=20, warm=3, graph=True):
@@ -150,7 +151,49 @@ def gpu_ops(dev=None, quick=False):
         t = _timeit(lambda: A.match_cost(x1, x2, mt), reps=5, warm=1)
         nb = b * (24 * n + 4 * n * n + 4)
         out.append(_row("match_cost", (b, n, n), t, nb, "hbm", nb))
+    out += sa_rows(dev, g)
     return out
+
+
+def sa_rows(dev, g):
+    """PointNet++ set-abstraction hot loop (pointnet_util.py:91-149) at the shapes of Common/ops.py:505-550, 4 clouds of 1024 points:
+    group -> centre -> 3-layer MLP (BatchNorm fold, ReLU) -> max over 64 samples, fused (csrc/sa_fused.hip: one launch, nothing of
+    size [b, m, 64, C] in HBM) next to the composition of the single ops it replaces.  Sampling / ball query are not in the figure."""
+    import numpy as np
+    import torch
+    from dispu_amd import pointnet_util as PU, tf_util
+    from dispu_amd.tf_grouping import group_point
+    rows = []
+    rng = np.random.default_rng(7)
+    for (b, n, m, c, mlp) in [(4, 1024, 1024, 0, [32, 32, 64]), (4, 1024, 384, 64, [64, 64, 128]), (4, 384, 128, 128, [128, 128, 256]),
+                              (32, 1024, 384, 64, [64, 64, 128])]:
+        xyz = torch.rand(b, n, 3, device=dev, generator=g)
+        pts = torch.randn(b, n, c, device=dev, generator=g) if c else None
+        new_xyz = xyz[:, :m].contiguous()
+        idx = torch.randint(0, n, (b, m, 64), dtype=torch.int32, device=dev, generator=g)
+        P, cin = {}, 3 + c
+        for i, co in enumerate(mlp):
+            sc = "sa/conv%d" % i
+            P[sc + "/weights"] = torch.from_numpy((rng.standard_normal((cin, co)) / np.sqrt(cin)).astype(np.float32)).to(dev)
+            P[sc + "/biases"] = torch.zeros(co, device=dev)
+            for leaf, v in (("gamma", 1.0), ("beta", 0.0), ("moving_mean", 0.0), ("moving_variance", 1.0)):
+                P[sc + "/bn/" + leaf] = np.full(co, v, np.float32)
+            cin = co
+
+        def unfused():
+            gx = PU._center(group_point(xyz, idx), new_xyz)
+            x = torch.cat([gx, group_point(pts, idx)], dim=-1) if c else gx
+            for i, co in enumerate(mlp):
+                x = tf_util.conv2d(x, co, (1, 1), "sa/conv%d" % i, P, bn=True)
+            return PU._pool(x, "max")
+
+        flops = 2.0 * b * m * 64 * sum(a * o for a, o in zip([3 + c] + mlp[:-1], mlp))
+        nb = 4 * b * (n * (3 + c) + m * 3 + m * 64 + m * mlp[-1])
+        t = _timeit(lambda: PU._sa_fused(xyz, new_xyz, pts, idx, mlp, "sa", P, True), graph=False)
+        tu = _timeit(unfused, graph=False)
+        rows.append(_row("sa_module fused (group+centre+mlp+max)", (b, n, m, 64, c) + tuple(mlp), t, nb, "mfma", flops,
+                         "unfused composition of the same ops: %.1f us" % (tu * 1e6)))
+    return rows
 
 
 def cpu_ops():
