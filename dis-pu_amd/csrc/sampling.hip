@@ -23,6 +23,56 @@ __device__ __forceinline__ int fps_key_to_index(uint64_t key) {
     return (int)(((t & 0x3FFFFFu) << 9) | (t >> 22));
 }
 
+// Wave arg-max of (distance, tie key) on 32-bit DPP steps (round 4).  The 64-bit key needs two DPP moves, a 64-bit compare and two
+// selects per step (wave_max_u64: ~45 dependent-ish instructions per round); running distances are >= 0 (or -1 = "no point"), so
+// their bit patterns + 1 order like unsigned integers and fold with ONE v_max_u32_dpp per step.  Two such reductions - the
+// largest distance, then the largest tie key among the lanes that hold it (tie keys are unique, 0 elsewhere) - give the same
+// (distance, key) pair, wave-uniform, in 12 single-instruction steps and two v_readlane.
+__device__ __forceinline__ uint32_t fps_dkey(float d) { return d >= 0.f ? __float_as_uint(d) + 1u : 0u; }
+template <int CTRL, int RM = 0xF>
+__device__ __forceinline__ uint32_t fps_umax_step(uint32_t v) {
+    const uint32_t o = dpp_u32<CTRL, RM>(0u, v);
+    return v > o ? v : o;
+}
+__device__ __forceinline__ uint32_t fps_wave_max_u32(uint32_t v) {
+    v = fps_umax_step<DPP_ROW_SHR1>(v);
+    v = fps_umax_step<DPP_ROW_SHR2>(v);
+    v = fps_umax_step<DPP_ROW_SHR4>(v);
+    v = fps_umax_step<DPP_ROW_SHR8>(v);
+    v = fps_umax_step<DPP_ROW_BCAST15, 0xA>(v);
+    v = fps_umax_step<DPP_ROW_BCAST31, 0xC>(v);
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+// -> the wave's best as the 64-bit key of fps_tiekey's scheme (distance bits << 32 | tie key), 0 when the wave holds no point
+__device__ __forceinline__ uint64_t fps_wave_best(float bd, int k) {
+    const uint32_t dk = fps_dkey(bd);
+    const uint32_t dmax = fps_wave_max_u32(dk);
+    const uint32_t tk = (dk == dmax) ? fps_tiekey(k) : 0u;
+    const uint32_t tmax = fps_wave_max_u32(tk);
+    return dmax ? (((uint64_t)(dmax - 1u) << 32) | tmax) : 0ull;
+}
+
+// The winner among the W <= 16 per-wave slots: lane l < W reads slot l (ONE ds_read_b64 per lane instead of W broadcast reads and
+// W 64-bit compare/select triples in every lane), then the same two-stage 32-bit reduction over DPP row 0.
+template <int W>
+__device__ __forceinline__ uint64_t fps_slots_best(const uint64_t* slots, int lane) {
+    static_assert(W <= 16, "one DPP row");
+    const uint64_t v = (lane < W) ? slots[lane] : 0ull;
+    auto row0_max = [](uint32_t x) -> uint32_t {
+        x = fps_umax_step<DPP_ROW_SHR1>(x);
+        if (W > 2) x = fps_umax_step<DPP_ROW_SHR2>(x);
+        if (W > 4) x = fps_umax_step<DPP_ROW_SHR4>(x);
+        if (W > 8) x = fps_umax_step<DPP_ROW_SHR8>(x);
+        return (uint32_t)__builtin_amdgcn_readlane((int)x, W - 1 < 15 ? (W <= 2 ? 1 : W <= 4 ? 3 : W <= 8 ? 7 : 15) : 15);
+    };
+    // distance bits are compared as (bits + 1) with 0 = empty slot, exactly as inside the waves
+    const uint32_t hi = (uint32_t)(v >> 32), lo = (uint32_t)v;
+    const uint32_t dk = v ? hi + 1u : 0u;
+    const uint32_t dmax = row0_max(dk);
+    const uint32_t tmax = row0_max(dk == dmax ? lo : 0u);
+    return dmax ? (((uint64_t)(dmax - 1u) << 32) | tmax) : 0ull;
+}
+
 // Visit order of a thread's P points such that the reference tie priority (k mod 512, then k) is
 // non-decreasing along the visit: then a strict '>' update keeps exactly the reference's winner
 // among equal distances inside the thread, and the 64-bit key is only built once per round.
@@ -90,14 +140,12 @@ __global__ __launch_bounds__(BS) void fps_reg_kernel(int n, int m, const float* 
             td[i] = d2;
             if (d2 > bd) { bd = d2; bi = i; }
         }
-        uint64_t best = (bd < 0.f) ? 0ull : (((uint64_t)__float_as_uint(bd) << 32) | fps_tiekey(tid + bi * BS));
-        best = wave_max_u64(best);
+        uint64_t best = fps_wave_best(bd, tid + bi * BS);
         if constexpr (W > 1) {
             const int par = j & 1;
             if ((tid & (kWave - 1)) == 0) slot[par][tid / kWave] = best;
             __syncthreads();
-#pragma unroll
-            for (int w = 0; w < W; ++w) best = u64_max(best, slot[par][w]);
+            best = fps_slots_best<W>(slot[par], tid & (kWave - 1));
         }
         old = fps_key_to_index(best);
         if (tid == 0) o[j] = old;
@@ -130,13 +178,11 @@ __global__ __launch_bounds__(1024) void fps_mem_kernel(int n, int m, const float
             t[k] = d2;
             if (d2 > bd) { bd = d2; bk = k; }
         }
-        uint64_t best = (bd < 0.f) ? 0ull : (((uint64_t)__float_as_uint(bd) << 32) | fps_tiekey(bk));
-        best = wave_max_u64(best);
+        uint64_t best = fps_wave_best(bd, bk);
         const int par = j & 1;
         if ((tid & (kWave - 1)) == 0) slot[par][tid / kWave] = best;
         __syncthreads();
-#pragma unroll
-        for (int w = 0; w < W; ++w) best = u64_max(best, slot[par][w]);
+        best = fps_slots_best<W>(slot[par], tid & (kWave - 1));
         old = fps_key_to_index(best);
         if (tid == 0) o[j] = old;
     }
