@@ -556,6 +556,14 @@ __global__ __launch_bounds__(256) void match_grad2_kernel(int n, int m, const fl
     if (lane == 0) { float* g = grad + ((size_t)cloud * m + l) * 3; g[0] = gx; g[1] = gy; g[2] = gz; }
 }
 
+// The persistent form must never fail silently: if a bounded spin timed out (`fail` raised: the workgroups of a cloud were not
+// co-resident after all) the plan is poisoned with NaN, so every consumer sees it (EMD, match_cost and their gradients turn NaN).
+__global__ void am_poison_on_fail_kernel(const int* __restrict__ fail, float* __restrict__ match, size_t total) {
+    if (*fail == 0) return;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x)
+        match[e] = __builtin_nanf("");
+}
+
 static int am_persistent_mode() {       // DISPU_AM_PERSISTENT=1: the one-launch form for small batches (opt-in, see am_persistent_kernel)
     const char* e = getenv("DISPU_AM_PERSISTENT");      // read per call: tests flip it inside one process
     return e ? atoi(e) : 0;
@@ -586,11 +594,23 @@ static int run_approx_match(int b, int n, int m, const float* xyz1, const float*
     if (wpc > most) wpc = (int)most;
     const int mode = am_persistent_mode();
     if (wpc >= 2 && mode == 1 && most * b <= 4096) {
+        // every workgroup of the launch has to be resident at once (they meet at software barriers): ask the runtime how many this
+        // device can hold instead of assuming 256 free CUs (a smaller part, or CUs taken by concurrent streams' kernels -> fewer)
+        int per_cu = 0, dev = 0;
+        hipDeviceProp_t prop;
+        DISPU_TRY(hipGetDevice(&dev));
+        DISPU_TRY(hipGetDeviceProperties(&prop, dev));
+        DISPU_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, am_persistent_kernel<FMA, PINNED>, AM_ROWS, 0));
+        if ((long)per_cu * prop.multiProcessorCount < (long)b * wpc) wpc = 0;
+    }
+    if (wpc >= 2 && mode == 1 && most * b <= 4096) {
         unsigned* ctr = reinterpret_cast<unsigned*>(temp + (size_t)b * am_cloud_floats(n, m));
         int* fail = reinterpret_cast<int*>(ctr + b);
         DISPU_TRY(hipMemsetAsync(ctr, 0, sizeof(unsigned) * ((size_t)b + 1), s));
         hipLaunchKernelGGL((am_persistent_kernel<FMA, PINNED>), dim3(b * wpc), blk, 0, s, n, m, wpc, lv, multiL, multiR, xyz1, xyz2, temp, match, ctr,
                            fail);
+        DISPU_CHECK_LAUNCH();
+        hipLaunchKernelGGL(am_poison_on_fail_kernel, dim3(256), dim3(256), 0, s, fail, match, (size_t)b * n * m);
         return (int)hipGetLastError();
     }
     hipLaunchKernelGGL(am_init_kernel, dim3(8, b), dim3(256), 0, s, n, m, multiL, multiR, temp);

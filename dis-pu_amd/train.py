@@ -129,6 +129,9 @@ class Trainer(object):
         self.bf16_min_macs = float(os.environ.get("DISPU_TRAIN_BF16_MIN_MACS", "1.5e9"))
 
         self._side_busy = []
+        self._group = None                  # (event, side streams that already wait for it) inside _fork_group()
+        self._cap_events = []               # events created while a hipGraph is being captured (see _ev)
+        self._aux_done = {}                 # branch i -> the completion event recorded at its last exit
         self.P = None
         if params is not None:
             self.load_params(params)
@@ -257,18 +260,59 @@ class Trainer(object):
         self._side_rr = (self._side_rr + 1) % len(self._sides)
         return self._side_rr
 
+    def _ev(self, cached):
+        """the event to record at this point: the cached object in eager mode; a FRESH one while a hipGraph is being captured.
+        Re-recording one event object several times inside a capture loses stream order on this runtime (round 4: the fused coarse-head
+        backward and the dup_sum_grad launch after it, separated by five re-records of one fork event, ran unordered in the replayed
+        graph -- stale d(up256), every gradient of the feature extractor wrong from the second replay on; eager order was never
+        affected).  Fresh events are kept alive until the capture ends (train_step_graphed clears the list)."""
+        if torch.cuda.is_current_stream_capturing():
+            ev = torch.cuda.Event()
+            self._cap_events.append(ev)
+            return ev
+        return cached
+
     def _fork(self):
         """-> (stream pointer, scratch key) for a dW product that may start once everything queued on the main stream so far is done."""
         i = self._side_next()
-        main = torch.cuda.current_stream(self.device)
-        self._fork_ev.record(main)
-        self._sides[i].wait_event(self._fork_ev)
+        if self._group is not None:
+            # inside _fork_group(): every product of the group hangs off ONE event; a side stream waits for it once
+            ev, waited = self._group
+            if i not in waited:
+                self._sides[i].wait_event(ev)
+                waited.add(i)
+        else:
+            main = torch.cuda.current_stream(self.device)
+            ev = self._ev(self._fork_ev)
+            ev.record(main)
+            self._sides[i].wait_event(ev)
         self._side_busy[i] = True
         return ctypes.c_void_p(self._sides[i].cuda_stream), "dw%d" % i
+
+    @contextlib.contextmanager
+    def _fork_group(self):
+        """Several dW products that all depend on the SAME point of the current stream (the four weight gradients of a fused head
+        chain): one event, one wait per side stream.  Besides saving events this is what keeps the step correct under hipGraph replay:
+        captured as record / wait / record / wait ... with nothing launched on the main stream in between (redundant edges from one
+        node to a chain of side-stream nodes), the replayed graph ran the NEXT main-stream kernel without waiting for its predecessor
+        (round 4, tools/debug/graph_vs_eager.py: stale d(up256) -> every gradient of the feature extractor wrong from the second
+        replay on; eager launches were never affected)."""
+        if not self.overlap_dw:
+            yield
+            return
+        self._side_next()                                  # make sure the side streams exist
+        self._side_rr -= 1
+        self._group = (self._fork_point(), set())
+        try:
+            yield
+        finally:
+            self._group = None
 
     def _fork_point(self):
         """an event at the current position of the main stream, for a dW product queued later (see _lin_bwd)."""
         ev = torch.cuda.Event()
+        if torch.cuda.is_current_stream_capturing():
+            self._cap_events.append(ev)
         ev.record(torch.cuda.current_stream(self.device))
         return ev
 
@@ -282,8 +326,9 @@ class Trainer(object):
         """the current stream waits for every dW product queued so far (before a buffer they read is overwritten, before Adam)."""
         for i, busy in enumerate(self._side_busy if self._sides else []):
             if busy:
-                self._join_evs[i].record(self._sides[i])
-                torch.cuda.current_stream(self.device).wait_event(self._join_evs[i])
+                ev = self._ev(self._join_evs[i])
+                ev.record(self._sides[i])
+                torch.cuda.current_stream(self.device).wait_event(ev)
                 self._side_busy[i] = False
 
     @contextlib.contextmanager
@@ -299,8 +344,8 @@ class Trainer(object):
             self._aux.append((_pool_stream(self.device, "aux", len(self._aux)), torch.cuda.Event(), torch.cuda.Event()))
         aux, ev_fork, ev_done = self._aux[i]
         if after is None:
-            ev_fork.record(torch.cuda.current_stream(self.device))
-            after = ev_fork
+            after = self._ev(ev_fork)
+            after.record(torch.cuda.current_stream(self.device))
         aux.wait_event(after)
         old_st, old_cur = self.st, self._cur
         with torch.cuda.stream(aux):
@@ -313,14 +358,18 @@ class Trainer(object):
                 # time lands behind whatever the other streams of that queue were given in between (measured: the local cell's
                 # backward started 0.33 ms late, behind dW products it does not depend on)
                 if self._sched & 1:
-                    ev_done.record(aux)
+                    done = self._ev(ev_done)
+                    done.record(aux)
+                    self._aux_done[i] = done
 
     def _merge(self, i):
         if self.overlap_dw and i < len(self._aux):
             aux, _, ev_done = self._aux[i]
             if not (self._sched & 1):
-                ev_done.record(aux)
-            torch.cuda.current_stream(self.device).wait_event(ev_done)
+                done = self._ev(ev_done)
+                done.record(aux)
+                self._aux_done[i] = done
+            torch.cuda.current_stream(self.device).wait_event(self._aux_done.get(i, ev_done))
 
     # ----------------------------------------------------------------------------------------------- helpers ----
     def _dl(self, batch, M, K, N, *rest):
@@ -574,7 +623,12 @@ class Trainer(object):
     def _recompute_pair_tensors(self):
         """h0 = relu(G[j] - A[i]), h1 = relu(h0.W1 + b1), wv = relu(BN(offsets.Ww + bw)) [B*M*16, .] and the inverted k-NN graph: what
         the local cell's backward reads.  The forward kernel (csrc/ps_local.hip) keeps them on chip; they are rebuilt here, on an
-        auxiliary stream next to the loss and the fine head's backward (same arithmetic, same ReLU decisions)."""
+        auxiliary stream next to the loss and the fine head's backward.  dtype "f32": the same fmaf chains as the forward kernel,
+        hence the same values and the same ReLU decisions.  dtype "bf16": conv1 is rebuilt with bf16 PRODUCTS (and h0 / h1 are stored as
+        bf16) while the forward's fused cell ran fp32 products -- the masks (h1 > 0) and the h1 values entering dwv are those of the
+        bf16 rebuild, i.e. they can differ from the forward's at pre-activations within bf16 rounding of zero; that is part of the
+        mixed-precision approximation and sits inside the tolerances of tests/test_train_bf16_gpu.py (loss terms 2 %, gradient cosine
+        >= 0.97), not a separate error source."""
         if self._stash_ready:
             return
         L = _lib.lib()
@@ -694,10 +748,11 @@ class Trainer(object):
                                               _p(ws["df64"]), 64, _p(ws["df256"]), 256, _p(ws["dagg"]), 256,
                                               _p(ws["aft"]), _p(ws["skip"]), _p(ws["nl"]), 256, _p(ws["daft"]), _p(ws["dskip"]), _p(ws["dnl"]), 256,
                                               self.st), "mlp_chain_grad[fine]")
-            self._lin_bwd(ws["f64"], 0, 64, fs + "fc_layer2", 3, ws["dz"], 0)
-            self._lin_bwd(ws["f256"], 0, 256, fs + "fc_layer1", 64, ws["df64"], 0)
-            self._lin_bwd(ws["agg"], 0, 256, fs + "fc_layer0", 256, ws["df256"], 0)
-            self._lin_bwd(ws["sum"], 0, 256, ag, 256, ws["dagg"], 0)
+            with self._fork_group():
+                self._lin_bwd(ws["f64"], 0, 64, fs + "fc_layer2", 3, ws["dz"], 0)
+                self._lin_bwd(ws["f256"], 0, 256, fs + "fc_layer1", 64, ws["df64"], 0)
+                self._lin_bwd(ws["agg"], 0, 256, fs + "fc_layer0", 256, ws["df256"], 0)
+                self._lin_bwd(ws["sum"], 0, 256, ag, 256, ws["dagg"], 0)
         else:
             self._lin_bwd(ws["f64"], 0, 64, fs + "fc_layer2", 3, ws["dz"], 0, ws["df64"], mask=(ws["f64"], 0, 64))
             self._lin_bwd(ws["f256"], 0, 256, fs + "fc_layer1", 64, ws["df64"], 0, ws["df256"], mask=(ws["f256"], 0, 256))
@@ -785,10 +840,17 @@ class Trainer(object):
                                               _p(ws["dup128s"]) if split_skip else None, 128, _p(ws["dc64"]), 64, _p(ws["dc256"]), 256, _p(dup128), 128,
                                               _p(ws["up256"]), None, None, 256, _p(ws["dup256"]), None, None, 256, self.st),
                        "mlp_chain_grad[coarse]")
-            self._lin_bwd(ws["c64"], 0, 64, cs + "fc_layer2", 3, dcoarse, 0)
-            self._lin_bwd(ws["c256"], 0, 256, cs + "fc_layer1", 64, ws["dc64"], 0)
-            self._lin_bwd(ws["up128"], 0, 128, cs + "fc_layer0", 256, ws["dc256"], 0)
-            self._lin_bwd(ws["up256"], 0, 256, c2, 128, dup128, 0)
+            # the chain goes on first (d(up256) summed over the four copies -> the 480-wide product below); the head's four weight
+            # gradients are queued on the side streams after it
+            _lib.check(L.dispu_dup_sum_grad(B, N, 256, self.up_ratio, _p(ws["dup256"]), 256, _p(ws["dh256"]), 256, self.st), "dup_sum_grad")
+            with self._fork_group():
+                self._lin_bwd(ws["c64"], 0, 64, cs + "fc_layer2", 3, dcoarse, 0)
+                self._lin_bwd(ws["c256"], 0, 256, cs + "fc_layer1", 64, ws["dc64"], 0)
+                self._lin_bwd(ws["up128"], 0, 128, cs + "fc_layer0", 256, ws["dc256"], 0)
+                self._lin_bwd(ws["up256"], 0, 256, c2, 128, dup128, 0)
+                w1, dw1 = P["generator/upshuffle_0/conv1/weights"], G["generator/upshuffle_0/conv1/weights"]
+                self._tn(1, rm, 2, 256, ws["gcode"], 0, 2, 0, ws["dup256"], 0, 256, 0, dw1, 480 * 256, 256, 0, 1,
+                         dbias=G["generator/upshuffle_0/conv1/biases"], side=True)     # read by Adam only: off the chain like every other dW
         else:
             self._lin_bwd(ws["c64"], 0, 64, cs + "fc_layer2", 3, dcoarse, 0, ws["dc64"], mask=(ws["c64"], 0, 64))
             self._lin_bwd(ws["c256"], 0, 256, cs + "fc_layer1", 64, ws["dc64"], 0, ws["dc256"], mask=(ws["c256"], 0, 256))
@@ -797,9 +859,10 @@ class Trainer(object):
             # duplicate_up
             self._lin_bwd(ws["up256"], 0, 256, c2, 128, dup128, 0, ws["dup256"], mask=(ws["up256"], 0, 256))
         w1, dw1 = P["generator/upshuffle_0/conv1/weights"], G["generator/upshuffle_0/conv1/weights"]
-        self._tn(1, rm, 2, 256, ws["gcode"], 0, 2, 0, ws["dup256"], 0, 256, 0, dw1, 480 * 256, 256, 0, 1,
-                 dbias=G["generator/upshuffle_0/conv1/biases"], side=True)     # read by Adam only: off the chain like every other dW
-        _lib.check(L.dispu_dup_sum_grad(B, N, 256, self.up_ratio, _p(ws["dup256"]), 256, _p(ws["dh256"]), 256, self.st), "dup_sum_grad")
+        if not self.fused_heads_bwd:
+            self._tn(1, rm, 2, 256, ws["gcode"], 0, 2, 0, ws["dup256"], 0, 256, 0, dw1, 480 * 256, 256, 0, 1,
+                     dbias=G["generator/upshuffle_0/conv1/biases"], side=True)     # read by Adam only: off the chain like every other dW
+            _lib.check(L.dispu_dup_sum_grad(B, N, 256, self.up_ratio, _p(ws["dup256"]), 256, _p(ws["dh256"]), 256, self.st), "dup_sum_grad")
         feat, dfeat = ws["feat"], ws["dfeat"]
         self._lin_bwd(feat, 0, 480, None, 256, ws["dh256"], 0, dfeat, 0, bias=False, W=w1, dW=dw1)
 
@@ -897,6 +960,8 @@ class Trainer(object):
                     st["terms"] = self.loss_backward(st["gt"], st["radius"])
                     self.backward()
             torch.cuda.current_stream(self.device).wait_stream(cap)
+            del self._cap_events[:]
+            self._aux_done.clear()           # the next eager use records the cached events again before anything waits on them
             st["graph"] = graph
             g = self._graphs[key] = st
         g["x"].copy_(inputs)

@@ -478,10 +478,13 @@ def test_conv2d_training_mode_batch_norm(dev):
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 def test_graphed_steps_equal_eager_steps(dev, dtype):
-    """train_step_graphed (forward + loss + backward replayed from one hipGraph) is the SAME step: after n steps the parameters,
-    both Adam moments, the BatchNorm moving statistics (ONE update per step -- the capture's warm-up passes must not count,
-    the reference updates them once per sess.run, DisPU/model.py:215-232) and every reported loss term equal the eager
-    trainer's, up to the order-free float atomics of the scatter gradients.  Crossing epoch 10 re-captures (weight_fine)."""
+    """train_step_graphed (forward + loss + backward replayed from one hipGraph) is the SAME step as train_step: from the same
+    state (parameters, both Adam moments, BatchNorm moving statistics, step counters) it produces the same gradients, the same
+    loss terms, the same moving statistics -- ONE update per step: the capture's warm-up passes must not count, the reference
+    updates them once per sess.run (DisPU/model.py:215-232) -- and the same parameters, up to the order-free float atomics of the
+    scatter gradients.  The two trainers are re-synchronised before every step (two Adam trajectories fed with atomics noise
+    drift apart chaotically: where a gradient entry is ~0 its noise decides the SIGN of a full lr-sized move); crossing epoch 10
+    re-captures (weight_fine is baked into the graph)."""
     from dispu_amd import synth
     from dispu_amd.train import Trainer
     P = OG.init_params(seed=21, bias_scale=0.05, bn_random=True)
@@ -492,34 +495,35 @@ def test_graphed_steps_equal_eager_steps(dev, dtype):
     g = Trainer(params=P, device=dev, dtype=dtype)
     e.epoch = g.epoch = 10
     kept = []
+    gtol = 2e-5 if dtype == "f32" else 2e-3
     for i, (x, gt) in enumerate(batches):
         if i == 2:
             e.epoch = g.epoch = 11                   # weight_fine 0.01 -> 0.1: a second capture with its own warm-up
+        for name in ("flat_p", "flat_m", "flat_v", "moving_mean", "moving_var"):
+            getattr(g, name).copy_(getattr(e, name))
+        g.adam_t, g.global_step = e.adam_t, e.global_step
         xs, gs = dv(x, dev), dv(gt, dev)
         te = e.train_step(xs, gs, rs)
         tg = g.train_step_graphed(xs, gs, rs)
         kept.append((te, tg))
         torch.cuda.synchronize()
-        # moving statistics: decay 0.95 applied exactly once per step on both sides
-        # (after the first Adam step single weights of the two trainers sit up to 2 lr apart -- see below -- so the batch statistics agree
-        # to ~1e-3, not to rounding; a warm-up pass counted as a step would move them by 5 % of (batch - moving) = O(1e-2))
-        assert np.allclose(N(g.moving_mean), N(e.moving_mean), rtol=2e-3, atol=2e-4), "moving_mean after step %d" % i
-        assert np.allclose(N(g.moving_var), N(e.moving_var), rtol=2e-3, atol=2e-4), "moving_variance after step %d" % i
-        if i == 0:                                    # before any Adam step the two forwards see identical weights: exact to atomics noise
-            assert np.allclose(N(g.moving_mean), N(e.moving_mean), rtol=1e-5, atol=1e-7)
+        # gradients of this step (still in the flat buffers), per tensor against its own scale
+        floor = 1e-7 * float(e.flat_g.abs().max())      # e.g. the bias in front of a BatchNorm: its true gradient is 0, what is stored is rounding noise
+        for k in e.G:
+            scale = float(e.G[k].abs().max()) + 1e-12
+            assert float((g.G[k] - e.G[k]).abs().max()) <= gtol * scale + floor + 2e-6, (i, k)
+        # moving statistics: decay 0.95 applied exactly once per step on both sides (a warm-up pass counted as a step would move
+        # them by 5 % of (batch - moving) = O(1e-2))
+        assert np.allclose(N(g.moving_mean), N(e.moving_mean), rtol=1e-5, atol=1e-6), "moving_mean after step %d" % i
+        assert np.allclose(N(g.moving_var), N(e.moving_var), rtol=1e-5, atol=1e-6), "moving_variance after step %d" % i
+        diff = N((g.flat_p - e.flat_p).abs())         # one Adam step from the same state: lr-sized sign flips on ~0 gradients only
+        assert diff.max() <= 2.5e-3 and np.quantile(diff, 0.99) <= (2e-5 if dtype == "f32" else 1e-3), (i, diff.max(), np.quantile(diff, 0.99))
     assert len(g._graphs) == 2 and g.global_step == e.global_step == 4 and g.adam_t == e.adam_t == 4
-    # Adam's first steps move every weight by ~lr whatever the gradient's size: where a gradient entry is ~0 the atomics noise
-    # decides the SIGN of a full lr-sized move, so single weights may sit up to steps x 2 lr apart; all but a sliver agree to rounding
-    diff = N((g.flat_p - e.flat_p).abs())
-    qtol = 2e-5 if dtype == "f32" else 2e-3
-    assert diff.max() <= 9e-3 and np.quantile(diff, 0.995) <= qtol and diff.mean() <= qtol / 10, (diff.max(), np.quantile(diff, 0.995), diff.mean())
-    md = N((g.flat_m - e.flat_m).abs())
-    assert np.quantile(md, 0.995) <= qtol * max(1.0, float(e.flat_m.abs().max()))
     # the returned terms are the caller's: a later replay must not overwrite them
     for i, (te, tg) in enumerate(kept):
         for k in te:
             a, b = float(te[k]), float(tg[k])
-            assert abs(a - b) <= (1e-4 if dtype == "f32" else 2e-2) * max(1.0, abs(a)), (i, k, a, b)
+            assert abs(a - b) <= (1e-5 if dtype == "f32" else 1e-2) * max(1.0, abs(a)), (i, k, a, b)
     assert float(kept[0][1]["pu_loss"]) != float(kept[3][1]["pu_loss"])
 
 
