@@ -55,6 +55,7 @@ SIGNATURES = {
                              _vp]),
     "dispu_linear_tile": (_i, [_i, _i, _i]),
     "dispu_sa_fused": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "dispu_edge_conv_fused": (_i, [_i, _i, _i, _i, _vp, _l, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
     "dispu_group_center": (_i, [_l, _i, _i, _vp, _vp, _vp]),
     "dispu_pool_nsample": (_i, [_l, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "dispu_idw_weights": (_i, [_l, _vp, _vp, _vp]),

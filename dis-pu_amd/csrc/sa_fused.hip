@@ -21,6 +21,11 @@ typedef float sa_f32x16 __attribute__((ext_vector_type(16)));
 constexpr int SA_MAXL = 3;
 
 struct SaArgs {
+    int mode;                            // 0: set abstraction rows [xyz_j - centre | points_j]; 1: EdgeConv rows [F_i | F_j - F_i]
+    int gk;                              // rows pooled together: NS (mode 0), k in {16, 32, 64} (mode 1: NS / k points per workgroup)
+    long total;                          // mode 1: number of points b * n (the last workgroup may be partial)
+    long ldf; int ldi;                   // mode 1: row stride of the feature matrix / of the neighbour table
+    int act_last;                        // ReLU on the last layer (hidden layers always have it)
     int n, m, c, nl;                     // dataset points / centres per cloud, feature channels of `points` (0: xyz only), layers
     const float* xyz;                    // [b, n, 3]
     const float* new_xyz;                // [b, m, 3]
@@ -36,11 +41,12 @@ struct SaArgs {
 };
 
 // One layer on the workgroup's NS rows: in [NS][pitch] (K columns, zero-padded to even) -> act(bn(in . W + b)).
-// Tasks = (row tile of 32, column tile of 32) dealt round-robin to the 4 waves.  LAST: no store, per-column maxima go to red[2][cout].
+// Tasks = (row tile of 32, column tile of 32) dealt round-robin to the 4 waves.  LAST: no store, per-column maxima of every 16-row
+// half tile go to red[NS / 16][cout] (the caller combines gk / 16 of them per pooled group).
 template <int NS, bool LAST>
 __device__ __forceinline__ void sa_layer(const float* __restrict__ in, float* __restrict__ outb, int pitch, int K, int cout,
                                          const float* __restrict__ W, const float* __restrict__ bias, const float* __restrict__ scale,
-                                         const float* __restrict__ shift, float* __restrict__ red, int wave, int lane) {
+                                         const float* __restrict__ shift, float* __restrict__ red, int wave, int lane, bool relu_last) {
     constexpr int RT = NS / 32;
     const int li = lane & 31, kh = lane >> 5;
     const int ct_n = (cout + 31) >> 5, ntask = RT * ct_n;
@@ -69,18 +75,19 @@ __device__ __forceinline__ void sa_layer(const float* __restrict__ in, float* __
         }
         const float bb = cok ? bias[col] : 0.f;
         const float sc = (cok && scale) ? scale[col] : 1.f, sh = (cok && scale) ? shift[col] : 0.f;
-        float mx = -__builtin_inff();
+        float mlo = -__builtin_inff(), mhi = -__builtin_inff();      // maxima over the tile's rows 0..15 / 16..31 (registers r < 8 / r >= 8)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             float v = acc[r] + bb;
             if (scale) { v = v * sc; v = v + sh; }
-            v = fmaxf(v, 0.f);
-            if constexpr (LAST) mx = fmaxf(mx, v);
+            if (!LAST || relu_last) v = fmaxf(v, 0.f);
+            if constexpr (LAST) { if (r < 8) mlo = fmaxf(mlo, v); else mhi = fmaxf(mhi, v); }
             else if (cok) outb[(rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh) * pitch + col] = v;
         }
         if constexpr (LAST) {
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            if (kh == 0 && cok) red[rt * cout + col] = mx;
+            mlo = fmaxf(mlo, __shfl_xor(mlo, 32, 64));
+            mhi = fmaxf(mhi, __shfl_xor(mhi, 32, 64));
+            if (kh == 0 && cok) { red[(2 * rt) * cout + col] = mlo; red[(2 * rt + 1) * cout + col] = mhi; }
         }
     }
 }
@@ -88,28 +95,46 @@ __device__ __forceinline__ void sa_layer(const float* __restrict__ in, float* __
 template <int NS>
 __global__ __launch_bounds__(256) void sa_fused_kernel(SaArgs a) {
     extern __shared__ __attribute__((aligned(16))) float sa_lds[];
-    constexpr int RT = NS / 32;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const long centre = xcd_block(blockIdx.x, gridDim.x);            // XCD-aware: one L2 serves a contiguous range of centres (= few clouds)
-    const long cloud = centre / a.m;
+    const long blk = xcd_block(blockIdx.x, gridDim.x);               // XCD-aware: one L2 serves a contiguous range of centres (= few clouds)
     float* bufA = sa_lds;
     float* bufB = sa_lds + NS * a.pitch;
-    float* red = bufB + NS * a.pitch;                                  // [RT][cout_last]
-    const int K0 = 3 + a.c, K0p = (K0 + 1) & ~1;
+    float* red = bufB + NS * a.pitch;                                  // [NS / 16][cout_last]
+    const int K0 = a.mode == 0 ? 3 + a.c : 2 * a.c, K0p = (K0 + 1) & ~1;
 
-    // ---- gather: row s = [xyz[idx[s]] - centre | points[idx[s]]], zero-padded to an even width
-    const int* __restrict__ ip = a.idx + centre * NS;
-    const float* __restrict__ xb = a.xyz + cloud * a.n * 3;
-    const float* __restrict__ pb = a.points ? a.points + cloud * (long)a.n * a.c : nullptr;
-    const float cx = a.new_xyz[centre * 3], cy = a.new_xyz[centre * 3 + 1], cz = a.new_xyz[centre * 3 + 2];
-    for (int s = wave; s < NS; s += 4) {
-        const int j = ip[s];
-        float* row = bufA + s * a.pitch;
-        for (int ch = lane; ch < K0p; ch += 64) {
-            float v = 0.f;
-            if (ch < 3) v = xb[(long)j * 3 + ch] - (ch == 0 ? cx : ch == 1 ? cy : cz);
-            else if (ch < K0) v = pb[(long)j * a.c + (ch - 3)];
-            row[ch] = v;
+    if (a.mode == 0) {
+        // ---- set abstraction: row s = [xyz[idx[s]] - centre | points[idx[s]]], zero-padded to an even width
+        const long cloud = blk / a.m;
+        const int* __restrict__ ip = a.idx + blk * NS;
+        const float* __restrict__ xb = a.xyz + cloud * a.n * 3;
+        const float* __restrict__ pb = a.points ? a.points + cloud * (long)a.n * a.c : nullptr;
+        const float cx = a.new_xyz[blk * 3], cy = a.new_xyz[blk * 3 + 1], cz = a.new_xyz[blk * 3 + 2];
+        for (int s = wave; s < NS; s += 4) {
+            const int j = ip[s];
+            float* row = bufA + s * a.pitch;
+            for (int ch = lane; ch < K0p; ch += 64) {
+                float v = 0.f;
+                if (ch < 3) v = xb[(long)j * 3 + ch] - (ch == 0 ? cx : ch == 1 ? cy : cz);
+                else if (ch < K0) v = pb[(long)j * a.c + (ch - 3)];
+                row[ch] = v;
+            }
+        }
+    } else {
+        // ---- EdgeConv (tf_util.get_edge_feature): row (p, s) = [F[i] | F[j] - F[i]], i = first point + p, j = idx[i][s] in i's cloud
+        const int ppw = NS / a.gk;
+        for (int s = wave; s < NS; s += 4) {
+            long i = blk * ppw + s / a.gk;
+            if (i >= a.total) i = a.total - 1;                       // partial last workgroup: computed, not stored
+            const long j = (i / a.n) * a.n + a.idx[i * a.ldi + (s % a.gk)];
+            const float* __restrict__ fi = a.points + i * a.ldf;
+            const float* __restrict__ fj = a.points + j * a.ldf;
+            float* row = bufA + s * a.pitch;
+            for (int ch = lane; ch < K0p; ch += 64) {
+                float v = 0.f;
+                if (ch < a.c) v = fi[ch];
+                else if (ch < K0) v = fj[ch - a.c] - fi[ch - a.c];
+                row[ch] = v;
+            }
         }
     }
     __syncthreads();
@@ -120,24 +145,26 @@ __global__ __launch_bounds__(256) void sa_fused_kernel(SaArgs a) {
     for (int l = 0; l < a.nl; ++l) {
         const int cout = a.cout[l];
         if (l + 1 < a.nl) {
-            sa_layer<NS, false>(in, outb, a.pitch, K, cout, a.W[l], a.bias[l], a.scale[l], a.shift[l], red, wave, lane);
+            sa_layer<NS, false>(in, outb, a.pitch, K, cout, a.W[l], a.bias[l], a.scale[l], a.shift[l], red, wave, lane, true);
             if (cout & 1) {                                            // the next layer reads an even number of columns
                 for (int s = threadIdx.x; s < NS; s += 256) outb[s * a.pitch + cout] = 0.f;
             }
         } else {
-            sa_layer<NS, true>(in, outb, a.pitch, K, cout, a.W[l], a.bias[l], a.scale[l], a.shift[l], red, wave, lane);
+            sa_layer<NS, true>(in, outb, a.pitch, K, cout, a.W[l], a.bias[l], a.scale[l], a.shift[l], red, wave, lane, a.act_last != 0);
         }
         __syncthreads();
         const float* t = in; in = outb; outb = const_cast<float*>(t);
         K = cout;
     }
-    const int co = a.cout[a.nl - 1];
-    float* __restrict__ op = a.out + centre * co;
-    for (int ch = threadIdx.x; ch < co; ch += 256) {
-        float v = red[ch];
-#pragma unroll
-        for (int rt = 1; rt < RT; ++rt) v = fmaxf(v, red[rt * co + ch]);
-        op[ch] = v;
+    // pooled groups: gk / 16 consecutive half tiles each
+    const int co = a.cout[a.nl - 1], halves = a.gk / 16, groups = NS / a.gk;
+    for (int e = threadIdx.x; e < groups * co; e += 256) {
+        const int g = e / co, ch = e - g * co;
+        const long orow = blk * groups + g;
+        if (a.mode == 1 && orow >= a.total) continue;
+        float v = red[(g * halves) * co + ch];
+        for (int h = 1; h < halves; ++h) v = fmaxf(v, red[(g * halves + h) * co + ch]);
+        a.out[orow * co + ch] = v;
     }
 }
 
@@ -158,6 +185,7 @@ DISPU_EXPORT int dispu_sa_fused(int b, int n, int m, int ns, int c, const float*
         return (int)hipErrorInvalidValue;
     if (b == 0) return 0;
     SaArgs a{};
+    a.mode = 0; a.gk = ns; a.act_last = 1;
     a.n = n; a.m = m; a.c = c; a.nl = nl;
     a.xyz = xyz; a.new_xyz = new_xyz; a.points = c > 0 ? points : nullptr; a.idx = idx; a.out = out;
     int width = (3 + c + 1) & ~1;
@@ -170,7 +198,7 @@ DISPU_EXPORT int dispu_sa_fused(int b, int n, int m, int ns, int c, const float*
         if (l + 1 < nl) width = width > ((cout[l] + 1) & ~1) ? width : ((cout[l] + 1) & ~1);
     }
     a.pitch = width | 1;
-    const size_t bytes = ((size_t)2 * ns * a.pitch + (size_t)(ns / 32) * cout[nl - 1]) * sizeof(float);
+    const size_t bytes = ((size_t)2 * ns * a.pitch + (size_t)(ns / 16) * cout[nl - 1]) * sizeof(float);
     if (bytes > 160 * 1024) return (int)hipErrorInvalidValue;
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid((unsigned)((long)b * m));
@@ -189,5 +217,44 @@ DISPU_EXPORT int dispu_sa_fused(int b, int n, int m, int ns, int c, const float*
         }
         hipLaunchKernelGGL((sa_fused_kernel<32>), grid, dim3(256), bytes, s, a);
     }
+    return (int)hipGetLastError();
+}
+
+// Fused EdgeConv (gcn_lib/tf_vertex.py:81-101 with tf_util.get_edge_feature, Common/tf_util.py:654-686): per point i
+//   out[i, :] = max_{s < k} mlp([F[i] | F[idx[i, s]] - F[i]])        nl <= 3 conv2d layers (bias, optional BatchNorm fold, ReLU;
+// the LAST layer's ReLU only when act_last), k in {16, 32, 64}; feat [b*n, c] with row stride ldf, idx [b*n, >= k] (row stride ldi,
+// cloud-relative neighbour ids).  The [b, n, k, 2c] edge tensor and the [b, n, k, C] layer outputs never reach HBM.  Bit-identical to
+// dispu_edge_feature -> dispu_linear_bn x nl -> dispu_pool_nsample(max).
+DISPU_EXPORT int dispu_edge_conv_fused(int b, int n, int k, int c, const float* feat, long ldf, const int* idx, int ldi, int nl,
+                                       const float* const* W, const float* const* bias, const float* const* scale,
+                                       const float* const* shift, const int* cout, int act_last, float* out, void* stream) {
+    if (b < 0 || n <= 0 || (k != 16 && k != 32 && k != 64) || c <= 0 || nl < 1 || nl > SA_MAXL || !feat || !idx || !W || !bias || !cout ||
+        !out || ldf < c || ldi < k)
+        return (int)hipErrorInvalidValue;
+    if (b == 0) return 0;
+    SaArgs a{};
+    a.mode = 1; a.gk = k; a.total = (long)b * n; a.ldf = ldf; a.ldi = ldi; a.act_last = act_last;
+    a.n = n; a.m = n; a.c = c; a.nl = nl;
+    a.points = feat; a.idx = idx; a.out = out;
+    int width = (2 * c + 1) & ~1;
+    for (int l = 0; l < nl; ++l) {
+        if (cout[l] <= 0 || !W[l] || !bias[l]) return (int)hipErrorInvalidValue;
+        a.W[l] = W[l]; a.bias[l] = bias[l];
+        a.scale[l] = (scale && shift && scale[l] && shift[l]) ? scale[l] : nullptr;
+        a.shift[l] = a.scale[l] ? shift[l] : nullptr;
+        a.cout[l] = cout[l];
+        if (l + 1 < nl) width = width > ((cout[l] + 1) & ~1) ? width : ((cout[l] + 1) & ~1);
+    }
+    a.pitch = width | 1;
+    constexpr int ns = 64;
+    const size_t bytes = ((size_t)2 * ns * a.pitch + (size_t)(ns / 16) * cout[nl - 1]) * sizeof(float);
+    if (bytes > 160 * 1024) return (int)hipErrorInvalidValue;
+    static DevOnce once;
+    if (once.needed()) {
+        DISPU_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(sa_fused_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        once.done();
+    }
+    const long ppw = ns / k;
+    hipLaunchKernelGGL((sa_fused_kernel<64>), dim3((unsigned)((a.total + ppw - 1) / ppw)), dim3(256), bytes, (hipStream_t)stream, a);
     return (int)hipGetLastError();
 }

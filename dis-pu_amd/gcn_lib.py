@@ -3,6 +3,9 @@ gcn_lib/tf_edge.py:19-28 `knn_graph`, Common/tf_util.py:618-686 pairwise_distanc
 gcn_lib/tf_vertex.py:20-79 `max_relat_conv_layer`, :103-180 `graphsage_conv_layer`, :182-251 `gin_conv_layer`),
 on the hot-path kernels.  `nn.build` of the reference (gcn_lib/tf_nn.py:37-56) is a single tf_util.conv2d; its
 options are keyword arguments here.  Dilated graphs are never instantiated by the reference and are not built."""
+import ctypes
+import os
+
 import torch
 
 from . import _lib, tf_util
@@ -33,6 +36,26 @@ def edge_conv_layer(inputs, neigh_idx, k, num_outputs, scope=None, is_training=F
     """tf_vertex.py:81-101 (EdgeConv): MLP over [x_i, x_j - x_i], max over the k neighbours, keep_dims.
     `nn.build` of the reference (gcn_lib/tf_nn.py:37-56) is a single tf_util.conv2d; its options are the keyword
     arguments here.  Returns [b, n, 1, num_outputs]."""
+    f = _squeeze(inputs)
+    c = f.shape[-1]
+    width = ((2 * c + 1) & ~1) | 1
+    if (k in (16, 32, 64) and not (bn and is_training) and os.environ.get("DISPU_EDGE_FUSED", "1") != "0"
+            and (2 * 64 * width + 4 * num_outputs) * 4 <= 160 * 1024):
+        # edge feature, the conv and the max over the neighbours in ONE launch (csrc/sa_fused.hip): no [b, n, k, 2c] tensor in HBM
+        b, n, _ = f.shape
+        dev = f.device
+        W, bias = tf_util._dev(params[scope + "/weights"], dev), tf_util._dev(params[scope + "/biases"], dev)
+        if tuple(W.shape) != (2 * c, num_outputs):
+            raise ValueError("%s/weights has shape %s, expected (%d, %d)" % (scope, tuple(W.shape), 2 * c, num_outputs))
+        scale, shift = tf_util.bn_fold(params, scope, dev) if bn else (None, None)
+        idx = neigh_idx.contiguous()
+        one = lambda t: (ctypes.c_void_p * 1)(_lib.ptr(t).value)
+        pooled = torch.empty((b, n, 1, num_outputs), dtype=torch.float32, device=dev)
+        act = {"relu": 1, None: 0, "none": 0}[activation_fn]
+        _lib.check(_lib.lib().dispu_edge_conv_fused(b, n, k, c, _lib.ptr(f), c, _lib.ptr(idx), idx.shape[-1], 1, one(W), one(bias), one(scale),
+                                                    one(shift), (ctypes.c_int * 1)(int(num_outputs)), act, _lib.ptr(pooled),
+                                                    _lib.stream_ptr(dev)), "dispu_edge_conv_fused")
+        return pooled
     edge = get_edge_feature(inputs, neigh_idx, k)
     out = tf_util.conv2d(edge, num_outputs, (1, 1), scope, params, bn=bn, is_training=is_training, activation_fn=activation_fn)
     b, n, _, co = out.shape

@@ -102,7 +102,7 @@ def _sa_fusable(points, nsample, mlp, mlp2, group_all, is_training, bn, pooling,
         return False
     c = 0 if points is None else points.shape[2]
     width = max([(3 + c + 1) & ~1] + [(co + 1) & ~1 for co in mlp[:-1]]) | 1
-    return (2 * nsample * width + (nsample // 32) * mlp[-1]) * 4 <= 160 * 1024
+    return (2 * nsample * width + (nsample // 16) * mlp[-1]) * 4 <= 160 * 1024
 
 
 def pointnet_sa_module(xyz, points, npoint, radius, nsample, mlp, mlp2, group_all, is_training, bn_decay, scope,

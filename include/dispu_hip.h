@@ -291,6 +291,14 @@ int dispu_group_center(long rows, int ns, int c, float* grouped, const float* ce
 int dispu_sa_fused(int b, int n, int m, int ns, int c, const float* xyz, const float* new_xyz, const float* points, const int* idx,
                    int nl, const float* const* W, const float* const* bias, const float* const* scale, const float* const* shift,
                    const int* cout, float* out, void* stream);
+/* EdgeConv fused (gcn_lib/tf_vertex.py:81-101 over tf_util.get_edge_feature, Common/tf_util.py:654-686):
+ * out[i,:] = max_{s<k} mlp([F[i] | F[idx[i,s]] - F[i]]), nl <= 3 conv2d layers (bias, optional BatchNorm fold, ReLU; the last layer's
+ * ReLU only when act_last), k in {16, 32, 64}; feat [b*n, c] (row stride ldf), idx [b*n, >= k] cloud-relative (row stride ldi).
+ * Neither the [b,n,k,2c] edge tensor nor a [b,n,k,C] layer output reaches HBM.  Bit-identical to dispu_edge_feature ->
+ * dispu_linear_bn x nl -> dispu_pool_nsample(max). */
+int dispu_edge_conv_fused(int b, int n, int k, int c, const float* feat, long ldf, const int* idx, int ldi, int nl,
+                          const float* const* W, const float* const* bias, const float* const* scale, const float* const* shift,
+                          const int* cout, int act_last, float* out, void* stream);
 /* pooling over nsample of X[rows,ns,c] (pointnet_util.py:121-140): mode 0 max, 1 avg, 2 "min" (= max(-x), as the
  * reference computes it), 3 weighted_avg (needs gxyz[rows,ns,3]), 4 max_and_avg -> [max|avg] (2c outputs),
  * 5 sum (GIN aggregation, gcn_lib/tf_vertex.py:248). */

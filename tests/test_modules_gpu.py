@@ -223,3 +223,26 @@ def test_sa_fused_refuses_bad_arguments(dev):
     bad = _lib.lib().dispu_sa_fused(1, 8, 1, 48, 0, _lib.ptr(z), _lib.ptr(z), None, _lib.ptr(z), 1, None, None, None, None, None, _lib.ptr(z),
                                     _lib.stream_ptr(dev))
     assert bad != 0
+
+
+@pytest.mark.parametrize("b,n,c,k,co,bn,act", [(3, 200, 20, 16, 64, False, "relu"), (2, 1024, 64, 16, 128, True, "relu"), (5, 33, 7, 16, 33, True, None),
+                                               (2, 256, 128, 32, 256, False, "relu"), (1, 70, 24, 64, 48, True, "relu"), (4, 1024, 256, 16, 128, False, "relu")])
+def test_edge_conv_fused_equals_unfused(dev, monkeypatch, b, n, c, k, co, bn, act):
+    """EdgeConv (gcn_lib/tf_vertex.py:81-101: get_edge_feature -> conv2d -> max over k) as ONE launch (dispu_edge_conv_fused) == the
+    three-launch composition bit for bit, and == oracle/modules.py; k = 16 / 32 / 64, odd widths, partial last workgroup (n = 33, 70),
+    with / without BatchNorm and activation, c up to 256 (2c = 512-wide rows in LDS)."""
+    from dispu_amd import gcn_lib as GL
+    rng = np.random.default_rng(b * 100 + c)
+    f = rng.standard_normal((b, n, c)).astype(np.float32)
+    P = make_params(rng, [("ec", 2 * c, co)], bn=bn)
+    if n >= k:
+        idx = np.stack([np.stack([rng.permutation(n)[:k] for _ in range(n)]) for _ in range(b)]).astype(np.int32)
+    else:
+        idx = rng.integers(0, n, (b, n, k)).astype(np.int32)
+    tf_, ti = T(f, dev).unsqueeze(2), T(idx, dev)
+    got = GL.edge_conv_layer(tf_, ti, k, co, scope="ec", params=P, bn=bn, activation_fn=act)
+    monkeypatch.setenv("DISPU_EDGE_FUSED", "0")
+    unf = GL.edge_conv_layer(tf_, ti, k, co, scope="ec", params=P, bn=bn, activation_fn=act)
+    assert N(got).shape == (b, n, 1, co) and np.array_equal(N(got), N(unf)), "fused EdgeConv != unfused composition"
+    want = OM.edge_conv_layer(P, "ec", f, idx, bn=bn, relu=act == "relu")
+    assert np.allclose(N(got), want, rtol=1e-5, atol=1e-5)
