@@ -2,7 +2,7 @@
 # Run on the GPU box (through gpurun): the end-of-round evidence in one call -- the GPU test suite, smoke(), the bench with its
 # rocprofv3 kernel statistics and PMC passes, the per-op table, the other BASELINE configurations, the train and FPS benches.
 # Usage: tools/final_round.sh [tag]   -> gpurun_out/<tag>/..., gpurun_out/<tag>_pmc/pmc_summary.json  (copy what is kept to profiles/)
-TAG=${1:-r03_l}
+TAG=${1:-r04_a}
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/$TAG
 timeout 2400 python -m pytest tests -m gpu -q -x 2>&1 | tail -5 > gpurun_out/$TAG/pytest_gpu.txt
