@@ -19,6 +19,9 @@ _vp, _i, _sz, _l = C.c_void_p, C.c_int, C.c_size_t, C.c_long
 SIGNATURES = {
     "dispu_version": (_i, []),
     "dispu_error_string": (C.c_char_p, [_i]),
+    "dispu_event_record": (_i, [_vp, _vp]),
+    "dispu_stream_wait_event": (_i, [_vp, _vp]),
+    "dispu_memset_async": (_i, [_vp, _i, _sz, _vp]),
     "dispu_fps_scratch_bytes": (_sz, [_i, _i, _i]),
     "dispu_fps": (_i, [_i, _i, _i, _vp, _vp, _vp, _i, _vp]),
     "dispu_fps_ws": (_i, [_i, _i, _i, _vp, _vp, _sz, _vp, _i, _vp]),
@@ -170,6 +173,84 @@ def lib():
                              "`python dis-pu_amd/build.py`" % (LIB_PATH, l.dispu_version(), ABI_VERSION))
         _LIB = l
     return _LIB
+
+
+# ---- launch tape -----------------------------------------------------------------------------------------------------------------
+# The training step is ~130 launches of 5 - 150 us; issued from Python each costs ~10 us of interpreter + ctypes argument conversion
+# (1.4 ms per step at 8 patches, as long as the GPU's own critical chain).  A Tape records the launch sequence of one step -- every C
+# call with its arguments already converted to ctypes objects, plus the stream / event operations between them -- and replays it as a
+# flat loop of foreign calls (~1.5 us each).  Unlike a hipGraph replay it keeps the eager step's stream assignment and submission order.
+class Tape(object):
+    def __init__(self):
+        self.calls = []          # (foreign function, ctypes args, label)
+        self.keep = []           # objects the recorded raw handles belong to (events, streams, tensors)
+
+    def replay(self):
+        for fn, args, what in self.calls:
+            rc = fn(*args)
+            if rc:
+                check(rc, what + " (tape replay)")
+
+    def __len__(self):
+        return len(self.calls)
+
+
+_TAPE = None                     # the Tape being recorded, if any
+_NO_TAPE = ("dispu_version", "dispu_error_string", "dispu_linear_tile")
+
+
+class _TapeLib(object):
+    """the library seen through a recorder: calls execute as usual; while a Tape is being recorded, calls that launch work
+    (int-returning, not a size query) are appended to it with their converted arguments."""
+
+    def __init__(self, real):
+        self._real = real
+        self._cache = {}
+
+    def __getattr__(self, name):
+        fn = self._cache.get(name)
+        if fn is None:
+            real = getattr(self._real, name)
+            if name in _NO_TAPE or real.restype is not _i or "scratch" in name:
+                fn = real
+            else:
+                argtypes = real.argtypes
+
+                def fn(*args, _real=real, _types=argtypes, _name=name):
+                    if _TAPE is None:
+                        return _real(*args)
+                    cargs = tuple(a if isinstance(a, C._SimpleCData) else t(a) for a, t in zip(args, _types))
+                    rc = _real(*cargs)
+                    _TAPE.calls.append((_real, cargs, _name))
+                    return rc
+            self._cache[name] = fn
+        return fn
+
+
+_TAPELIB = None
+
+
+def tape_lib():
+    global _TAPELIB
+    if _TAPELIB is None:
+        _TAPELIB = _TapeLib(lib())
+    return _TAPELIB
+
+
+def tape_begin():
+    global _TAPE
+    _TAPE = Tape()
+    return _TAPE
+
+
+def tape_end():
+    global _TAPE
+    t, _TAPE = _TAPE, None
+    return t
+
+
+def taping():
+    return _TAPE
 
 
 def check(code, what):

@@ -106,6 +106,7 @@ class Trainer(object):
         self._bn_scratch = None
         self._stash_ready = False
         self._graphs = {}
+        self._tapes = {}
         # weight-gradient products (dW = X^T dZ) are off the backward chain: only Adam reads them.  They run on a second
         # HIP stream next to the dX products that ARE the chain (both read dZ; at 8 patches neither fills 256 CUs alone).
         self.overlap_dw = os.environ.get("DISPU_TRAIN_OVERLAP", "1") != "0"
@@ -130,6 +131,14 @@ class Trainer(object):
 
         self._side_busy = []
         self._group = None                  # (event, side streams that already wait for it) inside _fork_group()
+        # Side work (weight-gradient products, the non-local / skip branches) is QUEUED ON THE HOST AFTER the chain's kernels: every
+        # launch costs ~10 us of Python / ctypes, and a chain kernel that is submitted behind a dozen side launches leaves the GPU's
+        # main queue idle for that long (round 4, profiles/r04_a_train_timeline.txt: 145 us before the fused local cell, 137 us before
+        # its backward).  Side work records its fork event where it belongs and is submitted later, at points where the main queue
+        # holds enough work (Trainer._flush); 0 restores the in-place submission (A/B)
+        self.defer_side = os.environ.get("DISPU_TRAIN_DEFER", "1") != "0"
+        self._deferred = []
+        self._pending = set()               # branches whose submission is still in _deferred
         self._cap_events = []               # events created while a hipGraph is being captured (see _ev)
         self._aux_done = {}                 # branch i -> the completion event recorded at its last exit
         self.P = None
@@ -260,6 +269,60 @@ class Trainer(object):
         self._side_rr = (self._side_rr + 1) % len(self._sides)
         return self._side_rr
 
+    def _defer(self, fn):
+        """run the side-stream submission `fn` now, or at the next _flush() when deferral is on (only while side streams are in use)."""
+        if self.defer_side and self.overlap_dw:
+            self._deferred.append(fn)
+        else:
+            fn()
+
+    def _flush(self, n=None):
+        """submit the first n (default: all) deferred side launches."""
+        while self._deferred and (n is None or n > 0):
+            self._deferred.pop(0)()
+            if n is not None:
+                n -= 1
+        if not self._deferred:
+            self._pending.clear()
+
+    def _defer_branch(self, i, body, after=None):
+        """`with self._branch(i, after): body()` -- submitted now, or at the next _flush() / _merge(i) when deferral is on.  The branch
+        is ordered after `after`, or after THIS point of the current stream (the event is recorded now, whenever the body is submitted)."""
+        if not (self.defer_side and self.overlap_dw):
+            with self._branch(i, after):
+                body()
+            return
+        ev = after if after is not None else self._fork_point()
+
+        def run():
+            with self._branch(i, ev):
+                body()
+        self._pending.add(i)
+        self._deferred.append(run)
+
+    # ---- stream / event operations (recorded on the launch tape as raw HIP calls when one is being taken, see train_step_taped)
+    def _rec(self, ev, stream):
+        ev.record(stream)
+        t = _lib.taping()
+        if t is not None:
+            t.keep += [ev, stream]
+            t.calls.append((_lib.lib().dispu_event_record, (ctypes.c_void_p(ev.cuda_event), ctypes.c_void_p(stream.cuda_stream)), "event_record"))
+
+    def _wait(self, stream, ev):
+        stream.wait_event(ev)
+        t = _lib.taping()
+        if t is not None:
+            t.keep += [ev, stream]
+            t.calls.append((_lib.lib().dispu_stream_wait_event, (ctypes.c_void_p(stream.cuda_stream), ctypes.c_void_p(ev.cuda_event)),
+                            "stream_wait_event"))
+
+    def _zero(self, t):
+        """t.zero_() on the stream launches currently go to, as a memset through the library (a plain C call: tape-able, and cheaper
+        than the torch op)."""
+        L = _lib.tape_lib()
+        st = self.st if getattr(self, "st", None) is not None else _lib.stream_ptr(self.device)
+        _lib.check(L.dispu_memset_async(_lib.C.c_void_p(t.data_ptr()), 0, t.numel() * t.element_size(), st), "memset")
+
     def _ev(self, cached):
         """the event to record at this point: the cached object in eager mode; a FRESH one while a hipGraph is being captured.
         Re-recording one event object several times inside a capture loses stream order on this runtime (round 4: the fused coarse-head
@@ -279,13 +342,13 @@ class Trainer(object):
             # inside _fork_group(): every product of the group hangs off ONE event; a side stream waits for it once
             ev, waited = self._group
             if i not in waited:
-                self._sides[i].wait_event(ev)
+                self._wait(self._sides[i], ev)
                 waited.add(i)
         else:
             main = torch.cuda.current_stream(self.device)
             ev = self._ev(self._fork_ev)
-            ev.record(main)
-            self._sides[i].wait_event(ev)
+            self._rec(ev, main)
+            self._wait(self._sides[i], ev)
         self._side_busy[i] = True
         return ctypes.c_void_p(self._sides[i].cuda_stream), "dw%d" % i
 
@@ -313,22 +376,23 @@ class Trainer(object):
         ev = torch.cuda.Event()
         if torch.cuda.is_current_stream_capturing():
             self._cap_events.append(ev)
-        ev.record(torch.cuda.current_stream(self.device))
+        self._rec(ev, torch.cuda.current_stream(self.device))
         return ev
 
     def _fork_after(self, ev):
         i = self._side_next()
-        self._sides[i].wait_event(ev)
+        self._wait(self._sides[i], ev)
         self._side_busy[i] = True
         return ctypes.c_void_p(self._sides[i].cuda_stream), "dw%d" % i
 
     def _join(self):
         """the current stream waits for every dW product queued so far (before a buffer they read is overwritten, before Adam)."""
+        self._flush()
         for i, busy in enumerate(self._side_busy if self._sides else []):
             if busy:
                 ev = self._ev(self._join_evs[i])
-                ev.record(self._sides[i])
-                torch.cuda.current_stream(self.device).wait_event(ev)
+                self._rec(ev, self._sides[i])
+                self._wait(torch.cuda.current_stream(self.device), ev)
                 self._side_busy[i] = False
 
     @contextlib.contextmanager
@@ -345,8 +409,8 @@ class Trainer(object):
         aux, ev_fork, ev_done = self._aux[i]
         if after is None:
             after = self._ev(ev_fork)
-            after.record(torch.cuda.current_stream(self.device))
-        aux.wait_event(after)
+            self._rec(after, torch.cuda.current_stream(self.device))
+        self._wait(aux, after)
         old_st, old_cur = self.st, self._cur
         with torch.cuda.stream(aux):
             self.st, self._cur = ctypes.c_void_p(aux.cuda_stream), "aux%d" % i
@@ -359,22 +423,24 @@ class Trainer(object):
                 # backward started 0.33 ms late, behind dW products it does not depend on)
                 if self._sched & 1:
                     done = self._ev(ev_done)
-                    done.record(aux)
+                    self._rec(done, aux)
                     self._aux_done[i] = done
 
     def _merge(self, i):
-        if self.overlap_dw and i < len(self._aux):
+        if i in self._pending:
+            self._flush()                                # a branch whose submission is still deferred cannot be waited for
+        if self.overlap_dw and (i < len(self._aux) or i in self._aux_done):
             aux, _, ev_done = self._aux[i]
             if not (self._sched & 1):
                 done = self._ev(ev_done)
-                done.record(aux)
+                self._rec(done, aux)
                 self._aux_done[i] = done
-            torch.cuda.current_stream(self.device).wait_event(self._aux_done.get(i, ev_done))
+            self._wait(torch.cuda.current_stream(self.device), self._aux_done.get(i, ev_done))
 
     # ----------------------------------------------------------------------------------------------- helpers ----
     def _dl(self, batch, M, K, N, *rest):
         """dispu_linear, or its bf16-product twin when the trainer runs mixed precision (narrow 3-wide layers stay fp32)."""
-        L = _lib.lib()
+        L = _lib.tape_lib()
         fn = L.dispu_linear_bf16 if self._use_bf16(batch, M, K, N) else L.dispu_linear
         return fn(batch, M, K, N, *rest)
 
@@ -386,7 +452,7 @@ class Trainer(object):
 
     def _lin(self, X, xoff, K, wname, act, Y, yoff, N, M=None, bias=True, W=None, woff=0):
         """Y[:, yoff:yoff+N] = act(X[:, xoff:xoff+K] . W + b)"""
-        L = _lib.lib()
+        L = _lib.tape_lib()
         M = X.shape[0] if M is None else M
         W = self.P[wname + "/weights"] if W is None else W
         b = self.P[wname + "/biases"] if bias else None
@@ -400,28 +466,48 @@ class Trainer(object):
                                   _p(Y, yoff), Y.stride(0), 0, None, 0, 0, None, 0, 0, self.st), "dispu_linear")
 
     def _tn(self, batch, M, K, N, X, xoff, ldx, sx, Zt, zoff, ldz, sz, out, ooff, ldo, so, accumulate, dbias=None, side=False, after=None):
-        """out (+)= X^T . Zt.  side=True: on the second stream (the caller guarantees nothing overwrites X / Zt before _join)."""
-        L = _lib.lib()
+        """out (+)= X^T . Zt.  side=True: on a side stream (the caller guarantees nothing overwrites X / Zt before _join), ordered after
+        `after` / the enclosing _fork_group's event / this point of the current stream; the launch itself may be deferred (_defer)."""
+        L = _lib.tape_lib()
         side = side and self.overlap_dw
         sto = (1 if X.dtype == torch.bfloat16 else 0) | (2 if Zt.dtype == torch.bfloat16 else 0)
         bf = self._use_bf16(batch, M, K, N) or bool(sto)
         need = (L.dispu_linear_tn_bf16_scratch_floats if bf else L.dispu_linear_tn_scratch_floats)(batch, M, K, N)
-        if side:
-            st, key = self._fork_after(after) if after is not None else self._fork()
-        else:
-            st, key = self.st, None
-        sc = self._scratch_floats(need, key)
-        if sto:
-            assert bf and xoff == 0 and zoff == 0
-            _lib.check(L.dispu_linear_tn_bf16s(batch, M, K, N, _p(X), ldx, sx, _p(Zt), ldz, sz, _p(out, ooff), ldo, so, accumulate, _p(dbias), _p(sc),
-                                               sc.numel(), sto, st), "dispu_linear_tn_bf16s")
+
+        def launch(st, key):
+            sc = self._scratch_floats(need, key)
+            if sto:
+                assert bf and xoff == 0 and zoff == 0
+                _lib.check(L.dispu_linear_tn_bf16s(batch, M, K, N, _p(X), ldx, sx, _p(Zt), ldz, sz, _p(out, ooff), ldo, so, accumulate, _p(dbias), _p(sc),
+                                                   sc.numel(), sto, st), "dispu_linear_tn_bf16s")
+                return
+            fn = L.dispu_linear_tn_bf16 if bf else L.dispu_linear_tn
+            _lib.check(fn(batch, M, K, N, _p(X, xoff), ldx, sx, _p(Zt, zoff), ldz, sz, _p(out, ooff), ldo, so, accumulate, _p(dbias), _p(sc),
+                          sc.numel(), st), "dispu_linear_tn_bf16" if bf else "dispu_linear_tn")
+
+        if not side:
+            launch(self.st, None)
             return
-        fn = L.dispu_linear_tn_bf16 if bf else L.dispu_linear_tn
-        _lib.check(fn(batch, M, K, N, _p(X, xoff), ldx, sx, _p(Zt, zoff), ldz, sz, _p(out, ooff), ldo, so, accumulate, _p(dbias), _p(sc),
-                      sc.numel(), st), "dispu_linear_tn_bf16" if bf else "dispu_linear_tn")
+        grp = self._group
+        ev = after if after is not None else (None if grp is not None else self._fork_point())
+
+        def submit():
+            if ev is not None:
+                st, key = self._fork_after(ev)
+            else:                                          # member of a _fork_group: one wait per side stream for the group's event
+                i = self._side_next()
+                gev, waited = grp
+                if i not in waited:
+                    self._wait(self._sides[i], gev)
+                    waited.add(i)
+                self._side_busy[i] = True
+                st, key = ctypes.c_void_p(self._sides[i].cuda_stream), "dw%d" % i
+            launch(st, key)
+
+        self._defer(submit)
 
     def _act_bias_grad(self, M, N, dY, dyoff, Y, yoff, act, dZ, dzoff, dbias):
-        L = _lib.lib()
+        L = _lib.tape_lib()
         need = L.dispu_act_bias_grad_scratch_floats(M, N)
         sc = self._scratch_floats(need)
         _lib.check(L.dispu_act_bias_grad(M, N, _p(dY, dyoff), dY.stride(0), _p(Y, yoff) if Y is not None else None,
@@ -433,7 +519,7 @@ class Trainer(object):
         """dX[:, dxoff:dxoff+K] (+)= dY[:, dyoff:dyoff+N] . W^T, then zeroed where mask <= 0: mask = (tensor, column offset, columns) is the
         ReLU output that fed this layer -- the relu_grad of the layer below rides in the GEMM epilogue (no separate pass over dX).
         WT: the step's transposed copy of W ([N, K] row-major): the product then runs untransposed (the forward GEMM's fast path)."""
-        L = _lib.lib()
+        L = _lib.tape_lib()
         bf = self._use_bf16(1, M, N, K)
         r1 = _p(dX, dxoff) if acc else None
         ldr = dX.stride(0) if acc else 0
@@ -493,7 +579,7 @@ class Trainer(object):
         req(M % 32 == 0, "the non-local cell's attention kernels work on 32-point tiles: %d * N must be a multiple of 32, got N = %d"
                          % (self.up_ratio, N))
         ws = self._workspace(B, N)
-        L = _lib.lib()
+        L = _lib.tape_lib()
         self.st = _lib.stream_ptr(x.device)
         self._shape = (B, N)
         self._x = x
@@ -570,13 +656,15 @@ class Trainer(object):
         w0 = P[ps + "conv0/weights"]
         self._lin(up128, 0, 128, None, 0, ws["gm"], 0, 128, bias=False, W=w0, woff=6 * 128)
         _lib.check(L.dispu_ps_prep(rm, 128, _p(coarse), _p(w0), _p(P[ps + "conv0/biases"]), _p(ws["gm"]), 128, _p(ws["am"]), 128, self.st), "ps_prep")
-        # non-local cell with materialised attention (kept for the backward).  It reads up128 only: a branch next to the grouping,
-        # the skip and the local cell; merged before add3
+        # non-local cell (its attention kept for the backward as O + one log-sum-exp per query).  It reads up128 only: a branch next to
+        # the grouping, the skip and the local cell; merged before add3.  Its ~8 launches are SUBMITTED after the local cell and
+        # after_conv below (the chain), but ordered after this point of the stream.
         S = ws["S"]
-        with self._branch(0):
+
+        def nl_branch():
             # what the backward needs and nothing in the forward touches rides on this branch (it has slack; no stream of its own: a
             # fourth auxiliary stream changed the stream -> hardware-queue mapping and cost 0.1 ms per step)
-            ws["zeroed"].zero_()         # the dense blocks' input gradients, the skip branch's d(up128): accumulated with atomics
+            self._zero(ws["zeroed"])      # the dense blocks' input gradients, the skip branch's d(up128): accumulated with atomics
             if (self.use_wt or self.fused_heads_bwd) and self._t_desc.numel():       # W^T copies for the dX products
                 _lib.check(L.dispu_transpose_batched(self._t_desc.numel() // 3, _p(self._t_desc), _p(self.flat_p), _p(self.flat_pT), self.st),
                            "transpose_batched")
@@ -594,11 +682,15 @@ class Trainer(object):
                                           M * 64, None, 0, 0, None, 0, 0, self.st), "att.V")
             self._lin(ws["att"], 0, 64, ps + "PointShuffle/conv_back_project", 1, ws["nl"], 0, 256)
 
+        self._defer_branch(0, nl_branch)
         self._merge(2)
+
         # skip (a second branch next to the local cell): gather-max straight from xyz / up128, then 134 -> 256
-        with self._branch(1):
+        def skip_branch():
             _lib.check(L.dispu_ps_skip_max(rm, M, k, 128, _p(ws["psidx"]), _p(coarse), _p(up128), 128, _p(ws["gmax"]), 144, self.st), "skip_max")
             self._lin(ws["gmax"], 0, 134, ps + "skip", 1, ws["skip"], 0, 256)
+
+        self._defer_branch(1, skip_branch)
         # the fused cell (conv1, weight_net with the folded BatchNorm, feature x weight)
         _lib.check(L.dispu_ps_local(rm, M, k, 128, _p(ws["psidx"]), _p(coarse), _p(ws["gm"]), 128, _p(ws["am"]),
                                     _p(P[ps + "conv1/weights"]), _p(P[ps + "conv1/biases"]), _p(ww), _p(bw), _p(ws["bn_scale"]),
@@ -631,7 +723,7 @@ class Trainer(object):
         >= 0.97), not a separate error source."""
         if self._stash_ready:
             return
-        L = _lib.lib()
+        L = _lib.tape_lib()
         B, N = self._shape
         M, k = N * self.up_ratio, K_NEIGH
         rm = B * M
@@ -656,7 +748,7 @@ class Trainer(object):
     def _chamfer(self, pred, gt, radius, coef, dpred, slot):
         """one Chamfer term (loss_utils.py:45-64 with nn_distance(gt, pred)): its un-scaled value into loss_vals[slot] and
         d(coef * CD)/d pred into dpred -- three launches (nn_distance, value, gradient) + one memset."""
-        L = _lib.lib()
+        L = _lib.tape_lib()
         full = self._workspace(*self._shape)
         ws = full["cd"][slot]
         B, n_gt, n_pred = gt.shape[0], gt.shape[1], pred.shape[1]
@@ -678,16 +770,16 @@ class Trainer(object):
 
     def loss_backward(self, gt, radius):
         """pu_loss of model.py:75-87 at the current epoch; fills dcoarse / dfine with its gradient."""
-        L = _lib.lib()
+        L = _lib.tape_lib()
         B, N = self._shape
         M = N * self.up_ratio
         ws = self._workspace(B, N)
         gt, radius = self._check_targets(gt, radius, B, M)
         wf = weight_fine(self.epoch)
-        with self._branch(2):                                   # off the chain: needed by the local cell's backward only
-            self._recompute_pair_tensors()
-        with self._branch(0):                                   # the coarse term next to the fine term and the repulsion term
-            self._chamfer(ws["coarse"], gt, radius, 1000.0, ws["dcoarse"], 0)
+        # side work is submitted behind the fine term's launches (the chain): the pair tensors of the local cell's backward (needed much
+        # later) and the coarse term
+        self._defer_branch(2, self._recompute_pair_tensors)    # off the chain: needed by the local cell's backward only
+        self._defer_branch(0, lambda: self._chamfer(ws["coarse"], gt, radius, 1000.0, ws["dcoarse"], 0))   # next to the fine / repulsion terms
         # fine term: nn_distance, then value + gradient (which zero-fills dfine); the repulsion term's ball query runs next to it and
         # adds its gradient once the Chamfer gradient is in place
         rep = None
@@ -706,6 +798,10 @@ class Trainer(object):
         out = ws["loss_vals"]
         _lib.check(L.dispu_pu_loss_finalize(_p(out), _p(rep) if rep is not None else None, B * M, wf, float(self.opts.repulsion_w),
                                             _p(out, 2), self.st), "pu_loss_finalize")
+        return self._terms(out, wf)
+
+    @staticmethod
+    def _terms(out, wf):
         vals = out[2:6].clone()                                 # device scalars that survive the next step
         return {"dis_coarse_cd": vals[0], "dis_fine_cd": vals[1], "repulsion_loss": vals[2], "pu_loss": vals[3], "weight_fine": wf}
 
@@ -714,7 +810,7 @@ class Trainer(object):
         """gradients of pu_loss w.r.t. every trainable variable, accumulated into the flat gradient buffer.
         ReLU gradients never run as separate passes: the dX product of a layer applies the mask of the layer below in its epilogue
         (`mask=`), so every dY arriving at _lin_bwd is already the pre-activation gradient dZ."""
-        L = _lib.lib()
+        L = _lib.tape_lib()
         B, N = self._shape
         M, k = N * self.up_ratio, K_NEIGH
         rn, rm = B * N, B * M
@@ -727,7 +823,7 @@ class Trainer(object):
         if not getattr(self, "_fresh", False):
             # a second backward() on the same forward (new targets / loss weights): the atomics accumulators still hold the previous,
             # already masked gradients -- clear them again, on this stream, before anything accumulates
-            ws["zeroed"].zero_()
+            self._zero(ws["zeroed"])
         self._fresh = False
         if not self._stash_ready:                       # backward() without loss_backward(): rebuild the pair tensors here
             with self._branch(2):
@@ -764,12 +860,12 @@ class Trainer(object):
 
         # local cell first: the host needs ~0.1 ms to queue the two branches below, the chain must not sit idle meanwhile; the
         # branches themselves only need the mask3 outputs, so they are ordered after THIS point of the stream, not after the product
-        ev_br = self._fork_point() if (self.overlap_dw and self._sched & 4) else None
+        ev_br = self._fork_point() if self.overlap_dw else None
         self._lin_bwd(ws["hp"], 0, 2048, ps + "after_conv", 256, ws["daft"], 0, ws["dhp"])
         # non-local cell: reads dnl, writes datt / dS / dkv / dq / dup128 -- nothing the local cell or the skip branch touches, so
         # it runs as a branch next to them; merged before anything else accumulates into dup128
         dup128 = ws["dup128"]
-        with self._branch(0, ev_br):
+        def nl_backward():
             self._lin_bwd(ws["att"], 0, 64, ps + "PointShuffle/conv_back_project", 256, ws["dnl"], 0, ws["datt"])
             S, dS, kv, dkv, q = ws["S"], ws["dS"], ws["kv"], ws["dkv"], ws["q"]
             if self.flash_attn:
@@ -791,30 +887,36 @@ class Trainer(object):
                 self._tn(B, M, M, 64, dS, 0, M, M * M, q, 0, 64, M * 64, dkv, 0, 128, M * 128, 0)
             self._lin_bwd(ws["up128"], 0, 128, ps + "PointShuffle/conv_kv", 128, dkv, 0, dup128)
             self._lin_bwd(ws["up128"], 0, 128, ps + "PointShuffle/conv_query", 64, ws["dq"], 0, dup128, 0, acc_dx=True)
+        self._defer_branch(0, nl_backward, ev_br)
         # skip branch (a second branch): 134 -> 256 backward; its max gradient is scattered after the merges below
         split_skip = self.fused_heads_bwd and self.overlap_dw      # the skip branch's d(up128) in its own buffer, summed in the coarse chain
-        with self._branch(1, ev_br):
+        def skip_backward():
             self._lin_bwd(ws["gmax"], 0, 134, ps + "skip", 256, ws["dskip"], 0, ws["dgmax"])
             if split_skip:
                 _lib.check(L.dispu_ps_skip_max_grad(rm, M, k, 128, _p(ws["psidx"]), _p(coarse), _p(ws["up128"]), 128, _p(ws["gmax"]), 144,
                                                     _p(ws["dgmax"]), 136, _p(dcoarse), _p(ws["dup128s"]), 128, 1, self.st), "ps_skip_max_grad")
+        self._defer_branch(1, skip_backward, ev_br)
         if not (self._sched & 2):
             self._merge(2)                               # h0 / h1 / wv / the inverted graph are in place
         _lib.check(L.dispu_ps_point_matmul_grad_relu_s(rm, k, 128, 16, _p(ws["h1"]), 128, _p(ws["wv"]), _p(ws["dhp"]), 2048, _p(ws["dz1"]),
                                                        128, _p(ws["dwv"]), 1 if ws["h1"].dtype == torch.bfloat16 else 0, self.st),
                    "point_matmul_grad")
         # the weight net's backward (dwv -> BatchNorm -> 3 -> 16 conv -> atomics into dcoarse) next to the conv1 / conv0 gradients
-        with self._branch(2):
+        def wnet_backward():
             ww, bw = P[ps + "weight_net/wconv0/weights"], P[ps + "weight_net/wconv0/biases"]
             _lib.check(L.dispu_ps_wnet_grad(rm, M, k, 16, _p(ws["psidx"]), _p(coarse), _p(ww), _p(bw), _p(ws["bn_stats"]), _p(ws["bn_scale"]),
                                             _p(ws["bn_shift"]), _p(P[BN + "gamma"]), _p(ws["dwv"]), _p(G[ps + "weight_net/wconv0/weights"]),
                                             _p(G[ps + "weight_net/wconv0/biases"]), _p(G[BN + "gamma"]), _p(G[BN + "beta"]), _p(dcoarse),
                                             _p(ws["bn_sums"]), _p(self._bn_scratch), self._bn_scratch.numel() * 8, self.st), "ps_wnet_grad")
+        self._defer_branch(2, wnet_backward)
         self._lin_bwd(ws["h0"], 0, 128, ps + "conv1", 128, ws["dz1"], 0, ws["dz0"])          # dz0 holds dh0: conv0's relu' rides in the gather
         # conv0 in its per-source-point form: dh0 * (G[j] - A[i] > 0) -> dG (gather through the inverted graph), -dA; then [B*M, 128] products
         _lib.check(L.dispu_ps_conv0_gather_grad_s(rm, M, k, 128, _p(ws["psidx"]), _p(ws["inv_off"]), _p(ws["inv"]), _p(ws["dz0"]), 128,
                                                   1 if ws["dz0"].dtype == torch.bfloat16 else 0, _p(ws["gm"]), 128, _p(ws["am"]), 128,
                                                   _p(ws["dG"]), 128, _p(ws["dAneg"]), 128, self.st), "conv0_gather_grad")
+        # the main queue now holds after_conv's dX, the feature x weight gradient, conv1's dX and the gather (~0.35 ms of kernels at 8
+        # patches): time to submit the side work that piled up behind them (five weight gradients, the non-local and skip branches)
+        self._flush()
         w0, dw0 = P[ps + "conv0/weights"], G[ps + "conv0/weights"]
         self._merge(0)                                   # dup128 holds the non-local cell's part from here on
         self._lin_bwd(ws["up128"], 0, 128, None, 128, ws["dG"], 0, dup128, 0, acc_dx=True, W=w0, dW=dw0, woff=6 * 128, bias=False,
@@ -884,10 +986,15 @@ class Trainer(object):
                                                                  _p(P[sc + "/l1/biases"]), _p(P[sc + "/l2/weights"]), _p(P[sc + "/l2/biases"]),
                                                                  _p(dfeat, col), 480, _p(dF, dfoff), dF.stride(0), _p(scr), scr.numel(), self.st),
                            "edge_dense_conv_grad_partials")
-                st_r = self._fork()[0] if self.overlap_dw else self.st
-                _lib.check(L.dispu_edge_dense_conv_grad_reduce(rn, C, _p(scr), scr.numel(), _p(G[sc + "/l0/weights"]), _p(G[sc + "/l0/biases"]),
-                                                               _p(G[sc + "/l1/weights"]), _p(G[sc + "/l1/biases"]), _p(G[sc + "/l2/weights"]),
-                                                               _p(G[sc + "/l2/biases"]), st_r), "edge_dense_conv_grad_reduce")
+                # the block's recomputing backward kernel (40 - 80 us) is queued: submit the side work deferred so far behind it (the
+                # coarse head's weight gradients before the first block, the previous block's reduction and prep gradient afterwards)
+                self._flush()
+                def reduce_partials(sc=sc, scr=scr, C=C, ev=(self._fork_point() if self.overlap_dw else None)):
+                    st_r = self._fork_after(ev)[0] if ev is not None else self.st
+                    _lib.check(L.dispu_edge_dense_conv_grad_reduce(rn, C, _p(scr), scr.numel(), _p(G[sc + "/l0/weights"]), _p(G[sc + "/l0/biases"]),
+                                                                   _p(G[sc + "/l1/weights"]), _p(G[sc + "/l1/biases"]), _p(G[sc + "/l2/weights"]),
+                                                                   _p(G[sc + "/l2/biases"]), st_r), "edge_dense_conv_grad_reduce")
+                self._defer(reduce_partials)
             else:
                 Eb, dE = self._edge_buffers(B, N)[0][d], self._edge_buffers(B, N)[1][d]
                 lde = dE.stride(0)
@@ -908,7 +1015,8 @@ class Trainer(object):
 
     # -------------------------------------------------------------------------------------------------- step ----
     def zero_grad(self):
-        self.flat_g.zero_()
+        self.st = _lib.stream_ptr(self.device)
+        self._zero(self.flat_g)
 
     def all_reduce_grads(self):
         """ONE flat-bucket all-reduce (RCCL over xGMI) of the 4.2 MB gradient buffer; the 1/world average is folded
@@ -925,7 +1033,7 @@ class Trainer(object):
         b1, b2 = float(self.opts.beta), 0.999
         lr = learning_rate(self.opts, self.epoch)
         lr_t = lr * math.sqrt(1.0 - b2 ** self.adam_t) / (1.0 - b1 ** self.adam_t)
-        _lib.check(_lib.lib().dispu_adam(self.flat_p.numel(), _p(self.flat_p), _p(self.flat_g), _p(self.flat_m), _p(self.flat_v),
+        _lib.check(_lib.tape_lib().dispu_adam(self.flat_p.numel(), _p(self.flat_p), _p(self.flat_g), _p(self.flat_m), _p(self.flat_v),
                                          lr_t, b1, b2, 1e-8, 1.0 / world, _lib.stream_ptr(self.device)), "dispu_adam")
 
     def train_step_graphed(self, inputs, gt, radius):
@@ -973,6 +1081,51 @@ class Trainer(object):
         self.global_step += 1
         # the captured scalars live in the graph's memory pool and are overwritten by the next replay: hand out copies
         return {k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in g["terms"].items()}
+
+    def train_step_taped(self, inputs, gt, radius):
+        """train_step with forward + loss + backward re-issued from a LAUNCH TAPE (dis-pu_amd/_lib.py:Tape): the same launches on the
+        same streams in the same order as the eager step, recorded once per (B, N, loss weights) with their ctypes arguments already
+        converted, then replayed as a flat loop of foreign calls.  The eager step spends ~10 us of Python per launch (1.4 ms for ~130
+        launches at 8 patches -- as long as the GPU's critical chain, so the main queue idles wherever a chain kernel is submitted
+        behind side work); the replay spends ~1.5 us.  Unlike train_step_graphed the GPU-side schedule is the eager one.  Inputs are
+        copied into static buffers (the tape holds raw pointers); the all-reduce and Adam stay eager."""
+        B, N = inputs.shape[0], inputs.shape[1]
+        gt, radius = self._check_targets(gt, radius, B, N * self.up_ratio)
+        wf = weight_fine(self.epoch)
+        key = (B, N, wf, self.opts.use_repulse, torch.cuda.current_stream(self.device).cuda_stream)
+        t = self._tapes.get(key)
+        if t is None:
+            st = dict(x=inputs.clone(), gt=gt.clone(), radius=radius.clone())
+            mm, mv = self.moving_mean.clone(), self.moving_var.clone()
+            for _ in range(2):                               # every workspace / scratch buffer exists and has its final size
+                self.zero_grad()
+                self.forward(st["x"])
+                self.loss_backward(st["gt"], st["radius"])
+                self.backward()
+            self.moving_mean.copy_(mm)                       # the warm-up passes are not training steps
+            self.moving_var.copy_(mv)
+            torch.cuda.synchronize(self.device)
+            _lib.tape_begin()
+            try:
+                self.zero_grad()
+                self.forward(st["x"])
+                self.loss_backward(st["gt"], st["radius"])
+                self.backward()
+            finally:
+                st["tape"] = _lib.tape_end()
+            self.moving_mean.copy_(mm)                       # ... and neither is the recording pass
+            self.moving_var.copy_(mv)
+            st["loss_vals"] = self._workspace(B, N)["loss_vals"]
+            t = self._tapes[key] = st
+        t["x"].copy_(inputs)
+        t["gt"].copy_(gt)
+        t["radius"].copy_(radius)
+        t["tape"].replay()
+        terms = self._terms(t["loss_vals"], wf)
+        world = self.all_reduce_grads()
+        self.adam(world)
+        self.global_step += 1
+        return terms
 
     def train_step(self, inputs, gt, radius):
         """one iteration of the loop body of Model.train (model.py:215-232) -> loss terms (device scalars)."""

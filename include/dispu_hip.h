@@ -50,6 +50,11 @@ extern "C" {
  * explicit size), dispu_prob_sample, dispu_selection_sort; the fused training kernels.  A symbol never changes signature again:
  * new forms get new names.  4 = round 4: additions only (dispu_attention_fwd_lse / dispu_attention_bwd, ...). */
 int dispu_version(void);
+/* Stream / event / memset operations on raw HIP handles (hipEventRecord, hipStreamWaitEvent, hipMemsetAsync): what a host that
+ * re-issues a recorded launch sequence needs beside the kernels (dis-pu_amd/_lib.py:Tape; no reference counterpart: TF's executor). */
+int dispu_event_record(void* event, void* stream);
+int dispu_stream_wait_event(void* stream, void* event);
+int dispu_memset_async(void* dst, int value, size_t bytes, void* stream);
 /* hipGetErrorString for the codes returned below. */
 const char* dispu_error_string(int code);
 

@@ -527,6 +527,45 @@ def test_graphed_steps_equal_eager_steps(dev, dtype):
     assert float(kept[0][1]["pu_loss"]) != float(kept[3][1]["pu_loss"])
 
 
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_taped_steps_equal_eager_steps(dev, dtype):
+    """train_step_taped re-issues the eager step's launch sequence from a recorded tape (dis-pu_amd/_lib.py:Tape): same kernels, same
+    streams, same order -> the same gradients, loss terms, moving statistics and parameters as train_step from the same state (up to
+    the float atomics), step after step with new inputs, across an epoch boundary that changes weight_fine (new tape)."""
+    from dispu_amd import synth
+    from dispu_amd.train import Trainer
+    P = OG.init_params(seed=22, bias_scale=0.05, bn_random=True)
+    B = 4
+    batches = [synth.patch_with_gt(B, 256, 1024, seed=40 + i) for i in range(4)]
+    rs = torch.ones(B, device=dev)
+    e = Trainer(params=P, device=dev, dtype=dtype)
+    g = Trainer(params=P, device=dev, dtype=dtype)
+    e.epoch = g.epoch = 20
+    gtol = 2e-5 if dtype == "f32" else 2e-3
+    for i, (x, gt) in enumerate(batches):
+        if i == 2:
+            e.epoch = g.epoch = 21
+        for name in ("flat_p", "flat_m", "flat_v", "moving_mean", "moving_var"):
+            getattr(g, name).copy_(getattr(e, name))
+        g.adam_t, g.global_step = e.adam_t, e.global_step
+        xs, gs = dv(x, dev), dv(gt, dev)
+        te = e.train_step(xs, gs, rs)
+        tg = g.train_step_taped(xs, gs, rs)
+        torch.cuda.synchronize()
+        floor = 1e-7 * float(e.flat_g.abs().max())
+        for k in e.G:
+            scale = float(e.G[k].abs().max()) + 1e-12
+            assert float((g.G[k] - e.G[k]).abs().max()) <= gtol * scale + floor + 2e-6, (i, k)
+        assert np.allclose(N(g.moving_mean), N(e.moving_mean), rtol=1e-5, atol=1e-6) and np.allclose(N(g.moving_var), N(e.moving_var), rtol=1e-5, atol=1e-6)
+        for k in te:
+            a, b = float(te[k]), float(tg[k])
+            assert abs(a - b) <= (1e-5 if dtype == "f32" else 1e-2) * max(1.0, abs(a)), (i, k, a, b)
+        diff = N((g.flat_p - e.flat_p).abs())
+        assert diff.max() <= 2.5e-3 and np.quantile(diff, 0.99) <= (2e-5 if dtype == "f32" else 1e-3)
+    assert len(g._tapes) == 2 and all(len(t["tape"]) > 150 for t in g._tapes.values())
+    assert g.global_step == 4 and g.adam_t == 4
+
+
 def test_forward_refuses_shapes_the_fused_kernels_cannot_take(dev):
     from dispu_amd import synth
     from dispu_amd.train import Trainer

@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--dtype", choices=("f32", "bf16"), default="f32",
                     help="f32: the reference's arithmetic; bf16: bf16 products / fp32 accumulation and storage (csrc/linear_bf16.hip)")
     ap.add_argument("--graph", action="store_true", help="forward + loss + backward replayed from one hipGraph (Trainer.train_step_graphed)")
+    ap.add_argument("--tape", action="store_true", help="forward + loss + backward re-issued from a launch tape (Trainer.train_step_taped)")
     args = ap.parse_args()
     from dispu_amd import synth
     from dispu_amd.train import Trainer
@@ -49,7 +50,7 @@ def main():
     x, gt = torch.from_numpy(x).to(dev), torch.from_numpy(gt).to(dev)
     radius = torch.ones(args.batch, device=dev)
 
-    step_fn = tr.train_step_graphed if args.graph else tr.train_step
+    step_fn = tr.train_step_graphed if args.graph else tr.train_step_taped if args.tape else tr.train_step
     for _ in range(args.warmup):
         step_fn(x, gt, radius)
     torch.cuda.synchronize()
@@ -87,7 +88,7 @@ def main():
         phases = dict(zip(("forward_ms", "loss_ms", "backward_ms", "allreduce_adam_ms"), (acc / 5).round(3).tolist()))
         print(json.dumps({"metric": "training patches/sec (256->1024 generator, full step)", "value": world * args.batch * args.steps / dt,
                           "unit": "patches/s", "n_gpus": world, "patches_per_gpu": args.batch, "steps": args.steps,
-                          "ms_per_step": dt / args.steps * 1e3, "launch": "hipgraph" if args.graph else "eager",
+                          "ms_per_step": dt / args.steps * 1e3, "launch": "hipgraph" if args.graph else "tape" if args.tape else "eager",
                           "dtype": "f32" if args.dtype == "f32" else "bf16 products, f32 accumulate / storage", "pu_loss": float(terms["pu_loss"]), **phases}))
     if world > 1:
         dist.destroy_process_group()
