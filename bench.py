@@ -171,6 +171,8 @@ def pmc_traffic(kern):
     except (OSError, ValueError):
         return None, None
     row = rows.get("linear_mfma_kernel" + kern[len("linear"):])
+    if row is None and kern.endswith(", 6>"):              # the counter passes of a build in which after_conv still ran as EPI 4 / EPI 0
+        row = rows.get("linear_mfma_kernel" + kern[len("linear"):-4] + ", 4>")
     if not row or "hbm_bytes_corrected" not in row:
         return None, None
     return row["hbm_bytes_corrected"], "profiles/pmc_traffic_latest.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"

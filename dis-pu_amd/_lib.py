@@ -116,6 +116,9 @@ SIGNATURES = {
     "dispu_mlp_chain": (_i, [_l, _i, _i, _i, _i, _vp, _l, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _l, _i, _vp, _l, _vp, _l, _vp]),
     "dispu_linear_masked": (_i, [_i, _i, _i, _i, _vp, _l, _l, _vp, _l, _l, _i, _vp, _i, _vp, _l, _l, _vp, _l, _l, _vp, _l, _i, _vp]),
     "dispu_linear_bf16_masked": (_i, [_i, _i, _i, _i, _vp, _l, _l, _vp, _l, _l, _i, _vp, _i, _vp, _l, _l, _vp, _l, _l, _vp, _l, _i, _vp]),
+    "dispu_mlp_chain_sum3": (_i, [_l, _i, _i, _i, _i, _vp, _vp, _vp, _l, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _l, _i, _vp, _l, _vp, _l, _vp]),
+    "dispu_mlp_chain_dup": (_i, [_i, _i, _i, _i, _i, _i, _i, _vp, _l, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _l, _i, _vp, _l,
+                                 _vp, _l, _vp]),
     "dispu_mlp_chain_stash": (_i, [_l, _i, _i, _i, _i, _vp, _l, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _l, _vp, _l, _vp, _l, _vp, _l,
                                    _i, _vp, _l, _vp, _l, _vp]),
     "dispu_mlp_chain_grad": (_i, [_l, _i, _i, _i, _vp, _l, _vp, _vp, _vp, _vp, _vp, _l, _vp, _l, _vp, _l, _vp, _l, _vp, _l, _vp, _l, _vp, _l, _vp, _l,

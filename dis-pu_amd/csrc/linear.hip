@@ -67,7 +67,7 @@ struct LinearLds {
 #ifdef LIN_CLOCK
 __device__ unsigned long long lin_clock_ticks[4];
 #endif
-template <int BM, int BN, int WM, int WN, int BK, bool TRANSB, bool EDGE, int EPI>
+template <int BM, int BN, int WM, int WN, int BK, bool TRANSB, bool EDGE, int EPI_T>
 __global__ __launch_bounds__(64 * (WM * WN + (LinearLds<BM, BN, BK, TRANSB, EDGE>::DMA ? 4 : WM * WN))) void linear_mfma_kernel(LinearArgs a) {
 #ifdef LIN_CLOCK
     const unsigned long long lc0 = __builtin_readcyclecounter();
@@ -351,6 +351,9 @@ __global__ __launch_bounds__(64 * (WM * WN + (LinearLds<BM, BN, BK, TRANSB, EDGE
     // ~5000 instructions with spills (9 us per launch).  EPI 0: bias + activation; 1: + BatchNorm fold;
     // 4: BatchNorm fold and whatever residuals are given (uniform branches around the residual loads: the compiler
     // keeps those loads in program order, whereas unconditional ones were all hoisted and spilled).
+    // EPI_T 6 = EPI 0 under a name of its own: the long contractions (K >= 1024: PointShuffle2's after_conv, the step's dominant
+    // kernel) no longer share an instantiation -- hence a row of `rocprofv3 --stats` -- with the K <= 480 products of the same tile
+    constexpr int EPI = (EPI_T == 6) ? 0 : EPI_T;
     constexpr bool E_SCALE = (EPI == 1 || EPI == 4), E_R1 = (EPI >= 2), E_R2 = (EPI >= 3);
     float* __restrict__ Y = a.Y + (size_t)z * a.sy;
     const float lo = (a.act == 1) ? 0.f : -__builtin_inff();
@@ -445,7 +448,12 @@ static int launch_epi(const LinearArgs& a, dim3 grid, hipStream_t s) {
 
 template <int BM, int BN, int WM, int WN, int BK, bool TRANSB, bool EDGE>
 static int launch_one(const LinearArgs& a, dim3 grid, hipStream_t s) {
-    if (!a.scale && !a.R1 && !a.R2 && !a.Mk) return launch_epi<BM, BN, WM, WN, BK, TRANSB, EDGE, 0>(a, grid, s);
+    if (!a.scale && !a.R1 && !a.R2 && !a.Mk) {
+        if constexpr (BM == 128 && BN == 256 && BK == 16 && !TRANSB && !EDGE) {
+            if (a.K >= 1024) return launch_epi<BM, BN, WM, WN, BK, TRANSB, EDGE, 6>(a, grid, s);
+        }
+        return launch_epi<BM, BN, WM, WN, BK, TRANSB, EDGE, 0>(a, grid, s);
+    }
     if (a.scale && !a.R1 && !a.R2 && !a.Mk) return launch_epi<BM, BN, WM, WN, BK, TRANSB, EDGE, 1>(a, grid, s);
     if (a.Mk) return launch_epi<BM, BN, WM, WN, BK, TRANSB, EDGE, 5>(a, grid, s);
     return launch_epi<BM, BN, WM, WN, BK, TRANSB, EDGE, 4>(a, grid, s);

@@ -30,6 +30,14 @@ struct ChainArgs {
     const float* R; long ldr;                       // mode 1: out = R + sigmoid(.) - 0.5
     float* out; long ldo;                           // [rows, 3]
     int mode;
+    // XMODE 1 (round 4): the input tile is (X + X2) + X3, formed by the loader waves -- PointShuffle2's
+    //   relu(after_conv) + skip + non-local (ops.py:1069-1075) no longer rides in the after_conv GEMM's epilogue, where 67 MB of
+    //   residual reads sat behind the product loop of 256 workgroups that all finish at the same moment
+    const float* X2 = nullptr; const float* X3 = nullptr;
+    // XMODE 2 (round 4): the input tile is duplicate_up's conv1 output (ops.py:1152-1192) evaluated on the fly from the per-source-
+    //   point product X = H [nclouds * n, K0]: row (cloud * up + r) * n + i = relu(fmaf(g[r][1], Wg[1], fmaf(g[r][0], Wg[0], H[cloud * n + i])) + bg)
+    //   -- the arithmetic of dup_grid_kernel (csrc/mlp_misc.hip), whose [rows, 256] output and launch disappear
+    const float* Wg = nullptr; const float* bg = nullptr; const float* grid = nullptr; int n = 0; int up = 0;
 };
 
 constexpr int MC_BM = 128, MC_KMAX = 256, MC_NMAX = 256;          // MC_BM: rows per workgroup of the large-batch variant (BM = 64 below
@@ -112,7 +120,7 @@ __device__ __forceinline__ void chain_layer(float* act, const float* wst, int g0
 // STASH: also write the second / third layer's outputs and the head's pre-activation (training forward).  A template flag, not a
 // run-time test: with the pointers as run-time arguments the inference launches lost 3 - 4 us each to the extra branches / address
 // arithmetic in every layer's store loop.
-template <int K0, int N1, int N2, int N3, int BM, bool STASH = false>
+template <int K0, int N1, int N2, int N3, int BM, bool STASH = false, int XMODE = 0>
 __global__ __launch_bounds__(512) void mlp_chain_kernel(ChainArgs a) {
     constexpr int MC_LDA = BM + 1, XU = BM / 32;                  // XU: float4 loads per loader thread and 32-column input chunk
     static_assert(K0 <= MC_KMAX && N1 <= MC_KMAX && N2 <= MC_KMAX && N3 == 64, "chain shape outside the LDS plan");
@@ -131,11 +139,48 @@ __global__ __launch_bounds__(512) void mlp_chain_kernel(ChainArgs a) {
         // input tile [128][K0] -> k-major act, in chunks of 32 k-columns (128 B per row, 4 float4 per thread); chunk c feeds
         // layer-1 slabs from k = 32 c on, so only chunk 0 is loaded before the MFMA waves start
         float4 xv[XU];
+        float4 xr1[XMODE == 1 ? XU : 1], xr2[XMODE == 1 ? XU : 1];
+        // XMODE 2: a thread's XU rows of a chunk share one column quad; their source rows / grid codes are fixed for the kernel
+        long dsrc[XMODE == 2 ? XU : 1];
+        float dg0[XMODE == 2 ? XU : 1], dg1[XMODE == 2 ? XU : 1];
+        if constexpr (XMODE == 2) {
+#pragma unroll
+            for (int u = 0; u < XU; ++u) {
+                const long row = row0 + ((tid + u * 256) >> 3);
+                const long cr = row / a.n;                        // cloud * up + r
+                const long cloud = cr / a.up;
+                const int r = (int)(cr - cloud * a.up);
+                dsrc[u] = cloud * a.n + (row - cr * a.n);
+                dg0[u] = a.grid[r * 2 + 0];
+                dg1[u] = a.grid[r * 2 + 1];
+            }
+        }
         auto load_x = [&](int c) {
+            if constexpr (XMODE == 2) {
+                const int col = c * 32 + (tid & 7) * 4;
+                const float4 w0 = *reinterpret_cast<const float4*>(a.Wg + col), w1 = *reinterpret_cast<const float4*>(a.Wg + K0 + col);
+                const float4 bb = *reinterpret_cast<const float4*>(a.bg + col);
+                float4 h[XU];
+#pragma unroll
+                for (int u = 0; u < XU; ++u) h[u] = *reinterpret_cast<const float4*>(a.X + (size_t)dsrc[u] * a.ldx + col);
+#pragma unroll
+                for (int u = 0; u < XU; ++u) {
+                    xv[u].x = fmaxf(__builtin_fmaf(dg1[u], w1.x, __builtin_fmaf(dg0[u], w0.x, h[u].x)) + bb.x, 0.f);
+                    xv[u].y = fmaxf(__builtin_fmaf(dg1[u], w1.y, __builtin_fmaf(dg0[u], w0.y, h[u].y)) + bb.y, 0.f);
+                    xv[u].z = fmaxf(__builtin_fmaf(dg1[u], w1.z, __builtin_fmaf(dg0[u], w0.z, h[u].z)) + bb.z, 0.f);
+                    xv[u].w = fmaxf(__builtin_fmaf(dg1[u], w1.w, __builtin_fmaf(dg0[u], w0.w, h[u].w)) + bb.w, 0.f);
+                }
+                return;
+            }
 #pragma unroll
             for (int u = 0; u < XU; ++u) {
                 const int idx = tid + u * 256;                    // BM rows x 8 quads
-                xv[u] = *reinterpret_cast<const float4*>(a.X + (size_t)(row0 + (idx >> 3)) * a.ldx + c * 32 + (idx & 7) * 4);
+                const size_t o = (size_t)(row0 + (idx >> 3)) * a.ldx + c * 32 + (idx & 7) * 4;
+                xv[u] = *reinterpret_cast<const float4*>(a.X + o);
+                if constexpr (XMODE == 1) {
+                    xr1[u] = *reinterpret_cast<const float4*>(a.X2 + o);
+                    xr2[u] = *reinterpret_cast<const float4*>(a.X3 + o);
+                }
             }
         };
         auto store_x = [&](int c) {
@@ -143,6 +188,10 @@ __global__ __launch_bounds__(512) void mlp_chain_kernel(ChainArgs a) {
             for (int u = 0; u < XU; ++u) {
                 const int idx = tid + u * 256;
                 const int r = idx >> 3, k = c * 32 + (idx & 7) * 4;
+                if constexpr (XMODE == 1) {                       // (x + x2) + x3, the association of the GEMM epilogue it replaces
+                    xv[u].x = (xv[u].x + xr1[u].x) + xr2[u].x; xv[u].y = (xv[u].y + xr1[u].y) + xr2[u].y;
+                    xv[u].z = (xv[u].z + xr1[u].z) + xr2[u].z; xv[u].w = (xv[u].w + xr1[u].w) + xr2[u].w;
+                }
                 act[(k + 0) * MC_LDA + r] = xv[u].x;
                 act[(k + 1) * MC_LDA + r] = xv[u].y;
                 act[(k + 2) * MC_LDA + r] = xv[u].z;
@@ -262,6 +311,59 @@ DISPU_EXPORT int dispu_mlp_chain_stash(long rows, int K0, int N1, int N2, int N3
                                        const float* W2, const float* b2, const float* W3, const float* b3, const float* W4, const float* b4,
                                        float* Y1, long ldy1, float* Y2, long ldy2, float* Y3, long ldy3, float* Z, long ldz, int mode,
                                        const float* R, long ldr, float* out, long ldo, void* stream);
+
+// shared launcher of the round-4 input modes (no stash variants: the training forward keeps its materialised inputs)
+template <int XMODE>
+static int mlp_chain_xmode(const ChainArgs& a, int K0, int N1, int N2, int N3, hipStream_t s) {
+    const long rows = a.rows;
+    const bool small = (rows % MC_BM) != 0 || rows / MC_BM < 192;
+    const bool coarse = (K0 == 256 && N1 == 128 && N2 == 256 && N3 == 64), fine = (K0 == 256 && N1 == 256 && N2 == 256 && N3 == 64);
+    if (!coarse && !fine) return (int)hipErrorInvalidValue;
+    const dim3 grid((unsigned)(rows / (small ? 64 : MC_BM)));
+    auto launch = [&](auto kern) -> int {
+        static DevOnce once;
+        if (once.needed()) {
+            DISPU_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)MC_LDS_BYTES));
+            once.done();
+        }
+        hipLaunchKernelGGL(kern, grid, dim3(512), MC_LDS_BYTES, s, a);
+        return (int)hipGetLastError();
+    };
+    if (coarse) return small ? launch(mlp_chain_kernel<256, 128, 256, 64, 64, false, XMODE>) : launch(mlp_chain_kernel<256, 128, 256, 64, 128, false, XMODE>);
+    return small ? launch(mlp_chain_kernel<256, 256, 256, 64, 64, false, XMODE>) : launch(mlp_chain_kernel<256, 256, 256, 64, 128, false, XMODE>);
+}
+
+// dispu_mlp_chain whose input is (X + X2) + X3 (three [rows, K0] matrices with one row stride), summed by the loader waves.
+DISPU_EXPORT int dispu_mlp_chain_sum3(long rows, int K0, int N1, int N2, int N3, const float* X, const float* X2, const float* X3, long ldx,
+                                      const float* W1, const float* b1, const float* W2, const float* b2, const float* W3, const float* b3,
+                                      const float* W4, const float* b4, float* Y1, long ldy1, int mode, const float* R, long ldr, float* out,
+                                      long ldo, void* stream) {
+    if (rows < 0 || (rows % 64) != 0 || (ldx & 3) || !X || !X2 || !X3 || !W1 || !W2 || !W3 || !W4 || !b1 || !b2 || !b3 || !b4 || !out ||
+        (mode == 1 && !R) || ((((uintptr_t)X) | ((uintptr_t)X2) | ((uintptr_t)X3) | ((uintptr_t)W1) | ((uintptr_t)W2) | ((uintptr_t)W3)) & 15))
+        return (int)hipErrorInvalidValue;
+    if (rows == 0) return 0;
+    ChainArgs a{rows, X, ldx, W1, b1, W2, b2, W3, b3, W4, b4, Y1, ldy1, nullptr, 0, nullptr, 0, nullptr, 0, R, ldr, out, ldo, mode};
+    a.X2 = X2; a.X3 = X3;
+    return mlp_chain_xmode<1>(a, K0, N1, N2, N3, (hipStream_t)stream);
+}
+
+// dispu_mlp_chain on duplicate_up's rows (ops.py:1152-1192) WITHOUT the [nclouds * up * n, K0] tensor: row (cloud * up + r) * n + i of
+// the chain's input = relu(fmaf(grid[r][1], Wg[1][:], fmaf(grid[r][0], Wg[0][:], H[cloud * n + i][:])) + bg) -- dispu_dup_grid's
+// arithmetic, evaluated by the loader waves.  H [nclouds * n, K0] (row stride ldh), Wg [2, K0], bg [K0], grid [up, 2].
+DISPU_EXPORT int dispu_mlp_chain_dup(int nclouds, int n, int up, int K0, int N1, int N2, int N3, const float* H, long ldh, const float* Wg,
+                                     const float* bg, const float* grid, const float* W1, const float* b1, const float* W2, const float* b2,
+                                     const float* W3, const float* b3, const float* W4, const float* b4, float* Y1, long ldy1, int mode,
+                                     const float* R, long ldr, float* out, long ldo, void* stream) {
+    const long rows = (long)nclouds * up * n;
+    if (nclouds < 0 || n <= 0 || up <= 0 || (rows % 64) != 0 || (ldh & 3) || !H || !Wg || !bg || !grid || !W1 || !W2 || !W3 || !W4 || !b1 || !b2 ||
+        !b3 || !b4 || !out || (mode == 1 && !R) ||
+        ((((uintptr_t)H) | ((uintptr_t)Wg) | ((uintptr_t)bg) | ((uintptr_t)W1) | ((uintptr_t)W2) | ((uintptr_t)W3)) & 15))
+        return (int)hipErrorInvalidValue;
+    if (rows == 0) return 0;
+    ChainArgs a{rows, H, ldh, W1, b1, W2, b2, W3, b3, W4, b4, Y1, ldy1, nullptr, 0, nullptr, 0, nullptr, 0, R, ldr, out, ldo, mode};
+    a.Wg = Wg; a.bg = bg; a.grid = grid; a.n = n; a.up = up;
+    return mlp_chain_xmode<2>(a, K0, N1, N2, N3, (hipStream_t)stream);
+}
 
 DISPU_EXPORT int dispu_mlp_chain(long rows, int K0, int N1, int N2, int N3, const float* X, long ldx, const float* W1, const float* b1,
                                  const float* W2, const float* b2, const float* W3, const float* b3, const float* W4, const float* b4,

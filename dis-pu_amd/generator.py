@@ -85,6 +85,10 @@ class Generator(object):
         self.fused_residual = bool(int(__import__('os').environ.get('DISPU_FUSED_RES', '1')))
         self.fused_heads = bool(int(__import__('os').environ.get('DISPU_FUSED_HEADS', '1')))   # one launch per head chain
         self.keep_intermediates = False   # fused heads: also write the aggregation output (tests compare it)
+        # round 4: the head chains form their own input tiles (csrc/mlp_chain.hip XMODE): duplicate_up's rows from the per-source-point
+        # product (no dup_grid launch, no [B*4N, 256] tensor) and relu(after_conv) + skip + non-local in the fine chain's loader (the
+        # residual reads leave the after_conv GEMM's epilogue).  0 = the producer kernels of rounds 1 - 3 (bit-identical results)
+        self.chain_inputs = bool(int(__import__('os').environ.get('DISPU_CHAIN_INPUTS', '1')))
         # forward() computes into a reusable per-(B, N) workspace.  By default the two results are returned as fresh
         # tensors (like sess.run in the reference); return_views = True hands out the workspace buffers themselves
         # (no copies -- bench.py / hipGraph capture), which the NEXT call with the same (B, N) overwrites.
@@ -196,6 +200,8 @@ class Generator(object):
             edge = not (M % bm == 0 and N % bn == 0 and K % bk == 0 and ldx % 4 == 0 and ldw % 4 == 0 and sx % 4 == 0
                         and sw % 4 == 0 and (X.data_ptr() + 4 * xoff) % 16 == 0 and (W.data_ptr() + 4 * woff) % 16 == 0)
             epi = 0 if (R1 is None and R2 is None) else 4       # epilogue variant: 0 bias/act, 4 with residual inputs
+            if epi == 0 and (bm, bn, bk) == (128, 256, 16) and not transb and not edge and K >= 1024:
+                epi = 6                                          # long contractions: an instantiation of their own (csrc/linear.hip)
             name = "linear<%d, %d, 2, 2, %d, %s, %s, %d>[%dx%dx%d]" % (bm, bn, bk, "true" if transb else "false",
                                                                       "true" if edge else "false", epi, M * batch, K, N)
             # latency-bound shapes leave the tiled kernel (csrc/linear_skinny.hip:linear_skinny_dispatch; same conditions)
@@ -271,12 +277,22 @@ class Generator(object):
         # ---- duplicate_up (ops.py:1152-1199) + coarse coordinate_regressor (:1089-1110)
         _, b1 = self._w("generator/upshuffle_0/conv1")
         self._linear(st, feat, 480, self.w_up_feat, None, 0, ws["h256"], 256)
-        self._call("dup_grid", L.dispu_dup_grid, B, N, 256, self.up_ratio, ptr(ws["h256"]), 256, ptr(self.w_up_grid), ptr(b1), ptr(self.grid),
-                             ptr(ws["up256"]), 256, st)
         cs = "generator/coarse_coordinate_regressor/"
         coarse = ws["coarse"]
         heads = self.fused_heads and rm % 128 == 0
-        if heads:
+        in_chain = heads and self.chain_inputs
+        if not in_chain:
+            self._call("dup_grid", L.dispu_dup_grid, B, N, 256, self.up_ratio, ptr(ws["h256"]), 256, ptr(self.w_up_grid), ptr(b1), ptr(self.grid),
+                       ptr(ws["up256"]), 256, st)
+        if in_chain:
+            w1, b1_ = self._w("generator/upshuffle_0/conv2")
+            w2, b2_ = self._w(cs + "fc_layer0")
+            w3, b3_ = self._w(cs + "fc_layer1")
+            w4, b4_ = self._w(cs + "fc_layer2")
+            self._call("mlp_chain[coarse]", L.dispu_mlp_chain_dup, B, N, self.up_ratio, 256, 128, 256, 64, ptr(ws["h256"]), 256, ptr(self.w_up_grid),
+                       ptr(b1), ptr(self.grid), ptr(w1), ptr(b1_), ptr(w2), ptr(b2_), ptr(w3), ptr(b3_), ptr(w4), ptr(b4_), ptr(ws["up128"]), 128,
+                       0, None, 0, ptr(coarse), 3, st)
+        elif heads:
             # conv2 -> fc_layer0 -> fc_layer1 -> fc_layer2 in one launch; up128 (needed by PointShuffle2) is written on the way
             w1, b1_ = self._w("generator/upshuffle_0/conv2")
             w2, b2_ = self._w(cs + "fc_layer0")
@@ -384,6 +400,8 @@ class Generator(object):
                 self._planes["after_conv"] = pl
             self._call("linear_bf16x3[%dx2048x256]" % rm, L.dispu_linear_bf16x3, rm, 2048, 256, ptr(ws["fp"]), 2048, ptr(pl), ptr(b), 1,
                        ptr(ws["aft"]), 256, ptr(ws["skip"]), 256, ptr(ws["nl"]), 256, st)
+        elif heads and self.chain_inputs:
+            self._linear(st, ws["fp"], 2048, w, b, 1, ws["aft"], 256)          # relu(after_conv) alone; + skip + nl in the fine chain's loader
         elif self.fused_residual:
             self._linear(st, ws["fp"], 2048, w, b, 1, ws["aft"], 256, R1=ws["skip"], R2=ws["nl"])
         else:
@@ -391,7 +409,15 @@ class Generator(object):
             self._linear(st, ws["fp"], 2048, w, b, 1, ws["aft"], 256)
             self._call("add3", L.dispu_add3, rm * 256, ptr(ws["aft"]), ptr(ws["skip"]), ptr(ws["nl"]), ptr(ws["aft"]), st)
         fs = "refine/fine_coordinate_regressor/"
-        if heads:
+        if heads and self.chain_inputs and not (self.split_bf16 and rm % 128 == 0):
+            w1, b1_ = self._w(ps + "aggregation")
+            w2, b2_ = self._w(fs + "fc_layer0")
+            w3, b3_ = self._w(fs + "fc_layer1")
+            w4, b4_ = self._w(fs + "fc_layer2")
+            self._call("mlp_chain[fine]", L.dispu_mlp_chain_sum3, rm, 256, 256, 256, 64, ptr(ws["aft"]), ptr(ws["skip"]), ptr(ws["nl"]), 256,
+                       ptr(w1), ptr(b1_), ptr(w2), ptr(b2_), ptr(w3), ptr(b3_), ptr(w4), ptr(b4_),
+                       ptr(ws["agg"]) if self.keep_intermediates else None, 256, 1, ptr(coarse), 3, ptr(ws["fine"]), 3, st)
+        elif heads:
             w1, b1_ = self._w(ps + "aggregation")
             w2, b2_ = self._w(fs + "fc_layer0")
             w3, b3_ = self._w(fs + "fc_layer1")

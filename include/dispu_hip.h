@@ -282,6 +282,20 @@ int dispu_softmax_rows(long rows, int n, float mul, float* S, long lds, void* st
 int dispu_mlp_chain(long rows, int K0, int N1, int N2, int N3, const float* X, long ldx, const float* W1, const float* b1,
                     const float* W2, const float* b2, const float* W3, const float* b3, const float* W4, const float* b4,
                     float* Y1, long ldy1, int mode, const float* R, long ldr, float* out, long ldo, void* stream);
+/* Round 4: the same chain with its input tile formed by the loader waves instead of a producer kernel.
+ * _sum3: input = (X + X2) + X3, three [rows, K0] matrices with one row stride (PointShuffle2's relu(after_conv) + skip + non-local,
+ *        ops.py:1069-1075: the two residual reads leave the after_conv GEMM's epilogue).
+ * _dup:  input = duplicate_up's conv1 rows (ops.py:1152-1192) evaluated from the per-source-point product H [nclouds*n, K0]:
+ *        row (cloud*up + r)*n + i = relu(fmaf(grid[r][1], Wg[1], fmaf(grid[r][0], Wg[0], H[cloud*n + i])) + bg) -- dispu_dup_grid's
+ *        arithmetic without its [nclouds*up*n, K0] output.  Both are bit-identical to producer + dispu_mlp_chain. */
+int dispu_mlp_chain_sum3(long rows, int K0, int N1, int N2, int N3, const float* X, const float* X2, const float* X3, long ldx,
+                         const float* W1, const float* b1, const float* W2, const float* b2, const float* W3, const float* b3,
+                         const float* W4, const float* b4, float* Y1, long ldy1, int mode, const float* R, long ldr, float* out, long ldo,
+                         void* stream);
+int dispu_mlp_chain_dup(int nclouds, int n, int up, int K0, int N1, int N2, int N3, const float* H, long ldh, const float* Wg,
+                        const float* bg, const float* grid, const float* W1, const float* b1, const float* W2, const float* b2,
+                        const float* W3, const float* b3, const float* W4, const float* b4, float* Y1, long ldy1, int mode, const float* R,
+                        long ldr, float* out, long ldo, void* stream);
 
 /* ---- glue kernels of the PointNet++ / EdgeConv / loss compositions --------------------------------------
  * (Common/pointnet_util.py, gcn_lib/tf_vertex.py, Common/loss_utils.py: chains of generic TF ops in the reference) */

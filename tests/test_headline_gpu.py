@@ -170,3 +170,19 @@ def test_oversize_batches_run_in_chunks(dev):
     gen.return_views = True
     with pytest.raises(ValueError):
         gen(x)
+
+
+def test_chain_input_modes_equal_producer_kernels(bench_setup, dev):
+    """round 4: the head chains form their own input tiles (dispu_mlp_chain_dup: duplicate_up's rows from the per-source-point product;
+    dispu_mlp_chain_sum3: relu(after_conv) + skip + non-local) -- bit-identical to dup_grid + the residual epilogue + dispu_mlp_chain,
+    at the bench's size (128-row workgroups) and at B = 1, 3 (64-row workgroups, partial clouds per workgroup)."""
+    from dispu_amd.generator import Generator
+    s = bench_setup
+    old = Generator(params=s["P"], device=dev)
+    old.chain_inputs = False
+    assert s["gen"].chain_inputs
+    for B in (32, 3, 1):
+        x = s["tx"][:B].contiguous()
+        c0, f0 = old(x)
+        c1, f1 = s["gen"](x)
+        assert np.array_equal(N(c0), N(c1)) and np.array_equal(N(f0), N(f1)), "B = %d" % B
