@@ -413,14 +413,17 @@ def main():
         if "train_step" in side and isinstance(side["train_step"], dict):
             roof["train_step_ms"] = {k: v.get("ms_per_step") for k, v in side["train_step"].items() if isinstance(v, dict)}
         side["headline"] = {k: out[k] for k in ("value", "ms_per_step", "steps", "warmup", "n_gpus")}
-        for d in (os.path.join(ROOT, "profiles"), os.path.join(ROOT, "gpurun_out")):
+        # only the full run writes the side file: the profiled / counter passes (--no-ops, timings inflated by the profiler) must not
+        # overwrite it
+        for d in ((os.path.join(ROOT, "profiles"), os.path.join(ROOT, "gpurun_out")) if (world == 1 and not args.no_ops) else ()):
             try:
                 os.makedirs(d, exist_ok=True)
                 with open(os.path.join(d, "bench_side_tables.json"), "w") as f:
                     json.dump(side, f, indent=1)
             except OSError:
                 pass
-        roof["side_tables"] = "profiles/bench_side_tables.json (keys: kernels, ops, train_step, ops_peaks, cpu_baseline_ops)"
+        if world == 1 and not args.no_ops:
+            roof["side_tables"] = "profiles/bench_side_tables.json (keys: kernels, ops, train_step, ops_peaks, cpu_baseline_ops)"
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
