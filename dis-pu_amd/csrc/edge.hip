@@ -64,7 +64,12 @@ __device__ __forceinline__ void edge_fill_frag(float* frag, const float* __restr
 // (tools/micro/gemm_lab.hip), and the 24 gathers per group cost more than the 132 MFMAs they feed.
 // LDSF workgroups have 8 waves (two per SIMD: one wave's DPP max / store epilogue overlaps the other's MFMA chain; the
 // rows come from LDS at the top of each group, so no prefetch registers are needed and 256 registers per wave suffice).
-template <int C, bool LDSF>
+// PRE (round 4, LDSF only): layer 0's input is [F_p (C), F_j - F_p (C)], so the first C terms of its fmaf chain depend on the POINT,
+// not on the pair.  They are evaluated once per point -- one MFMA pass over 32 points as columns per 32 points of the workgroup,
+// instead of C/2 steps in every 32-pair tile, where 16 columns repeat the same point -- parked in LDS, and a pair tile starts its
+// layer-0 accumulators from them and continues the chain with the F_j - F_p terms: the same sequence of fused multiply-adds per
+// output, bit for bit, with 24 of 132 (C = 48) / 12 of 84 (C = 24) MFMAs per tile gone.
+template <int C, bool LDSF, bool PRE = false>
 __global__ __launch_bounds__(LDSF ? 512 : 256) void edge_dense_conv_mfma_kernel(int npoints, int n_per_cloud, const float* __restrict__ F,
                                                                     long ldf, const int* __restrict__ idx, int ldi, int ioff,
                                                                     const float* __restrict__ W0, const float* __restrict__ b0,
@@ -80,6 +85,7 @@ __global__ __launch_bounds__(LDSF ? 512 : 256) void edge_dense_conv_mfma_kernel(
     float* frag = edge_lds;                                      // (S0 + S1 + S2) * 64 weight fragments
     float* stage = frag + (S0 + S1 + S2) * 64;                   // [4 waves][2 points][72 + C] output staging
     float* fl = stage + (LDSF ? 8 : 4) * 2 * (3 * G + C);        // LDSF: [n_per_cloud][C + 4] features of this cloud
+    static_assert(!PRE || LDSF, "the per-point prefix reads the LDS copy of the cloud");
     const bool vec_store = ((ldy & 3) == 0) && ((((uintptr_t)Y) & 15) == 0);
     constexpr int FLD = C + 4;                                   // row stride 52 / 28 floats: 16-byte aligned, spreads the banks
     float* f0 = frag;
@@ -107,12 +113,36 @@ __global__ __launch_bounds__(LDSF ? 512 : 256) void edge_dense_conv_mfma_kernel(
         }
     }
     __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row = lane & 31, h = lane >> 5;
+    float* pre = fl + n_per_cloud * FLD;                         // PRE: [points of this workgroup][2 halves][12] layer-0 prefixes
+    if constexpr (PRE) {
+        const int npts_wg = (g_hi - g_lo) * 2, p_base = g_lo * 2 - cloud0;
+        for (int t = wave; t * 32 < npts_wg; t += NWAVE) {
+            const int pl = min(t * 32 + row, npts_wg - 1);
+            const float* fr = fl + (p_base + pl) * FLD;
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+            for (int sq = 0; sq < C / 4; ++sq) {                 // steps 2 sq, 2 sq + 1: elements k = 4 sq + h and 4 sq + 2 + h of F_p
+                const float4 a = *reinterpret_cast<const float4*>(fr + sq * 4);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(f0[(2 * sq) * 64 + lane], h ? a.y : a.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(f0[(2 * sq + 1) * 64 + lane], h ? a.w : a.z, acc, 0, 0, 0);
+            }
+            if (t * 32 + row < npts_wg) {
+                float* pp = pre + ((t * 32 + row) * 2 + h) * 12;
+#pragma unroll
+                for (int q = 0; q < 3; ++q)
+                    *reinterpret_cast<float4*>(pp + q * 4) = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+            }
+        }
+        __syncthreads();
+    }
 #ifdef EDGE_STAMPS
     const unsigned long long e_k1 = __builtin_readcyclecounter();
 #endif
 
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int row = lane & 31, h = lane >> 5;
     const int ngroups = LDSF ? g_hi : (npoints + 1) / 2;         // 2 points per wave
     const int s_nb = row & 15;
     // the rows of the NEXT point group are fetched while the MFMAs of the current one run (ra/rb double as prefetch regs)
@@ -134,11 +164,13 @@ __global__ __launch_bounds__(LDSF ? 512 : 256) void edge_dense_conv_mfma_kernel(
     };
     const int grp0 = gfirst + wave, gstride = gstep0;
     if (grp0 < ngroups) fetch(grp0);
-    constexpr int WD = 12, STOT = S0 + S1 + S2;     // ring depth must divide STOT (84, 132): the ring wraps into the next group
+    constexpr int SKIP = PRE ? H : 0;               // PRE: the first H steps of layer 0 were taken per point
+    constexpr int WD = 12, STOT = S0 + S1 + S2 - SKIP;   // ring depth must divide STOT (84, 132; 72, 108 with PRE): the ring wraps into the next group
     static_assert(STOT % WD == 0, "fragment ring depth must divide the step count");
+    const float* fragG = frag + SKIP * 64;
     float wq[WD];
 #pragma unroll
-    for (int i = 0; i < WD; ++i) wq[i] = frag[i * 64 + lane];
+    for (int i = 0; i < WD; ++i) wq[i] = fragG[i * 64 + lane];
 #ifdef EDGE_STAMPS
     unsigned long long e_conv = 0, e_l0 = 0, e_l1 = 0, e_l2 = 0, e_epi = 0, e_n = 0;
 #define ED_T(v) __builtin_amdgcn_sched_barrier(0); const unsigned long long v = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0)
@@ -165,20 +197,28 @@ __global__ __launch_bounds__(LDSF ? 512 : 256) void edge_dense_conv_mfma_kernel(
         f32x16 l0, l1, l2;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { l0[r] = 0.f; l1[r] = 0.f; l2[r] = 0.f; }
+        if constexpr (PRE) {                                     // the chain over F_p, evaluated once for this point
+            const float* pp = pre + (((grp - g_lo) * 2 + (row >> 4)) * 2 + h) * 12;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const float4 v = *reinterpret_cast<const float4*>(pp + q * 4);
+                l0[4 * q] = v.x; l0[4 * q + 1] = v.y; l0[4 * q + 2] = v.z; l0[4 * q + 3] = v.w;
+            }
+        }
         // The weight fragments of all three layers are one contiguous LDS array of STOT steps.  They do not depend on
         // the data, so they run through a register ring WD steps ahead of the MFMA that consumes them (wrapping into
         // the next point group): with one wave per SIMD nothing else would hide the ds_read latency.
         auto step = [&](int sg, float bv, f32x16& acc) {
             const float w = wq[sg % WD];
-            wq[sg % WD] = frag[((sg + WD) % STOT) * 64 + lane];
+            wq[sg % WD] = fragG[((sg + WD) % STOT) * 64 + lane];
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w, bv, acc, 0, 0, 0);
         };
         ED_T(t1);
         // layer 0: k over [F_p (C), F_j - F_p (C)]
 #pragma unroll
-        for (int s = 0; s < S0; ++s) {
+        for (int s = SKIP; s < S0; ++s) {
             const float bv = (s < H) ? fp[s < H ? s : 0] : df[s < H ? 0 : s - H];
-            step(s, bv, l0);
+            step(s - SKIP, bv, l0);
         }
 #pragma unroll
         for (int r = 0; r < 12; ++r) l0[r] = fmaxf(l0[r] + b0[2 * r + h], 0.f);
@@ -187,7 +227,7 @@ __global__ __launch_bounds__(LDSF ? 512 : 256) void edge_dense_conv_mfma_kernel(
 #pragma unroll
         for (int s = 0; s < S1; ++s) {
             const float bv = (s < 12) ? l0[s < 12 ? s : 0] : fp[s < 12 ? 0 : s - 12];
-            step(S0 + s, bv, l1);
+            step(S0 - SKIP + s, bv, l1);
         }
 #pragma unroll
         for (int r = 0; r < 12; ++r) l1[r] = fmaxf(l1[r] + b1[2 * r + h], 0.f);
@@ -196,7 +236,7 @@ __global__ __launch_bounds__(LDSF ? 512 : 256) void edge_dense_conv_mfma_kernel(
 #pragma unroll
         for (int s = 0; s < S2; ++s) {
             const float bv = (s < 12) ? l1[s < 12 ? s : 0] : ((s < 24) ? l0[(s >= 12 && s < 24) ? s - 12 : 0] : fp[s >= 24 ? s - 24 : 0]);
-            step(S0 + S1 + s, bv, l2);
+            step(S0 + S1 - SKIP + s, bv, l2);
         }
         ED_T(t4);
         // max over the 16 neighbours (one DPP row); lane 15 of each row parks [l2 | l1 | l0 | F_p] of its point in an LDS
@@ -289,19 +329,29 @@ DISPU_EXPORT int dispu_edge_dense_conv(int npoints, int n_per_cloud, int C, cons
         const int gpc = n_per_cloud / 2;
         if (parts > (gpc + 7) / 8) parts = (gpc + 7) / 8;                 // at least one group per wave
         if (parts < 1) parts = 1;
-        const size_t bytes = frag_bytes + feat_bytes;
+        const int per = (gpc + parts - 1) / parts;                        // point groups per workgroup
+        const size_t pre_bytes = (size_t)per * 2 * 24 * sizeof(float);    // layer-0 prefixes of the workgroup's points
+        static int prefix = -1;             // DISPU_EDGE_PREFIX=0: every pair tile runs layer 0's whole chain (rounds 1 - 3; A/B tests)
+        if (prefix < 0) { const char* e = getenv("DISPU_EDGE_PREFIX"); prefix = e ? atoi(e) : 1; }
+        const bool pre = prefix != 0 && frag_bytes + feat_bytes + pre_bytes <= 160 * 1024;
+        const size_t bytes = frag_bytes + feat_bytes + (pre ? pre_bytes : 0);
         static DevOnce attr;      
         if (attr.needed()) {
             DISPU_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(edge_dense_conv_mfma_kernel<24, true>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             DISPU_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(edge_dense_conv_mfma_kernel<48, true>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            DISPU_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(edge_dense_conv_mfma_kernel<24, true, true>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            DISPU_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(edge_dense_conv_mfma_kernel<48, true, true>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             attr.done();
         }
-        if (C == 24)
-            hipLaunchKernelGGL((edge_dense_conv_mfma_kernel<24, true>), dim3(clouds, parts), dim3(512), bytes, s, npoints, n_per_cloud, F, ldf, idx, ldi, ioff, W0, b0, W1, b1, W2, b2, Y, ldy);
-        else
-            hipLaunchKernelGGL((edge_dense_conv_mfma_kernel<48, true>), dim3(clouds, parts), dim3(512), bytes, s, npoints, n_per_cloud, F, ldf, idx, ldi, ioff, W0, b0, W1, b1, W2, b2, Y, ldy);
+#define EDGE_LAUNCH(C_, PRE_) hipLaunchKernelGGL((edge_dense_conv_mfma_kernel<C_, true, PRE_>), dim3(clouds, parts), dim3(512), bytes, s, npoints, \
+                                                 n_per_cloud, F, ldf, idx, ldi, ioff, W0, b0, W1, b1, W2, b2, Y, ldy)
+        if (C == 24) { if (pre) EDGE_LAUNCH(24, true); else EDGE_LAUNCH(24, false); }
+        else { if (pre) EDGE_LAUNCH(48, true); else EDGE_LAUNCH(48, false); }
+#undef EDGE_LAUNCH
         return (int)hipGetLastError();
     }
     int g = (npoints + 7) / 8;          // 8 points (4 waves x 2) per workgroup pass
