@@ -136,7 +136,10 @@ class Trainer(object):
         # main queue idle for that long (round 4, profiles/r04_a_train_timeline.txt: 145 us before the fused local cell, 137 us before
         # its backward).  Side work records its fork event where it belongs and is submitted later, at points where the main queue
         # holds enough work (Trainer._flush); 0 restores the in-place submission (A/B)
-        self.defer_side = os.environ.get("DISPU_TRAIN_DEFER", "1") != "0"
+        # (default "auto": on up to 16 patches per step -- at 32 the chip is saturated by the chain's own kernels, side work submitted
+        # later only lengthens the tail: 4.58 -> 4.63 ms; "1" / "0" force it)
+        self._defer_mode = os.environ.get("DISPU_TRAIN_DEFER", "auto")
+        self.defer_side = self._defer_mode != "0"
         self._deferred = []
         self._pending = set()               # branches whose submission is still in _deferred
         self._cap_events = []               # events created while a hipGraph is being captured (see _ev)
@@ -269,20 +272,25 @@ class Trainer(object):
         self._side_rr = (self._side_rr + 1) % len(self._sides)
         return self._side_rr
 
-    def _defer(self, fn):
-        """run the side-stream submission `fn` now, or at the next _flush() when deferral is on (only while side streams are in use)."""
+    def _defer(self, fn, prio=1):
+        """run the side-stream submission `fn` now, or at a later _flush() when deferral is on (only while side streams are in use).
+        prio 0: branches the chain will wait for (non-local / skip / recompute); 1: weight gradients, read by Adam only."""
         if self.defer_side and self.overlap_dw:
-            self._deferred.append(fn)
+            self._deferred.append((prio, fn))
         else:
             fn()
 
-    def _flush(self, n=None):
-        """submit the first n (default: all) deferred side launches."""
-        while self._deferred and (n is None or n > 0):
-            self._deferred.pop(0)()
-            if n is not None:
-                n -= 1
-        if not self._deferred:
+    def _flush(self, n=None, prio=1):
+        """submit the deferred side launches of priority <= prio, in their order: all of them, or the first n."""
+        i = 0
+        while i < len(self._deferred) and (n is None or n > 0):
+            if self._deferred[i][0] <= prio:
+                self._deferred.pop(i)[1]()                # (may append: a branch defers its own weight gradients)
+                if n is not None:
+                    n -= 1
+            else:
+                i += 1
+        if not any(p == 0 for p, _ in self._deferred):
             self._pending.clear()
 
     def _defer_branch(self, i, body, after=None):
@@ -298,7 +306,7 @@ class Trainer(object):
             with self._branch(i, ev):
                 body()
         self._pending.add(i)
-        self._deferred.append(run)
+        self._deferred.append((0, run))
 
     # ---- stream / event operations (recorded on the launch tape as raw HIP calls when one is being taken, see train_step_taped)
     def _rec(self, ev, stream):
@@ -428,7 +436,7 @@ class Trainer(object):
 
     def _merge(self, i):
         if i in self._pending:
-            self._flush()                                # a branch whose submission is still deferred cannot be waited for
+            self._flush(prio=0)                          # a branch whose submission is still deferred cannot be waited for
         if self.overlap_dw and (i < len(self._aux) or i in self._aux_done):
             aux, _, ev_done = self._aux[i]
             if not (self._sched & 1):
@@ -581,6 +589,8 @@ class Trainer(object):
         ws = self._workspace(B, N)
         L = _lib.tape_lib()
         self.st = _lib.stream_ptr(x.device)
+        if self._defer_mode == "auto":
+            self.defer_side = rm <= 16 * 1024
         self._shape = (B, N)
         self._x = x
         P = self.P
@@ -779,7 +789,8 @@ class Trainer(object):
         # side work is submitted behind the fine term's launches (the chain): the pair tensors of the local cell's backward (needed much
         # later) and the coarse term
         self._defer_branch(2, self._recompute_pair_tensors)    # off the chain: needed by the local cell's backward only
-        self._defer_branch(0, lambda: self._chamfer(ws["coarse"], gt, radius, 1000.0, ws["dcoarse"], 0))   # next to the fine / repulsion terms
+        with self._branch(0):                                   # the coarse term next to the fine term and the repulsion term
+            self._chamfer(ws["coarse"], gt, radius, 1000.0, ws["dcoarse"], 0)
         # fine term: nn_distance, then value + gradient (which zero-fills dfine); the repulsion term's ball query runs next to it and
         # adds its gradient once the Chamfer gradient is in place
         rep = None
@@ -798,7 +809,9 @@ class Trainer(object):
         out = ws["loss_vals"]
         _lib.check(L.dispu_pu_loss_finalize(_p(out), _p(rep) if rep is not None else None, B * M, wf, float(self.opts.repulsion_w),
                                             _p(out, 2), self.st), "pu_loss_finalize")
-        return self._terms(out, wf)
+        terms = self._terms(out, wf)
+        self._flush(prio=0)                                     # the recompute branch: submitted behind the loss's own launches
+        return terms
 
     @staticmethod
     def _terms(out, wf):
@@ -896,6 +909,9 @@ class Trainer(object):
                 _lib.check(L.dispu_ps_skip_max_grad(rm, M, k, 128, _p(ws["psidx"]), _p(coarse), _p(ws["up128"]), 128, _p(ws["gmax"]), 144,
                                                     _p(ws["dgmax"]), 136, _p(dcoarse), _p(ws["dup128s"]), 128, 1, self.st), "ps_skip_max_grad")
         self._defer_branch(1, skip_backward, ev_br)
+        # after_conv's dX (0.1 - 0.15 ms on the GPU) is queued: submit the two branches the chain will wait for behind it; the weight
+        # gradients stay deferred until the chain's next three kernels are queued too
+        self._flush(prio=0)
         if not (self._sched & 2):
             self._merge(2)                               # h0 / h1 / wv / the inverted graph are in place
         _lib.check(L.dispu_ps_point_matmul_grad_relu_s(rm, k, 128, 16, _p(ws["h1"]), 128, _p(ws["wv"]), _p(ws["dhp"]), 2048, _p(ws["dz1"]),
@@ -986,9 +1002,10 @@ class Trainer(object):
                                                                  _p(P[sc + "/l1/biases"]), _p(P[sc + "/l2/weights"]), _p(P[sc + "/l2/biases"]),
                                                                  _p(dfeat, col), 480, _p(dF, dfoff), dF.stride(0), _p(scr), scr.numel(), self.st),
                            "edge_dense_conv_grad_partials")
-                # the block's recomputing backward kernel (40 - 80 us) is queued: submit the side work deferred so far behind it (the
-                # coarse head's weight gradients before the first block, the previous block's reduction and prep gradient afterwards)
-                self._flush()
+                # the block's recomputing backward kernel (40 - 80 us) is queued: submit some of the side work deferred so far behind it
+                # (the coarse head's weight gradients, the previous blocks' reductions and prep gradients) -- a few launches per block,
+                # as many as the kernel's duration hides
+                self._flush(n=5)
                 def reduce_partials(sc=sc, scr=scr, C=C, ev=(self._fork_point() if self.overlap_dw else None)):
                     st_r = self._fork_after(ev)[0] if ev is not None else self.st
                     _lib.check(L.dispu_edge_dense_conv_grad_reduce(rn, C, _p(scr), scr.numel(), _p(G[sc + "/l0/weights"]), _p(G[sc + "/l0/biases"]),
