@@ -89,6 +89,9 @@ class Generator(object):
         # product (no dup_grid launch, no [B*4N, 256] tensor) and relu(after_conv) + skip + non-local in the fine chain's loader (the
         # residual reads leave the after_conv GEMM's epilogue).  0 = the producer kernels of rounds 1 - 3 (bit-identical results)
         self.chain_inputs = bool(int(__import__('os').environ.get('DISPU_CHAIN_INPUTS', '1')))
+        # one launch per dense block (neighbour search + edge features + dense_conv, csrc/edge.hip KNN variant) for clouds of <= 256
+        # points; 0 = the dispu_knn_feat_strided -> dispu_edge_dense_conv pair (A/B tests; larger clouds always take the pair)
+        self.fused_stem = bool(int(os.environ.get('DISPU_STEM_FUSED', '1')))
         # forward() computes into a reusable per-(B, N) workspace.  By default the two results are returned as fresh
         # tensors (like sess.run in the reference); return_views = True hands out the workspace buffers themselves
         # (no copies -- bench.py / hipGraph capture), which the NEXT call with the same (B, N) overwrites.
@@ -152,7 +155,7 @@ class Generator(object):
             return torch.empty(shape, dtype=dtype, device=dev)
 
         ws = dict(
-            feat=E(rn, 480), prep=E(rn, 48), kidx=E(rn, k + 1, dtype=i32), h256=E(rn, 256),
+            feat=E(rn, 480), prep=E(rn, 48), prep_b=E(rn, 48), kidx=E(rn, k + 1, dtype=i32), h256=E(rn, 256),
             up256=E(rm, 256), up128=E(rm, 128), c256=E(rm, 256), c64=E(rm, 64), coarse=E(B, M, 3),
             psidx=E(rm, k, dtype=i32), up3=E(rm, 320), att=E(rm, 64), nl=E(rm, 256),
             skipin=torch.zeros((rm, 144), dtype=f32, device=dev), skip=E(rm, 256), am=E(rm, 128),
@@ -253,23 +256,38 @@ class Generator(object):
         w, b = self._w(fe + "layer0")
         self._call("layer0", L.dispu_linear_small_k, rn, 3, 24, ptr(inputs), 3, ptr(w), ptr(b), 0, off(feat, 456), 480, st)
         col = 456          # left edge of the features produced so far
+        stem = self.fused_stem and N <= 256 and N % 2 == 0 and N > k
+        prep_done = False  # the previous block's launch already ran this block's bottleneck conv (fused stem)
         for d in range(1, DENSE_BLOCKS + 1):
+            pbuf = ws["prep"] if d % 2 == 0 else ws["prep_b"]        # block d reads pbuf while its launch writes the other one
             if d == 1:
                 F, ldf, foff, C = feat, 480, 456, 24
             else:
-                w, b = self._w(fe + "layer%d_prep" % d)
-                self._linear(st, feat, 480 - col, w, b, 1, ws["prep"], 48, xoff=col)
-                F, ldf, foff, C = ws["prep"], 48, 0, 48
-            nbf = L.dispu_knn_feat_scratch_bytes(B, N, N, C, k + 1)   # > 0 for 512 < N <= 4096 (second pass of 16x): chunked search
-            if nbf and (ws.get("knnf_scratch") is None or ws["knnf_scratch"].numel() < nbf):
-                ws["knnf_scratch"] = torch.empty((nbf,), dtype=torch.uint8, device=self.device)
-            self._call("knn_feat", L.dispu_knn_feat_strided_ws, B, N, N, C, k + 1, off(F, foff), ldf, off(F, foff), ldf, None, ptr(ws["kidx"]),
-                       ptr(ws["knnf_scratch"]) if nbf else None, nbf, st)
+                if not prep_done:
+                    w, b = self._w(fe + "layer%d_prep" % d)
+                    self._linear(st, feat, 480 - col, w, b, 1, pbuf, 48, xoff=col)
+                F, ldf, foff, C = pbuf, 48, 0, 48
             w0, b0 = self._w(fe + "layer%d/l0" % d)
             w1, b1 = self._w(fe + "layer%d/l1" % d)
             w2, b2 = self._w(fe + "layer%d/l2" % d)
             width = 3 * GROWTH + C
             col -= width
+            if stem:
+                # + the next block's bottleneck conv over [this block's outputs | the 480 - (col + width) older columns] for d < 4
+                nxt = ws["prep_b"] if d % 2 == 0 else ws["prep"]
+                wp, bp = self._w(fe + "layer%d_prep" % (d + 1)) if d < DENSE_BLOCKS else (None, None)
+                self._call("stem_block", L.dispu_stem_block, rn, N, C, off(F, foff), ldf, k + 1, 1, ptr(w0), ptr(b0), ptr(w1), ptr(b1), ptr(w2),
+                           ptr(b2), off(feat, col), 480, ptr(ws["kidx"]) if self.keep_intermediates else None,
+                           ptr(wp) if d < DENSE_BLOCKS else None, ptr(bp) if d < DENSE_BLOCKS else None, 480 - col - width,
+                           ptr(nxt) if d < DENSE_BLOCKS else None, 48, st)
+                prep_done = d < DENSE_BLOCKS
+                continue
+            prep_done = False
+            nbf = L.dispu_knn_feat_scratch_bytes(B, N, N, C, k + 1)   # > 0 for 512 < N <= 4096 (second pass of 16x): chunked search
+            if nbf and (ws.get("knnf_scratch") is None or ws["knnf_scratch"].numel() < nbf):
+                ws["knnf_scratch"] = torch.empty((nbf,), dtype=torch.uint8, device=self.device)
+            self._call("knn_feat", L.dispu_knn_feat_strided_ws, B, N, N, C, k + 1, off(F, foff), ldf, off(F, foff), ldf, None, ptr(ws["kidx"]),
+                       ptr(ws["knnf_scratch"]) if nbf else None, nbf, st)
             self._call("edge_dense_conv", L.dispu_edge_dense_conv, rn, N, C, off(F, foff), ldf, ptr(ws["kidx"]), k + 1, 1, ptr(w0), ptr(b0), ptr(w1),
                                         ptr(b1), ptr(w2), ptr(b2), off(feat, col), 480, st)
         assert col == 0

@@ -138,6 +138,7 @@ class Trainer(object):
         # holds enough work (Trainer._flush); 0 restores the in-place submission (A/B)
         # (default "auto": on up to 16 patches per step -- at 32 the chip is saturated by the chain's own kernels, side work submitted
         # later only lengthens the tail: 4.58 -> 4.63 ms; "1" / "0" force it)
+        self.fused_stem = os.environ.get("DISPU_STEM_FUSED", "1") != "0"     # one launch per dense block in the forward pass
         self._defer_mode = os.environ.get("DISPU_TRAIN_DEFER", "auto")
         self.defer_side = self._defer_mode != "0"
         self._deferred = []
@@ -600,20 +601,32 @@ class Trainer(object):
                                           _p(feat, 456), 480, self.st), "layer0")
         col = 456
         self._blocks = []
+        prep_done = False                      # the previous block's launch already ran this block's bottleneck conv (fused stem)
         for d in range(1, DENSE_BLOCKS + 1):
             if d == 1:
                 F, foff, C = feat, 456, 24
             else:
-                self._lin(feat, col, 480 - col, fe + "layer%d_prep" % d, 1, ws["prep"][d], 0, 48)
+                if not prep_done:
+                    self._lin(feat, col, 480 - col, fe + "layer%d_prep" % d, 1, ws["prep"][d], 0, 48)
                 F, foff, C = ws["prep"][d], 0, 48
             ldf = F.stride(0)
             kidx = ws["kidx"][d]
-            _lib.check(L.dispu_knn_feat_strided(B, N, N, C, k + 1, _p(F, foff), ldf, _p(F, foff), ldf, None, _p(kidx), self.st), "knn_feat")
             sc = fe + "layer%d" % d
             width = 3 * GROWTH + C
             in_col = col
             col -= width
-            if self.fused_dense:
+            stem = self.fused_dense and self.fused_stem and N <= 256 and N % 2 == 0
+            if not stem:
+                _lib.check(L.dispu_knn_feat_strided(B, N, N, C, k + 1, _p(F, foff), ldf, _p(F, foff), ldf, None, _p(kidx), self.st), "knn_feat")
+            if stem:
+                # search + edge features + dense_conv in one launch (csrc/edge.hip, KNN variant); the neighbour table stays for the backward pass
+                _lib.check(L.dispu_stem_block(rn, N, C, _p(F, foff), ldf, k + 1, 1, _p(P[sc + "/l0/weights"]), _p(P[sc + "/l0/biases"]),
+                                              _p(P[sc + "/l1/weights"]), _p(P[sc + "/l1/biases"]), _p(P[sc + "/l2/weights"]),
+                                              _p(P[sc + "/l2/biases"]), _p(feat, col), 480, _p(kidx),
+                                              _p(P[fe + "layer%d_prep/weights" % (d + 1)]) if d < DENSE_BLOCKS else None,
+                                              _p(P[fe + "layer%d_prep/biases" % (d + 1)]) if d < DENSE_BLOCKS else None, 480 - in_col,
+                                              _p(ws["prep"][d + 1]) if d < DENSE_BLOCKS else None, 48, self.st), "stem_block")
+            elif self.fused_dense:
                 # the inference kernel (csrc/edge.hip): edge features, three chained convs and the max in one launch; nothing is kept
                 # for the backward pass, which recomputes the block on chip (csrc/edge_bwd.hip)
                 _lib.check(L.dispu_edge_dense_conv(rn, N, C, _p(F, foff), ldf, _p(kidx), k + 1, 1, _p(P[sc + "/l0/weights"]),
@@ -627,6 +640,7 @@ class Trainer(object):
                 self._lin(Eb, 48, 24 + C, sc + "/l1", 1, Eb, 24, 24)
                 self._lin(Eb, 24, 48 + C, sc + "/l2", 0, Eb, 0, 24)
                 _lib.check(L.dispu_max_k(rn, k, width, _p(Eb), Eb.stride(0), _p(feat, col), 480, self.st), "max_k")
+            prep_done = stem and d < DENSE_BLOCKS
             self._blocks.append((d, C, col, in_col, width))
         assert col == 0
 

@@ -225,6 +225,16 @@ int dispu_linear_small_n(long rows, int K, int N, const float* X, long ldx, cons
 int dispu_edge_dense_conv(int npoints, int n_per_cloud, int C, const float* F, long ldf, const int* idx, int ldi, int ioff,
                           const float* W0, const float* b0, const float* W1, const float* b1, const float* W2,
                           const float* b2, float* Y, long ldy, void* stream);
+/* One dense block of feature_extraction_GCN (ops.py:1437-1486) in one launch: knn_point_2(ksel, F, F) (tf_util.py:618-651; the
+ * dispu_knn_feat_strided search) -> get_edge_feature over neighbours ioff .. ioff + 15 (ops.py:1856-1877) -> dense_conv (:1897-1915).
+ * Bit-identical to dispu_knn_feat_strided followed by dispu_edge_dense_conv.  Clouds of up to 256 points (n_per_cloud even,
+ * >= ksel = ioff + 16 <= 20; npoints a multiple of n_per_cloud); idx_out (nullable): the [npoints, ksel] neighbour table.
+ * Wp (nullable) [72 + C + k_old, 48], bp [48]: the NEXT block's bottleneck conv (feature_extraction layer<d+1>_prep, ops.py:1455-1462)
+ * in the same launch: P[p, 0:48] = relu([Y[p, 0:72+C] | Y[p, 72+C : 72+C+k_old]] . Wp + bp) -- Y's row continues to the right with the
+ * k_old (a multiple of 24) older feature columns; bit-identical to dispu_linear on those rows. */
+int dispu_stem_block(int npoints, int n_per_cloud, int C, const float* F, long ldf, int ksel, int ioff, const float* W0, const float* b0,
+                     const float* W1, const float* b1, const float* W2, const float* b2, float* Y, long ldy, int* idx_out, const float* Wp,
+                     const float* bp, int k_old, float* P, long ldp, void* stream);
 /* Same contract as dispu_edge_dense_conv, VALU formulation (one lane per pair, weights through scalar loads).
  * Bit-identical results; kept as the A/B twin of the MFMA kernel for tests and profiling. */
 int dispu_edge_dense_conv_valu(int npoints, int n_per_cloud, int C, const float* F, long ldf, const int* idx, int ldi,

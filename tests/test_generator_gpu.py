@@ -275,6 +275,88 @@ def test_edge_dense_conv_mfma_equals_valu_and_oracle(dev, C, npts):
     assert (outs[0][:, 72 + C:] == 0).all()
 
 
+@pytest.mark.parametrize("C,nb,n_cloud,kind", [(24, 32, 256, "normal"), (48, 32, 256, "normal"), (48, 1, 256, "normal"), (48, 5, 256, "normal"),
+                                                (48, 8, 256, "normal"), (24, 3, 128, "normal"), (48, 70, 256, "normal"), (48, 2, 64, "normal"),
+                                                (48, 3, 34, "normal"), (48, 2, 256, "dups"), (24, 2, 256, "grid"), (48, 2, 250, "normal")])
+def test_stem_block_equals_search_then_edge_conv(dev, C, nb, n_cloud, kind):
+    """dispu_stem_block (neighbour search + edge features + dense_conv in one launch) vs dispu_knn_feat_strided followed by
+    dispu_edge_dense_conv: neighbour table and output bit-identical; vs the oracle on the small cases.  'dups': clouds made of 8
+    distinct rows (every distance a 32-way tie: the sort-everything path), 'grid': features on a coarse lattice (many exact ties)."""
+    from dispu_amd import _lib
+    from oracle import oracle as O
+    L = _lib.lib()
+    rng = np.random.default_rng(C + nb + n_cloud)
+    F = rng.standard_normal((nb, n_cloud, C)).astype(np.float32)
+    if kind == "dups":
+        F = F[:, rng.integers(0, 8, n_cloud)]
+    elif kind == "grid":
+        F = np.round(F * 2) / 2
+    npts = nb * n_cloud
+    ld = C + 8                                              # strided input rows
+    Fp = np.zeros((npts, ld), np.float32)
+    Fp[:, :C] = F.reshape(npts, C)
+    P = {k: (rng.standard_normal(s) * 0.2).astype(np.float32) for k, s in
+         dict(W0=(2 * C, 24), b0=(24,), W1=(24 + C, 24), b1=(24,), W2=(48 + C, 24), b2=(24,)).items()}
+    t = {k: torch.from_numpy(v).to(dev) for k, v in P.items()}
+    tF = torch.from_numpy(Fp).to(dev)
+    st = _lib.stream_ptr(dev)
+    w = [t[k].data_ptr() for k in ("W0", "b0", "W1", "b1", "W2", "b2")]
+    idx_a = torch.full((npts, 17), -1, dtype=torch.int32, device=dev)
+    y_a = torch.zeros((npts, 72 + C + 3), device=dev)
+    _lib.check(L.dispu_knn_feat_strided(nb, n_cloud, n_cloud, C, 17, tF.data_ptr(), ld, tF.data_ptr(), ld, None, idx_a.data_ptr(), st), "knn")
+    _lib.check(L.dispu_edge_dense_conv(npts, n_cloud, C, tF.data_ptr(), ld, idx_a.data_ptr(), 17, 1, *w, y_a.data_ptr(), 72 + C + 3, st), "edge")
+    for with_idx in (True, False):
+        idx_b = torch.full((npts, 17), -1, dtype=torch.int32, device=dev)
+        y_b = torch.zeros((npts, 72 + C + 3), device=dev)
+        # with_idx also exercises the bottleneck-conv epilogue: y rows continue with k_old older columns
+        k_old = 24 * (1 + (nb % 3)) if with_idx else 0
+        ldy = 72 + C + k_old + (4 if with_idx else 3)
+        y_b = torch.zeros((npts, ldy), device=dev)
+        y_b[:, 72 + C:] = torch.from_numpy(rng.standard_normal((npts, ldy - 72 - C)).astype(np.float32)).to(dev)
+        tail = N(y_b)[:, 72 + C:].copy()
+        Wp = torch.from_numpy((rng.standard_normal((72 + C + k_old, 48)) * 0.1).astype(np.float32)).to(dev)
+        bp = torch.from_numpy((rng.standard_normal((48,)) * 0.1).astype(np.float32)).to(dev)
+        pr = torch.full((npts, 50), -7.0, device=dev)
+        _lib.check(L.dispu_stem_block(npts, n_cloud, C, tF.data_ptr(), ld, 17, 1, *w, y_b.data_ptr(), ldy,
+                                      idx_b.data_ptr() if with_idx else None, Wp.data_ptr() if with_idx else None,
+                                      bp.data_ptr() if with_idx else None, k_old, pr.data_ptr() if with_idx else None, 50, st), "stem")
+        assert np.array_equal(N(y_a)[:, :72 + C], N(y_b)[:, :72 + C])
+        assert np.array_equal(N(y_b)[:, 72 + C:], tail)
+        if with_idx:
+            want = torch.zeros((npts, 48), device=dev)
+            _lib.check(L.dispu_linear(1, npts, 72 + C + k_old, 48, y_b.data_ptr(), ldy, 0, Wp.data_ptr(), 48, 0, 0, bp.data_ptr(), 1,
+                                      want.data_ptr(), 48, 0, None, 0, 0, None, 0, 0, st), "linear")
+            assert np.array_equal(N(pr)[:, :48], N(want))
+            assert (N(pr)[:, 48:] == -7.0).all()
+        else:
+            assert (N(pr) == -7.0).all()
+        if with_idx:
+            assert np.array_equal(N(idx_a), N(idx_b))
+        else:
+            assert (N(idx_b) == -1).all()
+    if npts <= 2048:
+        _, idx2 = O.knn_point_2(17, F, F)
+        assert np.array_equal(idx2[..., 1].reshape(npts, 17), N(idx_a))
+
+
+def test_stem_block_refuses_what_it_does_not_cover(dev):
+    from dispu_amd import _lib
+    L = _lib.lib()
+    x = torch.zeros((1024, 48), device=dev)
+    w = torch.zeros((4096,), device=dev)
+    y = torch.zeros((1024, 144), device=dev)
+    st = _lib.stream_ptr(dev)
+    a = lambda npts, n, C, ksel, ioff, k_old=0, wp=None: L.dispu_stem_block(npts, n, C, x.data_ptr(), 48, ksel, ioff, *([w.data_ptr()] * 6), y.data_ptr(),
+                                                                            120 + 24, None, wp, wp, k_old, wp, 48, st)
+    assert a(1024, 512, 48, 17, 1) != 0            # clouds of more than 256 points
+    assert a(1024, 256, 32, 17, 1) != 0            # C outside {24, 48}
+    assert a(1000, 256, 48, 17, 1) != 0            # ragged clouds
+    assert a(1024, 256, 48, 18, 1) != 0            # ksel != ioff + 16
+    assert a(1024, 16, 48, 17, 1) != 0             # fewer points than neighbours
+    assert a(1024, 256, 48, 17, 1, 20, w.data_ptr()) != 0   # older columns not a multiple of 24
+    assert a(1024, 256, 48, 17, 1) == 0
+
+
 def test_fused_head_chains_equal_separate_launches(dev):
     """dispu_mlp_chain (one launch per head, activations in LDS) vs the dispu_linear / dispu_linear_small_n launches:
     bit-identical coarse, fine, up128 and aggregation output."""
