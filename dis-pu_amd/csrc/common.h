@@ -50,6 +50,41 @@ __device__ __forceinline__ float sqdist3(float dx, float dy, float dz) {
     }
 }
 
+// Two distances per instruction on the packed fp32 ops (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32); element-wise the arithmetic is
+// sqdist3's, operation for operation.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <bool FMA>
+__device__ __forceinline__ f32x2 sqdist3_x2(f32x2 dx, f32x2 dy, f32x2 dz) {
+    if constexpr (FMA) {
+        return __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dx, dx, dy * dy));
+    } else {
+        const f32x2 s = dx * dx + dy * dy;
+        return s + dz * dz;
+    }
+}
+
+// A cloud [n][3] into LDS once per workgroup of NT threads (coalesced float4, UB per thread in flight), for the wave-per-query kernels
+// whose lanes keep R candidates each in registers: per-lane global loads (3 R strided dwords per lane, the same 12 KB in every wave of
+// the launch) cost a quarter of such a kernel (knn_xyz_wave_kernel: 8.8 k of 40 k cycles per wave).  Caller: __syncthreads() after.
+template <int NT, int UB>
+__device__ __forceinline__ void stage_cloud_xyz(float* sl, const float* __restrict__ s, int n) {
+    const int nf = 3 * n;
+    if ((((uintptr_t)s) & 15) == 0) {
+        const int nf4 = nf >> 2;
+        for (int e0 = threadIdx.x; e0 < nf4; e0 += UB * NT) {
+            float4 v[UB];
+#pragma unroll
+            for (int u = 0; u < UB; ++u) v[u] = *reinterpret_cast<const float4*>(s + (size_t)min(e0 + u * NT, nf4 - 1) * 4);
+#pragma unroll
+            for (int u = 0; u < UB; ++u)
+                if (e0 + u * NT < nf4) *reinterpret_cast<float4*>(sl + (e0 + u * NT) * 4) = v[u];
+        }
+        for (int e = (nf4 << 2) + threadIdx.x; e < nf; e += NT) sl[e] = s[e];
+    } else {
+        for (int e = threadIdx.x; e < nf; e += NT) sl[e] = s[e];
+    }
+}
+
 // ---- DPP wave64 reductions (result valid in lane 63; use readlane to broadcast) ---------------
 // row_shr:1,2,4,8 leave each 16-lane row's reduction in its lane 15; row_bcast:15 / :31 fold the
 // four rows into lane 63.  `old` (identity) fills lanes that have no DPP source.

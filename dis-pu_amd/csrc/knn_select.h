@@ -128,16 +128,24 @@ __device__ __forceinline__ uint32_t wave_bitonic_sort_u32(uint32_t v, int lane) 
 // pointer; CAP + 4 slots when GUARD, else room for every candidate + 4).  Writes the k results (ascending distance,
 // ties -> lower index) as idx_out[t] / word_out[t] and returns true; returns false - nothing written - when fewer than
 // k or more than 128 candidates pass the threshold (the caller then sorts everything).
+#ifdef KNN_STAMPS
+#define PF_STAMP(i) { __builtin_amdgcn_sched_barrier(0); if (pf_stamps) pf_stamps[i] = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); }
+#else
+#define PF_STAMP(i)
+#endif
 template <int R, bool GUARD, typename WORD2F>
 __device__ __forceinline__ bool prefilter_rank(const uint32_t (&od)[R], const int (&cp)[R], uint64_t* buf, int lane, int k, uint32_t tmax,
-                                               int* __restrict__ idx_out, float* __restrict__ dist_out, WORD2F word_to_float) {
+                                               int* __restrict__ idx_out, float* __restrict__ dist_out, WORD2F word_to_float,
+                                               unsigned long long* pf_stamps = nullptr) {
     constexpr int CAP = 128;
+    PF_STAMP(0);
     uint32_t dmin = od[0];
 #pragma unroll
     for (int r = 1; r < R; ++r) dmin = min(dmin, od[r]);
     // k-th smallest of the 64 lane minima: k distinct candidates are <= T, and on average only ~1.2 k candidates are
     uint32_t T = (uint32_t)__builtin_amdgcn_readlane((int)wave_bitonic_sort_u32(dmin, lane), k - 1);
     T = min(T, tmax);
+    PF_STAMP(1);
     int cnt = 0;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
@@ -147,6 +155,7 @@ __device__ __forceinline__ bool prefilter_rank(const uint32_t (&od)[R], const in
         if (flag && (!GUARD || cnt + pos < CAP)) (buf + cnt)[pos] = ((uint64_t)od[r] << 32) | (uint32_t)cp[r];
         cnt += __popcll(mk);
     }
+    PF_STAMP(2);
     if (cnt < k || cnt > CAP) return false;                             // wave-uniform
     // rank of every survivor among the survivors (keys are distinct): broadcast reads of the compacted list, one
     // compare + one add-with-carry per pair; the survivor of rank t < k IS result t
@@ -179,6 +188,7 @@ __device__ __forceinline__ bool prefilter_rank(const uint32_t (&od)[R], const in
             if (dist_out) dist_out[r1] = word_to_float((uint32_t)(m1 >> 32));
         }
     }
+    PF_STAMP(3);
     return true;
 }
 

@@ -14,14 +14,19 @@
 #include "common.h"
 #include "knn_select.h"
 
+#include <cstdlib>
+
 namespace dispu {
 
 
-template <int R, bool FMA>
+template <int R, bool FMA, bool PK = false>
 __global__ __launch_bounds__(256, 4) void knn_xyz_wave_kernel(int n, int m, int k, int qpb, const float* __restrict__ support,
                                                             long sstride, const float* __restrict__ query, int* __restrict__ idx,
                                                             float* __restrict__ dist) {
     __shared__ uint64_t sorted[4][R * 64 + 4];
+#ifdef KNN_STAMPS
+    const unsigned long long x_k0 = __builtin_readcyclecounter();
+#endif
     const int cloud = blockIdx.y, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const float* __restrict__ s = support + (size_t)cloud * sstride;      // sstride = 3 n, or 3 n_total when `support` is a chunk of a larger cloud
     const float* __restrict__ q = query + (size_t)cloud * m * 3;
@@ -32,19 +37,30 @@ __global__ __launch_bounds__(256, 4) void knn_xyz_wave_kernel(int n, int m, int 
     constexpr int ROT = (R >= 8) ? 17 : 0;
     float cx[R], cy[R], cz[R];
     int cp[R];
+    // The cloud goes through LDS once per workgroup (coalesced float4, over the selection scratch, which is not in use yet) and every
+    // wave takes its candidates from there.  Per-lane global loads (48 strided dwords per lane at R = 16, the same 12 KB in every one
+    // of the 4096 waves: 50 MB through L2 for a 0.4 MB input) were 8.8 k of a wave's 40 k cycles.
+    {
+        float* sl = reinterpret_cast<float*>(&sorted[0][0]);
+        stage_cloud_xyz<256, (R >= 16) ? 3 : 1>(sl, s, n);
+        __syncthreads();
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const int p = 64 * r + ((lane + ROT * r) & 63);
-        const bool ok = p < n;
-        cp[r] = p;
-        cx[r] = ok ? s[p * 3 + 0] : __builtin_inff();
-        cy[r] = ok ? s[p * 3 + 1] : __builtin_inff();
-        cz[r] = ok ? s[p * 3 + 2] : __builtin_inff();
+        for (int r = 0; r < R; ++r) {
+            const int p = 64 * r + ((lane + ROT * r) & 63);
+            const bool ok = p < n;
+            const int pc = ok ? p : 0;
+            cp[r] = p;
+            cx[r] = ok ? sl[pc * 3 + 0] : __builtin_inff();
+            cy[r] = ok ? sl[pc * 3 + 1] : __builtin_inff();
+            cz[r] = ok ? sl[pc * 3 + 2] : __builtin_inff();
+        }
+        __syncthreads();                                             // the scratch is free for the selections from here on
     }
     const int q0 = blockIdx.x * qpb, q1 = min(m, q0 + qpb);
 #ifdef KNN_STAMPS
 #define KX_T(v) __builtin_amdgcn_sched_barrier(0); const unsigned long long v = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0)
-    unsigned long long x_d = 0, x_t = 0, x_c = 0, x_s = 0, x_n = 0, x_f = 0;
+    unsigned long long x_d = 0, x_t = 0, x_c = 0, x_s = 0, x_n = 0, x_f = 0, x_r = 0;
+    __builtin_amdgcn_sched_barrier(0); const unsigned long long x_k1 = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0);
 #else
 #define KX_T(v)
 #endif
@@ -54,17 +70,37 @@ __global__ __launch_bounds__(256, 4) void knn_xyz_wave_kernel(int n, int m, int 
         const float qx = q[qi * 3 + 0], qy = q[qi * 3 + 1], qz = q[qi * 3 + 2];
         // distance words: the raw bits of the (non-negative) squared distance order like the floats themselves
         uint32_t od[R];
+        if constexpr (PK && R >= 2) {                            // candidate pairs on the packed fp32 ops: 64 instead of 128 instructions at R = 16
+            const f32x2 qx2 = {qx, qx}, qy2 = {qy, qy}, qz2 = {qz, qz};
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const float d = sqdist3<FMA>(qx - cx[r], qy - cy[r], qz - cz[r]);
-            od[r] = (R >= 8 || cp[r] < n) ? __float_as_uint(d) : 0xFFFFFFFFu;
+            for (int r = 0; r < R; r += 2) {
+                const f32x2 cxp = {cx[r], cx[r + 1]}, cyp = {cy[r], cy[r + 1]}, czp = {cz[r], cz[r + 1]};
+                const f32x2 d = sqdist3_x2<FMA>(qx2 - cxp, qy2 - cyp, qz2 - czp);
+                od[r] = (R >= 8 || cp[r] < n) ? __float_as_uint(d.x) : 0xFFFFFFFFu;
+                od[r + 1] = (R >= 8 || cp[r + 1] < n) ? __float_as_uint(d.y) : 0xFFFFFFFFu;
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const float d = sqdist3<FMA>(qx - cx[r], qy - cy[r], qz - cz[r]);
+                od[r] = (R >= 8 || cp[r] < n) ? __float_as_uint(d) : 0xFFFFFFFFu;
+            }
         }
         KX_T(u1);
         bool done = false;
         const size_t o = ((size_t)cloud * m + qi) * k;
+#ifdef KNN_STAMPS
+        unsigned long long pf[4] = {0, 0, 0, 0};
+        if constexpr (R >= 8) {
+            done = prefilter_rank<R, false>(od, cp, sorted[wave], lane, k, 0x7F7FFFFFu, idx + o, dist ? dist + o : nullptr,
+                                            [](uint32_t w) { return __uint_as_float(w); }, pf);
+            x_t += pf[1] - pf[0]; x_c += pf[2] - pf[1]; x_r += pf[3] - pf[2];
+        }
+#else
         if constexpr (R >= 8)      // tmax = largest finite float: never admits the padding (+inf / NaN)
             done = prefilter_rank<R, false>(od, cp, sorted[wave], lane, k, 0x7F7FFFFFu, idx + o, dist ? dist + o : nullptr,
                                             [](uint32_t w) { return __uint_as_float(w); });
+#endif
         if (!done) {
 #ifdef KNN_STAMPS
             ++x_f;
@@ -85,8 +121,9 @@ __global__ __launch_bounds__(256, 4) void knn_xyz_wave_kernel(int n, int m, int 
     }
 #ifdef KNN_STAMPS
     if (blockIdx.x == 3 && blockIdx.y == 1 && lane == 0) {
-        unsigned long long* st = reinterpret_cast<unsigned long long*>(idx + (size_t)gridDim.y * m * k) + wave * 5;
-        st[0] = x_d; st[1] = x_t; st[2] = x_c; st[3] = x_s; st[4] = x_n | (x_f << 32);
+        unsigned long long* st = reinterpret_cast<unsigned long long*>(idx + (size_t)gridDim.y * m * k) + wave * 8;
+        st[0] = x_d; st[1] = x_t; st[2] = x_c; st[3] = x_s; st[4] = x_n | (x_f << 32); st[5] = x_r; st[6] = x_k1 - x_k0;
+        st[7] = __builtin_readcyclecounter() - x_k0;
     }
 #endif
 }
@@ -362,7 +399,12 @@ static int launch_xyz_wave(int b, int n, int m, int k, const float* s, const flo
     if (arith & DISPU_ARITH_CONTRACT)
         hipLaunchKernelGGL((knn_xyz_wave_kernel<R, true>), grid, dim3(256), 0, st, n, m, k, qpb, s, sstride, q, idx, dist);
     else
-        hipLaunchKernelGGL((knn_xyz_wave_kernel<R, false>), grid, dim3(256), 0, st, n, m, k, qpb, s, sstride, q, idx, dist);
+    {
+        static int pk = -1;                 // DISPU_KNN_PK=1: distances on the packed fp32 ops (A/B switch)
+        if (pk < 0) { const char* e = getenv("DISPU_KNN_PK"); pk = e ? atoi(e) : 0; }
+        if (pk) hipLaunchKernelGGL((knn_xyz_wave_kernel<R, false, true>), grid, dim3(256), 0, st, n, m, k, qpb, s, sstride, q, idx, dist);
+        else hipLaunchKernelGGL((knn_xyz_wave_kernel<R, false>), grid, dim3(256), 0, st, n, m, k, qpb, s, sstride, q, idx, dist);
+    }
     return (int)hipGetLastError();
 }
 

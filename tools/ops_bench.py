@@ -95,54 +95,57 @@ def gpu_ops(dev=None, quick=False):
     g = torch.Generator(device=dev).manual_seed(1234)
     rand = lambda *s: torch.rand(*s, device=dev, generator=g)
     out = []
-    for (b, n, m) in [(256, 256, 64), (32, 1024, 384), (8, 2048, 24), (1, 24576, 8192), (8, 24576, 8192)]:
+    only = [t for t in os.environ.get("OPS_ONLY", "").split(",") if t]      # e.g. OPS_ONLY=knn,three_nn,nn_distance: those row families only
+    want = lambda name: not only or any(name.startswith(t) for t in only)
+    for (b, n, m) in [(256, 256, 64), (32, 1024, 384), (8, 2048, 24), (1, 24576, 8192), (8, 24576, 8192)] if want("farthest") else []:
         x = rand(b, n, 3)
         t = _timeit(lambda: S.farthest_point_sample(m, x), reps=3 if n > 8192 else 20, warm=1)
         out.append(_row("farthest_point_sample", (b, n, m), t, b * (12 * n + 4 * m), "valu", 10.0 * b * n * (m - 1),
                         "%.0f ns per dependent round" % (t / max(m - 1, 1) * 1e9)))
-    for (b, n, k) in [(32, 1024, 16), (256, 1024, 16), (32, 4096, 16)]:
+    for (b, n, k) in [(32, 1024, 16), (256, 1024, 16), (32, 4096, 16)] if want("knn_xyz") else []:
         x = rand(b, n, 3)
         t = _timeit(lambda: K.knn_query(k, x, x))
         out.append(_row("knn_xyz (self query)", (b, n, k), t, b * (12 * n + 4 * n * k), "valu", 8.0 * b * n * n,
                         "%.1f M queries/s" % (b * n / t / 1e6)))
-    for c in (24, 48):
+    for c in (24, 48) if want("knn_point_2") else []:
         f = torch.randn(32, 256, c, device=dev, generator=g)
         t = _timeit(lambda: G.knn_point_2(17, f, f))
         out.append(_row("knn_point_2 (feature kNN)", (32, 256, c, 17), t, 32 * (4 * 256 * c + 4 * 256 * 17), "valu",
                         2.0 * 32 * 256 * 256 * c, "dot products on MFMA, selection on VALU"))
-    for (b, n, ns, r) in [(32, 1024, 20, 0.07), (8, 4096, 20, 0.07)]:
+    for (b, n, ns, r) in [(32, 1024, 20, 0.07), (8, 4096, 20, 0.07)] if want("query_ball") else []:
         x = rand(b, n, 3)
         t = _timeit(lambda: G.query_ball_point(r, ns, x, x))
         out.append(_row("query_ball_point", (b, n, n, ns), t, b * (24 * n + 4 * n * ns + 4 * n), "valu", 9.0 * b * n * n,
                         "upper bound on the scanned prefix (n-bar = n)"))
-    for (b, n, m, ns, c) in [(32, 512, 128, 64, 64), (32, 1024, 1024, 16, 128), (64, 1024, 1024, 20, 3), (32, 1024, 384, 64, 256)]:
+    for (b, n, m, ns, c) in [(32, 512, 128, 64, 64), (32, 1024, 1024, 16, 128), (64, 1024, 1024, 20, 3), (32, 1024, 384, 64, 256)] if want("group_point") else []:
         p = torch.randn(b, n, c, device=dev, generator=g)
         idx = torch.randint(0, n, (b, m, ns), dtype=torch.int32, device=dev, generator=g)
         t = _timeit(lambda: G.group_point(p, idx))
         nb = 4 * b * (n * c + m * ns + m * ns * c)
         out.append(_row("group_point", (b, n, m, ns, c), t, nb, "hbm", nb))
-    x = rand(32, 16384, 3)
-    idx = torch.randint(0, 16384, (32, 8192), dtype=torch.int32, device=dev, generator=g)
-    t = _timeit(lambda: S.gather_point(x, idx))
-    nb = 4 * 32 * (16384 * 3 + 8192 + 8192 * 3)
-    out.append(_row("gather_point", (32, 16384, 8192), t, nb, "hbm", nb))
-    for (b, n, m) in [(32, 1024, 256), (32, 1024, 384)]:
+    if want("gather_point"):
+        x = rand(32, 16384, 3)
+        idx = torch.randint(0, 16384, (32, 8192), dtype=torch.int32, device=dev, generator=g)
+        t = _timeit(lambda: S.gather_point(x, idx))
+        nb = 4 * 32 * (16384 * 3 + 8192 + 8192 * 3)
+        out.append(_row("gather_point", (32, 16384, 8192), t, nb, "hbm", nb))
+    for (b, n, m) in [(32, 1024, 256), (32, 1024, 384)] if want("three_nn") else []:
         x1, x2 = rand(b, n, 3), rand(b, m, 3)
         t = _timeit(lambda: I.three_nn(x1, x2))
         out.append(_row("three_nn", (b, n, m), t, b * (12 * (n + m) + 24 * n), "valu", 8.0 * b * n * m))
-    for (b, m, c, n) in [(32, 256, 256, 1024), (32, 1024, 128, 4096)]:
+    for (b, m, c, n) in [(32, 256, 256, 1024), (32, 1024, 128, 4096)] if want("three_interpolate") else []:
         pts = torch.randn(b, m, c, device=dev, generator=g)
         _, i3 = I.three_nn(rand(b, n, 3), rand(b, m, 3))
         w = rand(b, n, 3)
         t = _timeit(lambda: I.three_interpolate(pts, i3, w))
         nb = b * (24 * n + 4 * m * c + 4 * n * c)
         out.append(_row("three_interpolate", (b, m, c, n), t, nb, "hbm", nb))
-    for (b, n) in [(32, 1024), (32, 4096), (1, 8192)]:
+    for (b, n) in [(32, 1024), (32, 4096), (1, 8192)] if want("nn_distance") else []:
         x1, x2 = rand(b, n, 3), rand(b, n, 3)
         t = _timeit(lambda: D.nn_distance(x1, x2))
         out.append(_row("nn_distance (both directions)", (b, n, n), t, b * 40 * n, "valu", 16.0 * b * n * n,
                         "%.1f G pair-evals/s" % (2 * b * n * n / t / 1e9)))
-    for (b, n) in [(4, 1024), (32, 1024), (1, 4096), (32, 4096)][: 3 if quick else 4]:
+    for (b, n) in [(4, 1024), (32, 1024), (1, 4096), (32, 4096)][: 3 if quick else 4] if want("approx_match") else []:
         x1, x2 = rand(b, n, 3), rand(b, n, 3)
         t = _timeit(lambda: A.approx_match(x1, x2), reps=5, warm=1)
         out.append(_row("approx_match", (b, n, n), t, b * (24 * n + 4 * n * n), "exp", 30.0 * b * n * n,
@@ -151,7 +154,8 @@ def gpu_ops(dev=None, quick=False):
         t = _timeit(lambda: A.match_cost(x1, x2, mt), reps=5, warm=1)
         nb = b * (24 * n + 4 * n * n + 4)
         out.append(_row("match_cost", (b, n, n), t, nb, "hbm", nb))
-    out += sa_rows(dev, g)
+    if want("sa_"):
+        out += sa_rows(dev, g)
     return out
 
 
