@@ -70,7 +70,8 @@ SIGNATURES = {
     "dispu_linear_small_k": (_i, [_l, _i, _i, _vp, _l, _vp, _vp, _i, _vp, _l, _vp]),
     "dispu_linear_small_n": (_i, [_l, _i, _i, _vp, _l, _vp, _vp, _i, _vp, _l, _vp, _l, _vp]),
     "dispu_edge_dense_conv": (_i, [_i, _i, _i, _vp, _l, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _l, _vp]),
-    "dispu_stem_block": (_i, [_i, _i, _i, _vp, _l, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _l, _vp, _vp, _vp, _i, _vp, _l, _vp]),
+    "dispu_stem_block": (_i, [_i, _i, _i, _vp, _l, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _l, _vp, _vp, _vp, _i, _vp, _l, _vp, _vp, _vp, _vp,
+                              _l, _vp]),
     "dispu_edge_dense_conv_valu": (_i, [_i, _i, _i, _vp, _l, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _l, _vp]),
     "dispu_dup_grid": (_i, [_i, _i, _i, _i, _vp, _l, _vp, _vp, _vp, _vp, _l, _vp]),
     "dispu_ps_prep": (_i, [_l, _i, _vp, _vp, _vp, _vp, _l, _vp, _l, _vp]),

@@ -101,7 +101,9 @@ __global__ __launch_bounds__(LDSF ? 512 : 256) void edge_dense_conv_mfma_kernel(
                                                                     const float* __restrict__ W2, const float* __restrict__ b2,
                                                                     float* __restrict__ Y, long ldy, int* __restrict__ idx_out, int ksel,
                                                                     const float* __restrict__ Wp, const float* __restrict__ bp, int k_old,
-                                                                    float* __restrict__ Pout, long ldp) {
+                                                                    float* __restrict__ Pout, long ldp, const float* __restrict__ xyz,
+                                                                    const float* __restrict__ Wl, const float* __restrict__ bl,
+                                                                    float* __restrict__ Lout, long ldl) {
     constexpr int G = 24, H = C / 2, K0 = 2 * C, K1 = G + C, K2 = 2 * G + C;
     constexpr int S0 = K0 / 2, S1 = K1 / 2, S2 = K2 / 2;
     extern __shared__ __attribute__((aligned(16))) float edge_lds[];
@@ -151,11 +153,41 @@ __global__ __launch_bounds__(LDSF ? 512 : 256) void edge_dense_conv_mfma_kernel(
             wv[u] = *reinterpret_cast<const float4*>(src);
         }
         const int ctotal = n_per_cloud * (C / 4);
+        // KNN, C = 24, xyz != nullptr: the block's input IS feature_extraction's layer0 (ops.py:1449-1451: a 3 -> 24 conv of the
+        // coordinates, no activation) -- every workgroup evaluates it for its whole cloud while it stages (the fmaf chain over k = 0, 1, 2
+        // and the separate bias add of linear_small_k_kernel, so the same bits), and writes the rows of its OWN points to Lout.
+        const bool layer0 = KNN && C == 24 && xyz != nullptr;        // workgroup-uniform
+        if (layer0) {
 #pragma unroll
-        for (int u = 0; u < CB; ++u) {
-            const int e = min((int)threadIdx.x + u * NT, ctotal - 1);
-            const int p = e / (C / 4), q = e - p * (C / 4);
-            cv[u] = *reinterpret_cast<const float4*>(F + (size_t)(cloud0 + p) * ldf + q * 4);
+            for (int u = 0; u < CB; ++u) {
+                const int e = (int)threadIdx.x + u * NT;
+                if (u * NT < ctotal) {                                // (compile-time for the usual n: three rounds of 512 threads)
+                    const int ec = min(e, ctotal - 1);
+                    const int p = ec / (C / 4), q = ec - p * (C / 4);
+                    const float* xr = xyz + (size_t)(cloud0 + p) * 3;
+                    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        const float x = xr[k];
+                        const float4 w = *reinterpret_cast<const float4*>(Wl + k * 24 + q * 4);
+                        acc.x = __builtin_fmaf(x, w.x, acc.x); acc.y = __builtin_fmaf(x, w.y, acc.y);
+                        acc.z = __builtin_fmaf(x, w.z, acc.z); acc.w = __builtin_fmaf(x, w.w, acc.w);
+                    }
+                    const float4 b = *reinterpret_cast<const float4*>(bl + q * 4);
+                    acc.x = acc.x + b.x; acc.y = acc.y + b.y; acc.z = acc.z + b.z; acc.w = acc.w + b.w;
+                    cv[u] = acc;
+                    const int pl = p - (g_lo * 2 - cloud0);
+                    if (e < ctotal && pl >= 0 && pl < (g_hi - g_lo) * 2)
+                        *reinterpret_cast<float4*>(Lout + (size_t)(cloud0 + p) * ldl + q * 4) = acc;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < CB; ++u) {
+                const int e = min((int)threadIdx.x + u * NT, ctotal - 1);
+                const int p = e / (C / 4), q = e - p * (C / 4);
+                cv[u] = *reinterpret_cast<const float4*>(F + (size_t)(cloud0 + p) * ldf + q * 4);
+            }
         }
 #pragma unroll
         for (int u = 0; u < WB; ++u) {
@@ -172,10 +204,11 @@ __global__ __launch_bounds__(LDSF ? 512 : 256) void edge_dense_conv_mfma_kernel(
             const int p = e / (C / 4), q = e - p * (C / 4);
             if (e < ctotal) *reinterpret_cast<float4*>(fl + p * FLD + q * 4) = cv[u];
         }
-        for (int e = threadIdx.x + CB * NT; e < ctotal; e += NT) {           // clouds of more than 8 float4 per thread (C = 48: n > 341)
-            const int p = e / (C / 4), q = e - p * (C / 4);
-            *reinterpret_cast<float4*>(fl + p * FLD + q * 4) = *reinterpret_cast<const float4*>(F + (size_t)(cloud0 + p) * ldf + q * 4);
-        }
+        if (!layer0)
+            for (int e = threadIdx.x + CB * NT; e < ctotal; e += NT) {       // clouds of more than 8 float4 per thread (C = 48: n > 341)
+                const int p = e / (C / 4), q = e - p * (C / 4);
+                *reinterpret_cast<float4*>(fl + p * FLD + q * 4) = *reinterpret_cast<const float4*>(F + (size_t)(cloud0 + p) * ldf + q * 4);
+            }
     }
     __syncthreads();
 #ifdef EDGE_STAMPS
@@ -639,7 +672,7 @@ DISPU_EXPORT int dispu_edge_dense_conv(int npoints, int n_per_cloud, int C, cons
             attr.done();
         }
 #define EDGE_LAUNCH(C_, PRE_) hipLaunchKernelGGL((edge_dense_conv_mfma_kernel<C_, true, PRE_>), dim3(clouds, parts), dim3(512), bytes, s, npoints, \
-                                                 n_per_cloud, F, ldf, idx, ldi, ioff, W0, b0, W1, b1, W2, b2, Y, ldy, nullptr, 0, nullptr, nullptr, 0, nullptr, 0)
+                                                 n_per_cloud, F, ldf, idx, ldi, ioff, W0, b0, W1, b1, W2, b2, Y, ldy, nullptr, 0, nullptr, nullptr, 0, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0)
         if (C == 24) { if (pre) EDGE_LAUNCH(24, true); else EDGE_LAUNCH(24, false); }
         else { if (pre) EDGE_LAUNCH(48, true); else EDGE_LAUNCH(48, false); }
 #undef EDGE_LAUNCH
@@ -650,9 +683,9 @@ DISPU_EXPORT int dispu_edge_dense_conv(int npoints, int n_per_cloud, int C, cons
     if (cap < 0) { const char* e = getenv("DISPU_EDGE_GRID"); cap = e ? atoi(e) : 256; }
     if (g > cap) g = cap;
     if (C == 24)
-        hipLaunchKernelGGL((edge_dense_conv_mfma_kernel<24, false>), dim3(g), dim3(256), frag_bytes, s, npoints, n_per_cloud, F, ldf, idx, ldi, ioff, W0, b0, W1, b1, W2, b2, Y, ldy, nullptr, 0, nullptr, nullptr, 0, nullptr, 0);
+        hipLaunchKernelGGL((edge_dense_conv_mfma_kernel<24, false>), dim3(g), dim3(256), frag_bytes, s, npoints, n_per_cloud, F, ldf, idx, ldi, ioff, W0, b0, W1, b1, W2, b2, Y, ldy, nullptr, 0, nullptr, nullptr, 0, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0);
     else
-        hipLaunchKernelGGL((edge_dense_conv_mfma_kernel<48, false>), dim3(g), dim3(256), frag_bytes, s, npoints, n_per_cloud, F, ldf, idx, ldi, ioff, W0, b0, W1, b1, W2, b2, Y, ldy, nullptr, 0, nullptr, nullptr, 0, nullptr, 0);
+        hipLaunchKernelGGL((edge_dense_conv_mfma_kernel<48, false>), dim3(g), dim3(256), frag_bytes, s, npoints, n_per_cloud, F, ldf, idx, ldi, ioff, W0, b0, W1, b1, W2, b2, Y, ldy, nullptr, 0, nullptr, nullptr, 0, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0);
     return (int)hipGetLastError();
 }
 
@@ -662,7 +695,12 @@ DISPU_EXPORT int dispu_edge_dense_conv(int npoints, int n_per_cloud, int C, cons
 // the [npoints, ksel] neighbour table.
 DISPU_EXPORT int dispu_stem_block(int npoints, int n_per_cloud, int C, const float* F, long ldf, int ksel, int ioff, const float* W0,
                                   const float* b0, const float* W1, const float* b1, const float* W2, const float* b2, float* Y, long ldy,
-                                  int* idx_out, const float* Wp, const float* bp, int k_old, float* P, long ldp, void* stream) {
+                                  int* idx_out, const float* Wp, const float* bp, int k_old, float* P, long ldp, const float* xyz,
+                                  const float* Wl, const float* bl, float* Lout, long ldl, void* stream) {
+    if (xyz != nullptr && (C != 24 || Wl == nullptr || bl == nullptr || Lout == nullptr || (ldl & 3) || (((uintptr_t)Lout) & 15) ||
+                           (((uintptr_t)Wl) & 15) || (((uintptr_t)bl) & 15) || n_per_cloud * 6 > 8 * 512))
+        return (int)hipErrorInvalidValue;
+    if (xyz == nullptr && F == nullptr) return (int)hipErrorInvalidValue;
     if (Wp != nullptr && (bp == nullptr || P == nullptr || k_old < 0 || k_old % 24 != 0 || ldp < 48)) return (int)hipErrorInvalidValue;
     if (npoints < 0 || n_per_cloud <= 0 || !(C == 24 || C == 48) || (ldf & 3) || (((uintptr_t)F) & 15)) return (int)hipErrorInvalidValue;
     if (n_per_cloud > 256 || (n_per_cloud & 1) || npoints % n_per_cloud != 0 || ioff < 0 || ksel != ioff + 16 || ksel > EK_KLD ||
@@ -693,9 +731,9 @@ DISPU_EXPORT int dispu_stem_block(int npoints, int n_per_cloud, int C, const flo
     }
     if (C == 24)
         hipLaunchKernelGGL((edge_dense_conv_mfma_kernel<24, true, true, true>), dim3(clouds, parts), dim3(512), bytes, s, npoints, n_per_cloud, F, ldf,
-                           nullptr, 0, ioff, W0, b0, W1, b1, W2, b2, Y, ldy, idx_out, ksel, Wp, bp, k_old, P, ldp);
+                           nullptr, 0, ioff, W0, b0, W1, b1, W2, b2, Y, ldy, idx_out, ksel, Wp, bp, k_old, P, ldp, xyz, Wl, bl, Lout, ldl);
     else
         hipLaunchKernelGGL((edge_dense_conv_mfma_kernel<48, true, true, true>), dim3(clouds, parts), dim3(512), bytes, s, npoints, n_per_cloud, F, ldf,
-                           nullptr, 0, ioff, W0, b0, W1, b1, W2, b2, Y, ldy, idx_out, ksel, Wp, bp, k_old, P, ldp);
+                           nullptr, 0, ioff, W0, b0, W1, b1, W2, b2, Y, ldy, idx_out, ksel, Wp, bp, k_old, P, ldp, xyz, Wl, bl, Lout, ldl);
     return (int)hipGetLastError();
 }

@@ -253,10 +253,11 @@ class Generator(object):
         fe = "generator/feature_extraction_coarse/"
 
         # ---- feature_extraction_GCN (ops.py:1437-1486): features accumulate right-to-left inside feat[:, 0:480]
-        w, b = self._w(fe + "layer0")
-        self._call("layer0", L.dispu_linear_small_k, rn, 3, 24, ptr(inputs), 3, ptr(w), ptr(b), 0, off(feat, 456), 480, st)
-        col = 456          # left edge of the features produced so far
+        wl0, bl0 = self._w(fe + "layer0")
         stem = self.fused_stem and N <= 256 and N % 2 == 0 and N > k
+        if not stem:       # (fused stem: the first block's launch evaluates layer0 while it stages its cloud)
+            self._call("layer0", L.dispu_linear_small_k, rn, 3, 24, ptr(inputs), 3, ptr(wl0), ptr(bl0), 0, off(feat, 456), 480, st)
+        col = 456          # left edge of the features produced so far
         prep_done = False  # the previous block's launch already ran this block's bottleneck conv (fused stem)
         for d in range(1, DENSE_BLOCKS + 1):
             pbuf = ws["prep"] if d % 2 == 0 else ws["prep_b"]        # block d reads pbuf while its launch writes the other one
@@ -279,7 +280,8 @@ class Generator(object):
                 self._call("stem_block", L.dispu_stem_block, rn, N, C, off(F, foff), ldf, k + 1, 1, ptr(w0), ptr(b0), ptr(w1), ptr(b1), ptr(w2),
                            ptr(b2), off(feat, col), 480, ptr(ws["kidx"]) if self.keep_intermediates else None,
                            ptr(wp) if d < DENSE_BLOCKS else None, ptr(bp) if d < DENSE_BLOCKS else None, 480 - col - width,
-                           ptr(nxt) if d < DENSE_BLOCKS else None, 48, st)
+                           ptr(nxt) if d < DENSE_BLOCKS else None, 48, ptr(inputs) if d == 1 else None, ptr(wl0) if d == 1 else None,
+                           ptr(bl0) if d == 1 else None, off(feat, 456) if d == 1 else None, 480, st)
                 prep_done = d < DENSE_BLOCKS
                 continue
             prep_done = False

@@ -597,8 +597,10 @@ class Trainer(object):
         P = self.P
         feat = ws["feat"]
         fe = "generator/feature_extraction_coarse/"
-        _lib.check(L.dispu_linear_small_k(rn, 3, 24, _p(x), 3, _p(P[fe + "layer0/weights"]), _p(P[fe + "layer0/biases"]), 0,
-                                          _p(feat, 456), 480, self.st), "layer0")
+        stem0 = self.fused_dense and self.fused_stem and N <= 256 and N % 2 == 0
+        if not stem0:      # (fused stem: the first block's launch evaluates layer0 while it stages its cloud)
+            _lib.check(L.dispu_linear_small_k(rn, 3, 24, _p(x), 3, _p(P[fe + "layer0/weights"]), _p(P[fe + "layer0/biases"]), 0,
+                                              _p(feat, 456), 480, self.st), "layer0")
         col = 456
         self._blocks = []
         prep_done = False                      # the previous block's launch already ran this block's bottleneck conv (fused stem)
@@ -625,7 +627,9 @@ class Trainer(object):
                                               _p(P[sc + "/l2/biases"]), _p(feat, col), 480, _p(kidx),
                                               _p(P[fe + "layer%d_prep/weights" % (d + 1)]) if d < DENSE_BLOCKS else None,
                                               _p(P[fe + "layer%d_prep/biases" % (d + 1)]) if d < DENSE_BLOCKS else None, 480 - in_col,
-                                              _p(ws["prep"][d + 1]) if d < DENSE_BLOCKS else None, 48, self.st), "stem_block")
+                                              _p(ws["prep"][d + 1]) if d < DENSE_BLOCKS else None, 48, _p(x) if d == 1 else None,
+                                              _p(P[fe + "layer0/weights"]) if d == 1 else None, _p(P[fe + "layer0/biases"]) if d == 1 else None,
+                                              _p(feat, 456) if d == 1 else None, 480, self.st), "stem_block")
             elif self.fused_dense:
                 # the inference kernel (csrc/edge.hip): edge features, three chained convs and the max in one launch; nothing is kept
                 # for the backward pass, which recomputes the block on chip (csrc/edge_bwd.hip)

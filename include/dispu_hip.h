@@ -231,10 +231,14 @@ int dispu_edge_dense_conv(int npoints, int n_per_cloud, int C, const float* F, l
  * >= ksel = ioff + 16 <= 20; npoints a multiple of n_per_cloud); idx_out (nullable): the [npoints, ksel] neighbour table.
  * Wp (nullable) [72 + C + k_old, 48], bp [48]: the NEXT block's bottleneck conv (feature_extraction layer<d+1>_prep, ops.py:1455-1462)
  * in the same launch: P[p, 0:48] = relu([Y[p, 0:72+C] | Y[p, 72+C : 72+C+k_old]] . Wp + bp) -- Y's row continues to the right with the
- * k_old (a multiple of 24) older feature columns; bit-identical to dispu_linear on those rows. */
+ * k_old (a multiple of 24) older feature columns; bit-identical to dispu_linear on those rows.
+ * xyz (nullable; C == 24, clouds of <= 680 points) [npoints, 3]: F is not read -- the block's input is feature_extraction's layer0
+ * (ops.py:1449-1451) = xyz . Wl [3, 24] + bl, evaluated while the cloud is staged (bit-identical to dispu_linear_small_k) and also
+ * written to Lout [npoints, 24] (row stride ldl). */
 int dispu_stem_block(int npoints, int n_per_cloud, int C, const float* F, long ldf, int ksel, int ioff, const float* W0, const float* b0,
                      const float* W1, const float* b1, const float* W2, const float* b2, float* Y, long ldy, int* idx_out, const float* Wp,
-                     const float* bp, int k_old, float* P, long ldp, void* stream);
+                     const float* bp, int k_old, float* P, long ldp, const float* xyz, const float* Wl, const float* bl, float* Lout,
+                     long ldl, void* stream);
 /* Same contract as dispu_edge_dense_conv, VALU formulation (one lane per pair, weights through scalar loads).
  * Bit-identical results; kept as the A/B twin of the MFMA kernel for tests and profiling. */
 int dispu_edge_dense_conv_valu(int npoints, int n_per_cloud, int C, const float* F, long ldf, const int* idx, int ldi,

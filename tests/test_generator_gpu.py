@@ -319,7 +319,8 @@ def test_stem_block_equals_search_then_edge_conv(dev, C, nb, n_cloud, kind):
         pr = torch.full((npts, 50), -7.0, device=dev)
         _lib.check(L.dispu_stem_block(npts, n_cloud, C, tF.data_ptr(), ld, 17, 1, *w, y_b.data_ptr(), ldy,
                                       idx_b.data_ptr() if with_idx else None, Wp.data_ptr() if with_idx else None,
-                                      bp.data_ptr() if with_idx else None, k_old, pr.data_ptr() if with_idx else None, 50, st), "stem")
+                                      bp.data_ptr() if with_idx else None, k_old, pr.data_ptr() if with_idx else None, 50, None, None, None, None, 0,
+                                      st), "stem")
         assert np.array_equal(N(y_a)[:, :72 + C], N(y_b)[:, :72 + C])
         assert np.array_equal(N(y_b)[:, 72 + C:], tail)
         if with_idx:
@@ -339,6 +340,41 @@ def test_stem_block_equals_search_then_edge_conv(dev, C, nb, n_cloud, kind):
         assert np.array_equal(idx2[..., 1].reshape(npts, 17), N(idx_a))
 
 
+@pytest.mark.parametrize("nb,n_cloud", [(32, 256), (3, 128), (5, 250)])
+def test_stem_block_with_layer0_from_coordinates(dev, nb, n_cloud):
+    """First dense block fed with coordinates (layer0 evaluated while the cloud is staged) vs dispu_linear_small_k followed by the
+    block on its output: layer0 rows, block output, neighbour table and the next block's bottleneck conv bit-identical."""
+    from dispu_amd import _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(nb + n_cloud)
+    npts = nb * n_cloud
+    xyz = torch.from_numpy(rng.uniform(-1, 1, (npts, 3)).astype(np.float32)).to(dev)
+    Wl = torch.from_numpy((rng.standard_normal((3, 24)) * 0.5).astype(np.float32)).to(dev)
+    bl = torch.from_numpy((rng.standard_normal((24,)) * 0.1).astype(np.float32)).to(dev)
+    P = {k: (rng.standard_normal(s) * 0.2).astype(np.float32) for k, s in
+         dict(W0=(48, 24), b0=(24,), W1=(48, 24), b1=(24,), W2=(72, 24), b2=(24,)).items()}
+    t = {k: torch.from_numpy(v).to(dev) for k, v in P.items()}
+    w = [t[k].data_ptr() for k in ("W0", "b0", "W1", "b1", "W2", "b2")]
+    Wp = torch.from_numpy((rng.standard_normal((120, 48)) * 0.1).astype(np.float32)).to(dev)
+    bp = torch.from_numpy((rng.standard_normal((48,)) * 0.1).astype(np.float32)).to(dev)
+    st = _lib.stream_ptr(dev)
+    outs = []
+    for fused in (False, True):
+        feat = torch.zeros((npts, 480), device=dev)                # the generator's layout: layer0 at 456:480, the block at 360:456
+        idx = torch.full((npts, 17), -1, dtype=torch.int32, device=dev)
+        pr = torch.zeros((npts, 48), device=dev)
+        off = lambda c: feat.data_ptr() + 4 * c
+        if not fused:
+            _lib.check(L.dispu_linear_small_k(npts, 3, 24, xyz.data_ptr(), 3, Wl.data_ptr(), bl.data_ptr(), 0, off(456), 480, st), "layer0")
+        _lib.check(L.dispu_stem_block(npts, n_cloud, 24, None if fused else off(456), 480, 17, 1, *w, off(360), 480, idx.data_ptr(), Wp.data_ptr(),
+                                      bp.data_ptr(), 24, pr.data_ptr(), 48, xyz.data_ptr() if fused else None, Wl.data_ptr() if fused else None,
+                                      bl.data_ptr() if fused else None, off(456) if fused else None, 480, st), "stem")
+        outs.append((N(feat).copy(), N(idx).copy(), N(pr).copy()))
+    for a_, b_ in zip(*outs):
+        assert np.array_equal(a_, b_)
+    assert np.abs(outs[0][0][:, 456:]).max() > 0 and np.abs(outs[0][2]).max() > 0
+
+
 def test_stem_block_refuses_what_it_does_not_cover(dev):
     from dispu_amd import _lib
     L = _lib.lib()
@@ -347,7 +383,7 @@ def test_stem_block_refuses_what_it_does_not_cover(dev):
     y = torch.zeros((1024, 144), device=dev)
     st = _lib.stream_ptr(dev)
     a = lambda npts, n, C, ksel, ioff, k_old=0, wp=None: L.dispu_stem_block(npts, n, C, x.data_ptr(), 48, ksel, ioff, *([w.data_ptr()] * 6), y.data_ptr(),
-                                                                            120 + 24, None, wp, wp, k_old, wp, 48, st)
+                                                                            120 + 24, None, wp, wp, k_old, wp, 48, None, None, None, None, 0, st)
     assert a(1024, 512, 48, 17, 1) != 0            # clouds of more than 256 points
     assert a(1024, 256, 32, 17, 1) != 0            # C outside {24, 48}
     assert a(1000, 256, 48, 17, 1) != 0            # ragged clouds
