@@ -305,6 +305,43 @@ def main():
             d1 = float(tt.item())
         loops.append(d1)
 
+    # ---- the same step with after_conv on the bf16 matrix pipe (operands split exactly into three bf16 terms, six partial products per
+    # k, fp32 accumulate: csrc/linear_bf16x3.hip).  fp32-accurate (tests/test_headline_gpu.py) but NOT the fmaf chain of the strict path,
+    # so it rides along as a second figure; `value` above stays the strict-fp32 step.
+    alt = None
+    if rank == 0 and world == 1 and not args.split_bf16 and not args.eager:
+        try:
+            g2 = Generator(params=params, device=dev)
+            g2.return_views = True
+            g2.split_bf16 = True
+            g2(x)
+            torch.cuda.synchronize()
+            side2 = torch.cuda.Stream()
+            side2.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side2):
+                g2(x)
+            torch.cuda.current_stream().wait_stream(side2)
+            gr2 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr2):
+                g2(x)
+            for _ in range(SETTLE_STEPS // 2):
+                gr2.replay()
+            torch.cuda.synchronize()
+            ts = []
+            for _ in range(3):
+                t1 = time.perf_counter()
+                for _ in range(args.steps):
+                    gr2.replay()
+                torch.cuda.synchronize()
+                ts.append((time.perf_counter() - t1) / args.steps)
+            ts.sort()
+            alt = {"ms_per_step": ts[1] * 1e3, "value": PATCHES_PER_GPU * NPOINT * UP / ts[1], "unit": "points/s",
+                   "dtype": "f32 storage and accumulate; after_conv's products as six bf16 MFMAs per k over exact 3-term splits of both operands",
+                   "note": "opt-in (Generator.split_bf16 / bench.py --split-bf16); median of 3 loops of K steps; coarse bit-exact, fine <= 1e-5 vs the oracle"}
+            del gr2, g2
+        except Exception as e:                                 # noqa: BLE001
+            alt = {"error": "%s: %s" % (type(e).__name__, e)}
+
     # ---- roofline of the dominant kernel: HIP events around every launch, on the launch stream (eager pass)
     roof = None
     if rank == 0:
@@ -400,6 +437,8 @@ def main():
                           "points_out_per_step": pts, "launch": launch, "weights": "xavier-uniform seed 1234, zero bias",
                           "parallelism": "patch-sharded x%d" % world},
                "roofline": roof}
+        if alt is not None:
+            out["alt_split_bf16"] = alt
         srt = sorted(loops)
         out["ms_per_step_repeats"] = {"n": len(loops), "min": srt[0] / args.steps * 1e3, "median": srt[len(srt) // 2] / args.steps * 1e3,
                                       "max": srt[-1] / args.steps * 1e3, "note": "the timed K-step loop run 5 times; value / ms_per_step = the first"}

@@ -19,6 +19,8 @@
 // as an opt-in, tested path; not used by default anywhere.
 #include "common.h"
 
+#include <cstdlib>
+
 namespace dispu {
 
 typedef __bf16 x3_bf16x8 __attribute__((ext_vector_type(8)));
@@ -168,14 +170,213 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(X3Args a) {
         }
 }
 
+
+// ---- round 4: the same products, wave-specialised -------------------------------------------------------------------------------
+// 128 x 256 tile (the activations are read once), K slabs of 32, 4 MFMA waves (64 x 128 each = 2 x 4 blocks of 32 x 32) + 4 loader
+// waves; one workgroup per CU; two LDS stages of A [plane][128 rows][32 k] and B [plane][256 cols][32 k] bf16 (144 KB).
+// * W planes are stored SLAB-MAJOR by dispu_bf16x3_split_weights for this kernel: [N / 256][K / 32][plane][256 cols][32 k], every
+//   slab the exact image of a B stage (swizzle included), so a loader lane copies twelve 16-byte pieces per slab from fully
+//   contiguous memory.  (With [plane][n][k] planes a slab touched 768 cache lines for 32 bytes each, 4 KB apart: the loader side alone
+//   took 1.0 - 1.2 us per 16-k slab whether it used LDS-DMA or registers, and the launch 199 - 240 us.)
+// * X: a loader lane owns (row, k quarter) of rows r and r + 64: two float4 each (four lanes = one 128-byte line), split into the
+//   three bf16 terms in registers and written as one 16-byte chunk per plane.
+// * Loads travel through REGISTERS, two slabs in flight per loader wave (128 VGPRs); the compiler counts vmcnt.
+// A row of a stage is 64 bytes = four 16-byte chunks (8 k each); chunk c of row r sits at position c ^ ((r >> 2) & 3): the sixteen lanes
+// of a ds_read_b128 lane group ({0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, ...) then touch sixteen different 16-byte slots of the
+// 256-byte bank row (rows that agree mod 4 differ in (r >> 2) & 3 within every group).
+// Per slab and MFMA wave: 36 ds_read_b128 feed 96 v_mfma_f32_32x32x16_bf16 (6 per block and 16 k: the partial products of order <= 2,
+// smallest first) = 3072 matrix-pipe cycles; the fp32 kernel needs 8192 for the same 32 k.
+constexpr int W3_BM = 128, W3_BN = 256, W3_BK = 32;
+constexpr int W3_B_STAGE = 3 * W3_BN * W3_BK;            // halves (48 KB)
+constexpr int W3_A_STAGE = 3 * W3_BM * W3_BK;            // halves (24 KB)
+constexpr size_t W3_LDS_BYTES = (size_t)2 * (W3_B_STAGE + W3_A_STAGE) * 2;   // 144 KB
+
+__device__ __host__ inline bool x3_ws_shape(int K, int N) { return N % W3_BN == 0 && K % W3_BK == 0 && K >= 4 * W3_BK; }
+
+// slab-major planes for gemm_bf16x3_ws_kernel: element (k, n) of plane p -> [n / 256][k / 32][p][n % 256][chunk ^ swizzle][k % 8]
+__global__ void bf16x3_split_weights_slab_kernel(int K, int N, const float* __restrict__ W, long ldw, __bf16* __restrict__ planes) {
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (long)K * N) return;
+    const int k = (int)(e / N), n = (int)(e % N);                    // consecutive threads: consecutive n (coalesced reads of W)
+    __bf16 q[3];
+    x3_split(W[(long)k * ldw + n], q[0], q[1], q[2]);
+    const int nt = n / W3_BN, nl = n % W3_BN, t = k / W3_BK, kl = k % W3_BK;
+    const int pc = (kl >> 3) ^ ((nl >> 2) & 3);
+    const long base = ((long)nt * (K / W3_BK) + t) * W3_B_STAGE + (long)nl * W3_BK + pc * 8 + (kl & 7);
+#pragma unroll
+    for (int p = 0; p < 3; ++p) planes[base + (long)p * W3_BN * W3_BK] = q[p];
+}
+
+__global__ __launch_bounds__(512) void gemm_bf16x3_ws_kernel(X3Args a) {
+    extern __shared__ __attribute__((aligned(16))) __bf16 w3_lds[];
+    __bf16* Bst = w3_lds;
+    __bf16* Ast = w3_lds + 2 * W3_B_STAGE;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int m0 = blockIdx.y * W3_BM, n0 = blockIdx.x * W3_BN;
+    const int ntile = a.K / W3_BK;
+
+    if (wave >= 4) {
+        // ------------------------------------------------------------------------------------------------ loader waves
+        const int ltid = threadIdx.x - 256;
+        // X: rows (ltid >> 2) and (ltid >> 2) + 64, k quarter ltid & 3 (8 values = two float4)
+        const int arow = ltid >> 2, aq = ltid & 3;
+        const float* px = a.X + (size_t)(m0 + arow) * a.ldx + aq * 8;
+        const size_t px64 = (size_t)64 * a.ldx;
+        const int adst = arow * W3_BK + ((aq ^ ((arow >> 2) & 3)) * 8);          // (row + 64: same swizzle bits)
+        // W: twelve 16-byte pieces per slab, piece j of this lane = halves [(j * 256 + ltid) * 8, + 8) of the slab image
+        const __bf16* pw = a.Wp + (size_t)blockIdx.x * ntile * W3_B_STAGE + (size_t)ltid * 8;
+        struct Slab { float4 x[4]; x3_bf16x8 w[12]; };
+        auto load = [&](int t, Slab& r) {
+            t = min(t, ntile - 1);                                   // past the end: a harmless repeat of the last slab, never stored
+#ifdef X3_NOLOAD
+            if (a.M > 0) return;
+#endif
+            const float* xs = px + (size_t)t * W3_BK;
+            r.x[0] = *reinterpret_cast<const float4*>(xs);
+            r.x[1] = *reinterpret_cast<const float4*>(xs + 4);
+            r.x[2] = *reinterpret_cast<const float4*>(xs + px64);
+            r.x[3] = *reinterpret_cast<const float4*>(xs + px64 + 4);
+            const __bf16* ws = pw + (size_t)t * W3_B_STAGE;
+#pragma unroll
+            for (int j = 0; j < 12; ++j) r.w[j] = *reinterpret_cast<const x3_bf16x8*>(ws + j * 2048);
+        };
+        auto store = [&](int t, const Slab& r) {
+#ifdef X3_NOLOAD
+            if (a.M > 0) return;
+#endif
+            __bf16* d = Ast + (t & 1) * W3_A_STAGE + adst;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const float4 v0 = r.x[2 * u], v1 = r.x[2 * u + 1];
+                const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+                x3_bf16x8 h0, h1, h2;
+#ifdef X3_NOSPLIT
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { h0[e] = (__bf16)v[e]; h1[e] = h0[e]; h2[e] = h0[e]; }
+#else
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { __bf16 q0, q1, q2; x3_split(v[e], q0, q1, q2); h0[e] = q0; h1[e] = q1; h2[e] = q2; }
+#endif
+                *reinterpret_cast<x3_bf16x8*>(d + u * 64 * W3_BK) = h0;
+                *reinterpret_cast<x3_bf16x8*>(d + u * 64 * W3_BK + W3_BM * W3_BK) = h1;
+                *reinterpret_cast<x3_bf16x8*>(d + u * 64 * W3_BK + 2 * W3_BM * W3_BK) = h2;
+            }
+            __bf16* b = Bst + (t & 1) * W3_B_STAGE + ltid * 8;
+#pragma unroll
+            for (int j = 0; j < 12; ++j) *reinterpret_cast<x3_bf16x8*>(b + j * 2048) = r.w[j];
+        };
+        Slab r0, r1;                                                 // even slabs travel in r0, odd slabs in r1
+        load(0, r0); load(1, r1);
+        store(0, r0);
+        load(2, r0);
+        __syncthreads();
+        // iteration t: slab t + 1 -> LDS (its stage was last read during slab t - 1), then request slab t + 3 into the freed registers
+        for (int t = 0; t < ntile; t += 2) {
+            if (t + 1 < ntile) store(t + 1, r1);
+            load(t + 3, r1);
+            __syncthreads();
+            if (t + 1 < ntile) {
+                if (t + 2 < ntile) store(t + 2, r0);
+                load(t + 4, r0);
+                __syncthreads();
+            }
+        }
+        return;
+    }
+
+    // ---------------------------------------------------------------------------------------------------- MFMA waves
+    const int wm = wave >> 1, wn = wave & 1, li = lane & 31, kq = lane >> 5;
+    x3_f32x16 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    // fragment (block, k16 step ks): chunk c = 2 ks + kq of the block's row -> position c ^ ((row >> 2) & 3)
+    int aoff[2][2], boff[4][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) { const int row = wm * 64 + i * 32 + li; aoff[i][ks] = row * W3_BK + (((2 * ks + kq) ^ ((row >> 2) & 3)) * 8); }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) { const int col = wn * 128 + j * 32 + li; boff[j][ks] = col * W3_BK + (((2 * ks + kq) ^ ((col >> 2) & 3)) * 8); }
+    __syncthreads();
+    for (int t = 0; t < ntile; ++t) {
+        const __bf16* As = Ast + (t & 1) * W3_A_STAGE;
+        const __bf16* Bs = Bst + (t & 1) * W3_B_STAGE;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            x3_bf16x8 fa[2][3], fb[4][3];
+            // fragments in the order the products below need them: (a3, b1) first
+#pragma unroll
+            for (int i = 0; i < 2; ++i) fa[i][2] = *reinterpret_cast<const x3_bf16x8*>(As + 2 * W3_BM * W3_BK + aoff[i][ks]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) fb[j][0] = *reinterpret_cast<const x3_bf16x8*>(Bs + boff[j][ks]);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) fa[i][1] = *reinterpret_cast<const x3_bf16x8*>(As + W3_BM * W3_BK + aoff[i][ks]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) fb[j][1] = *reinterpret_cast<const x3_bf16x8*>(Bs + W3_BN * W3_BK + boff[j][ks]);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) fa[i][0] = *reinterpret_cast<const x3_bf16x8*>(As + aoff[i][ks]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) fb[j][2] = *reinterpret_cast<const x3_bf16x8*>(Bs + 2 * W3_BN * W3_BK + boff[j][ks]);
+            // six rounds over the eight blocks: consecutive MFMAs never share an accumulator
+#define W3_ROUND(PA, PB)                                                                                             \
+            _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                            \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                            \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][PA], fb[j][PB], acc[i][j], 0, 0, 0);
+#ifdef X3_NOMFMA
+            W3_ROUND(2, 0)
+            if (a.M < 0) { W3_ROUND(1, 1) W3_ROUND(0, 2) W3_ROUND(1, 0) W3_ROUND(0, 1) W3_ROUND(0, 0) }
+#else
+            W3_ROUND(2, 0) W3_ROUND(1, 1) W3_ROUND(0, 2) W3_ROUND(1, 0) W3_ROUND(0, 1) W3_ROUND(0, 0)
+#endif
+#undef W3_ROUND
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int col = n0 + wn * 128 + j * 32 + li;
+            const float bv = a.bias ? a.bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kq;
+                float v = acc[i][j][r] + bv;
+                if (a.act == 1) v = fmaxf(v, 0.f);
+                if (a.R1) v += a.R1[(long)row * a.ldr1 + col];
+                if (a.R2) v += a.R2[(long)row * a.ldr2 + col];
+                a.Y[(long)row * a.ldy + col] = v;
+            }
+        }
+}
+
 }  // namespace dispu
 
 using namespace dispu;
+
+// DISPU_X3_WS=0: the round-2 single-role kernel and its [plane][n][k] planes for every shape (A/B tests); read once per process,
+// by the weight split and by the GEMM alike
+static bool x3_use_ws() {
+    static int ws = -1;
+    if (ws < 0) { const char* e = getenv("DISPU_X3_WS"); ws = e ? atoi(e) : 1; }
+    return ws != 0;
+}
 
 // planes: 3 * K * N bf16 values (6 K N bytes), [plane][n][k]
 DISPU_EXPORT int dispu_bf16x3_split_weights(int K, int N, const float* W, long ldw, void* planes, void* stream) {
     if (K <= 0 || N <= 0 || !W || !planes || ldw < N) return (int)hipErrorInvalidValue;
     const long total = (long)K * N;
+    if (x3_use_ws() && x3_ws_shape(K, N)) {      // the wave-specialised kernel's slab-major layout (the same rule picks the kernel below)
+        hipLaunchKernelGGL(bf16x3_split_weights_slab_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, K, N, W, ldw,
+                           reinterpret_cast<__bf16*>(planes));
+        return (int)hipGetLastError();
+    }
     hipLaunchKernelGGL(bf16x3_split_weights_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, K, N, W, ldw,
                        reinterpret_cast<__bf16*>(planes));
     return (int)hipGetLastError();
@@ -195,6 +396,15 @@ DISPU_EXPORT int dispu_linear_bf16x3(int M, int K, int N, const float* X, long l
         attr.done();
     }
     X3Args a{M, N, K, X, ldx, reinterpret_cast<const __bf16*>(planes), bias, act, Y, ldy, R1, ldr1, R2, ldr2};
+    if (x3_use_ws() && x3_ws_shape(K, N)) {
+        static DevOnce attr2;
+        if (attr2.needed()) {
+            DISPU_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x3_ws_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)W3_LDS_BYTES));
+            attr2.done();
+        }
+        hipLaunchKernelGGL(gemm_bf16x3_ws_kernel, dim3((unsigned)(N / W3_BN), (unsigned)(M / W3_BM)), dim3(512), W3_LDS_BYTES, (hipStream_t)stream, a);
+        return (int)hipGetLastError();
+    }
     hipLaunchKernelGGL(gemm_bf16x3_kernel, dim3((unsigned)((M / X3_BM) * (N / X3_BN))), dim3(256), X3_LDS_BYTES, (hipStream_t)stream, a);
     return (int)hipGetLastError();
 }

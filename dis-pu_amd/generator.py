@@ -418,8 +418,9 @@ class Generator(object):
                 pl = torch.empty((3 * 2048 * 256,), dtype=torch.bfloat16, device=self.device)
                 _lib.check(L.dispu_bf16x3_split_weights(2048, 256, ptr(w), 256, ptr(pl), st), "dispu_bf16x3_split_weights")
                 self._planes["after_conv"] = pl
+            in_chain = heads and self.chain_inputs            # + skip + nl then happen in the fine chain's loader
             self._call("linear_bf16x3[%dx2048x256]" % rm, L.dispu_linear_bf16x3, rm, 2048, 256, ptr(ws["fp"]), 2048, ptr(pl), ptr(b), 1,
-                       ptr(ws["aft"]), 256, ptr(ws["skip"]), 256, ptr(ws["nl"]), 256, st)
+                       ptr(ws["aft"]), 256, None if in_chain else ptr(ws["skip"]), 256, None if in_chain else ptr(ws["nl"]), 256, st)
         elif heads and self.chain_inputs:
             self._linear(st, ws["fp"], 2048, w, b, 1, ws["aft"], 256)          # relu(after_conv) alone; + skip + nl in the fine chain's loader
         elif self.fused_residual:
@@ -429,7 +430,7 @@ class Generator(object):
             self._linear(st, ws["fp"], 2048, w, b, 1, ws["aft"], 256)
             self._call("add3", L.dispu_add3, rm * 256, ptr(ws["aft"]), ptr(ws["skip"]), ptr(ws["nl"]), ptr(ws["aft"]), st)
         fs = "refine/fine_coordinate_regressor/"
-        if heads and self.chain_inputs and not (self.split_bf16 and rm % 128 == 0):
+        if heads and self.chain_inputs:
             w1, b1_ = self._w(ps + "aggregation")
             w2, b2_ = self._w(fs + "fc_layer0")
             w3, b3_ = self._w(fs + "fc_layer1")

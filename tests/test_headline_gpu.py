@@ -8,6 +8,8 @@ GEMMs take their interior 128x256 DMA tiles (rm = 32768), grid shapes the B <= 5
   * hipGraph replay == eager launch (bit-identical), the way bench.py times the step,
   * the same with non-zero biases / a non-trivial BN fold.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -126,8 +128,15 @@ def test_split_bf16_gemm_is_fp32_accurate(dev):
     planes = torch.empty(3 * K * Nn, dtype=torch.bfloat16, device=dev)
     st = _lib.stream_ptr(dev)
     _lib.check(L.dispu_bf16x3_split_weights(K, Nn, tw.data_ptr(), Nn, planes.data_ptr(), st), "split")
-    rec = planes.view(3, Nn, K).float().sum(0).t()                                 # the three planes add back up to W ...
-    assert float((rec - tw).abs().max()) <= 2.0 ** -22 * float(tw.abs().max())    # ... to 24 bits
+    # slab-major planes of the wave-specialised kernel: [K / 32][plane][256 cols][4 chunk positions][8], chunk c of column n at
+    # position c ^ ((n >> 2) & 3); the three planes add back up to W to 24 bits
+    if os.environ.get("DISPU_X3_WS", "1") == "0":                                   # the round-2 kernel's [plane][n][k] planes
+        rec = planes.view(3, Nn, K).float().sum(0).t()
+    else:
+        pl = planes.view(K // 32, 3, Nn, 4, 8).float().sum(1)                        # [t][n][position][8]
+        pos = (torch.arange(4, device=dev)[None, :] ^ ((torch.arange(Nn, device=dev)[:, None] >> 2) & 3))  # [n][c] -> position
+        rec = torch.gather(pl, 2, pos[None, :, :, None].expand(K // 32, Nn, 4, 8)).permute(0, 2, 3, 1).reshape(K, Nn)
+    assert float((rec - tw).abs().max()) <= 2.0 ** -22 * float(tw.abs().max())
     y = torch.zeros((M, Nn), device=dev)
     _lib.check(L.dispu_linear_bf16x3(M, K, Nn, tx.data_ptr(), K, planes.data_ptr(), tb.data_ptr(), 1, y.data_ptr(), Nn, t1.data_ptr(), Nn,
                                      t2.data_ptr(), Nn, st), "dispu_linear_bf16x3")
@@ -139,6 +148,32 @@ def test_split_bf16_gemm_is_fp32_accurate(dev):
     e3, e32 = np.abs(N(y) - want).max() / scale, np.abs(N(y32) - want).max() / scale
     print("max error / sum|a||b|: split-bf16 %.2e, fp32 MFMA %.2e" % (e3, e32))
     assert e3 <= 4e-7 and e3 <= 4 * e32 + 1e-7
+
+
+@pytest.mark.parametrize("M,K,Nn", [(256, 2048, 256), (128, 128, 512), (384, 160, 256), (256, 96, 256), (128, 256, 128)])
+def test_split_bf16_gemm_shapes(dev, M, K, Nn):
+    """Both split-bf16 kernels (wave-specialised: N % 256 == 0, K % 32 == 0, K >= 128; the single-role one otherwise) against float64,
+    with and without residuals; planes and kernel are chosen by the same shape rule."""
+    from dispu_amd import _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(M + K + Nn)
+    x = rng.standard_normal((M, K)).astype(np.float32)
+    w = (rng.standard_normal((K, Nn)) * 0.1).astype(np.float32)
+    b = rng.standard_normal(Nn).astype(np.float32)
+    r1 = rng.standard_normal((M, Nn)).astype(np.float32)
+    tx, tw, tb, t1 = (torch.from_numpy(a).to(dev) for a in (x, w, b, r1))
+    planes = torch.empty(3 * K * Nn, dtype=torch.bfloat16, device=dev)
+    st = _lib.stream_ptr(dev)
+    _lib.check(L.dispu_bf16x3_split_weights(K, Nn, tw.data_ptr(), Nn, planes.data_ptr(), st), "split")
+    scale = (np.abs(x).astype(np.float64) @ np.abs(w).astype(np.float64)).max()
+    for act, res in ((1, True), (0, False)):
+        y = torch.full((M, Nn + 8), -3.0, device=dev)
+        _lib.check(L.dispu_linear_bf16x3(M, K, Nn, tx.data_ptr(), K, planes.data_ptr(), tb.data_ptr(), act, y.data_ptr(), Nn + 8,
+                                         t1.data_ptr() if res else None, Nn, None, 0, st), "dispu_linear_bf16x3")
+        want = x.astype(np.float64) @ w.astype(np.float64) + b
+        want = (np.maximum(want, 0) if act else want) + (r1 if res else 0)
+        assert np.abs(N(y)[:, :Nn] - want).max() / scale <= 4e-7
+        assert (N(y)[:, Nn:] == -3.0).all()
 
 
 def test_generator_split_bf16_mode_within_tolerance(bench_setup, dev):
