@@ -80,7 +80,9 @@ class Generator(object):
         self.split_bf16 = False
         self._planes = {}
         self.split_up3 = bool(int(os.environ.get('DISPU_SPLIT_UP3', '1')))
-        self.branches = bool(int(os.environ.get('DISPU_BRANCHES', '0')))   # non-local cell on a second stream (measured: see DESIGN.md)
+        # non-local cell on a second stream next to the grouping / skip / local cell (round 4: on by default, -1 % since the head chains
+        # form their own inputs -- the branch now joins right before the fine chain; rounds 1 - 3 measured it +1 %)
+        self.branches = bool(int(os.environ.get('DISPU_BRANCHES', '1')))
         self._aux = None
         self.fused_residual = bool(int(__import__('os').environ.get('DISPU_FUSED_RES', '1')))
         self.fused_heads = bool(int(__import__('os').environ.get('DISPU_FUSED_HEADS', '1')))   # one launch per head chain
@@ -410,7 +412,8 @@ class Generator(object):
                        ptr(self.bn_scale), ptr(self.bn_shift), ptr(wv), st)
             self._call("point_matmul", L.dispu_ps_point_matmul, rm, k, 128, 16, ptr(x2), 128, ptr(wv), ptr(ws["fp"]), 2048, st)
         w, b = self._w(ps + "after_conv")
-        if br:
+        nl_late = br and heads and self.chain_inputs and int(os.environ.get("DISPU_NL_LATE", "1"))   # nl is first read by the fine chain's loader
+        if br and not nl_late:
             torch.cuda.current_stream(self.device).wait_event(ev_nl)
         if self.split_bf16 and rm % 128 == 0:
             pl = self._planes.get("after_conv")
@@ -430,6 +433,8 @@ class Generator(object):
             self._linear(st, ws["fp"], 2048, w, b, 1, ws["aft"], 256)
             self._call("add3", L.dispu_add3, rm * 256, ptr(ws["aft"]), ptr(ws["skip"]), ptr(ws["nl"]), ptr(ws["aft"]), st)
         fs = "refine/fine_coordinate_regressor/"
+        if nl_late:
+            torch.cuda.current_stream(self.device).wait_event(ev_nl)
         if heads and self.chain_inputs:
             w1, b1_ = self._w(ps + "aggregation")
             w2, b2_ = self._w(fs + "fc_layer0")

@@ -190,6 +190,39 @@ def test_generator_split_bf16_mode_within_tolerance(bench_setup, dev):
     assert np.abs(N(f)[11] - of[0]).max() <= 1e-5
 
 
+def test_two_stream_forward_equals_single_stream(bench_setup, dev):
+    """Generator.branches (default on: the non-local cell on a second stream, joined right before the fine head chain) runs the same
+    kernels on the same data: coarse and fine bit-identical to the single-stream forward, eagerly and replayed from a hipGraph."""
+    from dispu_amd.generator import Generator
+    s = bench_setup
+    outs = []
+    for br in (True, False):
+        gen = Generator(params=s["P"], device=dev)
+        gen.branches = br
+        gen.return_views = True
+        c, f = gen(s["tx"])
+        torch.cuda.synchronize()
+        outs.append((N(c).copy(), N(f).copy()))
+        if br:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                gen(s["tx"])
+            torch.cuda.current_stream().wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                c2, f2 = gen(s["tx"])
+            c2.zero_(); f2.zero_()
+            for _ in range(3):
+                graph.replay()
+            torch.cuda.synchronize()
+            outs.append((N(c2).copy(), N(f2).copy()))
+    assert Generator(params=s["P"], device=dev).branches                 # the default
+    for c, f in outs[1:]:
+        assert np.array_equal(c, outs[0][0]) and np.array_equal(f, outs[0][1])
+    assert np.array_equal(outs[0][0], s["c"]) and np.array_equal(outs[0][1], s["f"])
+
+
 def test_oversize_batches_run_in_chunks(dev):
     """Batches above Generator.MAX_BATCH (2048: keeps row * stride products below 2^31) are processed in chunks; patches are
     independent, so the result is the unchunked one.  Exercised here with a tiny limit."""
