@@ -347,6 +347,10 @@ def main():
     if rank == 0:
         reps = 5
         acc = {}
+        # every kernel ALONE on the device: the step's second stream (Generator.branches: the non-local cell beside the local cell) is
+        # folded back into the launch stream for this pass, so a kernel's time is its own and not that of two kernels sharing the CUs
+        # (same kernels, same data; tools/prof_bench.sh runs its rocprofv3 pass the same way, DISPU_BRANCHES=0)
+        two_streams, gen.branches = gen.branches, False
         for _ in range(reps):
             gen.profile = []
             gen(x)
@@ -356,6 +360,7 @@ def main():
                 a[0] += e0.elapsed_time(e1) * 1e-3
                 a[1] += 1
         gen.profile = None
+        gen.branches = two_streams
         # group the instrumented launches by the kernel name rocprofv3 reports (one template instantiation each)
         by_kernel = {}
         edge_c = [24, 48, 48, 48]                                           # dense block d reads C = 24 / 48 / 48 / 48 channels
