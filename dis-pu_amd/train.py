@@ -139,6 +139,8 @@ class Trainer(object):
         # (default "auto": on up to 16 patches per step -- at 32 the chip is saturated by the chain's own kernels, side work submitted
         # later only lengthens the tail: 4.58 -> 4.63 ms; "1" / "0" force it)
         self.fused_stem = os.environ.get("DISPU_STEM_FUSED", "1") != "0"     # one launch per dense block in the forward pass
+        self.prep_late = os.environ.get("DISPU_TRAIN_PREP_LATE", "1") != "0"     # zeroing / W^T copies for the backward behind the non-local branch's own kernels (0: in front of them, round 3)
+        self.prep_on_side = os.environ.get("DISPU_TRAIN_PREP_SIDE", "0") != "0"   # ... or on a weight-gradient stream during the forward (measured slower at 8 patches in fp32: 1.79 vs 1.71 ms)   # backward's zeroing / W^T copies on a dW stream during the forward
         self._defer_mode = os.environ.get("DISPU_TRAIN_DEFER", "auto")
         self.defer_side = self._defer_mode != "0"
         self._deferred = []
@@ -596,6 +598,16 @@ class Trainer(object):
             self.defer_side = rm <= 16 * 1024 and not torch.cuda.is_current_stream_capturing()
         self._shape = (B, N)
         self._x = x
+        if self.overlap_dw and self.prep_on_side:
+            # what the backward needs and nothing in the forward touches (zeroed accumulators, the W^T copies: ~45 us of kernels) goes to a
+            # weight-gradient stream, idle during the forward, right now; loss_backward() joins it.  (It used to ride at the head of the
+            # non-local branch "because that has slack" -- since the flash attention the main stream waits 75 us for exactly that branch.)
+            st_side, key = self._fork()
+            self._side_rr -= 1                                       # the weight gradients keep their round-robin assignment
+            main_st, self.st = self.st, st_side
+            self._backward_prep(ws)
+            self.st = main_st
+            self._prep_side = int(key[2:])
         P = self.P
         feat = ws["feat"]
         fe = "generator/feature_extraction_coarse/"
@@ -692,12 +704,8 @@ class Trainer(object):
         S = ws["S"]
 
         def nl_branch():
-            # what the backward needs and nothing in the forward touches rides on this branch (it has slack; no stream of its own: a
-            # fourth auxiliary stream changed the stream -> hardware-queue mapping and cost 0.1 ms per step)
-            self._zero(ws["zeroed"])      # the dense blocks' input gradients, the skip branch's d(up128): accumulated with atomics
-            if (self.use_wt or self.fused_heads_bwd) and self._t_desc.numel():       # W^T copies for the dX products
-                _lib.check(L.dispu_transpose_batched(self._t_desc.numel() // 3, _p(self._t_desc), _p(self.flat_p), _p(self.flat_pT), self.st),
-                           "transpose_batched")
+            if not (self.overlap_dw and self.prep_on_side) and not self.prep_late:
+                self._backward_prep(ws)
             self._lin(up128, 0, 128, ps + "PointShuffle/conv_kv", 0, ws["kv"], 0, 128)
             self._lin(up128, 0, 128, ps + "PointShuffle/conv_query", 0, ws["q"], 0, 64)
             if self.flash_attn:
@@ -711,6 +719,8 @@ class Trainer(object):
                 _lib.check(self._dl(B, M, M, 64, _p(S), M, M * M, _p(ws["kv"], 64), 128, M * 128, 0, None, 0, _p(ws["att"]), 64,
                                           M * 64, None, 0, 0, None, 0, 0, self.st), "att.V")
             self._lin(ws["att"], 0, 64, ps + "PointShuffle/conv_back_project", 1, ws["nl"], 0, 256)
+            if not (self.overlap_dw and self.prep_on_side) and self.prep_late:
+                self._backward_prep(ws)
 
         self._defer_branch(0, nl_branch)
         self._merge(2)
@@ -853,6 +863,12 @@ class Trainer(object):
         dcoarse, dfine = ws["dcoarse"].view(rm, 3), ws["dfine"].view(rm, 3)
         ps = "refine/PointShuffle/"
         fs = "refine/fine_coordinate_regressor/"
+        if self.overlap_dw and getattr(self, "_prep_side", None) is not None:
+            # the accumulators zeroed and the W^T copies made on a weight-gradient stream during the forward (see forward())
+            i, self._prep_side = self._prep_side, None
+            ev = self._ev(self._join_evs[i])
+            self._rec(ev, self._sides[i])
+            self._wait(torch.cuda.current_stream(self.device), ev)
         if not getattr(self, "_fresh", False):
             # a second backward() on the same forward (new targets / loss weights): the atomics accumulators still hold the previous,
             # already masked gradients -- clear them again, on this stream, before anything accumulates
@@ -1051,6 +1067,13 @@ class Trainer(object):
         self._join()                     # every dW is in the flat gradient buffer from here on (all-reduce, Adam)
 
     # -------------------------------------------------------------------------------------------------- step ----
+    def _backward_prep(self, ws):
+        L = _lib.tape_lib()
+        self._zero(ws["zeroed"])          # the dense blocks' input gradients, the skip branch's d(up128): accumulated with atomics
+        if (self.use_wt or self.fused_heads_bwd) and self._t_desc.numel():       # W^T copies for the dX products
+            _lib.check(L.dispu_transpose_batched(self._t_desc.numel() // 3, _p(self._t_desc), _p(self.flat_p), _p(self.flat_pT), self.st),
+                       "transpose_batched")
+
     def zero_grad(self):
         self.st = _lib.stream_ptr(self.device)
         self._zero(self.flat_g)

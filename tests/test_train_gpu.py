@@ -508,7 +508,9 @@ def test_graphed_steps_equal_eager_steps(dev, dtype):
         kept.append((te, tg))
         torch.cuda.synchronize()
         # gradients of this step (still in the flat buffers), per tensor against its own scale
-        floor = 1e-7 * float(e.flat_g.abs().max())      # e.g. the bias in front of a BatchNorm: its true gradient is 0, what is stored is rounding noise
+        # e.g. the bias in front of a BatchNorm: its true gradient is 0, what is stored is the rounding noise of float atomics that summed
+        # numbers up to |g|max in a run-dependent order -- a few ulp of THAT (1.2e-7 |g|max was observed once in ~15 runs)
+        floor = 4e-7 * float(e.flat_g.abs().max())
         for k in e.G:
             scale = float(e.G[k].abs().max()) + 1e-12
             assert float((g.G[k] - e.G[k]).abs().max()) <= gtol * scale + floor + 2e-6, (i, k)
@@ -552,7 +554,7 @@ def test_taped_steps_equal_eager_steps(dev, dtype):
         te = e.train_step(xs, gs, rs)
         tg = g.train_step_taped(xs, gs, rs)
         torch.cuda.synchronize()
-        floor = 1e-7 * float(e.flat_g.abs().max())
+        floor = 4e-7 * float(e.flat_g.abs().max())
         for k in e.G:
             scale = float(e.G[k].abs().max()) + 1e-12
             assert float((g.G[k] - e.G[k]).abs().max()) <= gtol * scale + floor + 2e-6, (i, k)
