@@ -361,9 +361,7 @@ def save_generator_params(prefix, params, scope="generator", step=None, epoch=No
     out["epoch"] = np.array(float(int(m.group(1)) if epoch is None else epoch), np.float32)
     out["global_step"] = np.array(int(global_step), np.int32)
     write_bundle(prefix, out)
-    d = os.path.dirname(os.path.abspath(prefix))
-    with open(os.path.join(d, "checkpoint"), "w") as f:
-        f.write('model_checkpoint_path: "%s"\nall_model_checkpoint_paths: "%s"\n' % (base, base))
+    _update_state_file(os.path.dirname(os.path.abspath(prefix)), base)
     return prefix
 
 
@@ -401,13 +399,42 @@ def restore_train_state(log_dir, trainer):
             flat[off:off + view.numel()].copy_(torch.from_numpy(np.ascontiguousarray(raw[name], np.float32).reshape(-1)))
     if missing:
         raise KeyError("checkpoint %s lacks %d Adam slots (a test-graph checkpoint?), e.g. %s" % (prefix, len(missing), missing[:2]))
-    # TF keeps beta^(t+1) after t updates (initial value beta, multiplied after every apply): adam_t = t
-    b1 = float(trainer.opts.beta)
-    p1 = float(raw["beta1_power"])
-    trainer.adam_t = max(0, int(round(math.log(p1) / math.log(b1))) - 1) if 0.0 < p1 < 1.0 else 0
+    trainer.adam_t = adam_steps_from_bundle(raw, float(trainer.opts.beta))
     trainer.epoch = int(round(float(raw["epoch"]))) if "epoch" in raw else epoch
+    # `global_step`: the reference calls minimize() without it (DisPU/model.py:178), so ITS bundles always hold 0; bundles written
+    # by save_train_state hold this repo's own step counter (Trainer.global_step, one per train_step).  Nothing on the compute path
+    # reads it (the learning rate follows `epoch`, Adam's bias correction follows adam_t).
     trainer.global_step = int(raw["global_step"]) if "global_step" in raw else 0
     return epoch
+
+
+ADAM_T_KEY = "dispu/adam_t"       # int64 scalar only this repo's writer emits (a tf.train.Saver ignores names its graph lacks)
+ADAM_T_SATURATED = 1 << 30        # both bias corrections are exactly 1.0f from ~1.6e4 steps on: any larger t behaves the same
+
+
+def adam_steps_from_bundle(raw, beta1, beta2=0.999):
+    """Number of Adam updates t behind a train-graph bundle.  TF keeps beta^(t+1) (initial value beta, one fp32 multiply per
+    apply) in `beta1_power` / `beta2_power`.  0.9^(t+1) leaves the normal fp32 range at t ~ 828, is denormal until ~ 980 and then
+    sticks at a denormal or 0, so beyond a few hundred steps it cannot give t -- the reference saves every 20 epochs (thousands of
+    steps).  Order of preference: (1) this repo's explicit counter; (2) beta1_power while it is a NORMAL fp32 (exact: the spacing of
+    log(p) between consecutive t is 0.105 against an accumulated rounding error < 1e-4); (3) beta2_power while normal (0.999^(t+1)
+    stays normal until t ~ 87 k; its accumulated rounding error blurs t by a few steps only where both corrections already equal 1
+    to ~1e-7, i.e. where the value no longer matters); (4) saturated: both corrections are 1."""
+    import math
+    if ADAM_T_KEY in raw:
+        return max(0, int(np.asarray(raw[ADAM_T_KEY]).reshape(-1)[0]))
+    tiny = float(np.finfo(np.float32).tiny)
+    p1 = float(np.asarray(raw["beta1_power"], np.float32)) if "beta1_power" in raw else None
+    p2 = float(np.asarray(raw["beta2_power"], np.float32)) if "beta2_power" in raw else None
+    if p1 is not None and p1 >= 1.0 and (p2 is None or p2 >= 1.0):
+        return 0
+    if p1 is not None and tiny <= p1 < 1.0:
+        return max(0, int(round(math.log(p1) / math.log(beta1))) - 1)
+    if p2 is not None and tiny <= p2 < 1.0:
+        return max(0, int(round(math.log(p2) / math.log(beta2))) - 1)
+    if p1 is None and p2 is None:
+        return 0
+    return ADAM_T_SATURATED
 
 
 def save_train_state(log_dir, trainer, epoch=None):
@@ -429,13 +456,31 @@ def save_train_state(log_dir, trainer, epoch=None):
         shp = out["generator/" + k].shape
         out["generator/%s/Adam" % k] = trainer.flat_m[off:off + view.numel()].cpu().numpy().reshape(shp).copy()
         out["generator/%s/Adam_1" % k] = trainer.flat_v[off:off + view.numel()].cpu().numpy().reshape(shp).copy()
-    out["beta1_power"] = np.array(float(trainer.opts.beta) ** (trainer.adam_t + 1), np.float32)
-    out["beta2_power"] = np.array(0.999 ** (trainer.adam_t + 1), np.float32)
+    # what TF's variables would hold after adam_t applies (beta^(t+1), flushed to the smallest denormal where TF's repeated
+    # fp32 multiply sticks), plus the exact counter under a name of this repo's own
+    t1 = min(trainer.adam_t, 1 << 20) + 1
+    out["beta1_power"] = np.maximum(np.array(float(trainer.opts.beta) ** t1, np.float32), np.float32(1e-45))
+    out["beta2_power"] = np.maximum(np.array(0.999 ** t1, np.float32), np.float32(1e-45))
+    out[ADAM_T_KEY] = np.array(int(trainer.adam_t), np.int64)
     out["epoch"] = np.array(float(epoch), np.float32)
     out["global_step"] = np.array(int(trainer.global_step), np.int32)
     os.makedirs(log_dir, exist_ok=True)
     prefix = os.path.join(log_dir, "model-%d" % epoch)
     write_bundle(prefix, out)
-    with open(os.path.join(log_dir, "checkpoint"), "w") as f:
-        f.write('model_checkpoint_path: "%s"\nall_model_checkpoint_paths: "%s"\n' % (os.path.basename(prefix), os.path.basename(prefix)))
+    _update_state_file(log_dir, os.path.basename(prefix))
     return prefix
+
+
+def _update_state_file(log_dir, base, max_to_keep=5):
+    """The `checkpoint` state file as tf.train.Saver(max_to_keep=5) maintains it: the newest prefix first as
+    model_checkpoint_path, then the last `max_to_keep` prefixes oldest-first as all_model_checkpoint_paths."""
+    path = os.path.join(log_dir, "checkpoint")
+    prev = []
+    if os.path.exists(path):
+        with open(path) as f:
+            prev = re.findall(r'all_model_checkpoint_paths:\s*"([^"]+)"', f.read())
+    keep = ([p for p in prev if p != base] + [base])[-max_to_keep:]
+    with open(path, "w") as f:
+        f.write('model_checkpoint_path: "%s"\n' % base)
+        for p in keep:
+            f.write('all_model_checkpoint_paths: "%s"\n' % p)

@@ -166,7 +166,9 @@ __device__ __forceinline__ void am_row_body(int cloud, int rb, int c, float4* ti
         x1 = p1[k * 3 + 0]; y1 = p1[k * 3 + 1]; z1 = p1[k * 3 + 2];
         if constexpr (!FIRST) rl = am_ld<COH>(&v.ratL[(size_t)t * n + k]);
     }
-    float s3 = 0.f, s1 = 0.f;
+    // m <= AM_CH: the one tile holds every partner of the point, so pass 1's chain IS the reference's sequential chain when it starts
+    // at 1e-9f (tf_approxmatch_g.cu:60 `suml = 1e-9f`) instead of being added to it afterwards; the consumer then takes p1[0] as is
+    float s3 = 0.f, s1 = (m <= AM_CH) ? 1e-9f : 0.f;
 #pragma unroll 4
     for (int i = 0; i < len; ++i) {
         const float4 q = tile[i];
@@ -215,7 +217,7 @@ __device__ __forceinline__ void am_col_body(int cloud, int cb, int c2, float4* t
             const float tot = am_sum_partials<COH>(v.p3 + k, (size_t)n, nc1, 0.f, true);
             reml = fmaxf(0.0f, am_ld<COH>(&v.remL[(size_t)(t - 1) * n + k]) - tot);
         }
-        const float suml = am_sum_partials<COH>(v.p1 + k, (size_t)n, nc1, 1e-9f, false);
+        const float suml = am_sum_partials<COH>(v.p1 + k, (size_t)n, nc1, 1e-9f, nc1 == 1);     // one chunk: its chain began at 1e-9f
         const float ratl = reml / suml;
         if (cb == 0) {
             if (t > 0) am_st<COH>(&v.remL[(size_t)t * n + k], reml);

@@ -152,8 +152,17 @@ class Trainer(object):
             self.load_params(params)
 
     # --------------------------------------------------------------------------------------------- parameters ----
+    def _invalidate_recordings(self):
+        """Launch tapes and captured hipGraphs hold RAW device pointers (flat parameter / gradient / moment buffers, W^T copies,
+        scratch, workspaces).  Whenever one of those buffers is re-allocated every recording is dropped, so the next
+        train_step_taped / train_step_graphed records afresh instead of replaying launches onto freed memory."""
+        self._tapes.clear()
+        self._graphs.clear()
+
     def load_params(self, params):
         dev = self.device
+        self._invalidate_recordings()
+        self._ws.clear()
         names = [k for k in params if k.endswith(("/weights", "/biases", "/gamma", "/beta"))]
         sizes = [int(np.asarray(params[k]).size) for k in names]
         # every tensor starts on a 16-byte boundary inside the flat buffers
@@ -261,6 +270,7 @@ class Trainer(object):
         if cur is None or cur.numel() < n:
             if cur is not None:
                 torch.cuda.synchronize(self.device)          # a launch on that stream may still be using the old buffer
+                self._invalidate_recordings()                # ... and a tape / graph recorded at a smaller shape points into it
             cur = self._scratch[key] = torch.empty(max(int(n), 1 << 20), dtype=torch.float32, device=self.device)
         return cur
 

@@ -463,7 +463,8 @@ ORC_API void orc_nn_distance_grad(int b, int n, int m, const float *xyz1, const 
 /* `chunk` selects the association of the three running sums.  chunk <= 0: one sequential chain per point, the
  * reference kernel's order (a thread adds its m or n terms one after the other).  chunk = C > 0: the chain is cut into
  * consecutive pieces of C partners, each piece summed sequentially from 0, and the pieces are added in ascending
- * order (to 1e-9f for pass 1, to the first piece for passes 2 and 3).  This is the order of the MI355X kernels
+ * order (to 1e-9f for pass 1 -- unless ONE piece holds all m partners, then its chain starts at 1e-9f, i.e. m <= C is the reference's
+ * order exactly -- to the first piece for passes 2 and 3).  This is the order of the MI355X kernels
  * (csrc/approxmatch.hip: one workgroup per (256 points) x (C partners) tile, AM_CH = 128), which lets one cloud
  * fill the chip; it differs from the sequential chain by reassociation only (tests bound the difference). */
 ORC_API void orc_approx_match_chunked(int b, int n, int m, const float *xyz1, const float *xyz2, float *match,
@@ -488,15 +489,16 @@ ORC_API void orc_approx_match_chunked(int b, int n, int m, const float *xyz1, co
             for (int k = 0; k < n; ++k) {
                 const float x1 = p1[k * 3], y1 = p1[k * 3 + 1], z1 = p1[k * 3 + 2];
                 float suml = 1e-9f;
+                const int seq1 = seq || m <= chunk;      /* one piece holds every partner: its chain starts at 1e-9f like the reference's */
                 for (int l0 = 0; l0 < m; l0 += chunk) {
                     const int lend = l0 + chunk < m ? l0 + chunk : m;
-                    float s = seq ? 1e-9f : 0.0f;
+                    float s = seq1 ? 1e-9f : 0.0f;
                     for (int l = l0; l < lend; ++l) {
                         const float d2 = sqdist3(p2[l * 3] - x1, p2[l * 3 + 1] - y1, p2[l * 3 + 2] - z1, contract);
                         const float e = ORC_EXP(level * d2);
                         s = contract ? fmaf(e, remainR[l], s) : s + e * remainR[l];
                     }
-                    suml = seq ? s : suml + s;
+                    suml = seq1 ? s : suml + s;
                 }
                 ratioL[k] = remainL[k] / suml;
             }

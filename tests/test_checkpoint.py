@@ -203,3 +203,57 @@ def test_product_writer_read_back_by_the_independent_parser(tmp_path):
         keys += [k for k, _ in block(o, z)]
     assert keys == sorted(keys) and keys[0] == b"" and len(keys) > 2 * len(P)
     assert b"generator/generator/upshuffle_0/conv1/weights/Adam_1" in keys and b"global_step" in keys
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Adam's step count behind a train-graph bundle (round-4 advisor: beta1_power underflows long before a real checkpoint)
+# ------------------------------------------------------------------------------------------------------------------
+def _tf_powers(t, beta1=0.9, beta2=0.999):
+    """beta1_power / beta2_power exactly as TF's AdamOptimizer leaves them after t applies: initial value beta, then one fp32
+    multiply per apply (training/adam.py:_finish)."""
+    b1, b2 = np.float32(beta1), np.float32(beta2)
+    p1 = np.full((), b1, np.float32)
+    p2 = np.full((), b2, np.float32)
+    with np.errstate(under="ignore"):
+        for _ in range(t):
+            p1 = np.float32(p1 * b1)
+            p2 = np.float32(p2 * b2)
+    return p1, p2
+
+
+@pytest.mark.parametrize("t", [0, 1, 3, 9, 500, 827])
+def test_adam_steps_exact_while_beta1_power_is_normal(t):
+    p1, p2 = _tf_powers(t)
+    assert CK.adam_steps_from_bundle({"beta1_power": p1, "beta2_power": p2}, 0.9) == t
+
+
+@pytest.mark.parametrize("t", [900, 966, 1000, 2000, 4000, 20000, 60000])
+def test_adam_steps_from_beta2_power_once_beta1_power_underflowed(t):
+    p1, p2 = _tf_powers(t)
+    assert float(p1) < float(np.finfo(np.float32).tiny)         # denormal or stuck: useless
+    got = CK.adam_steps_from_bundle({"beta1_power": p1, "beta2_power": p2}, 0.9)
+    # beta2_power carries the accumulated rounding of t fp32 multiplies: t comes back to a few steps, where it no longer matters --
+    # what has to agree is the bias-corrected learning-rate factor Adam derives from it
+    assert abs(got - t) <= max(2, t // 2000), (got, t)
+    lr_t = lambda n: np.sqrt(1.0 - 0.999 ** n) / (1.0 - 0.9 ** n)
+    assert abs(lr_t(got) - lr_t(t)) <= 1e-6 * lr_t(t)
+    assert got != 0 and (t == 966 or got != 966)                # the two values the old formula produced for every real checkpoint
+
+
+def test_adam_steps_saturate_when_both_powers_underflowed_and_explicit_counter_wins():
+    p1, p2 = _tf_powers(120000)
+    got = CK.adam_steps_from_bundle({"beta1_power": p1, "beta2_power": p2}, 0.9)
+    assert got == CK.ADAM_T_SATURATED
+    assert np.sqrt(1.0 - 0.999 ** got) / (1.0 - 0.9 ** got) == 1.0
+    assert CK.adam_steps_from_bundle({"beta1_power": p1, "beta2_power": p2, CK.ADAM_T_KEY: np.array(123456, np.int64)}, 0.9) == 123456
+    assert CK.adam_steps_from_bundle({}, 0.9) == 0             # a test-graph bundle: a fresh optimizer
+
+
+def test_state_file_keeps_the_last_five_prefixes_like_tf_saver(tmp_path):
+    P = PP.init_params(2)
+    for ep in (20, 40, 60, 80, 100, 120):
+        CK.save_generator_params(str(tmp_path / "model"), P, step=ep)
+    txt = (tmp_path / "checkpoint").read_text().splitlines()
+    assert txt[0] == 'model_checkpoint_path: "model-120"'
+    assert txt[1:] == ['all_model_checkpoint_paths: "model-%d"' % e for e in (40, 60, 80, 100, 120)]
+    assert CK.pre_load_checkpoint(str(tmp_path))[0] == 120

@@ -115,3 +115,38 @@ def test_train_state_restore_resumes_the_same_trajectory(tmp_path, dev):
     CK.save_generator_params(str(tmp_path / "model"), a.params(), step=13)
     with pytest.raises(KeyError):
         CK.restore_train_state(str(tmp_path), b)
+
+
+def test_train_state_round_trip_far_into_training(tmp_path, dev):
+    """beta1_power = 0.9^(t+1) is denormal from t ~ 830 and 0 from ~ 990; the reference saves every 20 epochs (thousands of steps).
+    A bundle written at adam_t = 2500 must restore adam_t = 2500 (explicit counter), and one that only carries TF's two power
+    variables (as a real TF checkpoint would) must restore the same bias-corrected learning rate -- not adam_t = 0 or 966."""
+    from dispu_amd import checkpoint as CK, synth
+    from dispu_amd.train import Trainer
+    P = _weights(8)
+    B, n = 2, 256
+    x = torch.from_numpy(synth.patches(B, n, seed=1)).to(dev)
+    gt = torch.from_numpy(synth.patches(B, 4 * n, seed=2)).to(dev)
+    radius = torch.ones(B, device=dev)
+    a = Trainer(params=P, device=dev)
+    a.epoch = 40
+    a.train_step(x, gt, radius)
+    a.adam_t = 2500                                   # as if 2500 updates had been applied
+    prefix = CK.save_train_state(str(tmp_path), a)
+    raw = CK.read_bundle(prefix)
+    assert int(raw[CK.ADAM_T_KEY]) == 2500 and 0.0 < float(raw["beta1_power"]) < 1.2e-38
+    b = Trainer(params=_weights(9), device=dev)
+    CK.restore_train_state(str(tmp_path), b)
+    assert b.adam_t == 2500
+    # the same bundle as TensorFlow would have written it: no explicit counter, beta1_power stuck at the smallest denormal
+    del raw[CK.ADAM_T_KEY]
+    raw["beta1_power"] = np.array(1e-45, np.float32)
+    CK.write_bundle(prefix, raw)
+    c = Trainer(params=_weights(10), device=dev)
+    CK.restore_train_state(str(tmp_path), c)
+    assert abs(c.adam_t - 2500) <= 2, c.adam_t
+    for t in (a, c):
+        t.train_step(x, gt, radius)
+    torch.cuda.synchronize()
+    diff = np.abs(N(a.flat_p) - N(c.flat_p))
+    assert diff.max() <= 2.5e-3 and np.quantile(diff, 0.999) <= 2e-5, (diff.max(), np.quantile(diff, 0.999))

@@ -343,7 +343,9 @@ def test_three_nn_exact(ops, dev, b, n, m, arith):
 
 
 @pytest.mark.parametrize("arith", [PLAIN, CONTRACT])
-@pytest.mark.parametrize("b,n,m", [(4, 1024, 1024), (2, 4096, 4096), (3, 100, 777), (1, 1, 1), (2, 2049, 513)])
+@pytest.mark.parametrize("b,n,m", [(4, 1024, 1024), (2, 4096, 4096), (3, 100, 777), (1, 1, 1), (2, 2049, 513),
+                                   # either side of the reference kernel's 512-point staging batch (tf_nndistance_g.cu:6) and of 6 x 512
+                                   (2, 511, 513), (2, 512, 512), (1, 513, 511), (1, 3072, 3073), (1, 3073, 3072), (2, 512, 3073)])
 def test_nn_distance_exact(ops, dev, b, n, m, arith):
     rng = np.random.default_rng(n + m)
     x1, x2 = rng.standard_normal((b, n, 3)).astype(np.float32), rng.standard_normal((b, m, 3)).astype(np.float32)
@@ -368,7 +370,9 @@ def test_nn_distance_grad_and_autograd(ops, dev):
 
 
 @pytest.mark.parametrize("b,n,m", [(2, 256, 256), (1, 1024, 1024), (2, 100, 300), (2, 300, 100), (1, 1100, 1030), (3, 1, 5), (2, 129, 127),
-                                   (1, 2048, 512)])
+                                   (1, 2048, 512),
+                                   # either side of the reference kernel's 1024-point batch (tf_approxmatch_g.cu:11 `Block = 1024`)
+                                   (1, 1023, 1025), (1, 1025, 1023), (1, 1024, 1023)])
 def test_approx_match_and_cost(ops, dev, b, n, m):
     if min(n, m) < 8:                 # the patch synthesiser normalises by the max radius: undefined for a single point
         rng = np.random.default_rng(n * 1000 + m)
@@ -751,6 +755,22 @@ def test_match_cost_reference_signature_entries(dev, b, n, m):
     o1, o2 = O.match_cost_grad(x1, x2, mo)
     assert np.allclose(N(g1), o1, atol=3e-5) and np.allclose(N(g2), o2, atol=3e-5)
     assert np.allclose(N(h1), o1, atol=3e-5) and np.array_equal(N(h2), N(g2))
+
+
+@pytest.mark.parametrize("b,n,m", [(2, 128, 128), (3, 100, 128), (2, 77, 50), (2, 64, 128), (1, 128, 1), (4, 16, 16)])
+@pytest.mark.parametrize("arith", [PLAIN, CONTRACT])
+def test_approx_match_reference_association_bit_exact_at_one_tile(ops, dev, b, n, m, arith):
+    """Ties the kernels to the REFERENCE's own summation order with no reassociation in between: for n, m <= 128 one tile holds
+    every partner of every point, so each running sum of the auction is a single sequential chain -- pass 1 starting at 1e-9f
+    (tf_approxmatch_g.cu:60), passes 2 / 3 at their first term -- which is oracle chunk = 0, the restatement pinned to the
+    reference's approxmatch_cpu golden (tests/test_oracle.py).  Bit-exact in pinned-exp mode; and chunk = 128 degenerates to it."""
+    rng = np.random.default_rng(1000 * n + m)
+    x1, x2 = rng.random((b, n, 3), dtype=np.float32), rng.random((b, m, 3), dtype=np.float32)
+    contract = 1 if arith == CONTRACT else 0
+    seq = O.approx_match(x1, x2, contract=contract, pinned_exp=True, chunk=0)
+    assert np.array_equal(seq, O.approx_match(x1, x2, contract=contract, pinned_exp=True, chunk=O.AM_CHUNK))
+    got = N(ops["A"].approx_match(T(x1, dev), T(x2, dev), arith=arith | PINNED_EXP))
+    assert np.array_equal(got, seq)
 
 
 def test_approx_match_4096_against_the_sequential_order(ops, dev):

@@ -568,6 +568,46 @@ def test_taped_steps_equal_eager_steps(dev, dtype):
     assert g.global_step == 4 and g.adam_t == 4
 
 
+def test_tapes_are_dropped_when_their_buffers_move(dev):
+    """A launch tape / captured graph holds raw device pointers.  A later, larger batch that grows a scratch buffer, or
+    load_params (checkpoint restore) re-allocating the flat parameter / gradient buffers, must invalidate every recording: the
+    next taped step at the old shape records afresh and still equals the eager step (round-4 advisor finding)."""
+    from dispu_amd import synth
+    from dispu_amd.train import Trainer
+    P = OG.init_params(seed=23, bias_scale=0.05, bn_random=True)
+    e = Trainer(params=P, device=dev)
+    g = Trainer(params=P, device=dev)
+
+    def both(B, seed):
+        x, gt = synth.patch_with_gt(B, 256, 1024, seed=seed)
+        rs = torch.ones(B, device=dev)
+        for name in ("flat_p", "flat_m", "flat_v", "moving_mean", "moving_var"):
+            getattr(g, name).copy_(getattr(e, name))
+        g.adam_t, g.global_step = e.adam_t, e.global_step
+        te = e.train_step(dv(x, dev), dv(gt, dev), rs)
+        tg = g.train_step_taped(dv(x, dev), dv(gt, dev), rs)
+        torch.cuda.synchronize()
+        floor = 4e-7 * float(e.flat_g.abs().max())
+        for k in e.G:
+            scale = float(e.G[k].abs().max()) + 1e-12
+            assert float((g.G[k] - e.G[k]).abs().max()) <= 2e-5 * scale + floor + 2e-6, (B, seed, k)
+        for k in te:
+            assert abs(float(te[k]) - float(tg[k])) <= 1e-5 * max(1.0, abs(float(te[k]))), (B, seed, k)
+
+    both(2, 60)
+    small_tape = next(iter(g._tapes.values()))["tape"]
+    ptrs_before = {k: v.data_ptr() for k, v in g._scratch.items()}
+    both(16, 61)                                   # larger shape: scratch buffers grow -> the B = 2 tape must not survive
+    grew = any(g._scratch[k].data_ptr() != p for k, p in ptrs_before.items())
+    if grew:
+        assert all(t["tape"] is not small_tape for t in g._tapes.values())
+    both(2, 62)                                    # replays (or re-records) at the small shape: still the eager step
+    g.load_params(e.params())                      # checkpoint restore path: flat buffers re-allocated
+    assert not g._tapes and not g._graphs and not g._ws
+    g.adam_t = e.adam_t
+    both(2, 63)
+
+
 def test_forward_refuses_shapes_the_fused_kernels_cannot_take(dev):
     from dispu_amd import synth
     from dispu_amd.train import Trainer
