@@ -171,12 +171,26 @@ def pmc_traffic(kern):
             rows = json.load(f)
     except (OSError, ValueError):
         return None, None
+    # the row of exactly THIS kernel instantiation or nothing: no fall-back to a sibling instantiation of an older build
     row = rows.get("linear_mfma_kernel" + kern[len("linear"):])
-    if row is None and kern.endswith(", 6>"):              # the counter passes of a build in which after_conv still ran as EPI 4 / EPI 0
-        row = rows.get("linear_mfma_kernel" + kern[len("linear"):-4] + ", 4>")
     if not row or "hbm_bytes_corrected" not in row:
         return None, None
-    return row["hbm_bytes_corrected"], "profiles/pmc_traffic_latest.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
+    meta = rows.get("_meta", {})
+    src = "profiles/pmc_traffic_latest.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes"
+    try:
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("dispu_build", os.path.join(ROOT, "dis-pu_amd", "build.py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        cur = mod.source_hash()
+    except Exception:                                          # noqa: BLE001
+        cur = None
+    if meta.get("csrc_sha1") and cur:
+        src += "; taken at commit %s, kernel sources %s this tree's" % (str(meta.get("git_head"))[:10],
+                                                                       "==" if meta["csrc_sha1"] == cur else "!=")
+    else:
+        src += "; build of the counter passes not recorded"
+    return row["hbm_bytes_corrected"], src + ")"
 
 
 def main():
@@ -225,20 +239,36 @@ def main():
     gen.return_views = True                                   # results stay in the workspace: no copy kernels in the step
     gen.split_bf16 = bool(args.split_bf16)
     x = torch.from_numpy(synth.patches(PATCHES_PER_GPU, NPOINT, seed=1000 * 2 + rank)).to(dev)   # 1000*config + rank
-    gathered = torch.empty((world * PATCHES_PER_GPU, NPOINT * UP, 3), dtype=torch.float32, device=dev) if world > 1 else None
-
     from dispu_amd import parallel
 
+    # N > 1: the all-gather of step i runs on a comm lane (side HIP stream under RCCL) while step i + 1 computes: two result buffers,
+    # the fine head writes its clouds into the slot's own [32, 1024, 3] buffer (Generator.fine_out), nothing waits on the compute
+    # stream.  DISPU_BENCH_GATHER=sync keeps round 4's exposed gather (A/B), =off drops the collective (the compute-only reference the
+    # two-rank dry run compares against).
+    gather_mode = os.environ.get("DISPU_BENCH_GATHER", "overlap") if world > 1 else "off"
+    pipe = parallel.GatherPipeline((PATCHES_PER_GPU, NPOINT * UP, 3), dev) if gather_mode == "overlap" else None
+    gathered = torch.empty((world * PATCHES_PER_GPU, NPOINT * UP, 3), dtype=torch.float32, device=dev) if gather_mode == "sync" else None
+
     def step_eager():
+        if pipe is not None:
+            slot, gen.fine_out = pipe.acquire()
         _, fine = gen(x)
-        if world > 1:
+        if pipe is not None:
+            pipe.launch(slot)
+        elif gathered is not None:
             parallel.all_gather_clouds(fine, n_items=world * PATCHES_PER_GPU, out=gathered)
         return fine
 
+    def drain():
+        if pipe is not None:
+            pipe.drain()                                       # every gather launched so far is complete before the clock stops
+
     step_eager()
+    step_eager()
+    drain()
     torch.cuda.synchronize()
     launch = "eager"
-    graph = None
+    graphs = None
     if not args.eager:
         try:
             side = torch.cuda.Stream()
@@ -246,34 +276,45 @@ def main():
             with torch.cuda.stream(side):
                 gen(x)
             torch.cuda.current_stream().wait_stream(side)
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                gen(x)                                         # generator only; the collective stays outside the graph
+            graphs = []
+            for buf in (pipe.local if pipe is not None else [None]):   # one graph per result slot (the output pointer is baked in)
+                gen.fine_out = buf
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    gen(x)                                     # generator only; the collective stays outside the graph
+                graphs.append(g)
             launch = "hipgraph"
         except Exception as e:                                 # noqa: BLE001
-            graph = None
+            graphs = None
             launch = "eager (graph capture failed: %s)" % type(e).__name__
             torch.cuda.synchronize()
+    gen.fine_out = None
 
     fine_buf = gen._ws[(PATCHES_PER_GPU, NPOINT)]["fine"]
 
     def step():
-        if graph is not None:
-            graph.replay()
-            if world > 1:
-                parallel.all_gather_clouds(fine_buf, n_items=world * PATCHES_PER_GPU, out=gathered)
-        else:
+        if graphs is None:
             step_eager()
+        elif pipe is not None:
+            slot, _ = pipe.acquire()
+            graphs[slot].replay()
+            pipe.launch(slot)
+        else:
+            graphs[0].replay()
+            if gathered is not None:
+                parallel.all_gather_clouds(fine_buf, n_items=world * PATCHES_PER_GPU, out=gathered)
 
     # setup, before the contract's W warm-up steps: the replays that bring the device to its sustained clocks (a cold device runs the
     # first ~20 steps 2 % slower than every later loop: ms_per_step_repeats of round 4); reported as "settle_steps"
     for _ in range(SETTLE_STEPS):
         step()
+    drain()
     torch.cuda.synchronize()
     # still setup: which way of launching the step is faster on this box?  A hipGraph replay costs the host nothing, but this runtime's
     # graph executor overlaps the step's two streams less than eager submission does; the eager step needs ~17 launches of
     # host time per 0.94 ms.  40 steps each, the better one runs the warm-up and the timed steps; config.launch says which.
-    if graph is not None and not args.graph_only:
+    calib = None
+    if graphs is not None and not args.graph_only:
         def _time(fn, n=40):
             torch.cuda.synchronize()
             if world > 1:
@@ -281,6 +322,7 @@ def main():
             t = time.perf_counter()
             for _ in range(n):
                 fn()
+            drain()
             torch.cuda.synchronize()
             return (time.perf_counter() - t) / n
         def _eager_step():
@@ -293,18 +335,20 @@ def main():
             dist.all_reduce(pick, op=dist.ReduceOp.MIN)
         calib = {"hipgraph_ms": t_graph * 1e3, "eager_ms": t_eager * 1e3}
         if float(pick.item()) > 0.5:
-            graph = None
+            graphs = None
             launch = "eager (two streams; picked over hipGraph replay in setup: %.4f vs %.4f ms per step)" % (t_eager * 1e3, t_graph * 1e3)
         else:
             launch = "hipgraph (picked over eager launches in setup: %.4f vs %.4f ms per step)" % (t_graph * 1e3, t_eager * 1e3)
     for _ in range(args.warmup):
         step()
+    drain()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    drain()                                                    # the K-th step's gather is inside the timed region too
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -323,6 +367,7 @@ def main():
         t1 = time.perf_counter()
         for _ in range(args.steps):
             step()
+        drain()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -481,7 +526,13 @@ def main():
                                       "fp32%s" % (1 if world == 1 else 2, PATCHES_PER_GPU, NPOINT,
                                                   "" if world == 1 else ", + %s all-gather of the upsampled clouds" % ("RCCL" if backend == "nccl" else backend)),
                           "patches_per_gpu": PATCHES_PER_GPU, "global_patches": world * PATCHES_PER_GPU,
-                          "points_out_per_step": pts, "launch": launch, "weights": "xavier-uniform seed 1234, zero bias",
+                          "points_out_per_step": pts, "launch": launch, "launch_calibration_ms": calib,
+                          "collective": (None if world == 1 else
+                                         {"overlap": "all-gather of step i on a comm lane while step i + 1 computes (two result slots, "
+                                                     "parallel.GatherPipeline); the K-th gather completes inside the timed region",
+                                          "sync": "all-gather on the compute stream after every step (round-4 behaviour)",
+                                          "off": "none (compute-only reference)"}[gather_mode]),
+                          "weights": "xavier-uniform seed 1234, zero bias",
                           "parallelism": "patch-sharded x%d" % world},
                "roofline": roof}
         if alt is not None:
@@ -517,6 +568,8 @@ def main():
         if world == 1 and not args.no_ops:
             roof["side_tables"] = "profiles/bench_side_tables.json (keys: kernels, ops, train_step, ops_peaks, cpu_baseline_ops)"
         print(json.dumps(out))
+    if pipe is not None:
+        pipe.close()
     if world > 1:
         dist.destroy_process_group()
 

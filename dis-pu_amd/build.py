@@ -24,6 +24,18 @@ def _headers():
     return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h"))
 
 
+def source_hash():
+    """sha1 over the kernel sources (csrc/*.hip, csrc/*.h, this file's flags): names the build a profile was taken from -- the GPU box
+    has no .git, so counter summaries are stamped with this and bench.py checks it against the tree it runs from."""
+    import hashlib
+    h = hashlib.sha1(" ".join(FLAGS).encode())
+    for f in _sources() + _headers():
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
 def _stale(target, deps):
     if not os.path.exists(target):
         return True

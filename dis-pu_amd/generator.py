@@ -98,6 +98,9 @@ class Generator(object):
         # tensors (like sess.run in the reference); return_views = True hands out the workspace buffers themselves
         # (no copies -- bench.py / hipGraph capture), which the NEXT call with the same (B, N) overwrites.
         self.return_views = False
+        # optional caller-owned [B, 4N, 3] float32 buffer the fine head writes its clouds into instead of the workspace's (the
+        # sharded serving loop alternates two of them so that the all-gather of one step overlaps the next step: parallel.GatherPipeline)
+        self.fine_out = None
         self._trainer = None
         if params is not None:
             self.load_params(params)
@@ -303,6 +306,12 @@ class Generator(object):
         coarse = ws["coarse"]
         heads = self.fused_heads and rm % 128 == 0
         in_chain = heads and self.chain_inputs
+        fine = ws["fine"]
+        if self.fine_out is not None:
+            fine = self.fine_out
+            if not (isinstance(fine, torch.Tensor) and fine.device == inputs.device and fine.dtype == torch.float32
+                    and tuple(fine.shape) == (B, M, 3) and fine.is_contiguous()):
+                raise ValueError("fine_out must be a contiguous float32 [%d, %d, 3] tensor on %s" % (B, M, inputs.device))
         if not in_chain:
             self._call("dup_grid", L.dispu_dup_grid, B, N, 256, self.up_ratio, ptr(ws["h256"]), 256, ptr(self.w_up_grid), ptr(b1), ptr(self.grid),
                        ptr(ws["up256"]), 256, st)
@@ -442,7 +451,7 @@ class Generator(object):
             w4, b4_ = self._w(fs + "fc_layer2")
             self._call("mlp_chain[fine]", L.dispu_mlp_chain_sum3, rm, 256, 256, 256, 64, ptr(ws["aft"]), ptr(ws["skip"]), ptr(ws["nl"]), 256,
                        ptr(w1), ptr(b1_), ptr(w2), ptr(b2_), ptr(w3), ptr(b3_), ptr(w4), ptr(b4_),
-                       ptr(ws["agg"]) if self.keep_intermediates else None, 256, 1, ptr(coarse), 3, ptr(ws["fine"]), 3, st)
+                       ptr(ws["agg"]) if self.keep_intermediates else None, 256, 1, ptr(coarse), 3, ptr(fine), 3, st)
         elif heads:
             w1, b1_ = self._w(ps + "aggregation")
             w2, b2_ = self._w(fs + "fc_layer0")
@@ -450,7 +459,7 @@ class Generator(object):
             w4, b4_ = self._w(fs + "fc_layer2")
             self._call("mlp_chain[fine]", L.dispu_mlp_chain, rm, 256, 256, 256, 64, ptr(ws["aft"]), 256, ptr(w1), ptr(b1_), ptr(w2), ptr(b2_),
                        ptr(w3), ptr(b3_), ptr(w4), ptr(b4_), ptr(ws["agg"]) if self.keep_intermediates else None, 256, 1, ptr(coarse), 3,
-                       ptr(ws["fine"]), 3, st)
+                       ptr(fine), 3, st)
         else:
             w, b = self._w(ps + "aggregation")
             self._linear(st, ws["aft"], 256, w, b, 1, ws["agg"], 256)
@@ -460,7 +469,7 @@ class Generator(object):
             w, b = self._w(fs + "fc_layer1")
             self._linear(st, ws["f256"], 256, w, b, 1, ws["f64"], 64)
             w, b = self._w(fs + "fc_layer2")
-            self._call("fine", L.dispu_linear_small_n, rm, 64, 3, ptr(ws["f64"]), 64, ptr(w), ptr(b), 1, ptr(coarse), 3, ptr(ws["fine"]), 3, st)
+            self._call("fine", L.dispu_linear_small_n, rm, 64, 3, ptr(ws["f64"]), 64, ptr(w), ptr(b), 1, ptr(coarse), 3, ptr(fine), 3, st)
         if self.return_views:
-            return coarse, ws["fine"]
-        return coarse.clone(), ws["fine"].clone()
+            return coarse, fine
+        return coarse.clone(), fine.clone()

@@ -115,3 +115,227 @@ def average_replica_stats(tensors, group=None):
         else:
             dist.all_reduce(t, group=group)
             t.div_(world)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Collectives off the compute stream (round 5).  Both data-path collectives are latency-bound (393 KB of clouds per rank, a
+# 4.2 MB gradient bucket) against a 0.9 / 1.7 ms step; issued on the compute stream after the step they are fully exposed.
+#   * GatherPipeline: the all-gather of step i runs on a side stream while step i + 1 computes (double-buffered results);
+#   * BucketedAllReduce: the gradient buffer is reduced in contiguous buckets, each launched as soon as the backward pass has
+#     produced it (the refine branch's gradients are final half a backward before the feature extractor's).
+# Transport: RCCL (backend "nccl") -> a side HIP stream ordered against compute by events, the launching thread returns at
+# once.  gloo (CPU tests, ranks sharing a GPU) has no stream semantics: ONE background thread drains a FIFO of jobs (FIFO =
+# the same collective order on every rank) and stages device tensors through host memory, so the launching thread also
+# returns at once and the GPU keeps computing.
+# ------------------------------------------------------------------------------------------------------------------
+import queue
+import threading
+
+
+class _Ticket(object):
+    __slots__ = ("flag", "event", "error")
+
+    def __init__(self):
+        self.flag, self.event, self.error = threading.Event(), None, None
+
+
+class _Lane(object):
+    """Asynchronous collectives, issued strictly in submission order."""
+
+    def __init__(self, device, group=None):
+        self.group = group
+        self.backend = dist.get_backend(group)
+        self.device = torch.device(device)
+        self.cuda = self.device.type == "cuda"
+        self.stream = torch.cuda.Stream(device=self.device) if self.cuda else None
+        self.threaded = self.backend == "gloo"
+        self._q, self._thread = None, None
+        if self.threaded:
+            # the background thread's collectives must not interleave with the launching thread's on one gloo context (the pairing
+            # of sends and receives is by call order): the lane talks over a group of its own.  (RCCL needs none: there every
+            # collective, the lane's included, is ENQUEUED by the launching thread, in program order on every rank.)
+            self.group = dist.new_group(ranks=dist.get_process_group_ranks(group if group is not None else dist.group.WORLD), backend="gloo")
+            self._q = queue.Queue()
+            self._thread = threading.Thread(target=self._run, name="dispu-comm", daemon=True)
+            self._thread.start()
+
+    # ---- the collectives themselves (device tensors hop through host memory under gloo) ----
+    def all_gather(self, out, local):
+        world = dist.get_world_size(self.group)
+        if local.is_cuda and self.backend == "gloo":
+            host = local.detach().cpu()
+            parts = [torch.empty_like(host) for _ in range(world)]
+            dist.all_gather(parts, host, group=self.group)
+            out.copy_(torch.cat(parts, dim=0))
+        else:
+            dist.all_gather_into_tensor(out, local, group=self.group)
+
+    def all_reduce(self, t, scale=None):
+        if t.is_cuda and self.backend == "gloo":
+            host = t.detach().cpu()
+            dist.all_reduce(host, group=self.group)
+            t.copy_(host if scale is None else host * scale)
+        else:
+            dist.all_reduce(t, group=self.group)
+            if scale is not None:
+                t.mul_(scale)
+
+    # ---- submission ----
+    def submit(self, job, after=()):
+        """`job()` issues collectives; it starts once the HIP events in `after` have completed.  Returns a ticket for wait()."""
+        ticket = _Ticket()
+        if self.threaded:
+            self._q.put((job, tuple(after), ticket))
+            return ticket
+        with torch.cuda.stream(self.stream):
+            for ev in after:
+                self.stream.wait_event(ev)
+            job()                                  # RCCL: enqueued behind the waits; the lane stream is blocked until it completes
+            ticket.event = torch.cuda.Event()
+            ticket.event.record(self.stream)
+        ticket.flag.set()
+        return ticket
+
+    def _run(self):
+        if self.cuda:
+            torch.cuda.set_device(self.device)
+        while True:
+            item = self._q.get()
+            if item is None:
+                return
+            job, after, ticket = item
+            try:
+                if self.cuda:
+                    with torch.cuda.stream(self.stream):
+                        for ev in after:
+                            ev.synchronize()       # blocks this thread only
+                        job()
+                        ticket.event = torch.cuda.Event()
+                        ticket.event.record(self.stream)
+                else:
+                    job()
+            except BaseException as e:             # noqa: BLE001 -- re-raised in the thread that waits for the ticket
+                ticket.error = e
+            ticket.flag.set()
+
+    def wait(self, ticket):
+        """the CURRENT stream (and, under gloo, the calling thread) waits for the job behind `ticket`."""
+        if ticket is None:
+            return
+        ticket.flag.wait()
+        if ticket.error is not None:
+            raise ticket.error
+        if ticket.event is not None:
+            torch.cuda.current_stream(self.device).wait_event(ticket.event)
+
+    def close(self):
+        if self._thread is not None:
+            self._q.put(None)
+            self._thread.join(timeout=30)
+            self._thread = None
+
+
+def _here(device):
+    """an event at the current position of the current stream (None for CPU tensors: the data is there when the call returns)."""
+    if torch.device(device).type != "cuda":
+        return ()
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(device))
+    return (ev,)
+
+
+class GatherPipeline(object):
+    """Reassembly of the upsampled clouds (BASELINE config 3) overlapped with the next step's compute.
+
+        pipe = GatherPipeline((b_local, M, 3), device)
+        slot, buf = pipe.acquire()      # the step writes its clouds into `buf` (Generator.fine_out = buf)
+        ... launch the step ...
+        pipe.launch(slot)               # all-gather of `buf` on the comm lane, ordered after everything queued so far
+        ... next step (other slot) ...
+        clouds = pipe.result(slot)      # [world * b_local, M, 3]; the current stream waits for that gather only
+
+    `depth` result buffers: a slot is reused `depth` steps later, and acquire() makes the current stream wait for the gather that
+    last used it (finished long before -- it never stalls a steady-state loop).  Equal shards only (the sharded bench / serving
+    loop); ragged batches go through all_gather_clouds."""
+
+    def __init__(self, local_shape, device, dtype=torch.float32, depth=2, group=None):
+        if not (dist.is_available() and dist.is_initialized()):
+            raise RuntimeError("GatherPipeline needs an initialised process group")
+        self.world = dist.get_world_size(group)
+        self.device = torch.device(device)
+        self.lane = _Lane(self.device, group)
+        local_shape = tuple(int(s) for s in local_shape)
+        self.local = [torch.empty(local_shape, dtype=dtype, device=self.device) for _ in range(depth)]
+        self.out = [torch.empty((self.world * local_shape[0],) + local_shape[1:], dtype=dtype, device=self.device) for _ in range(depth)]
+        self.tickets = [None] * depth
+        self.steps = 0
+
+    def acquire(self):
+        s = self.steps % len(self.local)
+        self.steps += 1
+        self.lane.wait(self.tickets[s])
+        return s, self.local[s]
+
+    def launch(self, s):
+        loc, out, lane = self.local[s], self.out[s], self.lane
+        self.tickets[s] = lane.submit(lambda: lane.all_gather(out, loc), after=_here(self.device))
+
+    def result(self, s):
+        self.lane.wait(self.tickets[s])
+        return self.out[s]
+
+    def drain(self):
+        for t in self.tickets:
+            self.lane.wait(t)
+
+    def close(self):
+        self.drain()
+        self.lane.close()
+
+
+class BucketedAllReduce(object):
+    """sum-all-reduce of one flat buffer in contiguous buckets, each launched when ITS producers are done.
+
+    `bounds` = [(lo, hi), ...] element ranges that tile `flat`, in the order the backward pass completes them.  launch(i, after)
+    queues bucket i on the comm lane behind the HIP events `after` (default: the current position of the current stream);
+    finish() launches whatever was not launched, makes the current stream wait for every bucket and returns the world size (the
+    1/world average is the caller's: Trainer folds it into the Adam launch).  Summation order inside a bucket is the
+    transport's, exactly as for the single-bucket all_reduce_gradients: same values, sooner."""
+
+    def __init__(self, flat, bounds, group=None):
+        if not (dist.is_available() and dist.is_initialized()):
+            raise RuntimeError("BucketedAllReduce needs an initialised process group")
+        bounds = [(int(lo), int(hi)) for lo, hi in bounds]
+        cover = sorted(bounds)
+        if cover[0][0] != 0 or cover[-1][1] != flat.numel() or any(cover[i][1] != cover[i + 1][0] for i in range(len(cover) - 1)):
+            raise ValueError("buckets %r do not tile the %d-element buffer" % (bounds, flat.numel()))
+        self.flat, self.bounds, self.group = flat, bounds, group
+        self.world = dist.get_world_size(group)
+        self.lane = _Lane(flat.device, group)
+        self.tickets = [None] * len(bounds)
+
+    def launch(self, i, after=None):
+        if self.tickets[i] is not None:
+            raise RuntimeError("bucket %d launched twice in one step" % i)
+        lo, hi = self.bounds[i]
+        view, lane = self.flat[lo:hi], self.lane
+        self.tickets[i] = lane.submit(lambda: lane.all_reduce(view), after=_here(self.flat.device) if after is None else after)
+
+    def launched(self, i):
+        return self.tickets[i] is not None
+
+    def finish(self, extra=()):
+        """`extra`: small tensors AVERAGED over the replicas behind the last bucket (BatchNorm moving statistics)."""
+        for i in range(len(self.bounds)):
+            if self.tickets[i] is None:
+                self.launch(i)
+        tickets, self.tickets = self.tickets, [None] * len(self.bounds)
+        if extra:
+            lane, inv = self.lane, 1.0 / self.world
+            tickets.append(lane.submit(lambda: [lane.all_reduce(t, scale=inv) for t in extra], after=_here(self.flat.device)))
+        for t in tickets:
+            self.lane.wait(t)
+        return self.world
+
+    def close(self):
+        self.lane.close()

@@ -107,6 +107,8 @@ class Trainer(object):
         self._stash_ready = False
         self._graphs = {}
         self._tapes = {}
+        self._ar = None                       # parallel.BucketedAllReduce over flat_g (data parallel only, see _reducer)
+        self._ar_armed = False                # True inside train_step(): backward() may start a bucket's all-reduce as soon as it is complete
         # weight-gradient products (dW = X^T dZ) are off the backward chain: only Adam reads them.  They run on a second
         # HIP stream next to the dX products that ARE the chain (both read dZ; at 8 patches neither fills 256 CUs alone).
         self.overlap_dw = os.environ.get("DISPU_TRAIN_OVERLAP", "1") != "0"
@@ -163,6 +165,9 @@ class Trainer(object):
         dev = self.device
         self._invalidate_recordings()
         self._ws.clear()
+        if self._ar is not None:              # the reducer holds views of the old gradient buffer
+            self._ar.close()
+            self._ar = None
         names = [k for k in params if k.endswith(("/weights", "/biases", "/gamma", "/beta"))]
         sizes = [int(np.asarray(params[k]).size) for k in names]
         # every tensor starts on a 16-byte boundary inside the flat buffers
@@ -990,6 +995,7 @@ class Trainer(object):
             _lib.check(L.dispu_ps_skip_max_grad(rm, M, k, 128, _p(ws["psidx"]), _p(coarse), _p(ws["up128"]), 128, _p(ws["gmax"]), 144,
                                                 _p(ws["dgmax"]), 136, _p(dcoarse), _p(dup128), 128, 1, self.st), "ps_skip_max_grad")
         self._merge(2)                                   # the weight net's share of dcoarse
+        self._bucket_point(0)                            # data parallel: every refine/* gradient is queued -> its all-reduce starts
 
         # coarse regressor
         cs = "generator/coarse_coordinate_regressor/"
@@ -1088,14 +1094,47 @@ class Trainer(object):
         self.st = _lib.stream_ptr(self.device)
         self._zero(self.flat_g)
 
+    def _reducer(self):
+        """data parallel (process group of > 1 rank): the flat gradient buffer as TWO all-reduce buckets in the order the backward
+        pass completes them -- [refine/*] (3.1 MB: final once the local / non-local / skip cells are through, half a backward
+        before the rest) and [generator/*] (1.0 MB: feature extractor, duplicate_up, coarse regressor) -- on a comm lane next to
+        the compute streams (parallel.BucketedAllReduce).  None without a process group."""
+        if self._ar is None:
+            import torch.distributed as dist
+            if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(self.pg) == 1:
+                return None
+            from . import parallel
+            first = next(k for k in self.names if k.startswith("refine/"))
+            split = (self.P[first].data_ptr() - self.flat_p.data_ptr()) // 4
+            assert all(k.startswith("refine/") == ((self.P[k].data_ptr() - self.flat_p.data_ptr()) // 4 >= split) for k in self.names)
+            self._ar = parallel.BucketedAllReduce(self.flat_g, [(split, self.flat_g.numel()), (0, split)], self.pg)
+        return self._ar
+
+    def _bucket_point(self, i):
+        """every gradient of bucket i has been QUEUED (main stream, or a weight-gradient stream): start its all-reduce behind them,
+        while the backward pass goes on.  Eager steps only: a launch tape / hipGraph replays kernels, not collectives -- there every
+        bucket is launched by all_reduce_grads() after the replay."""
+        if not self._ar_armed:                           # backward() on its own never communicates: only train_step() arms the early launch
+            return
+        ar = self._reducer()
+        if ar is None or _lib.taping() is not None or torch.cuda.is_current_stream_capturing() or ar.launched(i):
+            return
+        self._flush()                                    # deferred weight gradients of the bucket go to their streams first
+        evs = []
+        for s in [torch.cuda.current_stream(self.device)] + list(self._sides):
+            ev = torch.cuda.Event()
+            ev.record(s)
+            evs.append(ev)
+        ar.launch(i, after=evs)
+
     def all_reduce_grads(self):
-        """ONE flat-bucket all-reduce (RCCL over xGMI) of the 4.2 MB gradient buffer; the 1/world average is folded
-        into the Adam launch.  BN moving statistics (per-rank batch statistics) are averaged alongside."""
-        from . import parallel
-        world = parallel.all_reduce_gradients(self.flat_g, self.pg)
-        if world > 1:
-            parallel.average_replica_stats([self.moving_mean, self.moving_var], self.pg)
-        return world
+        """gradient all-reduce (RCCL over xGMI) of the 4.2 MB buffer, in the buckets of _reducer(): whatever backward() has not
+        launched yet is launched here, then the current stream waits for all of it.  The 1/world average is folded into the Adam
+        launch.  BN moving statistics (per-rank batch statistics) are averaged behind the last bucket."""
+        ar = self._reducer()
+        if ar is None:
+            return 1
+        return ar.finish(extra=[self.moving_mean, self.moving_var])
 
     def adam(self, world=1):
         """tf.train.AdamOptimizer(lr, beta1=opts.beta) (model.py:178)."""
@@ -1204,7 +1243,11 @@ class Trainer(object):
         self.zero_grad()
         self.forward(inputs)
         terms = self.loss_backward(gt, radius)
-        self.backward()
+        self._ar_armed = True                            # data parallel: the refine bucket's all-reduce starts inside backward()
+        try:
+            self.backward()
+        finally:
+            self._ar_armed = False
         world = self.all_reduce_grads()
         self.adam(world)
         self.global_step += 1

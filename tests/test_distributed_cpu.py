@@ -107,3 +107,78 @@ def test_all_reduce_is_noop_without_process_group():
     from dispu_amd import parallel
     t = torch.arange(4.0)
     assert parallel.all_reduce_gradients(t) == 1 and torch.equal(t, torch.arange(4.0))
+
+
+# ---- round 5: collectives off the critical path (parallel.GatherPipeline / BucketedAllReduce) ----------------------------
+def _pipeline_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from dispu_amd import parallel
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        b, m = 3, 16
+        pipe = parallel.GatherPipeline((b, m, 3), "cpu")
+        ok, pending = True, []
+
+        def produce(step, r):                                 # what rank r's "generator" writes at `step`
+            g = torch.Generator().manual_seed(1000 * step + r)
+            return torch.rand(b, m, 3, generator=g)
+
+        def check(step, slot):
+            want = torch.cat([produce(step, r) for r in range(world)], dim=0)
+            return torch.equal(pipe.result(slot), want) and torch.equal(pipe.result(slot), parallel.all_gather_clouds(produce(step, rank)))
+
+        for step in range(7):                                 # consume step i only AFTER step i + 1 was launched (the overlap pattern)
+            slot, buf = pipe.acquire()
+            buf.copy_(produce(step, rank))
+            pipe.launch(slot)
+            if pending:
+                ok = ok and check(*pending.pop())
+            pending.append((step, slot))
+        ok = ok and check(*pending.pop())
+        pipe.close()
+
+        # gradient buckets: [60, 100) first (the part the backward pass finishes first), then [0, 60); stats averaged behind them
+        g = torch.Generator().manual_seed(50 + rank)
+        flat = torch.randn(100, generator=g, dtype=torch.float64)
+        want = sum(torch.randn(100, generator=torch.Generator().manual_seed(50 + r), dtype=torch.float64) for r in range(world))
+        ref = flat.clone()
+        parallel.all_reduce_gradients(ref)
+        ar = parallel.BucketedAllReduce(flat, [(60, 100), (0, 60)])
+        stats = [torch.full((16,), float(rank)), torch.full((16,), 10.0 + rank)]
+        ar.launch(0)
+        early = ar.launched(0) and not ar.launched(1)
+        n = ar.finish(extra=stats)
+        ok2 = n == world and torch.equal(flat, want) and torch.equal(flat, ref) and early
+        flat.copy_(torch.randn(100, generator=torch.Generator().manual_seed(50 + rank), dtype=torch.float64))
+        n = ar.finish()                                       # second step, nothing launched early: everything goes out in finish()
+        ok2 = ok2 and torch.equal(flat, want)
+        try:
+            parallel.BucketedAllReduce(flat, [(0, 50), (60, 100)])
+            ok2 = False
+        except ValueError:
+            pass
+        ar.close()
+        q.put((rank, ok, ok2, float(stats[0][0]), float(stats[1][0])))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_overlapped_collectives_gloo_world2():
+    """GatherPipeline: seven steps through two result slots, each result read one step late -> equal to the blocking
+    all_gather_clouds of the same step.  BucketedAllReduce: two buckets in backward-completion order == the single-bucket
+    all-reduce, replica statistics averaged behind them."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_pipeline_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(r[1] for r in res), "pipelined all-gather differs from the blocking one"
+    assert all(r[2] for r in res), "bucketed all-reduce differs from the single-bucket one"
+    assert all(r[3] == 0.5 and r[4] == 10.5 for r in res)

@@ -10,10 +10,9 @@ for f in bench.json configs.json emd_bench.txt fps_bench.txt kernel_stats.csv op
     cp $G/$T/$f $P/${T}_$f
 done
 cp $G/$T/bench_profiled.json $P/${T}_bench_under_rocprof.json
-cp $G/${T}_pmc/pmc_summary.json $P/${T}_pmc_summary.json
+python3 tools/stamp_profile.py $G/${T}_pmc/pmc_summary.json $P/${T}_pmc_summary.json --latest    # + commit stamp, refreshes pmc_traffic_latest.json
 cp $G/${T}_train/kernel_stats.csv $P/${T}_train_b8_kernel_stats.csv
 cp $G/${T}_trace/timeline.txt $P/${T}_train_timeline.txt
 [ -f $G/${T}_valu/valu_summary.json ] && cp $G/${T}_valu/valu_summary.json $P/${T}_valu_summary.json
 [ -f $G/bench_side_tables.json ] && cp $G/bench_side_tables.json $P/bench_side_tables.json
-[ -f $G/${T}_pmc/pmc_traffic_latest.json ] && cp $G/${T}_pmc/pmc_traffic_latest.json $P/pmc_traffic_latest.json
 ls $P | grep ${T}_ | wc -l

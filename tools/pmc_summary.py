@@ -36,6 +36,16 @@ def main():
         if "SQ_VALU_MFMA_BUSY_CYCLES" in row and row.get("SQ_BUSY_CYCLES"):
             row["mfma_busy_over_sq_busy"] = row["SQ_VALU_MFMA_BUSY_CYCLES"] / row["SQ_BUSY_CYCLES"]
         out[k] = row
+    # which build these counters belong to: sha1 of the kernel sources (the GPU box has no .git); tools/stamp_profile.py adds the commit
+    try:
+        import importlib.util
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        spec = importlib.util.spec_from_file_location("dispu_build", os.path.join(root, "dis-pu_amd", "build.py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        out["_meta"] = {"csrc_sha1": mod.source_hash()}
+    except Exception as e:                                     # noqa: BLE001
+        out["_meta"] = {"csrc_sha1": None, "error": str(e)}
     print(json.dumps(out, indent=1))
 
 
