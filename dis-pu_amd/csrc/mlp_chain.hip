@@ -15,6 +15,7 @@
 namespace dispu {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int mc_u32x4 __attribute__((ext_vector_type(4)));
 
 struct ChainArgs {
     long rows;
@@ -47,7 +48,9 @@ constexpr int MC_ACT = MC_KMAX * (MC_BM + 1);                     // 8192 rows: 
 __host__ __device__ constexpr int mc_bk(int n) { return 2048 / n; }
 constexpr int MC_WST = 32 * (64 + 4);                             // floats per weight stage (largest: 32 x 68)
 constexpr int MC_HEAD = 64 * 3 + 4;
-constexpr size_t MC_LDS_BYTES = (size_t)(MC_ACT + 2 * MC_WST + MC_HEAD) * sizeof(float);
+constexpr int MC_NST = 3;                                         // weight stages (round 5): slab g is consumed, g + 1 is complete, g + 2 is being stored
+constexpr size_t MC_LDS_BYTES = (size_t)(MC_ACT + MC_NST * MC_WST + MC_HEAD) * sizeof(float);
+static_assert(MC_LDS_BYTES <= 160 * 1024, "the chain's LDS plan");
 
 // one layer on the MFMA waves: acc = act[0:K] . W (slabs g0 .. g0 + K/8 - 1 of the weight stream), then
 // act[0:N] <- relu(acc + bias) (k-major), optionally also to global memory.
@@ -76,21 +79,77 @@ __device__ __forceinline__ void chain_layer(float* act, const float* wst, int g0
         for (int j = 0; j < TNW; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    for (int s = 0; s < K / BK; ++s) {
-        const float* ws = wst + ((g0 + s) & 1) * MC_WST;
+    // Round 5: the operands of k-step j + 1 are requested BEFORE the MFMAs of step j, across the slab barrier too.  A slab is only 32
+    // MFMAs per wave (2048 pipe cycles); with the reads of a slab's first step issued behind its barrier, and every other step's reads
+    // placed by the compiler right in front of the MFMAs that need them, a wave sat through an LDS round trip per step with the matrix
+    // pipe drained (2600 - 2750 cycles of its own per slab, tools/micro/chain_lab.hip).  Reading ahead over the barrier needs slab
+    // s + 1 COMPLETE while slab s is consumed: three weight stages, the loaders store slab g + 2 during slab g (and the input chunk
+    // of slab g + 2 likewise).
+    constexpr int NS = K / BK, NSTEP = BK / 2;
+    static_assert(NSTEP % 2 == 0, "the fragment double buffer starts every slab in set 0");
+    float af[2][RT], bf[2][TNW];
+    int st = g0 % MC_NST;                                          // stage of the slab being consumed
+#ifdef MC_X_NOREAD                                                 // lab: no fragment reads at all (timing experiment, wrong results)
+#pragma unroll
+    for (int i = 0; i < RT; ++i) { af[0][i] = 1.0f + fi; af[1][i] = 2.0f + fi; }
+#pragma unroll
+    for (int j = 0; j < TNW; ++j) { bf[0][j] = 0.5f + fk; bf[1][j] = 0.25f + fk; }
+#else
+    {
+        const float* ws = wst + st * MC_WST;
+#pragma unroll
+        for (int i = 0; i < RT; ++i) af[0][i] = act[fk * MC_LDA + wm * (BM / 2) + i * 32 + fi];
+#pragma unroll
+        for (int j = 0; j < TNW; ++j) bf[0][j] = ws[fk * LDW + wn * (N / 2) + j * 32 + fi];
+    }
+#endif
+    for (int s = 0; s < NS; ++s) {
+        const float* ws = wst + st * MC_WST;
+        const int stn = (st + 1 == MC_NST) ? 0 : st + 1;
+        const float* wsn = wst + stn * MC_WST;
         const float* as = act + (s * BK) * MC_LDA;
+        const bool more = s + 1 < NS;
 #pragma unroll
-        for (int kk = 0; kk < BK; kk += 2) {
-            float af[RT], bf[TNW];
+        for (int s2 = 0; s2 < NSTEP; ++s2) {
+            const int cur = s2 & 1, nxt = cur ^ 1;
+#ifndef MC_X_NOREAD
+            if (s2 + 1 < NSTEP) {
+                const int kk = 2 * (s2 + 1);
 #pragma unroll
-            for (int i = 0; i < RT; ++i) af[i] = as[(kk + fk) * MC_LDA + wm * (BM / 2) + i * 32 + fi];
+                for (int i = 0; i < RT; ++i) af[nxt][i] = as[(kk + fk) * MC_LDA + wm * (BM / 2) + i * 32 + fi];
 #pragma unroll
-            for (int j = 0; j < TNW; ++j) bf[j] = ws[(kk + fk) * LDW + wn * (N / 2) + j * 32 + fi];
+                for (int j = 0; j < TNW; ++j) bf[nxt][j] = ws[(kk + fk) * LDW + wn * (N / 2) + j * 32 + fi];
+            } else if (more) {                                     // first step of the next slab (uniform branch; its stage is complete)
+#pragma unroll
+                for (int i = 0; i < RT; ++i) af[nxt][i] = as[(BK + fk) * MC_LDA + wm * (BM / 2) + i * 32 + fi];
+#pragma unroll
+                for (int j = 0; j < TNW; ++j) bf[nxt][j] = wsn[fk * LDW + wn * (N / 2) + j * 32 + fi];
+            }
+#endif
 #pragma unroll
             for (int i = 0; i < RT; ++i)
 #pragma unroll
-                for (int j = 0; j < TNW; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < TNW; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][i], bf[cur][j], acc[i][j], 0, 0, 0);
+#if defined(MC_SCHED) && MC_SCHED == 1
+            // lab: the DS reads spread between the MFMAs
+#pragma unroll
+            for (int q = 0; q < (RT + TNW) / 2; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, (RT * TNW) / ((RT + TNW) / 2), 0);
+            }
+#elif defined(MC_SCHED) && MC_SCHED == 2
+            // lab: MFMAs first, reads behind them
+            __builtin_amdgcn_sched_group_barrier(0x008, RT * TNW, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, RT + TNW, 0);
+#elif defined(MC_SCHED) && MC_SCHED == 3
+            // lab: no pinning
+#else
+            // pin: this step's DS reads (the next step's operands) first, then its RT * TNW MFMAs
+            __builtin_amdgcn_sched_group_barrier(0x100, RT + TNW, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, RT * TNW, 0);
+#endif
         }
+        st = stn;
 #ifdef MC_CLOCK
         const unsigned long long b0_ = __builtin_readcyclecounter();
         __syncthreads();
@@ -127,42 +186,67 @@ __global__ __launch_bounds__(512) void mlp_chain_kernel(ChainArgs a) {
     static_assert((K0 / mc_bk(N1)) % 2 == 0 && (N1 / mc_bk(N2)) % 2 == 0 && (N2 / mc_bk(N3)) % 2 == 0, "layers must start on stage 0");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* act = lds;                                             // [k][MC_LDA]
-    float* wst = act + MC_ACT;                                    // [2][8][N + 4]
-    float* whead = wst + 2 * MC_WST;                              // W4 [64][3] + b4
+    float* wst = act + MC_ACT;                                    // [MC_NST][8][N + 4]
+    float* whead = wst + MC_NST * MC_WST;                              // W4 [64][3] + b4
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long row0 = (long)blockIdx.x * BM;
     constexpr int S1 = K0 / mc_bk(N1), S2 = N1 / mc_bk(N2), S3 = N2 / mc_bk(N3), G = S1 + S2 + S3;
 
     if (wave >= 4) {
         // ------------------------------------------------------------------------------------ loader waves
+        // Round 5: every instruction a loader wave issues next to an MFMA wave of its SIMD takes ~100 - 250 cycles to get out
+        // (tools/micro/chain_lab.hip: with the MFMA waves' LDS reads compiled out the slab still took 2900 cycles -- the loaders, at
+        // ~35 instructions per slab, were the bound).  So the loop is fully unrolled (stage, layer, LDS offsets and chunk schedule
+        // are compile-time), global memory goes through buffer loads whose per-slab offset is a scalar (no address VALU), and the LDS
+        // destinations are one precomputed register per layer plus immediates: ~8 instructions per slab.
         const int tid = threadIdx.x - 256;
-        // input tile [128][K0] -> k-major act, in chunks of 32 k-columns (128 B per row, 4 float4 per thread); chunk c feeds
-        // layer-1 slabs from k = 32 c on, so only chunk 0 is loaded before the MFMA waves start
+        const __amdgpu_buffer_rsrc_t rw1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.W1), 0, K0 * N1 * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rw2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.W2), 0, N1 * N2 * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rw3 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.W3), 0, N2 * N3 * 4, 0x00020000);
+        auto bload = [](__amdgpu_buffer_rsrc_t rs, int voff, int soff) -> float4 {
+            const mc_u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0);
+            return make_float4(__uint_as_float(r[0]), __uint_as_float(r[1]), __uint_as_float(r[2]), __uint_as_float(r[3]));
+        };
+        // input tile [BM][K0] -> k-major act, in chunks of 32 k-columns (128 B per row, XU float4 per thread); chunk c feeds
+        // layer-1 slabs from k = 32 c on, so only chunk 0 is loaded before the MFMA waves start.  Row offsets are per-thread
+        // constants (relative to the workgroup's first row: 32-bit offsets whatever the batch), the chunk is the scalar offset.
+        const int xbytes = (int)(a.ldx * 4);
+        const long xbase = (XMODE == 2) ? 0 : row0 * a.ldx;
+        const int xrecs = (XMODE == 2) ? 0x7ffffff0 : BM * xbytes;
+        const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.X + xbase), 0, xrecs, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rx2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>((XMODE == 1 ? a.X2 : a.X) + xbase), 0, xrecs, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rx3 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>((XMODE == 1 ? a.X3 : a.X) + xbase), 0, xrecs, 0x00020000);
         float4 xv[XU];
         float4 xr1[XMODE == 1 ? XU : 1], xr2[XMODE == 1 ? XU : 1];
+        int xoff[XU];                                             // byte offset of the thread's row u, column quad (tid & 7), chunk 0
         // XMODE 2: a thread's XU rows of a chunk share one column quad; their source rows / grid codes are fixed for the kernel
-        long dsrc[XMODE == 2 ? XU : 1];
         float dg0[XMODE == 2 ? XU : 1], dg1[XMODE == 2 ? XU : 1];
-        if constexpr (XMODE == 2) {
 #pragma unroll
-            for (int u = 0; u < XU; ++u) {
+        for (int u = 0; u < XU; ++u) {
+            if constexpr (XMODE == 2) {
                 const long row = row0 + ((tid + u * 256) >> 3);
                 const long cr = row / a.n;                        // cloud * up + r
                 const long cloud = cr / a.up;
                 const int r = (int)(cr - cloud * a.up);
-                dsrc[u] = cloud * a.n + (row - cr * a.n);
+                xoff[u] = (int)(cloud * a.n + (row - cr * a.n)) * xbytes + (tid & 7) * 16;
                 dg0[u] = a.grid[r * 2 + 0];
                 dg1[u] = a.grid[r * 2 + 1];
+            } else {
+                xoff[u] = ((tid + u * 256) >> 3) * xbytes + (tid & 7) * 16;
             }
         }
+        const int xdst = ((tid & 7) * 4) * MC_LDA + (tid >> 3);    // act index of (row of u = 0, first column of the quad), chunk 0
         auto load_x = [&](int c) {
+#ifdef MC_X_NOLOADER
+            return;
+#endif
             if constexpr (XMODE == 2) {
                 const int col = c * 32 + (tid & 7) * 4;
                 const float4 w0 = *reinterpret_cast<const float4*>(a.Wg + col), w1 = *reinterpret_cast<const float4*>(a.Wg + K0 + col);
                 const float4 bb = *reinterpret_cast<const float4*>(a.bg + col);
                 float4 h[XU];
 #pragma unroll
-                for (int u = 0; u < XU; ++u) h[u] = *reinterpret_cast<const float4*>(a.X + (size_t)dsrc[u] * a.ldx + col);
+                for (int u = 0; u < XU; ++u) h[u] = bload(rx, xoff[u], c * 128);
 #pragma unroll
                 for (int u = 0; u < XU; ++u) {
                     xv[u].x = fmaxf(__builtin_fmaf(dg1[u], w1.x, __builtin_fmaf(dg0[u], w0.x, h[u].x)) + bb.x, 0.f);
@@ -174,66 +258,73 @@ __global__ __launch_bounds__(512) void mlp_chain_kernel(ChainArgs a) {
             }
 #pragma unroll
             for (int u = 0; u < XU; ++u) {
-                const int idx = tid + u * 256;                    // BM rows x 8 quads
-                const size_t o = (size_t)(row0 + (idx >> 3)) * a.ldx + c * 32 + (idx & 7) * 4;
-                xv[u] = *reinterpret_cast<const float4*>(a.X + o);
+                xv[u] = bload(rx, xoff[u], c * 128);
                 if constexpr (XMODE == 1) {
-                    xr1[u] = *reinterpret_cast<const float4*>(a.X2 + o);
-                    xr2[u] = *reinterpret_cast<const float4*>(a.X3 + o);
+                    xr1[u] = bload(rx2, xoff[u], c * 128);
+                    xr2[u] = bload(rx3, xoff[u], c * 128);
                 }
             }
         };
         auto store_x = [&](int c) {
+#ifdef MC_X_NOLOADER
+            return;
+#endif
 #pragma unroll
             for (int u = 0; u < XU; ++u) {
-                const int idx = tid + u * 256;
-                const int r = idx >> 3, k = c * 32 + (idx & 7) * 4;
+                float* d = act + xdst + (c * 32) * MC_LDA + u * 32;      // rows of u are 32 apart (256 threads / 8 quads)
                 if constexpr (XMODE == 1) {                       // (x + x2) + x3, the association of the GEMM epilogue it replaces
                     xv[u].x = (xv[u].x + xr1[u].x) + xr2[u].x; xv[u].y = (xv[u].y + xr1[u].y) + xr2[u].y;
                     xv[u].z = (xv[u].z + xr1[u].z) + xr2[u].z; xv[u].w = (xv[u].w + xr1[u].w) + xr2[u].w;
                 }
-                act[(k + 0) * MC_LDA + r] = xv[u].x;
-                act[(k + 1) * MC_LDA + r] = xv[u].y;
-                act[(k + 2) * MC_LDA + r] = xv[u].z;
-                act[(k + 3) * MC_LDA + r] = xv[u].w;
+                d[0 * MC_LDA] = xv[u].x;
+                d[1 * MC_LDA] = xv[u].y;
+                d[2 * MC_LDA] = xv[u].z;
+                d[3 * MC_LDA] = xv[u].w;
             }
         };
         if (tid < 64 * 3) whead[tid] = a.W4[tid];
         if (tid < 3) whead[192 + tid] = a.b4[tid];
-        // the weight stream: slab g of the concatenation W1 | W2 | W3, mc_bk(N) rows each = 512 float4 -> 2 per thread.
+        // the weight stream: slab g of the concatenation W1 | W2 | W3, mc_bk(N) rows each = 512 float4 -> 2 per thread (the second
+        // one 256 float4 = 4096 bytes further on, in global memory and -- 256 / (N / 4) rows further down -- in the stage).
         // Two slabs in flight (named registers wa0 wa1 / wb0 wb1; slab g travels in set g & 1): with 2048-cycle slabs a
         // single slab of lookahead does not cover an L2 round trip.  (Plain scalars + macros: register arrays passed by
         // reference into lambdas ended up in scratch memory.)
         float4 wa0, wa1, wb0, wb1;
-        auto slab_ptr = [&](int g) -> const float* {
-            if (g < S1) return a.W1 + (size_t)g * 2048;            // slabs are contiguous 2048-float pieces of the row-major W
-            if (g < S1 + S2) return a.W2 + (size_t)(g - S1) * 2048;
-            return a.W3 + (size_t)(g - S1 - S2) * 2048;
-        };
-        auto slab_dst = [&](int g, int idx) -> float* {
-            const int n = (g < S1) ? N1 : (g < S1 + S2) ? N2 : N3;
-            const int q = n / 4;
-            return wst + (g & 1) * MC_WST + (idx / q) * (n + 4) + (idx % q) * 4;
-        };
+        const int wvoff = tid * 16;
+        // LDS float index of the thread's first float4 inside a stage, per layer width
+        const int wd1 = (tid / (N1 / 4)) * (N1 + 4) + (tid % (N1 / 4)) * 4;
+        const int wd2 = (tid / (N2 / 4)) * (N2 + 4) + (tid % (N2 / 4)) * 4;
+        const int wd3 = (tid / (N3 / 4)) * (N3 + 4) + (tid % (N3 / 4)) * 4;
 #define MC_LOAD(g, r0, r1)                                                                    \
         do {                                                                                  \
-            const float* p_ = slab_ptr(g);                                                    \
-            r0 = *reinterpret_cast<const float4*>(p_ + tid * 4);                              \
-            r1 = *reinterpret_cast<const float4*>(p_ + (tid + 256) * 4);                      \
+            if ((g) < S1) { r0 = bload(rw1, wvoff, (g) * 8192); r1 = bload(rw1, wvoff, (g) * 8192 + 4096); }                                   \
+            else if ((g) < S1 + S2) { r0 = bload(rw2, wvoff, ((g) - S1) * 8192); r1 = bload(rw2, wvoff, ((g) - S1) * 8192 + 4096); }           \
+            else { r0 = bload(rw3, wvoff, ((g) - S1 - S2) * 8192); r1 = bload(rw3, wvoff, ((g) - S1 - S2) * 8192 + 4096); }                    \
         } while (0)
 #define MC_STORE(g, r0, r1)                                                                   \
         do {                                                                                  \
-            *reinterpret_cast<float4*>(slab_dst(g, tid)) = r0;                                \
-            *reinterpret_cast<float4*>(slab_dst(g, tid + 256)) = r1;                          \
+            float* st_ = wst + ((g) % MC_NST) * MC_WST;                                       \
+            if ((g) < S1) { *reinterpret_cast<float4*>(st_ + wd1) = r0; *reinterpret_cast<float4*>(st_ + wd1 + (1024 / N1) * (N1 + 4)) = r1; }           \
+            else if ((g) < S1 + S2) { *reinterpret_cast<float4*>(st_ + wd2) = r0; *reinterpret_cast<float4*>(st_ + wd2 + (1024 / N2) * (N2 + 4)) = r1; }  \
+            else { *reinterpret_cast<float4*>(st_ + wd3) = r0; *reinterpret_cast<float4*>(st_ + wd3 + (1024 / N3) * (N3 + 4)) = r1; }                    \
         } while (0)
-#define MC_STEP(g, r0, r1) /* r0 r1 hold slab g + 1; refilled with slab g + 3 */              \
+#ifdef MC_X_NOLOADER                                               // lab: the loader waves only keep the barrier count (timing experiment)
+#undef MC_LOAD
+#undef MC_STORE
+#define MC_LOAD(g, r0, r1) do { } while (0)
+#define MC_STORE(g, r0, r1) do { } while (0)
+#endif
+        // During slab g: slab g + 2 goes to its stage (the one slab g - 1 was read from: its readers passed barrier g - 1) and slab g + 4 is
+        // requested -- the MFMA waves read the first operands of slab g + 1 before barrier g, so slab g + 1 must be complete by barrier
+        // g - 1.  The same holds for the input tile: the chunk that feeds slab g + 2 is stored during slab g.
+#define MC_STEP(g, r0, r1) /* r0 r1 hold slab g + 2; refilled with slab g + 4 */              \
         do {                                                                                  \
-            if ((g) + 1 < G) {                                                                \
-                MC_STORE((g) + 1, r0, r1);                                                    \
-                if ((g) + 3 < G) MC_LOAD((g) + 3, r0, r1);                                    \
+            if ((g) + 2 < G) {                                                                \
+                MC_STORE((g) + 2, r0, r1);                                                    \
+                if ((g) + 4 < G) MC_LOAD((g) + 4, r0, r1);                                    \
             }                                                                                 \
-            if ((g) + 1 < S1 && ((g) + 1) % SPC == 0) {                                       \
-                const int c_ = ((g) + 1) / SPC;                                               \
+            if ((g) + 2 < S1 && ((g) + 2) % SPC == 0) {                                       \
+                const int c_ = ((g) + 2) / SPC;                                               \
                 store_x(c_);                                                                  \
                 if (c_ + 1 < NCH) load_x(c_ + 1);                                             \
             }                                                                                 \
@@ -243,21 +334,27 @@ __global__ __launch_bounds__(512) void mlp_chain_kernel(ChainArgs a) {
                 __syncthreads();                                                              \
             }                                                                                 \
         } while (0)
-        // layer-1 slab s needs input columns [s * bk1, (s+1) * bk1): chunk c must be stored before slab c * (32 / bk1)
+        // layer-1 slab s needs input columns [s * bk1, (s+1) * bk1): chunk c must be stored before slab c * (32 / bk1) - 1 starts
         constexpr int BK1 = mc_bk(N1), SPC = 32 / BK1;            // slabs per input chunk (4 for N1 = 256, 2 for N1 = 128)
         constexpr int NCH = K0 / 32;
-        static_assert(G % 2 == 0, "the loader loop is unrolled by two");
-        load_x(0);
-        store_x(0);
-        if (NCH > 1) load_x(1);
-        MC_LOAD(0, wa0, wa1);
-        MC_STORE(0, wa0, wa1);
-        MC_LOAD(1, wb0, wb1);
-        MC_LOAD(2, wa0, wa1);
-        __syncthreads();                                          // input chunk 0, head weights and slab 0 are in place
+        static_assert(G % 2 == 0 && SPC % 2 == 0 && G >= 4, "the loader loop is unrolled by two; chunk stores fall on even slabs");
+        {
+            float4 t0, t1, t2, t3;
+            load_x(0);
+            MC_LOAD(0, t0, t1);
+            MC_LOAD(1, t2, t3);
+            MC_LOAD(2, wa0, wa1);
+            MC_LOAD(3, wb0, wb1);
+            store_x(0);
+            if (NCH > 1) load_x(1);
+            MC_STORE(0, t0, t1);
+            MC_STORE(1, t2, t3);
+        }
+        __syncthreads();                                          // input chunk 0, head weights and slabs 0, 1 are in place
+#pragma unroll
         for (int g = 0; g < G; g += 2) {
-            MC_STEP(g, wb0, wb1);
-            MC_STEP(g + 1, wa0, wa1);
+            MC_STEP(g, wa0, wa1);
+            MC_STEP(g + 1, wb0, wb1);
         }
 #undef MC_LOAD
 #undef MC_STORE

@@ -149,4 +149,6 @@ def test_train_state_round_trip_far_into_training(tmp_path, dev):
         t.train_step(x, gt, radius)
     torch.cuda.synchronize()
     diff = np.abs(N(a.flat_p) - N(c.flat_p))
-    assert diff.max() <= 2.5e-3 and np.quantile(diff, 0.999) <= 2e-5, (diff.max(), np.quantile(diff, 0.999))
+    # (after ONE real step m / sqrt(v) = 0.1 g / sqrt(0.001 g^2) = 3.2, and at t = 2500 the bias correction no longer damps it: where the
+    # float atomics flip the sign of a ~0 gradient entry two replicas move 2 x 3.2 x lr apart; everything else agrees to rounding)
+    assert diff.max() <= 7e-3 and np.quantile(diff, 0.999) <= 2e-5, (diff.max(), np.quantile(diff, 0.999))
