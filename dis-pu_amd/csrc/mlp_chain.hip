@@ -88,6 +88,23 @@ __device__ __forceinline__ void chain_layer(float* act, const float* wst, int g0
     constexpr int NS = K / BK, NSTEP = BK / 2;
     static_assert(NSTEP % 2 == 0, "the fragment double buffer starts every slab in set 0");
     float af[2][RT], bf[2][TNW];
+#ifdef MC_X_NOA
+#define MC_RDA(x) (1.0f + fi)
+#else
+#define MC_RDA(x) (x)
+#endif
+#if defined(MC_X_NOB)
+    for (int j = 0; j < TNW; ++j) { bf[0][j] = 0.5f + fk; bf[1][j] = 0.25f + fk; }
+#endif
+#ifdef MC_X_NOB
+#define MC_RDB(dst, ptr) do { } while (0)
+#elif defined(MC_X_B128)
+#define MC_RDB(dst, ptr) do { if constexpr (TNW == 4) { const float4 t_ = *reinterpret_cast<const float4*>((ptr) + 3 * fi); dst[0] = t_.x; dst[1] = t_.y; dst[2] = t_.z; dst[3] = t_.w; } \
+                              else if constexpr (TNW == 2) { const float2 t_ = *reinterpret_cast<const float2*>((ptr) + fi); dst[0] = t_.x; dst[1] = t_.y; } \
+                              else { dst[0] = *(ptr); } } while (0)
+#else
+#define MC_RDB(dst, ptr) do { _Pragma("unroll") for (int j = 0; j < TNW; ++j) dst[j] = (ptr)[j * 32]; } while (0)
+#endif
     int st = g0 % MC_NST;                                          // stage of the slab being consumed
 #ifdef MC_X_NOREAD                                                 // lab: no fragment reads at all (timing experiment, wrong results)
 #pragma unroll
@@ -98,11 +115,14 @@ __device__ __forceinline__ void chain_layer(float* act, const float* wst, int g0
     {
         const float* ws = wst + st * MC_WST;
 #pragma unroll
-        for (int i = 0; i < RT; ++i) af[0][i] = act[fk * MC_LDA + wm * (BM / 2) + i * 32 + fi];
-#pragma unroll
-        for (int j = 0; j < TNW; ++j) bf[0][j] = ws[fk * LDW + wn * (N / 2) + j * 32 + fi];
+        for (int i = 0; i < RT; ++i) af[0][i] = MC_RDA(act[fk * MC_LDA + wm * (BM / 2) + i * 32 + fi]);
+        MC_RDB(bf[0], ws + fk * LDW + wn * (N / 2) + fi);
     }
 #endif
+    // unrolled by 4: the per-slab LDS addresses become immediates (one base per four slabs) instead of 6 - 8 VALU instructions per slab
+    // between the MFMAs (-3 % per slab, tools/micro/chain_lab.hip)
+    static_assert(NS % 4 == 0, "slab loop unrolled by four");
+#pragma unroll 4
     for (int s = 0; s < NS; ++s) {
         const float* ws = wst + st * MC_WST;
         const int stn = (st + 1 == MC_NST) ? 0 : st + 1;
@@ -116,14 +136,12 @@ __device__ __forceinline__ void chain_layer(float* act, const float* wst, int g0
             if (s2 + 1 < NSTEP) {
                 const int kk = 2 * (s2 + 1);
 #pragma unroll
-                for (int i = 0; i < RT; ++i) af[nxt][i] = as[(kk + fk) * MC_LDA + wm * (BM / 2) + i * 32 + fi];
-#pragma unroll
-                for (int j = 0; j < TNW; ++j) bf[nxt][j] = ws[(kk + fk) * LDW + wn * (N / 2) + j * 32 + fi];
+                for (int i = 0; i < RT; ++i) af[nxt][i] = MC_RDA(as[(kk + fk) * MC_LDA + wm * (BM / 2) + i * 32 + fi]);
+                MC_RDB(bf[nxt], ws + (kk + fk) * LDW + wn * (N / 2) + fi);
             } else if (more) {                                     // first step of the next slab (uniform branch; its stage is complete)
 #pragma unroll
-                for (int i = 0; i < RT; ++i) af[nxt][i] = as[(BK + fk) * MC_LDA + wm * (BM / 2) + i * 32 + fi];
-#pragma unroll
-                for (int j = 0; j < TNW; ++j) bf[nxt][j] = wsn[fk * LDW + wn * (N / 2) + j * 32 + fi];
+                for (int i = 0; i < RT; ++i) af[nxt][i] = MC_RDA(as[(BK + fk) * MC_LDA + wm * (BM / 2) + i * 32 + fi]);
+                MC_RDB(bf[nxt], wsn + fk * LDW + wn * (N / 2) + fi);
             }
 #endif
 #pragma unroll

@@ -228,6 +228,11 @@ constexpr int PW_WRES = PL_K * PW_LDB;                               // resident
 constexpr int PW_FLOATS = PW_WRES + 2 * PW_ASTG + 2 * 2048 + 2 * 1024 + 512;
 constexpr size_t PW_LDS_BYTES = (size_t)PW_FLOATS * sizeof(float);
 
+// UNI (round 5): n_per_cloud % 8 == 0 and npoints % 8 == 0 -- every 8-point group lies inside one cloud and none is ragged.  The helpers'
+// instruction count is what the MFMA waves end up waiting for (PL_STAMPS: 1450 - 2600 cycles per group at the slab barriers): with UNI
+// a group's cloud base is ONE scalar division (it was an unsigned vector division, ~25 instructions, per gathered row), every index /
+// coordinate / A-row / G-row load is a buffer load whose group offset is a scalar, and nothing is clamped.
+template <bool UNI>
 __global__ __launch_bounds__(512) void ps_local_ws_kernel(long npoints, int n_per_cloud, const int* __restrict__ idx,
                                                            const float* __restrict__ xyz, const float* __restrict__ Gm, int ldg,
                                                            const float* __restrict__ Am, const float* __restrict__ W1,
@@ -261,24 +266,53 @@ __global__ __launch_bounds__(512) void ps_local_ws_kernel(long npoints, int n_pe
         // order the 16x16 MFMA result layout dictates: row 4 a + b of the block <-> s = 4 b + a (see the MFMA waves).
         const int rho = ht >> 3;
         const int rq = rho >> 4, rs = 4 * (rho & 3) + ((rho >> 2) & 3);
-        auto clampi = [&](int i) { return i < np ? i : np - 1; };
+        auto clampi = [&](int i) { return (UNI || i < np) ? i : np - 1; };
         auto cloud_base = [&](int i) { return (int)((unsigned)i / (unsigned)n_per_cloud) * n_per_cloud; };
-        int goff[4], goff_n[4];                                      // element offsets of the gathered G rows (+ kq * 4)
-        auto rows_of = [&](int g, int (&go)[4]) {
+        // UNI: the cloud base of group g as a scalar
+        auto cloud_base_g = [&](int g) { return __builtin_amdgcn_readfirstlane((int)((unsigned)(g * 8) / (unsigned)n_per_cloud) * n_per_cloud); };
+        const __amdgpu_buffer_rsrc_t r_idx = __builtin_amdgcn_make_buffer_rsrc(const_cast<int*>(idx), 0, (int)((unsigned)np * 64u), 0x00020000);
+        const __amdgpu_buffer_rsrc_t r_g = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Gm), 0, (int)((unsigned)np * (unsigned)ldg * 4u), 0x00020000);
+        const __amdgpu_buffer_rsrc_t r_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Am), 0, (int)((unsigned)np * 512u), 0x00020000);
+        const __amdgpu_buffer_rsrc_t r_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xyz), 0, (int)((unsigned)np * 12u), 0x00020000);
+        auto bload4 = [](__amdgpu_buffer_rsrc_t rs, int voff, int soff) -> float4 {
+            const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0);
+            return make_float4(__uint_as_float(r[0]), __uint_as_float(r[1]), __uint_as_float(r[2]), __uint_as_float(r[3]));
+        };
+        int goff[4], goff_n[4];                                      // offsets of the gathered G rows (+ kq * 4): elements; UNI: bytes
+        int ioff[4];                                                 // UNI: byte offset of this thread's four neighbour ids inside a group's [8][16] block
 #pragma unroll
-            for (int it = 0; it < 4; ++it) {
-                const int i = clampi(g * 8 + 2 * it + rq);
-                go[it] = (cloud_base(i) + idx[i * 16 + rs]) * ldg + kq * 4;
+        for (int it = 0; it < 4; ++it) ioff[it] = ((2 * it + rq) * 16 + rs) * 4;
+        auto rows_of = [&](int g, int (&go)[4]) {
+            if constexpr (UNI) {
+                const int cb = cloud_base_g(g);
+#pragma unroll
+                for (int it = 0; it < 4; ++it)
+                    go[it] = ((cb + (int)__builtin_amdgcn_raw_buffer_load_b32(r_idx, ioff[it], g * 512, 0)) * ldg + kq * 4) * 4;
+            } else {
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const int i = clampi(g * 8 + 2 * it + rq);
+                    go[it] = (cloud_base(i) + idx[i * 16 + rs]) * ldg + kq * 4;
+                }
             }
         };
         int ri[4];                                                   // neighbour ids of the next group: loaded one interval before use
         auto rows_load = [&](int g) {
 #pragma unroll
-            for (int it = 0; it < 4; ++it) ri[it] = idx[clampi(g * 8 + 2 * it + rq) * 16 + rs];
+            for (int it = 0; it < 4; ++it) {
+                if constexpr (UNI) ri[it] = (int)__builtin_amdgcn_raw_buffer_load_b32(r_idx, ioff[it], g * 512, 0);
+                else ri[it] = idx[clampi(g * 8 + 2 * it + rq) * 16 + rs];
+            }
         };
         auto rows_finish = [&](int g, int (&go)[4]) {
+            if constexpr (UNI) {
+                const int cb = cloud_base_g(g);
 #pragma unroll
-            for (int it = 0; it < 4; ++it) go[it] = (cloud_base(clampi(g * 8 + 2 * it + rq)) + ri[it]) * ldg + kq * 4;
+                for (int it = 0; it < 4; ++it) go[it] = ((cb + ri[it]) * ldg + kq * 4) * 4;
+            } else {
+#pragma unroll
+                for (int it = 0; it < 4; ++it) go[it] = (cloud_base(clampi(g * 8 + 2 * it + rq)) + ri[it]) * ldg + kq * 4;
+            }
         };
         // two register sets: the gathers of a slab are issued TWO slab intervals before they are consumed (one interval =
         // 4300 cycles of MFMAs; a gather from the 17 MB working set of G takes about that long: with one set the helpers spent the
@@ -286,7 +320,10 @@ __global__ __launch_bounds__(512) void ps_local_ws_kernel(long npoints, int n_pe
         float4 pg0[4], pg1[4];
         auto load_g = [&](float4 (&pg)[4], int k0, const int (&go)[4]) {
 #pragma unroll
-            for (int it = 0; it < 4; ++it) pg[it] = *reinterpret_cast<const float4*>(Gm + go[it] + k0);
+            for (int it = 0; it < 4; ++it) {
+                if constexpr (UNI) pg[it] = bload4(r_g, go[it], k0 * 4);
+                else pg[it] = *reinterpret_cast<const float4*>(Gm + go[it] + k0);
+            }
         };
         auto store_a = [&](const float4 (&pg)[4], int stage, int k0, const float* ab) {     // relu(G_j - A_i) -> slab `stage`
             float* As = astg + stage * PW_ASTG;
@@ -303,8 +340,12 @@ __global__ __launch_bounds__(512) void ps_local_ws_kernel(long npoints, int n_pe
         // A rows of the 8 points of a group: 8 x 128 floats = 256 float4, one per helper thread
         float4 arow;
         auto load_arow = [&](int g) {
-            const int i = clampi(g * 8 + (ht >> 5));
-            arow = *reinterpret_cast<const float4*>(Am + (size_t)i * PL_K + (ht & 31) * 4);
+            if constexpr (UNI) {
+                arow = bload4(r_a, ht * 16, g * (8 * PL_K * 4));          // the group's 8 rows are 256 consecutive float4
+            } else {
+                const int i = clampi(g * 8 + (ht >> 5));
+                arow = *reinterpret_cast<const float4*>(Am + (size_t)i * PL_K + (ht & 31) * 4);
+            }
         };
         auto store_arow = [&](float* ab) { *reinterpret_cast<float4*>(ab + (ht >> 5) * PL_K + (ht & 31) * 4) = arow; };
         // weight net, staged: (a) neighbour id of pair ht (threads < 128), (b) its coordinates, (c) x_j - x_i -> cxbuf,
@@ -315,14 +356,28 @@ __global__ __launch_bounds__(512) void ps_local_ws_kernel(long npoints, int n_pe
         float px[6];
         auto wn_a = [&](int g) {
             if (ht < 128) {
-                pi_ = clampi(g * 8 + (ht >> 4));
-                pj = cloud_base(pi_) + idx[pi_ * 16 + (ht & 15)];
+                if constexpr (UNI) {
+                    pi_ = g * 8 + (ht >> 4);
+                    pj = cloud_base_g(g) + (int)__builtin_amdgcn_raw_buffer_load_b32(r_idx, ht * 4, g * 512, 0);
+                } else {
+                    pi_ = clampi(g * 8 + (ht >> 4));
+                    pj = cloud_base(pi_) + idx[pi_ * 16 + (ht & 15)];
+                }
             }
         };
         auto wn_b = [&]() {
             if (ht < 128) {
+                if constexpr (UNI) {
+                    const int oj = pj * 12, oi = pi_ * 12;
 #pragma unroll
-                for (int c = 0; c < 3; ++c) { px[c] = xyz[pj * 3 + c]; px[3 + c] = xyz[pi_ * 3 + c]; }
+                    for (int c = 0; c < 3; ++c) {
+                        px[c] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r_x, oj, c * 4, 0));
+                        px[3 + c] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r_x, oi, c * 4, 0));
+                    }
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) { px[c] = xyz[pj * 3 + c]; px[3 + c] = xyz[pi_ * 3 + c]; }
+                }
             }
         };
         auto wn_c = [&]() {
@@ -336,7 +391,7 @@ __global__ __launch_bounds__(512) void ps_local_ws_kernel(long npoints, int n_pe
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 float v = 0.f;
-                if (g * 8 + u < np) {
+                if (UNI || g * 8 + u < np) {
                     const float4 cx = *reinterpret_cast<const float4*>(cxbuf + (u * 16 + wsn) * 4);
                     float acc = 0.f;
                     acc = __builtin_fmaf(cx.x, ww0, acc);
@@ -462,26 +517,18 @@ __global__ __launch_bounds__(512) void ps_local_ws_kernel(long npoints, int n_pe
         for (int cb = 0; cb < 4; ++cb) o[pt][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
     const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(out, 0, (int)((unsigned)np * 8192u), 0x00020000);
     int g_prev = 0;
-    const int tq = lc & 3, t0 = lc & ~3;
-    // tile (pt, cb) of group gp -> F': lane (c = t, a) holds channels 16 cb + 4 a + b (b = 0..3) at t; a 4 x 4 transpose inside the
-    // quad of lanes t = 4 q .. 4 q + 3 (two DPP quad_perm exchanges) gives every lane ONE channel with four consecutive t = one
-    // 16-byte store
+    // tile (pt, cb) of group gp -> F'.  Round 5: the contraction runs TRANSPOSED, O^T[t][ch] = sum_s wv[s][t] * X2[s][ch] (wv^T is the A
+    // operand, relu(acc + b1) -- already in the lane that holds it, see above -- the B operand; the same products in the same s order,
+    // multiplication commutes: identical bits), so lane (column = channel 16 cb + lc, a) holds t = 4 a .. 4 a + 3 of ITS channel in
+    // registers 0..3 = one 16-byte store as it is.  (Rounds 2 - 4 computed O[ch][t] and transposed every tile inside lane quads: 8 DPP /
+    // select pairs = ~20 VALU instructions per tile, 3200 cycles per group that the MFMAs did not hide, PL_STAMPS / PL_NOFLUSH.)
     auto flush_tile = [&](int gp, int pt, int cb, bool live) {
         const int pi = gp * 8 + 4 * wm + pt;
-        const float a0 = o[pt][cb][0], a1 = o[pt][cb][1], a2 = o[pt][cb][2], a3 = o[pt][cb][3];
-        const bool odd = tq & 1;                                      // exchange across lane bit 0 (quad_perm [1,0,3,2])
-        const float s0 = pl_quad<0xB1>(odd ? a0 : a1), s2 = pl_quad<0xB1>(odd ? a2 : a3);
-        const float b0 = odd ? s0 : a0, b1v = odd ? a1 : s0, b2 = odd ? s2 : a2, b3 = odd ? a3 : s2;
-        const bool hi = tq & 2;                                       // exchange across lane bit 1 (quad_perm [2,3,0,1])
-        const float u0 = pl_quad<0x4E>(hi ? b0 : b2), u1 = pl_quad<0x4E>(hi ? b1v : b3);
-        f32x4 v;
-        v.x = hi ? u0 : b0; v.y = hi ? u1 : b1v; v.z = hi ? b2 : u0; v.w = hi ? b3 : u1;
-        const int ch = wn * 64 + cb * 16 + 4 * la + tq;
+        const int ch = wn * 64 + cb * 16 + lc;
         // a BUFFER store: an offset beyond the resource's range is dropped by the hardware, so "nothing to flush yet" (first group)
-        // and "point beyond np" (ragged last group) need no branch -- a branch here ends the scheduling region and the tile's
-        // ~25 VALU instructions run after the k-step's MFMAs instead of between them (+200 cycles per tile, measured)
-        const unsigned off = (live && pi < np) ? ((unsigned)pi * 2048u + (unsigned)(ch * 16 + t0)) * 4u : 0xFFFFFFF0u;
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), out_rsrc, (int)off, 0, 0);
+        // and "point beyond np" (ragged last group) need no branch -- a branch here ends the scheduling region
+        const unsigned off = (live && pi < np) ? ((unsigned)pi * 2048u + (unsigned)(ch * 16 + 4 * la)) * 4u : 0xFFFFFFF0u;
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o[pt][cb]), out_rsrc, (int)off, 0, 0);
     };
     for (int g = g_first; g < ng; g += gstep, ++n) {
         const bool have_prev = n > 0;
@@ -499,10 +546,20 @@ __global__ __launch_bounds__(512) void ps_local_ws_kernel(long npoints, int n_pe
             // scheduler read each B pair right before its 8 MFMAs and waited out the LDS latency 4 times per k-step)
             float af[2][4], bf[2][4];
             auto load_frags = [&](int k0, float (&a)[4], float (&b)[4]) {
+#ifdef PL_X_NOA                                                      // lab (tools/micro/ps_local_lab.hip): timing experiments, wrong results
+#pragma unroll
+                for (int pt = 0; pt < 4; ++pt) a[pt] = 1.0f + lc;
+#else
 #pragma unroll
                 for (int pt = 0; pt < 4; ++pt) a[pt] = As[(wm * 64 + pt * 16 + lc) * PW_LDAR + k0 + la];
+#endif
+#ifdef PL_X_NOB
+#pragma unroll
+                for (int cb = 0; cb < 4; ++cb) b[cb] = 0.5f + la;
+#else
 #pragma unroll
                 for (int cb = 0; cb < 4; ++cb) b[cb] = Bs[(k0 + la) * PW_LDB + wn * 64 + cb * 16 + lc];
+#endif
             };
             load_frags(0, af[0], bf[0]);
 #pragma unroll
@@ -541,7 +598,7 @@ __global__ __launch_bounds__(512) void ps_local_ws_kernel(long npoints, int n_pe
             for (int b = 0; b < 4; ++b)                               // four independent chains (cb) between dependent MFMAs
 #pragma unroll
                 for (int cb = 0; cb < 4; ++cb)
-                    o[pt][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(fmaxf(acc[pt][cb][b] + bias[cb], 0.f), bw[b], o[pt][cb], 0, 0, 0);
+                    o[pt][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[b], fmaxf(acc[pt][cb][b] + bias[cb], 0.f), o[pt][cb], 0, 0, 0);
         }
         g_prev = g;
 #ifdef PL_STAMPS
@@ -575,7 +632,10 @@ DISPU_EXPORT int dispu_ps_local(long npoints, int n_per_cloud, int k, int c, con
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ps_local_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)PL_LDS_BYTES);
         if (e != hipSuccess) return (int)e;
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(ps_local_ws_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(ps_local_ws_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)PW_LDS_BYTES);
+        if (e != hipSuccess) return (int)e;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(ps_local_ws_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)PW_LDS_BYTES);
         if (e != hipSuccess) return (int)e;
         attr.done();
@@ -593,8 +653,14 @@ DISPU_EXPORT int dispu_ps_local(long npoints, int n_per_cloud, int k, int c, con
             const long np = (npoints - p0 < per) ? npoints - p0 : per;
             const long ngroups = (np + 7) / 8;
             const unsigned grid = (unsigned)(ngroups < 256 ? ngroups : 256);      // one persistent workgroup per CU
-            hipLaunchKernelGGL(ps_local_ws_kernel, dim3(grid), dim3(512), PW_LDS_BYTES, (hipStream_t)stream, np, n_per_cloud, idx + p0 * 16,
-                               xyz + p0 * 3, G + p0 * ldg, (int)ldg, A + p0 * PL_K, W1, b1, Ww, bw, scale, shift, out + p0 * 2048);
+            // whole 8-point groups inside one cloud, 32-bit byte offsets for the helpers' buffer loads
+            const bool uni = (n_per_cloud % 8) == 0 && (np % 8) == 0 && np * ldg * 4 < 0x7fffffffL;
+            if (uni)
+                hipLaunchKernelGGL(ps_local_ws_kernel<true>, dim3(grid), dim3(512), PW_LDS_BYTES, (hipStream_t)stream, np, n_per_cloud, idx + p0 * 16,
+                                   xyz + p0 * 3, G + p0 * ldg, (int)ldg, A + p0 * PL_K, W1, b1, Ww, bw, scale, shift, out + p0 * 2048);
+            else
+                hipLaunchKernelGGL(ps_local_ws_kernel<false>, dim3(grid), dim3(512), PW_LDS_BYTES, (hipStream_t)stream, np, n_per_cloud, idx + p0 * 16,
+                                   xyz + p0 * 3, G + p0 * ldg, (int)ldg, A + p0 * PL_K, W1, b1, Ww, bw, scale, shift, out + p0 * 2048);
         }
     }
     return (int)hipGetLastError();
