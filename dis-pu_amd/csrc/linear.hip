@@ -250,6 +250,24 @@ __global__ __launch_bounds__(64 * (WM * WN + (LinearLds<BM, BN, BK, TRANSB, EDGE
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int fi = lane & 31, fk = lane >> 5;
+    // CI (round 5), interleaved column ownership: the TN accumulator tiles of a lane cover the TN CONSECUTIVE columns TN fi .. TN fi + TN - 1
+    // of the wave's column range (tile j <-> column TN fi + j) instead of fi, 32 + fi, ...  Which column an MFMA column stands for is
+    // free, the arithmetic per output is untouched; but a lane's B operands of a k-step are now adjacent in the LDS slab -- ONE
+    // ds_read_b128 (TN = 4) instead of two ds_read2_b32 -- and in the epilogue a lane owns TN adjacent outputs of a row: one 16-byte
+    // store / bias / residual load where there were four 4-byte ones (128 -> 32 global stores per wave and 32 x 32 tile pair).
+    constexpr bool CI = !EDGE && !TRANSB && (TN == 4 || TN == 2);
+    auto rdB = [&](const float* Bs, int krow, float (&b)[TN]) {
+        if constexpr (CI && TN == 4) {
+            const float4 t4 = *reinterpret_cast<const float4*>(&Bs[krow * LDB + wn * (TN * 32) + 4 * fi]);
+            b[0] = t4.x; b[1] = t4.y; b[2] = t4.z; b[3] = t4.w;
+        } else if constexpr (CI && TN == 2) {
+            const float2 t2 = *reinterpret_cast<const float2*>(&Bs[krow * LDB + wn * (TN * 32) + 2 * fi]);
+            b[0] = t2.x; b[1] = t2.y;
+        } else {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = Bs[krow * LDB + wn * (TN * 32) + j * 32 + fi];
+        }
+    };
     __syncthreads();
     // Fragment registers are double-buffered by hand: the ds_reads of k-step s+1 are issued BEFORE the MFMAs of step s.
     // Left to itself the compiler places a step's reads right in front of the MFMAs that need them, behind the previous
@@ -271,8 +289,7 @@ __global__ __launch_bounds__(64 * (WM * WN + (LinearLds<BM, BN, BK, TRANSB, EDGE
                 const float* pr = Asf + (wm * (TM * 32) + i * 32 + fi) * 4;
                 a2[0][i][0] = pr[0]; a2[0][i][1] = pr[2];
             }
-#pragma unroll
-            for (int j = 0; j < TN; ++j) bf[0][j] = Bs[fk * LDB + wn * (TN * 32) + j * 32 + fi];
+            rdB(Bs, fk, bf[0]);
 #pragma unroll
             for (int s2 = 0; s2 < BK / 2; ++s2) {
                 const int kg = s2 >> 1, u = s2 & 1, cur = s2 & 1, nxt = cur ^ 1;
@@ -285,16 +302,16 @@ __global__ __launch_bounds__(64 * (WM * WN + (LinearLds<BM, BN, BK, TRANSB, EDGE
                             a2[(kg + 1) & 1][i][0] = pr[0]; a2[(kg + 1) & 1][i][1] = pr[2];
                         }
                     }
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) bf[nxt][j] = Bs[(kk + fk) * LDB + wn * (TN * 32) + j * 32 + fi];
+                    rdB(Bs, kk + fk, bf[nxt]);
                 }
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[kg & 1][i][u], bf[cur][j], acc[i][j], 0, 0, 0);
-                if (u == 1) __builtin_amdgcn_sched_group_barrier(0x100, TM + TN / 2, 0);        // ds_read2_b32: one per row tile + one per B pair
-                else __builtin_amdgcn_sched_group_barrier(0x100, TN / 2, 0);
+                constexpr int NB = CI ? 1 : TN / 2;                                          // B reads per k-step: one b128 / one ds_read2_b32 per pair
+                if (u == 1) __builtin_amdgcn_sched_group_barrier(0x100, TM + NB, 0);         // + ds_read2_b32: one per row tile
+                else __builtin_amdgcn_sched_group_barrier(0x100, NB, 0);
                 __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
             }
 #ifdef LIN_CLOCK
@@ -312,8 +329,7 @@ __global__ __launch_bounds__(64 * (WM * WN + (LinearLds<BM, BN, BK, TRANSB, EDGE
         float af[2][TM], bf[2][TN];
 #pragma unroll
         for (int i = 0; i < TM; ++i) af[0][i] = As[fk * LDA + wm * (TM * 32) + i * 32 + fi];
-#pragma unroll
-        for (int j = 0; j < TN; ++j) bf[0][j] = Bs[fk * LDB + wn * (TN * 32) + j * 32 + fi];
+        rdB(Bs, fk, bf[0]);
 #pragma unroll
         for (int s2 = 0; s2 < BK / 2; ++s2) {
             const int cur = s2 & 1, nxt = cur ^ 1;
@@ -321,8 +337,7 @@ __global__ __launch_bounds__(64 * (WM * WN + (LinearLds<BM, BN, BK, TRANSB, EDGE
                 const int kk = 2 * (s2 + 1);
 #pragma unroll
                 for (int i = 0; i < TM; ++i) af[nxt][i] = As[(kk + fk) * LDA + wm * (TM * 32) + i * 32 + fi];
-#pragma unroll
-                for (int j = 0; j < TN; ++j) bf[nxt][j] = Bs[(kk + fk) * LDB + wn * (TN * 32) + j * 32 + fi];
+                rdB(Bs, kk + fk, bf[nxt]);
             }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
@@ -330,7 +345,7 @@ __global__ __launch_bounds__(64 * (WM * WN + (LinearLds<BM, BN, BK, TRANSB, EDGE
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][i], bf[cur][j], acc[i][j], 0, 0, 0);
             // pin: this step's DS reads (the next step's operands) first, then its TM*TN MFMAs
-            __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, TM + (CI ? 1 : TN), 0);
             __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
         }
 #ifdef LIN_CLOCK
@@ -367,6 +382,77 @@ __global__ __launch_bounds__(64 * (WM * WN + (LinearLds<BM, BN, BK, TRANSB, EDGE
     const long ldy = a.ldy, ldr1 = a.ldr1, ldr2 = a.ldr2, ldm = a.ldm;
     const unsigned offy = (unsigned)(4 * fk * ldy + fi), off1 = (unsigned)(4 * fk * ldr1 + fi), off2 = (unsigned)(4 * fk * ldr2 + fi);
     const unsigned offm = (unsigned)(4 * fk * ldm + fi);
+    if constexpr (CI) {
+        // a lane owns columns cbase + TN fi + j (j < TN) of rows rowu + 4 fk: TN-wide vector accesses throughout
+        typedef float vecT __attribute__((ext_vector_type(TN)));
+        const int col0 = cbase + TN * fi;
+        const unsigned voy = (unsigned)(4 * fk * ldy + TN * fi), vo1 = (unsigned)(4 * fk * ldr1 + TN * fi), vo2 = (unsigned)(4 * fk * ldr2 + TN * fi);
+        const unsigned vom = (unsigned)(4 * fk * ldm + TN * fi);
+        vecT bv, sc, sh;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) { bv[j] = 0.f; sc[j] = 1.f; sh[j] = 0.f; }
+        if (has_bias) bv = *reinterpret_cast<const vecT*>(a.bias + col0);
+        if constexpr (E_SCALE) {
+            if (a.scale) { sc = *reinterpret_cast<const vecT*>(a.scale + col0); sh = *reinterpret_cast<const vecT*>(a.shift + col0); }
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int rb = 0; rb < 16; rb += 8) {              // residual rows in batches of 8 (8 + 8 vector loads in flight)
+                vecT r1v[8], r2v[8], mkv[8];
+                if constexpr (EPI == 5) {
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) {
+                        const int rowu = rbase + i * 32 + ((rb + r) & 3) + 8 * ((rb + r) >> 2);
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) mkv[r][j] = 1.f;
+                        if (a.Mk != nullptr) {
+                            const vecT m = *reinterpret_cast<const vecT*>(a.Mk + (size_t)rowu * ldm + cbase + vom);
+#pragma unroll
+                            for (int j = 0; j < TN; ++j) mkv[r][j] = (col0 + j < a.mcols) ? m[j] : 1.f;
+                        }
+                    }
+                }
+                if constexpr (EPI >= 4) {
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) {
+                        const int rowu = rbase + i * 32 + ((rb + r) & 3) + 8 * ((rb + r) >> 2);
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) { r1v[r][j] = 0.f; r2v[r][j] = 0.f; }
+                        if (R1) r1v[r] = *reinterpret_cast<const vecT*>(R1 + (size_t)rowu * ldr1 + cbase + vo1);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) {
+                        const int rowu = rbase + i * 32 + ((rb + r) & 3) + 8 * ((rb + r) >> 2);
+                        if (R2) r2v[r] = *reinterpret_cast<const vecT*>(R2 + (size_t)rowu * ldr2 + cbase + vo2);
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    const int rowu = rbase + i * 32 + ((rb + r) & 3) + 8 * ((rb + r) >> 2);   // wave-uniform; the lane's row is rowu + 4*fk
+                    vecT v;
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        float e = acc[i][j][rb + r];
+                        if (has_bias) e = e + bv[j];
+                        if constexpr (E_SCALE) {
+                            if (a.scale) e = e * sc[j] + sh[j];
+                        }
+                        e = fmaxf(e, lo);
+                        if constexpr (EPI >= 4) {
+                            if (R1) e = e + r1v[r][j];
+                            if (R2) e = e + r2v[r][j];
+                        }
+                        if constexpr (EPI == 5) e = (mkv[r][j] > 0.f) ? e : 0.f;
+                        v[j] = e;
+                    }
+                    *reinterpret_cast<vecT*>(Y + (size_t)rowu * ldy + cbase + voy) = v;
+                }
+                if constexpr (EPI >= 4) __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int colu = cbase + j * 32;                      // wave-uniform first column of this 32-wide tile
@@ -464,7 +550,14 @@ static int launch_linear(const LinearArgs& a, int batch, bool transb, hipStream_
     dim3 grid((a.N + BN - 1) / BN, (a.M + BM - 1) / BM, batch);
     const bool aligned = ((a.ldx & 3) == 0) && ((a.ldw & 3) == 0) && ((a.sx & 3) == 0) && ((a.sw & 3) == 0) &&
                          ((((uintptr_t)a.X) & 15) == 0) && ((((uintptr_t)a.W) & 15) == 0);
-    const bool interior = aligned && (a.M % BM == 0) && (a.N % BN == 0) && (a.K % BK == 0);
+    // (round 5: interior tiles store / fetch TN-wide vectors in the epilogue -- Y, bias and the optional epilogue operands must allow it)
+    const auto al16 = [](const void* p) { return (((uintptr_t)p) & 15) == 0; };
+    const bool out_aligned = ((a.ldy & 3) == 0) && ((a.sy & 3) == 0) && al16(a.Y) && (!a.bias || al16(a.bias)) &&
+                             (!a.scale || (al16(a.scale) && al16(a.shift))) &&
+                             (!a.R1 || (((a.ldr1 & 3) == 0) && ((a.sr1 & 3) == 0) && al16(a.R1))) &&
+                             (!a.R2 || (((a.ldr2 & 3) == 0) && ((a.sr2 & 3) == 0) && al16(a.R2))) &&
+                             (!a.Mk || (((a.ldm & 3) == 0) && al16(a.Mk)));
+    const bool interior = aligned && out_aligned && (a.M % BM == 0) && (a.N % BN == 0) && (a.K % BK == 0);
     if (interior) {
         if (transb) return launch_one<BM, BN, WM, WN, BK, true, false>(a, grid, s);
         return launch_one<BM, BN, WM, WN, BK, false, false>(a, grid, s);

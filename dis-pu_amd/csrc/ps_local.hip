@@ -327,9 +327,15 @@ __global__ __launch_bounds__(512) void ps_local_ws_kernel(long npoints, int n_pe
         };
         auto store_a = [&](const float4 (&pg)[4], int stage, int k0, const float* ab) {     // relu(G_j - A_i) -> slab `stage`
             float* As = astg + stage * PW_ASTG;
+            // the four A-row reads go out together, ahead of the arithmetic: one LDS round trip per slab instead of four in a row (the
+            // compiler's order was read, wait, subtract, store per row)
+            float4 avs[4];
+#pragma unroll
+            for (int it = 0; it < 4; ++it) avs[it] = *reinterpret_cast<const float4*>(ab + (2 * it + rq) * PL_K + k0 + kq * 4);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
-                const float4 av = *reinterpret_cast<const float4*>(ab + (2 * it + rq) * PL_K + k0 + kq * 4);
+                const float4 av = avs[it];
                 const int r = rho + 32 * it;
                 const f32x2 dlo = f32x2{pg[it].x, pg[it].y} - f32x2{av.x, av.y};      // v_pk_add_f32 with neg
                 const f32x2 dhi = f32x2{pg[it].z, pg[it].w} - f32x2{av.z, av.w};
@@ -387,9 +393,13 @@ __global__ __launch_bounds__(512) void ps_local_ws_kernel(long npoints, int n_pe
                 cxbuf[ht * 4 + 3] = 0.f;                              // read as part of a float4
             }
         };
-        auto wn_d = [&](int g, float* wv) {
+        // wn_d(g, wv, U0, U1): points U0 .. U1 - 1 of the group.  Round 5: the eight points are spread over three slab intervals (the
+        // last one of the previous group and the first two of the group itself: cxbuf is rewritten in the third, the contraction
+        // reads wv after the fourth) -- all eight in one interval made that interval's helper work twice the others' and the MFMA
+        // waves waited 1.5 - 2 k cycles per group at its barrier (PL_STAMPS)
+        auto wn_d = [&](int g, float* wv, int U0, int U1) {
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = U0; u < U1; ++u) {
                 float v = 0.f;
                 if (UNI || g * 8 + u < np) {
                     const float4 cx = *reinterpret_cast<const float4*>(cxbuf + (u * 16 + wsn) * 4);
@@ -422,7 +432,7 @@ __global__ __launch_bounds__(512) void ps_local_ws_kernel(long npoints, int n_pe
         load_g(pg0, 0, goff);
         load_g(pg1, PL_BK, goff);
         __syncthreads();                                             // #1: abuf, cxbuf, wres visible
-        wn_d(g, wvbuf);
+        wn_d(g, wvbuf, 0, 8);
         store_a(pg0, 0, 0, abuf);
         load_g(pg0, 2 * PL_BK, goff);
         __syncthreads();                                             // #2: slab 0 and wv of the first group ready
@@ -443,6 +453,7 @@ __global__ __launch_bounds__(512) void ps_local_ws_kernel(long npoints, int n_pe
             store_a(pg1, 1, PL_BK, ab);
             PL_H(a1);
             load_g(pg1, 3 * PL_BK, goff);
+            if (n > 0) wn_d(g, wvbuf + (n & 1) * 2048, 3, 6);         // this group's weight net, second part (cxbuf still holds its offsets)
             if (has_next) { rows_load(gn); load_arow(gn); wn_a(gn); }
             PL_H(a2);
             pl_lds_barrier();
@@ -450,6 +461,7 @@ __global__ __launch_bounds__(512) void ps_local_ws_kernel(long npoints, int n_pe
             PL_H(b0);
             store_a(pg0, 0, 2 * PL_BK, ab);
             PL_H(b1);
+            if (n > 0) wn_d(g, wvbuf + (n & 1) * 2048, 6, 8);         // ... third part; cxbuf is free for the next group from here on
             if (has_next) { rows_finish(gn, goff_n); load_g(pg0, 0, goff_n); store_arow(ab_n); wn_b(); }
             PL_H(b2);
             pl_lds_barrier();
@@ -468,7 +480,7 @@ __global__ __launch_bounds__(512) void ps_local_ws_kernel(long npoints, int n_pe
             PL_H(d1);
             if (has_next) {
                 load_g(pg0, 2 * PL_BK, goff_n);
-                wn_d(gn, wvbuf + ((n + 1) & 1) * 2048);                // that buffer's last reader was the contraction of group n-1
+                wn_d(gn, wvbuf + ((n + 1) & 1) * 2048, 0, 3);          // next group's weight net, first part (that buffer's last reader was the contraction of group n-1)
             }
             PL_H(d2);
             pl_lds_barrier();
@@ -505,7 +517,7 @@ __global__ __launch_bounds__(512) void ps_local_ws_kernel(long npoints, int n_pe
     __syncthreads();                                                 // #2
     int n = 0;
 #ifdef PL_STAMPS
-    unsigned long long c_mma = 0, c_bar = 0, c_con = 0;
+    unsigned long long c_mma = 0, c_bar = 0, c_con = 0, c_bt[4] = {0, 0, 0, 0};
 #define PL_T(v) const unsigned long long v = __builtin_readcyclecounter()
 #else
 #define PL_T(v)
@@ -582,7 +594,7 @@ __global__ __launch_bounds__(512) void ps_local_ws_kernel(long npoints, int n_pe
             pl_lds_barrier();
             PL_T(s2);
 #ifdef PL_STAMPS
-            c_mma += s1 - s0; c_bar += s2 - s1;
+            c_mma += s1 - s0; c_bar += s2 - s1; c_bt[t] += s2 - s1;
 #endif
         }
         PL_T(p0s);
@@ -611,6 +623,8 @@ __global__ __launch_bounds__(512) void ps_local_ws_kernel(long npoints, int n_pe
     if (blockIdx.x == 5 && lane == 0) {
         unsigned long long* st = reinterpret_cast<unsigned long long*>(out + (size_t)npoints * 2048) + wave * 5;
         st[0] = c_mma; st[1] = c_bar; st[2] = 0; st[3] = c_con; st[4] = n;
+        unsigned long long* sb = reinterpret_cast<unsigned long long*>(out + (size_t)npoints * 2048) + 40 + wave * 4;
+        sb[0] = c_bt[0]; sb[1] = c_bt[1]; sb[2] = c_bt[2]; sb[3] = c_bt[3];
     }
 #endif
 }

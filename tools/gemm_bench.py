@@ -17,6 +17,8 @@ def run_one():
     import torch
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from dispu_amd import _lib
+    if os.environ.get("GEMM_LIB"):                       # A/B against another build of the library
+        _lib.LIB_PATH = os.environ["GEMM_LIB"]
     L = _lib.lib()
     dev = torch.device("cuda:0")
     out = []

@@ -26,7 +26,7 @@ int main() {
     for (int rep = 0; rep < 10; ++rep) dispu_ps_local(np, n, 16, 128, idx, xyz, G, 128, A, W1, b1, Ww, bw, sc, sh, out, nullptr);
     hipEventRecord(e1); hipDeviceSynchronize();
     float ms; hipEventElapsedTime(&ms, e0, e1);
-    unsigned long long st[40];
+    unsigned long long st[56];
     hipMemcpy(st, out + (size_t)np * 2048, sizeof(st), hipMemcpyDeviceToHost);
     printf("ps_local %.1f us per call\n", ms * 100);
     for (int w = 0; w < 4; ++w)
@@ -36,5 +36,8 @@ int main() {
         printf("  helper wave %d over %llu groups, cycles per group: store_a (incl. waiting for its gathers) %.0f  issue loads / weight net %.0f  barriers %.0f\n", w,
                st[20 + w * 4 + 3], st[20 + w * 4] / (double)st[20 + w * 4 + 3], st[20 + w * 4 + 1] / (double)st[20 + w * 4 + 3],
                st[20 + w * 4 + 2] / (double)st[20 + w * 4 + 3]);
+    for (int w = 0; w < 4; ++w)
+        printf("  mfma wave %d: wait at the barrier after slab 0 / 1 / 2 / 3: %.0f %.0f %.0f %.0f cycles per group\n", w, st[40 + w * 4] / (double)st[w * 5 + 4],
+               st[41 + w * 4] / (double)st[w * 5 + 4], st[42 + w * 4] / (double)st[w * 5 + 4], st[43 + w * 4] / (double)st[w * 5 + 4]);
     return 0;
 }
