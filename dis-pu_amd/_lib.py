@@ -114,6 +114,7 @@ SIGNATURES = {
     "dispu_sigmoid_offset_grad": (_i, [_l, _vp, _vp, _vp, _vp, _vp]),
     "dispu_repulsion_grad": (_i, [_l, _i, _i, C.c_float, C.c_float, _vp, _vp, _vp, _vp]),
     "dispu_add3": (_i, [_l, _vp, _vp, _vp, _vp, _vp]),
+    "dispu_linear_splitk_finish": (_i, [_l, _i, _i, _vp, _l, _vp, _i, _vp, _l, _vp]),
     "dispu_fill_rows": (_i, [_i, _i, _vp, C.c_float, _vp, _vp]),
     "dispu_mlp_chain": (_i, [_l, _i, _i, _i, _i, _vp, _l, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _l, _i, _vp, _l, _vp, _l, _vp]),
     "dispu_linear_masked": (_i, [_i, _i, _i, _i, _vp, _l, _l, _vp, _l, _l, _i, _vp, _i, _vp, _l, _l, _vp, _l, _l, _vp, _l, _i, _vp]),

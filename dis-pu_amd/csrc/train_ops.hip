@@ -440,6 +440,26 @@ static int bn_blocks(long rows, int& rows_per_block) {
     return (int)nb;
 }
 
+// Y[r][c] = act((((P_0 + P_1) + ...) + P_{np-1})[r][c] + bias[c]) on float4 quads: the fixed-order sum of the K-chunk partials of a
+// split-K product (Trainer.forward: after_conv at 8 - 16 patches, see dispu_linear_splitk_finish in include/dispu_hip.h)
+__global__ void splitk_finish_kernel(unsigned quads, unsigned n4, int np, const float* __restrict__ part, size_t stride, const float* __restrict__ bias,
+                                     int act, float* __restrict__ Y, unsigned ldy) {
+    for (unsigned e = blockIdx.x * blockDim.x + threadIdx.x; e < quads; e += gridDim.x * blockDim.x) {
+        const unsigned r = e / n4, c = (e - r * n4) * 4;
+        const float* p = part + (size_t)e * 4;
+        float4 v[8];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) v[s] = (s < np) ? *reinterpret_cast<const float4*>(p + (size_t)s * stride) : make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 t = v[0];
+#pragma unroll
+        for (int s = 1; s < 8; ++s)
+            if (s < np) { t.x += v[s].x; t.y += v[s].y; t.z += v[s].z; t.w += v[s].w; }
+        if (bias) { const float4 b = *reinterpret_cast<const float4*>(bias + c); t.x += b.x; t.y += b.y; t.z += b.z; t.w += b.w; }
+        if (act) { t.x = fmaxf(t.x, 0.f); t.y = fmaxf(t.y, 0.f); t.z = fmaxf(t.z, 0.f); t.w = fmaxf(t.w, 0.f); }
+        *reinterpret_cast<float4*>(Y + (size_t)r * ldy + c) = t;
+    }
+}
+
 }  // namespace dispu
 
 using namespace dispu;
@@ -575,6 +595,19 @@ DISPU_EXPORT int dispu_repulsion_grad(long rows, int n_per_cloud, int ns, float 
     if (rows < 0 || n_per_cloud <= 0 || ns < 5) return (int)hipErrorInvalidValue;
     if (rows == 0) return 0;
     LAUNCH1D(repulsion_grad_kernel, rows, rows, n_per_cloud, ns, h, scale, pred, idx, dpred);
+}
+
+DISPU_EXPORT int dispu_linear_splitk_finish(long rows, int n, int nparts, const float* part, long part_stride, const float* bias, int act,
+                                            float* Y, long ldy, void* stream) {
+    if (rows < 0 || n <= 0 || (n & 3) || nparts < 1 || nparts > 8 || !part || !Y || (ldy & 3) || (part_stride & 3) ||
+        ((((uintptr_t)part) | ((uintptr_t)Y) | ((uintptr_t)bias)) & 15) || (long)rows * n / 4 >= 0x7fffffffl)
+        return (int)hipErrorInvalidValue;
+    if (rows == 0) return 0;
+    const unsigned quads = (unsigned)((long)rows * n / 4);
+    const unsigned g = (quads + 255) / 256;
+    hipLaunchKernelGGL(splitk_finish_kernel, dim3(g > 16384 ? 16384 : g), dim3(256), 0, (hipStream_t)stream, quads, (unsigned)(n / 4), nparts, part,
+                       (size_t)part_stride, bias, act, Y, (unsigned)ldy);
+    return (int)hipGetLastError();
 }
 
 DISPU_EXPORT int dispu_add3(long total, const float* a, const float* b, const float* c, float* out, void* stream) {

@@ -750,7 +750,22 @@ class Trainer(object):
         _lib.check(L.dispu_ps_local(rm, M, k, 128, _p(ws["psidx"]), _p(coarse), _p(ws["gm"]), 128, _p(ws["am"]),
                                     _p(P[ps + "conv1/weights"]), _p(P[ps + "conv1/biases"]), _p(ww), _p(bw), _p(ws["bn_scale"]),
                                     _p(ws["bn_shift"]), _p(ws["hp"]), self.st), "ps_local")
-        self._lin(ws["hp"], 0, 2048, ps + "after_conv", 1, ws["aft"], 0, 256)
+        # after_conv, [rows x 2048] x [2048 x 256].  At <= 16 patches the rows give 32 - 128 tiles of 128 x 256 -- a fraction of the chip --
+        # and the tile rule falls back to 512 L2-bound 64 x 64 tiles (139 us in the 8-patch step for a 55 us product): the contraction is
+        # split into K-chunks run as one batched launch that fills the chip with 128 x 256 tiles, a second launch adds the chunks in
+        # order, then bias and ReLU (reassociated; `fine` is tolerance-checked).  fp32 products only (bf16 products have their own tiles)
+        nsp = 4 if rm >= 8192 else 8
+        if rm <= 16384 and rm % 128 == 0 and ws["hp"].dtype == torch.float32 and not self._use_bf16(1, rm, 2048, 256):
+            if ws.get("aft_parts") is None or ws["aft_parts"].numel() < nsp * rm * 256:
+                ws["aft_parts"] = torch.empty((nsp * rm, 256), dtype=torch.float32, device=self.device)
+            wa, ba = P[ps + "after_conv/weights"], P[ps + "after_conv/biases"]
+            kc = 2048 // nsp
+            _lib.check(L.dispu_linear(nsp, rm, kc, 256, _p(ws["hp"]), 2048, kc, _p(wa), 256, kc * 256, 0, None, 0, _p(ws["aft_parts"]), 256, rm * 256,
+                                      None, 0, 0, None, 0, 0, self.st), "dispu_linear[split-K]")
+            _lib.check(L.dispu_linear_splitk_finish(rm, 256, nsp, _p(ws["aft_parts"]), rm * 256, _p(ba), 1, _p(ws["aft"]), 256, self.st),
+                       "dispu_linear_splitk_finish")
+        else:
+            self._lin(ws["hp"], 0, 2048, ps + "after_conv", 1, ws["aft"], 0, 256)
         self._merge(0)
         self._merge(1)
         _lib.check(L.dispu_add3(rm * 256, _p(ws["aft"]), _p(ws["skip"]), _p(ws["nl"]), _p(ws["sum"]), self.st), "add3")

@@ -433,6 +433,13 @@ int dispu_repulsion_grad(long rows, int n_per_cloud, int ns, float h, float scal
                          float* dpred, void* stream);
 /* out = (a + b) + c  (tf.add x2, ops.py:1072-1075). */
 int dispu_add3(long total, const float* a, const float* b, const float* c, float* out, void* stream);
+/* Second half of a split-K product for FEW rows and a LONG contraction (the training forward's after_conv at 8 - 16 patches:
+ * [8192 x 2048] x [2048 x 256] gives 64 tiles of 128 x 256 -- a quarter of the chip -- or 512 L2-bound 64 x 64 tiles): the caller runs
+ * dispu_linear with batch = nparts over K-chunks (sx = K / nparts, sw = (K / nparts) * ldw, no bias / activation, partials [nparts][rows][n]
+ * with stride part_stride) and this adds them in ascending chunk order, then bias, then the activation:
+ * Y = act(((P_0 + P_1) + ...) + bias).  A reassociation of the ascending-k chain: only used where the result is tolerance-checked. */
+int dispu_linear_splitk_finish(long rows, int n, int nparts, const float* part, long part_stride, const float* bias, int act, float* Y,
+                               long ldy, void* stream);
 /* out[b, j] = val[b] * mul (the constant rows d loss / d dist of chamfer's means, loss_utils.py:59-63). */
 int dispu_fill_rows(int b, int n, const float* val, float mul, float* out, void* stream);
 /* tf.train.AdamOptimizer update on flat buffers (model.py:178); g is scaled by gscale first (1/world after the
