@@ -131,20 +131,20 @@ def cpu_baseline(target_seconds=14.0, with_ops=True):
 
 def train_step_table(dev, steps=20, warmup=4):
     """Side table `roofline.train_step` (BASELINE configs[4]'s per-GPU share: 8 patches per GPU, full train step = training-mode forward,
-    pu_loss, backward, gradient all-reduce (a no-op on one rank), Adam): ms per step eager and hipGraph-replayed, fp32 and bf16, plus the
+    pu_loss, backward, gradient all-reduce (a no-op on one rank), Adam): ms per step (eager launches), fp32 and bf16, plus the
     B = 32 step; `mfma_frac` prices 3 x the forward's executed flops against the fp32 MFMA peak (a lower bound on the work: the backward
     recomputes the dense blocks and conv1).  Every row is tools/train_bench.py in a FRESH process: inside this one, after the headline /
     per-op benches and the Trainers of the earlier rows, the same step measured 10 - 15 % slower than on its own (2.2 vs 1.9 ms)."""
     import subprocess
     out = {}
-    for dtype, B, graphed in (("f32", 8, False), ("f32", 8, True), ("bf16", 8, False), ("bf16", 8, True), ("f32", 32, False)):
+    for dtype, B in (("f32", 8), ("bf16", 8), ("f32", 32)):
         cmd = [sys.executable, os.path.join(ROOT, "tools", "train_bench.py"), "--batch", str(B), "--steps", str(steps), "--warmup", str(warmup),
-               "--dtype", dtype] + (["--graph"] if graphed else [])
+               "--dtype", dtype]
         env = dict(os.environ)
         for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
             env.pop(k, None)
         r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, env=env)
-        key = "%s_b%d_%s" % (dtype, B, "hipgraph" if graphed else "eager")
+        key = "%s_b%d_eager" % (dtype, B)
         if r.returncode != 0:
             out[key] = {"error": r.stderr.decode(errors="replace")[-300:]}
             continue

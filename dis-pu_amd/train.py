@@ -105,7 +105,6 @@ class Trainer(object):
         self._scratch = {}                    # per stream: scratch of the split reductions / column sums
         self._bn_scratch = None
         self._stash_ready = False
-        self._graphs = {}
         self._tapes = {}
         self._ar = None                       # parallel.BucketedAllReduce over flat_g (data parallel only, see _reducer)
         self._ar_armed = False                # True inside train_step(): backward() may start a bucket's all-reduce as soon as it is complete
@@ -155,11 +154,10 @@ class Trainer(object):
 
     # --------------------------------------------------------------------------------------------- parameters ----
     def _invalidate_recordings(self):
-        """Launch tapes and captured hipGraphs hold RAW device pointers (flat parameter / gradient / moment buffers, W^T copies,
+        """Launch tapes hold RAW device pointers (flat parameter / gradient / moment buffers, W^T copies,
         scratch, workspaces).  Whenever one of those buffers is re-allocated every recording is dropped, so the next
-        train_step_taped / train_step_graphed records afresh instead of replaying launches onto freed memory."""
+        train_step_taped records afresh instead of replaying launches onto freed memory."""
         self._tapes.clear()
-        self._graphs.clear()
 
     def load_params(self, params):
         dev = self.device
@@ -1160,58 +1158,13 @@ class Trainer(object):
         _lib.check(_lib.tape_lib().dispu_adam(self.flat_p.numel(), _p(self.flat_p), _p(self.flat_g), _p(self.flat_m), _p(self.flat_v),
                                          lr_t, b1, b2, 1e-8, 1.0 / world, _lib.stream_ptr(self.device)), "dispu_adam")
 
-    def train_step_graphed(self, inputs, gt, radius):
-        """train_step with forward + loss + backward replayed from ONE hipGraph (the ~200 launches of 5 - 50 us each are queued by
-        the HIP runtime instead of by Python: at 8 patches per GPU the eager step is partly launch-bound).  The graph is captured on
-        first use for this (B, N) and re-captured when weight_fine changes (epochs 10 / 20 / 30: the only scalar baked into its
-        kernel arguments); the gradient all-reduce and Adam (bias-corrected learning rate changes every step) stay eager."""
-        B, N = inputs.shape[0], inputs.shape[1]
-        self._check_targets(gt, radius, B, N * self.up_ratio)
-        key = (B, N, weight_fine(self.epoch), self.opts.use_repulse)
-        g = self._graphs.get(key)
-        if g is None:
-            st = dict(x=inputs.clone(), gt=gt.clone(), radius=radius.clone())
-            # warm-up: every workspace / scratch buffer exists before the capture.  The warm-up forwards must not count as training
-            # steps: the weight net's BatchNorm moving statistics are put back afterwards (the reference updates them once per step)
-            mm, mv = self.moving_mean.clone(), self.moving_var.clone()
-            for _ in range(2):
-                self.zero_grad()
-                self.forward(st["x"])
-                self.loss_backward(st["gt"], st["radius"])
-                self.backward()
-            self.moving_mean.copy_(mm)
-            self.moving_var.copy_(mv)
-            torch.cuda.synchronize(self.device)
-            graph = torch.cuda.CUDAGraph()
-            cap = torch.cuda.Stream(device=self.device)
-            cap.wait_stream(torch.cuda.current_stream(self.device))
-            with torch.cuda.stream(cap):
-                with torch.cuda.graph(graph, stream=cap):
-                    self.zero_grad()
-                    self.forward(st["x"])
-                    st["terms"] = self.loss_backward(st["gt"], st["radius"])
-                    self.backward()
-            torch.cuda.current_stream(self.device).wait_stream(cap)
-            del self._cap_events[:]
-            self._aux_done.clear()           # the next eager use records the cached events again before anything waits on them
-            st["graph"] = graph
-            g = self._graphs[key] = st
-        g["x"].copy_(inputs)
-        g["gt"].copy_(gt)
-        g["radius"].copy_(radius)
-        g["graph"].replay()
-        world = self.all_reduce_grads()
-        self.adam(world)
-        self.global_step += 1
-        # the captured scalars live in the graph's memory pool and are overwritten by the next replay: hand out copies
-        return {k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in g["terms"].items()}
-
     def train_step_taped(self, inputs, gt, radius):
         """train_step with forward + loss + backward re-issued from a LAUNCH TAPE (dis-pu_amd/_lib.py:Tape): the same launches on the
         same streams in the same order as the eager step, recorded once per (B, N, loss weights) with their ctypes arguments already
         converted, then replayed as a flat loop of foreign calls.  The eager step spends ~10 us of Python per launch (1.4 ms for ~130
         launches at 8 patches -- as long as the GPU's critical chain, so the main queue idles wherever a chain kernel is submitted
-        behind side work); the replay spends ~1.5 us.  Unlike train_step_graphed the GPU-side schedule is the eager one.  Inputs are
+        behind side work); the replay spends ~1.5 us and the GPU-side schedule is the eager one (a hipGraph replay of the same step ran
+        its branches nearly one after the other on this runtime, 11 - 15 % slower than eager: removed in round 5).  Inputs are
         copied into static buffers (the tape holds raw pointers); the all-reduce and Adam stay eager."""
         B, N = inputs.shape[0], inputs.shape[1]
         gt, radius = self._check_targets(gt, radius, B, N * self.up_ratio)

@@ -6,7 +6,7 @@ T=$1
 G=gpurun_out
 P=profiles
 for f in bench.json configs.json emd_bench.txt fps_bench.txt kernel_stats.csv ops_microbench.json pytest_gpu.txt train_b32_bench.json \
-         train_b8_bench.json train_b8_bf16_bench.json train_b8_bf16_graph_bench.json train_b8_graph_bench.json; do
+         train_b8_bench.json train_b8_bf16_bench.json; do
     cp $G/$T/$f $P/${T}_$f
 done
 cp $G/$T/bench_profiled.json $P/${T}_bench_under_rocprof.json

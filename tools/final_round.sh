@@ -13,12 +13,10 @@ bash tools/pmc_traffic.sh ${TAG}_pmc > gpurun_out/$TAG/pmc.log 2>&1; tail -c 600
 timeout 900 python tools/ops_bench.py > gpurun_out/$TAG/ops_microbench.json 2> gpurun_out/$TAG/ops.log; tail -c 300 gpurun_out/$TAG/ops_microbench.json
 timeout 600 python tools/config_bench.py > gpurun_out/$TAG/configs.json 2>> gpurun_out/$TAG/ops.log
 timeout 300 python tools/train_bench.py > gpurun_out/$TAG/train_b8_bench.json 2>> gpurun_out/$TAG/ops.log
-timeout 300 python tools/train_bench.py --graph > gpurun_out/$TAG/train_b8_graph_bench.json 2>> gpurun_out/$TAG/ops.log
-timeout 300 python tools/train_bench.py --dtype bf16 --graph > gpurun_out/$TAG/train_b8_bf16_graph_bench.json 2>> gpurun_out/$TAG/ops.log
 timeout 300 python tools/train_bench.py --batch 32 > gpurun_out/$TAG/train_b32_bench.json 2>> gpurun_out/$TAG/ops.log
 bash tools/prof_train.sh ${TAG}_train 8 > gpurun_out/$TAG/prof_train.log 2>&1
 timeout 300 python tools/emd_bench.py > gpurun_out/$TAG/emd_bench.txt 2>> gpurun_out/$TAG/ops.log
 timeout 300 python tools/train_bench.py --dtype bf16 > gpurun_out/$TAG/train_b8_bf16_bench.json 2>> gpurun_out/$TAG/ops.log
 timeout 300 python tools/fps_bench.py > gpurun_out/$TAG/fps_bench.txt 2>> gpurun_out/$TAG/ops.log
-bash tools/trace_train.sh ${TAG}_trace 8 f32 --graph > gpurun_out/$TAG/trace.log 2>&1
+bash tools/trace_train.sh ${TAG}_trace 8 f32 > gpurun_out/$TAG/trace.log 2>&1
 echo done

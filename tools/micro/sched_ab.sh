@@ -2,7 +2,7 @@
 # environment switch changed (DESIGN.md section 8 lists what was measured with it).
 cd $GRAFT_REPO_ROOT
 run() { python tools/train_bench.py "$@" 2>/dev/null | python -c 'import json,sys; d=json.loads(sys.stdin.read()); print(round(d["ms_per_step"],4), d["forward_ms"], d["loss_ms"], d["backward_ms"])'; }
-echo "default             f32: $(run)   bf16: $(run --dtype bf16)   f32 B=32: $(run --batch 32)   f32 hipGraph: $(run --graph)"
+echo "default             f32: $(run)   bf16: $(run --dtype bf16)   f32 B=32: $(run --batch 32)"
 echo "SCHED=0             f32: $(DISPU_TRAIN_SCHED=0 run)"
 echo "SCHED=7             f32: $(DISPU_TRAIN_SCHED=7 run)"
 echo "FUSED_HEADS_BWD=0   f32: $(DISPU_TRAIN_FUSED_HEADS_BWD=0 run)"

@@ -29,7 +29,6 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--dtype", choices=("f32", "bf16"), default="f32",
                     help="f32: the reference's arithmetic; bf16: bf16 products / fp32 accumulation and storage (csrc/linear_bf16.hip)")
-    ap.add_argument("--graph", action="store_true", help="forward + loss + backward replayed from one hipGraph (Trainer.train_step_graphed)")
     ap.add_argument("--tape", action="store_true", help="forward + loss + backward re-issued from a launch tape (Trainer.train_step_taped)")
     args = ap.parse_args()
     from dispu_amd import synth
@@ -50,7 +49,7 @@ def main():
     x, gt = torch.from_numpy(x).to(dev), torch.from_numpy(gt).to(dev)
     radius = torch.ones(args.batch, device=dev)
 
-    step_fn = tr.train_step_graphed if args.graph else tr.train_step_taped if args.tape else tr.train_step
+    step_fn = tr.train_step_taped if args.tape else tr.train_step
     for _ in range(args.warmup):
         step_fn(x, gt, radius)
     torch.cuda.synchronize()
