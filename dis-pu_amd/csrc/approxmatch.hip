@@ -83,7 +83,8 @@ __device__ __forceinline__ float am_exp_level(float d2, float level) {
     else return __builtin_amdgcn_exp2f(d2 * (level * AM_LOG2E));   // level * AM_LOG2E is loop-invariant (hoisted)
 }
 
-// COH: the persistent kernel's workgroups exchange the scratch vectors while the kernel runs, across XCDs (separate L2s).  Fencing
+// COH (always false since round 5, kept as the documented way to exchange data between co-resident workgroups): a persistent kernel's
+// workgroups exchange the scratch vectors while the kernel runs, across XCDs (separate L2s).  Fencing
 // them with agent-scope release / acquire costs an L2 write-back + invalidate per workgroup and stage (measured: ~12 us per stage,
 // the persistent form was SLOWER than 22 launches).  Instead every access to the exchanged arrays is itself an agent-scope atomic
 // (relaxed): global_load / global_store ... sc1, coherent at the device's memory side without touching the rest of the cache.
@@ -297,78 +298,9 @@ __global__ __launch_bounds__(AM_ROWS) void am_assemble_kernel(int n, int m, AmLe
     am_assemble_body<FMA, PINNED>(blockIdx.z, blockIdx.x, blockIdx.y, tile, n, m, lv, xyz1, xyz2, temp, match);
 }
 
-// ---- the whole auction of SMALL batches in ONE persistent launch (OPT-IN: DISPU_AM_PERSISTENT=1; measured SLOWER, kept as the
-// documented negative result of round 3 and as a tested alternative) ------------------------------------------------------------------
-// 22 launches of a few microseconds each are launch-latency-bound when b * n * m is small ((4, 1024^2): 167 us = 22 x 7.6 us).
-// Measured on MI355X: the persistent form needs 11 us per stage -- (4, 1024^2) 247 us, (32, 1024^2) 723 us against 167 / 368 us for
-// the launches: an in-kernel barrier across XCDs (uncached agent-scope exchange of the partial sums + the counter round trip) costs
-// MORE than a kernel boundary inside a hipGraph (~4 us).  With release / acquire fences instead of per-access atomics: 281 - 333 us.
-// The same 22 stages run inside one kernel: cloud `c` is served by `wpc` workgroups (all co-resident: the grid
-// never exceeds one workgroup per CU) that walk the stage's (row block, chunk) tiles round-robin -- the SAME tiles, bodies and
-// fixed-order combines as the separate kernels, so the results are bit-identical -- and meet at a per-cloud barrier between stages:
-// an agent-scope release increment of a counter in scratch, acquire-polled by one lane (tools/micro/xwg_sync.hip: 0.8 - 1.3 us per
-// exchange).  Spins are bounded; a timeout raises `fail` (results are then invalid, the launch still ends).
-__device__ __forceinline__ bool am_cloud_barrier(unsigned* ctr, unsigned target, int* fail) {
-    __shared__ int ok_s;
-    // every exchanged store of this stage is an agent-scope atomic store (am_st<true>): once the wave's vmcnt reaches 0 they have
-    // been performed at the device's coherence point; no cache-wide release / acquire is needed (or wanted: see am_ld)
-    __builtin_amdgcn_s_waitcnt(0);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        int spins = 0;
-        bool ok = false;
-        while (!(ok = __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) && ++spins < (1 << 22)) __builtin_amdgcn_s_sleep(2);
-        if (!ok) *fail = 1;
-        ok_s = ok ? 1 : 0;
-    }
-    __syncthreads();
-    return ok_s != 0;
-}
+// (Rounds 3 - 4 also carried the whole auction as ONE persistent launch with per-cloud software barriers -- bit-identical and slower: an
+// in-kernel barrier across XCDs costs more than a kernel boundary; removed in round 5, see profiles/EXPERIMENTS.md.)
 
-template <bool FMA, bool PINNED>
-__global__ __launch_bounds__(AM_ROWS) void am_persistent_kernel(int n, int m, int wpc, AmLevels lv, float multiL, float multiR,
-                                                                 const float* __restrict__ xyz1, const float* __restrict__ xyz2,
-                                                                 float* __restrict__ temp, float* __restrict__ match, unsigned* __restrict__ ctr,
-                                                                 int* __restrict__ fail) {
-    __shared__ AmPartner atile[AM_ACH];                  // 4 KB; the row / column bodies use its front as their float4 tile
-    __shared__ float tilew[AM_CH];
-    float4* tile = reinterpret_cast<float4*>(atile);
-    const int cloud = blockIdx.x / wpc, w = blockIdx.x % wpc, tid = threadIdx.x;
-    unsigned* my = ctr + cloud;
-    unsigned stage = 0;
-    const int nrb = (n + AM_ROWS - 1) / AM_ROWS, ncb = (m + AM_ROWS - 1) / AM_ROWS, nc1 = am_chunks(m), nc2 = am_chunks(n);
-    {   // init (am_init_kernel)
-        const AmView v = am_view(temp, cloud, n, m);
-        for (int e = w * AM_ROWS + tid; e < n; e += wpc * AM_ROWS) am_st<true>(&v.remL[e], multiL);
-        for (int e = w * AM_ROWS + tid; e < m; e += wpc * AM_ROWS) am_st<true>(&v.remR[e], multiR);
-    }
-    if (!am_cloud_barrier(my, ++stage * wpc, fail)) return;
-    for (int vb = w; vb < nrb * nc1; vb += wpc) {        // pass 1 of level 0
-        am_row_body<true, FMA, PINNED, true>(cloud, vb % nrb, vb / nrb, tile, tilew, n, m, 0, 0.f, lv.v[0], xyz1, xyz2, temp);
-        __syncthreads();
-    }
-    if (!am_cloud_barrier(my, ++stage * wpc, fail)) return;
-    for (int t = 0; t < AM_LEVELS; ++t) {
-        for (int vb = w; vb < ncb * nc2; vb += wpc) {
-            am_col_body<FMA, PINNED, true>(cloud, vb % ncb, vb / ncb, tile, n, m, t, lv.v[t], xyz1, xyz2, temp);
-            __syncthreads();
-        }
-        if (!am_cloud_barrier(my, ++stage * wpc, fail)) return;
-        if (t + 1 < AM_LEVELS) {
-            for (int vb = w; vb < nrb * nc1; vb += wpc) {
-                am_row_body<false, FMA, PINNED, true>(cloud, vb % nrb, vb / nrb, tile, tilew, n, m, t, lv.v[t], lv.v[t + 1], xyz1, xyz2, temp);
-                __syncthreads();
-            }
-            if (!am_cloud_barrier(my, ++stage * wpc, fail)) return;
-        }
-    }
-    const int nac = (m + AM_ACH - 1) / AM_ACH;
-    for (int vb = w; vb < nrb * nac; vb += wpc) {
-        am_assemble_body<FMA, PINNED, true>(cloud, vb % nrb, vb / nrb, atile, n, m, lv, xyz1, xyz2, temp, match);
-        __syncthreads();
-    }
-}
 
 // ---- match_cost -----------------------------------------------------------------------------------------------------------
 // cost[b] = sum_{k,l} sqrt(d2(k,l)) * match[l*n+k]   (matchcost, tf_approxmatch_g.cu:183-225: one block per cloud).
@@ -558,19 +490,6 @@ __global__ __launch_bounds__(256) void match_grad2_kernel(int n, int m, const fl
     if (lane == 0) { float* g = grad + ((size_t)cloud * m + l) * 3; g[0] = gx; g[1] = gy; g[2] = gz; }
 }
 
-// The persistent form must never fail silently: if a bounded spin timed out (`fail` raised: the workgroups of a cloud were not
-// co-resident after all) the plan is poisoned with NaN, so every consumer sees it (EMD, match_cost and their gradients turn NaN).
-__global__ void am_poison_on_fail_kernel(const int* __restrict__ fail, float* __restrict__ match, size_t total) {
-    if (*fail == 0) return;
-    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x)
-        match[e] = __builtin_nanf("");
-}
-
-static int am_persistent_mode() {       // DISPU_AM_PERSISTENT=1: the one-launch form for small batches (opt-in, see am_persistent_kernel)
-    const char* e = getenv("DISPU_AM_PERSISTENT");      // read per call: tests flip it inside one process
-    return e ? atoi(e) : 0;
-}
-
 template <bool FMA, bool PINNED>
 static int run_approx_match(int b, int n, int m, const float* xyz1, const float* xyz2, float* match, float* temp,
                             hipStream_t s) {
@@ -588,33 +507,6 @@ static int run_approx_match(int b, int n, int m, const float* xyz1, const float*
     }
     const dim3 blk(AM_ROWS);
     const dim3 grow((n + AM_ROWS - 1) / AM_ROWS, am_chunks(m), b), gcol((m + AM_ROWS - 1) / AM_ROWS, am_chunks(n), b);
-    // small batches: all 22 stages in one persistent launch (see am_persistent_kernel).  Used when a stage has at most 512 tiles
-    // in total (the separate launches would then leave most CUs idle and pay 22 launch latencies) and every cloud gets >= 2 workgroups.
-    const long tiles_r = (long)grow.x * grow.y, tiles_c = (long)gcol.x * gcol.y;
-    const long most = tiles_r > tiles_c ? tiles_r : tiles_c;
-    int wpc = b <= 128 ? 256 / b : 0;
-    if (wpc > most) wpc = (int)most;
-    const int mode = am_persistent_mode();
-    if (wpc >= 2 && mode == 1 && most * b <= 4096) {
-        // every workgroup of the launch has to be resident at once (they meet at software barriers): ask the runtime how many this
-        // device can hold instead of assuming 256 free CUs (a smaller part, or CUs taken by concurrent streams' kernels -> fewer)
-        int per_cu = 0, dev = 0;
-        hipDeviceProp_t prop;
-        DISPU_TRY(hipGetDevice(&dev));
-        DISPU_TRY(hipGetDeviceProperties(&prop, dev));
-        DISPU_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, am_persistent_kernel<FMA, PINNED>, AM_ROWS, 0));
-        if ((long)per_cu * prop.multiProcessorCount < (long)b * wpc) wpc = 0;
-    }
-    if (wpc >= 2 && mode == 1 && most * b <= 4096) {
-        unsigned* ctr = reinterpret_cast<unsigned*>(temp + (size_t)b * am_cloud_floats(n, m));
-        int* fail = reinterpret_cast<int*>(ctr + b);
-        DISPU_TRY(hipMemsetAsync(ctr, 0, sizeof(unsigned) * ((size_t)b + 1), s));
-        hipLaunchKernelGGL((am_persistent_kernel<FMA, PINNED>), dim3(b * wpc), blk, 0, s, n, m, wpc, lv, multiL, multiR, xyz1, xyz2, temp, match, ctr,
-                           fail);
-        DISPU_CHECK_LAUNCH();
-        hipLaunchKernelGGL(am_poison_on_fail_kernel, dim3(256), dim3(256), 0, s, fail, match, (size_t)b * n * m);
-        return (int)hipGetLastError();
-    }
     hipLaunchKernelGGL(am_init_kernel, dim3(8, b), dim3(256), 0, s, n, m, multiL, multiR, temp);
     hipLaunchKernelGGL((am_row_kernel<true, FMA, PINNED>), grow, blk, 0, s, n, m, 0, 0.f, lv.v[0], xyz1, xyz2, temp);
     for (int t = 0; t < AM_LEVELS; ++t) {

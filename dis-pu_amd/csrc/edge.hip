@@ -17,7 +17,6 @@
 #include "common.h"
 #include "knn_select.h"
 
-#include <cstdlib>
 
 namespace dispu {
 
@@ -645,9 +644,7 @@ DISPU_EXPORT int dispu_edge_dense_conv(int npoints, int n_per_cloud, int C, cons
     // LDS-resident cloud features when a cloud fits next to the weight fragments (n <= ~600 points at C = 48) and the
     // points are whole clouds; each cloud is split over `parts` workgroups so that ~256 of them exist
     const size_t feat_bytes = (size_t)n_per_cloud * (C + 4) * sizeof(float);
-    static int mode = -1;               // DISPU_EDGE_LDS=0 forces the global-gather kernel (A/B tests)
-    if (mode < 0) { const char* e = getenv("DISPU_EDGE_LDS"); mode = e ? atoi(e) : 1; }
-    if (mode != 0 && npoints % n_per_cloud == 0 && n_per_cloud % 2 == 0 && frag_bytes + feat_bytes <= 160 * 1024) {
+    if (npoints % n_per_cloud == 0 && n_per_cloud % 2 == 0 && frag_bytes + feat_bytes <= 160 * 1024) {
         const int clouds = npoints / n_per_cloud;
         int parts = (256 + clouds - 1) / clouds;
         const int gpc = n_per_cloud / 2;
@@ -655,9 +652,7 @@ DISPU_EXPORT int dispu_edge_dense_conv(int npoints, int n_per_cloud, int C, cons
         if (parts < 1) parts = 1;
         const int per = (gpc + parts - 1) / parts;                        // point groups per workgroup
         const size_t pre_bytes = (size_t)per * 2 * 24 * sizeof(float);    // layer-0 prefixes of the workgroup's points
-        static int prefix = -1;             // DISPU_EDGE_PREFIX=0: every pair tile runs layer 0's whole chain (rounds 1 - 3; A/B tests)
-        if (prefix < 0) { const char* e = getenv("DISPU_EDGE_PREFIX"); prefix = e ? atoi(e) : 1; }
-        const bool pre = prefix != 0 && frag_bytes + feat_bytes + pre_bytes <= 160 * 1024;
+        const bool pre = frag_bytes + feat_bytes + pre_bytes <= 160 * 1024;   // layer 0's per-point prefix (round 4) whenever it fits
         const size_t bytes = frag_bytes + feat_bytes + (pre ? pre_bytes : 0);
         static DevOnce attr;      
         if (attr.needed()) {
@@ -679,9 +674,7 @@ DISPU_EXPORT int dispu_edge_dense_conv(int npoints, int n_per_cloud, int C, cons
         return (int)hipGetLastError();
     }
     int g = (npoints + 7) / 8;          // 8 points (4 waves x 2) per workgroup pass
-    static int cap = -1;                // workgroups loop over point groups: the LDS weight image is built once per CU
-    if (cap < 0) { const char* e = getenv("DISPU_EDGE_GRID"); cap = e ? atoi(e) : 256; }
-    if (g > cap) g = cap;
+    if (g > 256) g = 256;               // workgroups loop over point groups: the LDS weight image is built once per CU
     if (C == 24)
         hipLaunchKernelGGL((edge_dense_conv_mfma_kernel<24, false>), dim3(g), dim3(256), frag_bytes, s, npoints, n_per_cloud, F, ldf, idx, ldi, ioff, W0, b0, W1, b1, W2, b2, Y, ldy, nullptr, 0, nullptr, nullptr, 0, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0);
     else

@@ -536,17 +536,9 @@ bool fps_wave_wants_scratch(int n, int m) { return n > 4096 && n <= FW_BS * 24 &
 int fps_wave_dispatch(int b, int n, int m, const float* xyz, void* temp, int* out, int arith, hipStream_t s) {
     if (!temp || !fps_wave_wants_scratch(n, m)) return -1;
     int* perm = reinterpret_cast<int*>(temp);
-    static const bool whole_waves = [] { const char* e = getenv("DISPU_FPS_WAVE1"); return e && e[0] == '1'; }();   // A/B: skip whole waves only
+    // n <= 8192: a skip region is a wave; above: four regions per wave.  (Measured and not kept as switches: whole-wave regions above
+    // 8192 points, 9.6 - 10.4 vs 8.5 - 9.5 ms at (8, 24576, 8192); eight regions per wave, -2 %: profiles/EXPERIMENTS.md.)
     if (n <= FW_BS * 8) return launch_fps_wave<8, 0>(b, n, m, xyz, perm, out, arith, s);
-    if (whole_waves) {
-        if (n <= FW_BS * 16) return launch_fps_wave<16, 0>(b, n, m, xyz, perm, out, arith, s);
-        return launch_fps_wave<24, 4>(b, n, m, xyz, perm, out, arith, s);
-    }
-    static const bool eight = [] { const char* e = getenv("DISPU_FPS_GROUPS8"); return e && e[0] == '1'; }();     // A/B: 8 skip groups per wave
-    if (eight) {
-        if (n <= FW_BS * 16) return launch_fps_wave4<16, 0, 8>(b, n, m, xyz, perm, out, arith, s);
-        return launch_fps_wave4<24, 8, 8>(b, n, m, xyz, perm, out, arith, s);
-    }
     if (n <= FW_BS * 16) return launch_fps_wave4<16, 0>(b, n, m, xyz, perm, out, arith, s);
     return launch_fps_wave4<24, 8>(b, n, m, xyz, perm, out, arith, s);
 }

@@ -331,7 +331,7 @@ DISPU_EXPORT int dispu_query_ball(int b, int n, int m, const float* radius, int 
         else launch_query_ball_wave<16>(b, n, m, radius, nsample, xyz1, xyz2, idx, pts_cnt, arith, st);
         return (int)hipGetLastError();
     }
-    if (!getenv("DISPU_QB_LANE")) {                 // wave-per-query over 1024-candidate chunks (DISPU_QB_LANE=1: the lane-per-query twin)
+    {                                               // wave-per-query over 1024-candidate chunks
         const int qpb = ((long)b * m >= 32768) ? 32 : 16;
         dim3 g((m + qpb - 1) / qpb, b);
         if ((arith & DISPU_ARITH_CONTRACT))

@@ -399,12 +399,7 @@ static int launch_xyz_wave(int b, int n, int m, int k, const float* s, const flo
     if (arith & DISPU_ARITH_CONTRACT)
         hipLaunchKernelGGL((knn_xyz_wave_kernel<R, true>), grid, dim3(256), 0, st, n, m, k, qpb, s, sstride, q, idx, dist);
     else
-    {
-        static int pk = -1;                 // DISPU_KNN_PK=1: distances on the packed fp32 ops (A/B switch)
-        if (pk < 0) { const char* e = getenv("DISPU_KNN_PK"); pk = e ? atoi(e) : 0; }
-        if (pk) hipLaunchKernelGGL((knn_xyz_wave_kernel<R, false, true>), grid, dim3(256), 0, st, n, m, k, qpb, s, sstride, q, idx, dist);
-        else hipLaunchKernelGGL((knn_xyz_wave_kernel<R, false>), grid, dim3(256), 0, st, n, m, k, qpb, s, sstride, q, idx, dist);
-    }
+        hipLaunchKernelGGL((knn_xyz_wave_kernel<R, false>), grid, dim3(256), 0, st, n, m, k, qpb, s, sstride, q, idx, dist);
     return (int)hipGetLastError();
 }
 
@@ -555,8 +550,7 @@ __global__ __launch_bounds__(64 * KXL_W, 4) void knn_xyz_lds_kernel(int n, int m
 
 // -1: shape outside this path
 int knn_xyz_lds_dispatch(int b, int n, int m, int k, const float* s, const float* q, int* idx, float* dist, int arith, hipStream_t st) {
-    static const int off = [] { const char* e = getenv("DISPU_KNN_LDS"); return (e && *e == '0') ? 1 : 0; }();   // A/B: the chunked path
-    if (off || n <= 1024 || n > KXL_N || k > 32) return -1;
+    if (n <= 1024 || n > KXL_N || k > 32) return -1;
     const size_t bytes = (size_t)3 * KXL_N * sizeof(float) + (size_t)KXL_W * (KXL_CAP + 4) * sizeof(uint64_t);
     static DevOnce attr;
     if (attr.needed()) {

@@ -276,7 +276,6 @@ __global__ __launch_bounds__(64 * (WM * WN + (LinearLds<BM, BN, BK, TRANSB, EDGE
     if constexpr (DMA) {
         for (int t = 0; t < ntile; ++t) {
             const float* st = lds + (t & 3) * L::STAGE;
-            const float4* As4 = reinterpret_cast<const float4*>(st);
             const float* Bs = st + BK * LDA;
             // operands of k-step s+1 are requested before the MFMAs of step s (see the register path below).  A: lane
             // (row, fk) reads the dwords fk and fk + 2 of its row's float4 (one ds_read2_b32): X[row][4 kg + fk] for the
@@ -570,15 +569,6 @@ int linear_skinny_dispatch(int M, int K, int N, const float* X, long ldx, const 
                            int act, float* Y, long ldy, const float* R1, long ldr1, const float* Mk, long ldm, int mcols,
                            hipStream_t st);   // linear_skinny.hip
 
-static int tile_override() {            // DISPU_LINEAR_TILE=<code>: force one variant (benchmarking only)
-    static int v = -2;
-    if (v == -2) {
-        const char* e = getenv("DISPU_LINEAR_TILE");
-        v = e ? atoi(e) : -1;
-    }
-    return v;
-}
-
 }  // namespace dispu
 
 using namespace dispu;
@@ -586,8 +576,6 @@ using namespace dispu;
 // Block-tile choice of dispu_linear as BM*1000 + BN (128128, 64128, 128064, 64064): the largest tile that still
 // yields >= 256 workgroups (one per CU).  Exported so a profiler can name the kernel instantiation.
 DISPU_EXPORT int dispu_linear_tile(int batch, int M, int N) {
-    const int ov = tile_override();
-    if (ov > 0) return ov;
     const long mb128 = (long)((M + 127) / 128) * batch;
     if (N >= 256 && N % 256 == 0 && mb128 * (N / 256) >= 256) return 128257;   // 128x256 tile, BK 16: 64x128 per wave
     if (N > 64 && N % 128 != 0 && N % 64 == 0 && mb128 >= 64) return 64064;    // e.g. N = 320: five full 64-wide tiles beat a half-empty edge tile (64 x 64: 34 us, 128 x 64: 41 us at 32768 x 128 x 320)
@@ -636,18 +624,7 @@ static int linear_impl(int batch, int M, int K, int N, const float* X, long ldx,
         return (int)hipErrorInvalidValue;
     if (batch == 0 || M == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
-    {
-        static int trace = -1;          // DISPU_LINEAR_TRACE=1: one stderr line per call (which shapes take which path)
-        if (trace < 0) { const char* e = getenv("DISPU_LINEAR_TRACE"); trace = (e && *e == '1') ? 1 : 0; }
-        if (trace) {
-            const int code = dispu_linear_tile(batch, M, N);
-            const int bm = code / 1000, bn = (code % 1000) >= 256 ? 256 : code % 1000, bk = (code % 1000) > 256 || bn == 256 ? 16 : 32;
-            const bool al = ((ldx & 3) == 0) && ((ldw & 3) == 0) && ((sx & 3) == 0) && ((sw & 3) == 0) && ((((uintptr_t)X) & 15) == 0) && ((((uintptr_t)W) & 15) == 0);
-            fprintf(stderr, "dispu_linear batch %d M %d K %d N %d transb %d ldx %ld ldw %ld ldy %ld tile %d interior %d res %d%d bn %d\n", batch, M, K, N, transb, ldx,
-                    ldw, ldy, code, (int)(al && M % bm == 0 && N % bn == 0 && K % bk == 0), R1 != nullptr, R2 != nullptr, scale != nullptr);
-        }
-    }
-    if (batch == 1 && !scale && !R2 && tile_override() <= 0) {
+    if (batch == 1 && !scale && !R2) {
         const int rc = linear_skinny_dispatch(M, K, N, X, ldx, W, ldw, transb, bias, act, Y, ldy, R1, ldr1, Mk, ldm, mcols, s);   // latency-bound shapes
         if (rc >= 0) return rc;
         // a few columns past a multiple of 128 (N = 134: the PointShuffle conv0 gradient): the tiled kernel would spend a second,

@@ -360,13 +360,8 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_ws_kernel(X3Args a) {
 
 using namespace dispu;
 
-// DISPU_X3_WS=0: the round-2 single-role kernel and its [plane][n][k] planes for every shape (A/B tests); read once per process,
-// by the weight split and by the GEMM alike
-static bool x3_use_ws() {
-    static int ws = -1;
-    if (ws < 0) { const char* e = getenv("DISPU_X3_WS"); ws = e ? atoi(e) : 1; }
-    return ws != 0;
-}
+// the wave-specialised kernel and its slab-major planes wherever the shape allows (round 2's single-role kernel otherwise)
+static bool x3_use_ws() { return true; }
 
 // planes: 3 * K * N bf16 values (6 K N bytes), [plane][n][k]
 DISPU_EXPORT int dispu_bf16x3_split_weights(int K, int N, const float* W, long ldw, void* planes, void* stream) {

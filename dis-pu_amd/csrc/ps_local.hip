@@ -639,8 +639,7 @@ DISPU_EXPORT int dispu_ps_local(long npoints, int n_per_cloud, int k, int c, con
     if (npoints < 0 || n_per_cloud <= 0 || k != 16 || c != 128 || ldg < 128 || (ldg & 3) || npoints * ldg > 0x7fffffffL) return (int)hipErrorInvalidValue;
     if ((((uintptr_t)G) | ((uintptr_t)A) | ((uintptr_t)W1) | ((uintptr_t)out)) & 15) return (int)hipErrorInvalidValue;
     if (npoints == 0) return 0;
-    static int mode = -1;               // DISPU_PS_LOCAL=0: single-role kernel (A/B tests); default: wave-specialised persistent kernel
-    if (mode < 0) { const char* e = getenv("DISPU_PS_LOCAL"); mode = e ? atoi(e) : 1; }
+    const int mode = 1;                 // the wave-specialised persistent kernel (mode 0 = round 1's single-role kernel, kept as the documented baseline)
     static DevOnce attr;      
     if (attr.needed()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ps_local_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -219,10 +219,7 @@ __global__ void gather_point_grad_kernel(int n, int m, size_t total, const float
 bool fps_wave_wants_scratch(int n, int m);
 int fps_wave_dispatch(int b, int n, int m, const float* xyz, void* temp, int* out, int arith, hipStream_t s);
 
-static bool fps_dense_only() {
-    static const bool v = [] { const char* e = getenv("DISPU_FPS_DENSE"); return e && e[0] == '1'; }();
-    return v;
-}
+static bool fps_dense_only() { return false; }     // (the region-skipping kernels of csrc/fps_wave.hip whenever scratch is given)
 
 // the dense (scratch-free for n <= 24576) kernels
 static int fps_dense(int b, int n, int m, const float* inp, float* temp, int* out, int arith, hipStream_t s) {

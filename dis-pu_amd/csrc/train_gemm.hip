@@ -381,14 +381,8 @@ static int tn_narrow_chunks(int batch, int M, int K, int N, int& rows) {
     return (M + rows - 1) / rows;
 }
 
-static int tn_env(const char* name, int dflt) {
-    const char* e = getenv(name);
-    return (e && *e) ? atoi(e) : dflt;
-}
-
 static void tn_plan(int batch, int M, int K, int N, int& tk, int& tnn, int& splits, int& rows) {
-    static const int want_wgs = tn_env("DISPU_TN_WGS", 768), min_slabs = tn_env("DISPU_TN_MIN_SLABS", 16), force_tnn = tn_env("DISPU_TN_TNN", 0);
-    static const int fill = tn_env("DISPU_TN_FILL", 256);
+    constexpr int want_wgs = 768, min_slabs = 16, force_tnn = 0, fill = 256;     // (swept in rounds 3 - 4: profiles/r03_tn_bench_variants.txt)
     const int max_splits = (M + min_slabs * TN_SLAB - 1) / (min_slabs * TN_SLAB);  // at least 16 slabs (256 rows) per split
     // the largest block tile whose (tiles x possible M-splits) still fills the chip: with M = 8192 rows (8 training patches) a
     // 256 x 256 output as two 128 x 256 tiles gave 64 workgroups on 256 CUs (44 us); as eight 64 x 128 tiles it is 256
@@ -529,12 +523,6 @@ DISPU_EXPORT int dispu_linear_tn(int batch, int M, int K, int N, const float* X,
     }
     int tk, tnn, splits, rows;
     tn_plan(batch, M, K, N, tk, tnn, splits, rows);
-    {
-        static int trace = -1;          // DISPU_LINEAR_TRACE=1: one stderr line per call
-        if (trace < 0) { const char* e = getenv("DISPU_LINEAR_TRACE"); trace = (e && *e == '1') ? 1 : 0; }
-        if (trace) fprintf(stderr, "dispu_linear_tn batch %d M %d K %d N %d tile %dx%d splits %d rows %d partial_MB %.1f\n", batch, M, K, N, 64 * tk, 64 * tnn,
-                           splits, rows, (double)batch * splits * (K + 1) * N * 4 / 1e6);
-    }
     // (measured and not kept: every split adding its tile to `out` with float atomics instead of partial tiles + reduction --
     // 124 vs 111 us for the 2048 x 256 gradient, 69 vs 54 us for 131072 rows x 128 x 128, a few us better only on the small ones)
     const int direct = (splits == 1 && !accumulate && !dbias) ? 1 : 0;

@@ -11,6 +11,8 @@ import torch
 from . import _lib, tf_util
 from .tf_grouping import group_point, knn_point_2
 
+FUSED_EDGE_CONV = True       # EdgeConv as one launch (dispu_edge_conv_fused); False: the unfused composition (A/B tests)
+
 
 def knn_graph(vertex_features, k):
     """tf_edge.py:19-28: neighbour indices [b, n, k] from `||x||^2 - 2 x.x^T + ||x||^2` + top_k(-D, k)
@@ -39,7 +41,7 @@ def edge_conv_layer(inputs, neigh_idx, k, num_outputs, scope=None, is_training=F
     f = _squeeze(inputs)
     c = f.shape[-1]
     width = ((2 * c + 1) & ~1) | 1
-    if (k in (16, 32, 64) and not (bn and is_training) and os.environ.get("DISPU_EDGE_FUSED", "1") != "0"
+    if (k in (16, 32, 64) and not (bn and is_training) and FUSED_EDGE_CONV
             and (2 * 64 * width + 4 * num_outputs) * 4 <= 160 * 1024):
         # edge feature, the conv and the max over the neighbours in ONE launch (csrc/sa_fused.hip): no [b, n, k, 2c] tensor in HBM
         b, n, _ = f.shape

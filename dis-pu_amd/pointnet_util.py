@@ -16,6 +16,8 @@ from .tf_grouping import group_point, knn_point, query_ball_point
 from .tf_interpolate import three_interpolate, three_nn
 from .tf_sampling import farthest_point_sample, gather_point
 
+FUSED_SA = True               # set abstraction as one launch (dispu_sa_fused); False: the single ops (A/B tests)
+
 _POOL = {"max": 0, "avg": 1, "min": 2, "weighted_avg": 3, "max_and_avg": 4}
 
 
@@ -96,7 +98,7 @@ def _sa_fused(xyz, new_xyz, points, idx, mlp, scope, params, bn):
 
 
 def _sa_fusable(points, nsample, mlp, mlp2, group_all, is_training, bn, pooling, tnet_spec, use_xyz):
-    if os.environ.get("DISPU_SA_FUSED", "1") == "0" or group_all or mlp2 or pooling != "max" or tnet_spec is not None or not use_xyz:
+    if not FUSED_SA or group_all or mlp2 or pooling != "max" or tnet_spec is not None or not use_xyz:
         return False
     if (bn and is_training) or nsample not in (32, 64) or not 1 <= len(mlp) <= 3:
         return False
@@ -110,7 +112,7 @@ def pointnet_sa_module(xyz, points, npoint, radius, nsample, mlp, mlp2, group_al
     """pointnet_util.py:91-149 -> (new_xyz, new_points[b,npoint,mlp[-1] or mlp2[-1]], idx).
 
     Max pooling over 32 / 64 samples without mlp2 in inference mode (every call of Common/ops.py:505-550) runs as ONE fused
-    kernel after the sampling / ball query; other configurations compose the single ops (DISPU_SA_FUSED=0 forces that)."""
+    kernel after the sampling / ball query; other configurations compose the single ops (pointnet_util.FUSED_SA = False forces that)."""
     if _sa_fusable(points, nsample, mlp, mlp2, group_all, is_training, bn, pooling, tnet_spec, use_xyz):
         new_xyz = gather_point(xyz, farthest_point_sample(npoint, xyz))
         if knn:

@@ -106,29 +106,30 @@ class Trainer(object):
         self._bn_scratch = None
         self._stash_ready = False
         self._tapes = {}
+        self.dw_streams = 2                   # side streams the weight-gradient products are spread over (round-robin)
         self._ar = None                       # parallel.BucketedAllReduce over flat_g (data parallel only, see _reducer)
         self._ar_armed = False                # True inside train_step(): backward() may start a bucket's all-reduce as soon as it is complete
         # weight-gradient products (dW = X^T dZ) are off the backward chain: only Adam reads them.  They run on a second
         # HIP stream next to the dX products that ARE the chain (both read dZ; at 8 patches neither fills 256 CUs alone).
-        self.overlap_dw = os.environ.get("DISPU_TRAIN_OVERLAP", "1") != "0"
+        self.overlap_dw = True
         # dense blocks: forward = the fused inference kernel, backward = one recomputing kernel per block (csrc/edge_bwd.hip);
         # 0 = round 2's path through materialised edge tensors (A/B tests)
-        self.fused_dense = os.environ.get("DISPU_TRAIN_FUSED_DENSE", "1") != "0"
-        self.use_wt = os.environ.get("DISPU_TRAIN_WT", "1") != "0"
+        self.fused_dense = True
+        self.use_wt = True
         # dtype "bf16": the big activation / gradient tensors of the local cell are STORED as bf16 (0: fp32 storage, bf16 products only)
-        self.bf16_storage = os.environ.get("DISPU_TRAIN_BF16_STORAGE", "1") != "0"          # dX products through per-step W^T copies (A/B switch)
+        self.bf16_storage = True          # dX products through per-step W^T copies (A/B switch)
         self._aux = []
         self._cur = "main"
         self._sides = []
         self._side_rr = -1
         self._fork_ev = None
         self._join_ev = None
-        self._sched = int(os.environ.get("DISPU_TRAIN_SCHED", "1"))
-        self.fused_heads_bwd = os.environ.get("DISPU_TRAIN_FUSED_HEADS_BWD", "1") != "0"
+        self._sched = 1
+        self.fused_heads_bwd = True
         # non-local cell: flash-style attention forward (+ per-row log-sum-exp) and a recomputing backward (csrc/attention_train.hip);
         # 0 = round 3's path through a materialised [B, M, M] probability tensor (A/B tests, the parity twin)
-        self.flash_attn = os.environ.get("DISPU_TRAIN_FLASH_ATTN", "1") != "0"
-        self.bf16_min_macs = float(os.environ.get("DISPU_TRAIN_BF16_MIN_MACS", "1.5e9"))
+        self.flash_attn = True
+        self.bf16_min_macs = 1.5e9
 
         self._side_busy = []
         self._group = None                  # (event, side streams that already wait for it) inside _fork_group()
@@ -139,10 +140,10 @@ class Trainer(object):
         # holds enough work (Trainer._flush); 0 restores the in-place submission (A/B)
         # (default "auto": on up to 16 patches per step -- at 32 the chip is saturated by the chain's own kernels, side work submitted
         # later only lengthens the tail: 4.58 -> 4.63 ms; "1" / "0" force it)
-        self.fused_stem = os.environ.get("DISPU_STEM_FUSED", "1") != "0"     # one launch per dense block in the forward pass
-        self.prep_late = os.environ.get("DISPU_TRAIN_PREP_LATE", "1") != "0"     # zeroing / W^T copies for the backward behind the non-local branch's own kernels (0: in front of them, round 3)
-        self.prep_on_side = os.environ.get("DISPU_TRAIN_PREP_SIDE", "0") != "0"   # ... or on a weight-gradient stream during the forward (measured slower at 8 patches in fp32: 1.79 vs 1.71 ms)   # backward's zeroing / W^T copies on a dW stream during the forward
-        self._defer_mode = os.environ.get("DISPU_TRAIN_DEFER", "auto")
+        self.fused_stem = True     # one launch per dense block in the forward pass
+        self.prep_late = True     # zeroing / W^T copies for the backward behind the non-local branch's own kernels (0: in front of them, round 3)
+        self.prep_on_side = False   # ... or on a weight-gradient stream during the forward (measured slower at 8 patches in fp32: 1.79 vs 1.71 ms)   # backward's zeroing / W^T copies on a dW stream during the forward
+        self._defer_mode = "auto"
         self.defer_side = self._defer_mode != "0"
         self._deferred = []
         self._pending = set()               # branches whose submission is still in _deferred
@@ -256,7 +257,7 @@ class Trainer(object):
 
     def _edge_buffers(self, B, N):
         """edge tensors [B*N*16, 72 + 2C] and their gradients, one pair per dense block: only the UNFUSED dense-block path
-        (DISPU_TRAIN_FUSED_DENSE=0, kept for A/B tests) materialises them."""
+        (Trainer.fused_dense = False, kept for A/B tests) materialises them."""
         key = ("edge", B, N)
         if key not in self._ws:
             rows = B * N * K_NEIGH
@@ -277,10 +278,10 @@ class Trainer(object):
             cur = self._scratch[key] = torch.empty(max(int(n), 1 << 20), dtype=torch.float32, device=self.device)
         return cur
 
-    # ---- side stream(s) for the weight-gradient products (DISPU_TRAIN_DW_STREAMS of them, used round-robin; each has its own scratch)
+    # ---- side stream(s) for the weight-gradient products (Trainer.dw_streams of them, used round-robin; each has its own scratch)
     def _side_next(self):
         if not self._sides:
-            n = max(1, int(os.environ.get("DISPU_TRAIN_DW_STREAMS", "2")))
+            n = max(1, int(self.dw_streams))
             self._sides = [_pool_stream(self.device, "dw", j) for j in range(n)]
             self._fork_ev = torch.cuda.Event()
             self._join_evs = [torch.cuda.Event() for _ in range(n)]

@@ -130,12 +130,9 @@ def test_split_bf16_gemm_is_fp32_accurate(dev):
     _lib.check(L.dispu_bf16x3_split_weights(K, Nn, tw.data_ptr(), Nn, planes.data_ptr(), st), "split")
     # slab-major planes of the wave-specialised kernel: [K / 32][plane][256 cols][4 chunk positions][8], chunk c of column n at
     # position c ^ ((n >> 2) & 3); the three planes add back up to W to 24 bits
-    if os.environ.get("DISPU_X3_WS", "1") == "0":                                   # the round-2 kernel's [plane][n][k] planes
-        rec = planes.view(3, Nn, K).float().sum(0).t()
-    else:
-        pl = planes.view(K // 32, 3, Nn, 4, 8).float().sum(1)                        # [t][n][position][8]
-        pos = (torch.arange(4, device=dev)[None, :] ^ ((torch.arange(Nn, device=dev)[:, None] >> 2) & 3))  # [n][c] -> position
-        rec = torch.gather(pl, 2, pos[None, :, :, None].expand(K // 32, Nn, 4, 8)).permute(0, 2, 3, 1).reshape(K, Nn)
+    pl = planes.view(K // 32, 3, Nn, 4, 8).float().sum(1)                            # [t][n][position][8]
+    pos = (torch.arange(4, device=dev)[None, :] ^ ((torch.arange(Nn, device=dev)[:, None] >> 2) & 3))  # [n][c] -> position
+    rec = torch.gather(pl, 2, pos[None, :, :, None].expand(K // 32, Nn, 4, 8)).permute(0, 2, 3, 1).reshape(K, Nn)
     assert float((rec - tw).abs().max()) <= 2.0 ** -22 * float(tw.abs().max())
     y = torch.zeros((M, Nn), device=dev)
     _lib.check(L.dispu_linear_bf16x3(M, K, Nn, tx.data_ptr(), K, planes.data_ptr(), tb.data_ptr(), 1, y.data_ptr(), Nn, t1.data_ptr(), Nn,

@@ -188,7 +188,7 @@ def test_sa_fused_equals_unfused_chain(dev, monkeypatch, c, mlp, ns, bn, knn):
     monkeypatch.setattr(PU, "_sa_fused", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
     fx, fp, fi = PU.pointnet_sa_module(T(xyz, dev), tp, m, 0.25, ns, mlp, None, False, False, None, "sa", bn=bn, knn=knn, params=P)
     assert calls, "the fused kernel was not used"
-    monkeypatch.setenv("DISPU_SA_FUSED", "0")
+    monkeypatch.setattr("dispu_amd.pointnet_util.FUSED_SA", False)
     ux, up, ui = PU.pointnet_sa_module(T(xyz, dev), tp, m, 0.25, ns, mlp, None, False, False, None, "sa", bn=bn, knn=knn, params=P)
     assert len(calls) == 1
     assert np.array_equal(N(fi), N(ui)) and np.array_equal(N(fx), N(ux))
@@ -210,7 +210,7 @@ def test_hierachy_feature_extractor_at_reference_shapes(dev, monkeypatch):
     assert N(got).shape == (4, 1024, 128)
     scale = np.abs(want).max()
     assert np.abs(N(got) - want).max() <= 1e-5 * max(scale, 1.0), np.abs(N(got) - want).max()
-    monkeypatch.setenv("DISPU_SA_FUSED", "0")
+    monkeypatch.setattr("dispu_amd.pointnet_util.FUSED_SA", False)
     unf = DO.hierachy_feature_extractor(T(x, dev), False, params=P)
     assert np.array_equal(N(unf), N(got))
     # the variable inventory is the checkpoint's: 21 conv layers with their BatchNorm quartets
@@ -241,7 +241,7 @@ def test_edge_conv_fused_equals_unfused(dev, monkeypatch, b, n, c, k, co, bn, ac
         idx = rng.integers(0, n, (b, n, k)).astype(np.int32)
     tf_, ti = T(f, dev).unsqueeze(2), T(idx, dev)
     got = GL.edge_conv_layer(tf_, ti, k, co, scope="ec", params=P, bn=bn, activation_fn=act)
-    monkeypatch.setenv("DISPU_EDGE_FUSED", "0")
+    monkeypatch.setattr("dispu_amd.gcn_lib.FUSED_EDGE_CONV", False)
     unf = GL.edge_conv_layer(tf_, ti, k, co, scope="ec", params=P, bn=bn, activation_fn=act)
     assert N(got).shape == (b, n, 1, co) and np.array_equal(N(got), N(unf)), "fused EdgeConv != unfused composition"
     want = OM.edge_conv_layer(P, "ec", f, idx, bn=bn, relu=act == "relu")

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Micro-benchmark of dispu_linear on the generator's GEMM shapes (run through gpurun).
-usage: python tools/gemm_bench.py [tile codes ...]     e.g. 0 128128 128256 256128 256256 128257
-Each tile code is run in its own subprocess (DISPU_LINEAR_TILE is read once per process); 0 = default heuristic."""
+usage: python tools/gemm_bench.py            (GEMM_LIB=<path> times another build of the library: A/B on one box)
+(Rounds 2 - 4 could force a tile through an environment switch; the sweeps are in profiles/r03_gemm_tile_sweep_headline_shapes.txt.)"""
 import os
 import subprocess
 import sys
@@ -50,9 +50,4 @@ if __name__ == "__main__":
     if os.environ.get("_GEMM_CHILD"):
         run_one()
     else:
-        for code in (sys.argv[1:] or ["0"]):
-            env = dict(os.environ, _GEMM_CHILD="1")
-            if code != "0":
-                env["DISPU_LINEAR_TILE"] = code
-            print("== DISPU_LINEAR_TILE=%s" % code, flush=True)
-            subprocess.run([sys.executable, os.path.abspath(__file__)], env=env)
+        subprocess.run([sys.executable, os.path.abspath(__file__)], env=dict(os.environ, _GEMM_CHILD="1"))

@@ -1,5 +1,5 @@
 """Times dispu_linear_tn (weight-gradient product + split reduction) on the shapes of the 8-patch training step (run on the GPU box).
-Environment: DISPU_TN_WGS / DISPU_TN_MIN_SLABS / DISPU_TN_TNN override the split plan (csrc/train_gemm.hip:tn_plan)."""
+(The split plan is fixed in csrc/train_gemm.hip:tn_plan; rounds 3 - 4 swept it through environment switches: profiles/r03_tn_bench_variants.txt.)"""
 import ctypes as C
 import os
 import sys
