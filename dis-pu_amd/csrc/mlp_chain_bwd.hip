@@ -196,27 +196,36 @@ __global__ __launch_bounds__(512) void mlp_chain_bwd_kernel(ChainBwdArgs a) {
     if (wave >= 4) {
         // ------------------------------------------------------------------------------------ loader waves: the weight stream
         const int tid = threadIdx.x - 256;
+        // Round 5 (as in csrc/mlp_chain.hip): a loader instruction next to an MFMA wave takes 100 - 250 cycles to issue, and with 64-row
+        // workgroups a slab is only 16 MFMAs per wave (1024 pipe cycles) -- the ~35 instructions per slab of the rolled loop (runtime layer
+        // selects, 64-bit address arithmetic, LDS offsets from divisions) were the bound.  Fully unrolled schedule, buffer loads whose slab
+        // offset is a scalar, one precomputed LDS offset per layer width: ~8 instructions per slab.
         float4 wa0, wa1, wb0, wb1;
-        auto slab_ptr = [&](int g) -> const float* {
-            if (g < S1) return a.Wt3 + (size_t)g * 2048;
-            if (g < S1 + S2) return a.Wt2 + (size_t)(g - S1) * 2048;
-            return a.Wt1 + (size_t)(g - S1 - S2) * 2048;
+        typedef unsigned int mb_u32x4 __attribute__((ext_vector_type(4)));
+        const __amdgpu_buffer_rsrc_t rw3 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.Wt3), 0, 64 * N2 * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rw2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.Wt2), 0, N2 * N1 * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rw1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.Wt1), 0, N1 * K0 * 4, 0x00020000);
+        auto bload = [](__amdgpu_buffer_rsrc_t rs, int voff, int soff) -> float4 {
+            const mb_u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0);
+            return make_float4(__uint_as_float(r[0]), __uint_as_float(r[1]), __uint_as_float(r[2]), __uint_as_float(r[3]));
         };
-        auto slab_dst = [&](int g, int idx) -> float* {
-            const int n = (g < S1) ? N2 : (g < S1 + S2) ? N1 : K0;
-            const int q = n / 4;
-            return wst + (g & 1) * MB_WST + (idx / q) * (n + 4) + (idx % q) * 4;
-        };
+        const int wvoff = tid * 16;
+        // LDS float index of the thread's first float4 inside a stage, per layer width (the second one is 256 float4 further on)
+        const int wd3 = (tid / (N2 / 4)) * (N2 + 4) + (tid % (N2 / 4)) * 4;
+        const int wd2 = (tid / (N1 / 4)) * (N1 + 4) + (tid % (N1 / 4)) * 4;
+        const int wd1 = (tid / (K0 / 4)) * (K0 + 4) + (tid % (K0 / 4)) * 4;
 #define MB_LOAD(g, r0, r1)                                                                    \
         do {                                                                                  \
-            const float* p_ = slab_ptr(g);                                                    \
-            r0 = *reinterpret_cast<const float4*>(p_ + tid * 4);                              \
-            r1 = *reinterpret_cast<const float4*>(p_ + (tid + 256) * 4);                      \
+            if ((g) < S1) { r0 = bload(rw3, wvoff, (g) * 8192); r1 = bload(rw3, wvoff, (g) * 8192 + 4096); }                                   \
+            else if ((g) < S1 + S2) { r0 = bload(rw2, wvoff, ((g) - S1) * 8192); r1 = bload(rw2, wvoff, ((g) - S1) * 8192 + 4096); }           \
+            else { r0 = bload(rw1, wvoff, ((g) - S1 - S2) * 8192); r1 = bload(rw1, wvoff, ((g) - S1 - S2) * 8192 + 4096); }                    \
         } while (0)
 #define MB_STORE(g, r0, r1)                                                                   \
         do {                                                                                  \
-            *reinterpret_cast<float4*>(slab_dst(g, tid)) = r0;                                \
-            *reinterpret_cast<float4*>(slab_dst(g, tid + 256)) = r1;                          \
+            float* st_ = wst + ((g) & 1) * MB_WST;                                            \
+            if ((g) < S1) { *reinterpret_cast<float4*>(st_ + wd3) = r0; *reinterpret_cast<float4*>(st_ + wd3 + (1024 / N2) * (N2 + 4)) = r1; }           \
+            else if ((g) < S1 + S2) { *reinterpret_cast<float4*>(st_ + wd2) = r0; *reinterpret_cast<float4*>(st_ + wd2 + (1024 / N1) * (N1 + 4)) = r1; }  \
+            else { *reinterpret_cast<float4*>(st_ + wd1) = r0; *reinterpret_cast<float4*>(st_ + wd1 + (1024 / K0) * (K0 + 4)) = r1; }                    \
         } while (0)
 #define MB_STEP(g, r0, r1) /* r0 r1 hold slab g + 1; refilled with slab g + 3 */              \
         do {                                                                                  \
@@ -236,6 +245,7 @@ __global__ __launch_bounds__(512) void mlp_chain_bwd_kernel(ChainBwdArgs a) {
         MB_LOAD(1, wb0, wb1);
         MB_LOAD(2, wa0, wa1);
         __syncthreads();                                          // dY3 tile and slab 0 are in place
+#pragma unroll
         for (int g = 0; g < G; g += 2) {
             MB_STEP(g, wb0, wb1);
             MB_STEP(g + 1, wa0, wa1);

@@ -109,7 +109,7 @@ def main():
                           "unit": "patches/s", "n_gpus": world, "patches_per_gpu": args.batch, "steps": args.steps,
                           "ms_per_step": dt / args.steps * 1e3,
                           "ms_per_step_repeats": {"n": 5, "min": srt[0] / args.steps * 1e3, "median": srt[2] / args.steps * 1e3,
-                                                  "max": srt[4] / args.steps * 1e3}, "launch": "hipgraph" if args.graph else "tape" if args.tape else "eager",
+                                                  "max": srt[4] / args.steps * 1e3}, "launch": "tape" if args.tape else "eager",
                           "dtype": "f32" if args.dtype == "f32" else "bf16 products, f32 accumulate / storage", "pu_loss": float(terms["pu_loss"]), **phases}))
     if world > 1:
         dist.destroy_process_group()
