@@ -57,6 +57,7 @@ SIGNATURES = {
     "dispu_linear_bn": (_i, [_i, _i, _i, _i, _vp, _l, _l, _vp, _l, _l, _i, _vp, _vp, _vp, _i, _vp, _l, _l, _vp, _l, _l, _vp, _l, _l,
                              _vp]),
     "dispu_linear_tile": (_i, [_i, _i, _i]),
+    "dispu_debug_linear_tile": (None, [_i]),
     "dispu_sa_fused": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "dispu_edge_conv_fused": (_i, [_i, _i, _i, _i, _vp, _l, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
     "dispu_group_center": (_i, [_l, _i, _i, _vp, _vp, _vp]),

@@ -46,10 +46,14 @@ struct LinearArgs {
 // and an MFMA lane gets its A operands of two k-steps from one ds_read_b128 (component fk / 2 + fk).
 template <int BM, int BN, int BK, bool TRANSB, bool EDGE>
 struct LinearLds {
-    static constexpr bool DMA = !EDGE && !TRANSB && BM == 128 && BN == 256 && BK == 16;
+    // round 5: every interior, untransposed BK = 16 tile of 64 / 128 rows x 64 / 128 / 256 columns takes the DMA path (it was 128 x 256
+    // only; the register-staged loaders of the smaller tiles cost ~30 instructions per slab next to MFMA waves that need 1024 - 2048
+    // cycles for theirs: loader-bound by 2 - 3x, the "26 us whatever the tile" of round 3)
+    static constexpr bool DMA = !EDGE && !TRANSB && BK == 16 && (BM == 64 || BM == 128) && (BN == 64 || BN == 128 || BN == 256);
     static constexpr int NST = DMA ? 4 : 2;
     static constexpr int LDA = DMA ? BM : BM + 1;   // register path: A tile stored k-major [BK][BM+1]: conflict-free b32 frag reads and writes
-    static constexpr int LDB = TRANSB ? BN + 1 : BN + 4;
+    // DMA: one instruction lands 1 KB = 256 / BN consecutive k rows of the B slab back to back; the +4 pad per row only exists for BN = 256
+    static constexpr int LDB = TRANSB ? BN + 1 : (DMA && BN < 256) ? BN : BN + 4;
     static constexpr int STAGE = ((BK * (LDA + LDB) + 3) / 4) * 4;          // floats per stage (16-byte multiple)
     static constexpr size_t BYTES = (size_t)NST * STAGE * sizeof(float);
 };
@@ -93,33 +97,49 @@ __global__ __launch_bounds__(64 * (WM * WN + (LinearLds<BM, BN, BK, TRANSB, EDGE
     if (wave >= WM * WN) {
         // ------------------------------------------------------------------------------------ loader waves
         if constexpr (DMA) {
-            // loader wave lw moves, per slab: A k-group lw (2 instructions: rows 0-63, 64-127) and B k-rows 4 lw .. 4 lw + 3.
-            // Slab t+3 is requested while slab t is computed; before the barrier that ends slab t, slab t+1 must have landed:
-            // at most the 12 newest DMA instructions of this wave may still be in flight (s_waitcnt vmcnt(12)).
+            // Per slab: A = [4 k-groups][BM rows] float4 -> 4 * BM / 64 instructions (64 rows x 16 bytes each), B = 16 k-rows of BN floats
+            // -> 16 * BN / 256 instructions (1 KB each: 256 / BN consecutive k rows); dealt round-robin to the four loader waves, PER of them
+            // each.  Slab t+3 is requested while slab t is computed; before the barrier that ends slab t, slab t+1 must have landed:
+            // at most the 2 * PER newest DMA instructions of this wave may still be in flight.
             const int lw = __builtin_amdgcn_readfirstlane(wave - WM * WN);
             const float* __restrict__ X = a.X + (size_t)z * a.sx;
             const float* __restrict__ W = a.W + (size_t)z * a.sw;
-            const float* pa0 = X + (size_t)(m0 + lane) * a.ldx + 4 * lw;
-            const float* pa1 = X + (size_t)(m0 + 64 + lane) * a.ldx + 4 * lw;
-            const float* pb = W + (size_t)(4 * lw) * a.ldw + n0 + 4 * lane;
-            const long ldw = a.ldw;
+            constexpr int NA = 4 * BM / 64, NB = 16 * BN / 256, PER = (NA + NB) / 4;
+            static_assert((NA + NB) % 4 == 0, "DMA instructions must split evenly over the four loader waves");
+            constexpr int RPI = 256 / BN;                                 // k rows per B instruction
+            const long ldw = a.ldw, ldx = a.ldx;
+            // instruction q = lw + 4 u (u < PER): q < NA -> A piece (k-group q / (BM / 64), row block q % (BM / 64)), else B piece q - NA
+            const float* gsrc[PER];
+            int ldst[PER];                                                // LDS float offset inside a stage
+#pragma unroll
+            for (int u = 0; u < PER; ++u) {
+                const int q = lw + 4 * u;
+                if (q < NA) {
+                    const int kg = q / (BM / 64), rb = q % (BM / 64);
+                    gsrc[u] = X + (size_t)(m0 + rb * 64 + lane) * ldx + 4 * kg;
+                    ldst[u] = (kg * BM + rb * 64) * 4;
+                } else {
+                    const int pb = q - NA, kr = pb * RPI + lane / (BN / 4);
+                    gsrc[u] = W + (size_t)kr * ldw + n0 + 4 * (lane % (BN / 4));
+                    ldst[u] = BK * LDA + (pb * RPI) * LDB;
+                }
+            }
             auto issue = [&](int t) {
                 float* st = lds + (t & 3) * L::STAGE;
-                float* As = st + (lw * BM) * 4;
-                float* Bs = st + BK * LDA + (4 * lw) * LDB;
                 const size_t ko = (size_t)t * BK;
-                __builtin_amdgcn_global_load_lds(pa0 + ko, (__attribute__((address_space(3))) void*)(As), 16, 0, 0);
-                __builtin_amdgcn_global_load_lds(pa1 + ko, (__attribute__((address_space(3))) void*)(As + 64 * 4), 16, 0, 0);
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    __builtin_amdgcn_global_load_lds(pb + (ko + j) * ldw, (__attribute__((address_space(3))) void*)(Bs + j * LDB), 16, 0, 0);
+                for (int u = 0; u < PER; ++u) {
+                    const int q = lw + 4 * u;
+                    const float* src = (q < NA) ? gsrc[u] + ko : gsrc[u] + ko * ldw;
+                    __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)(st + ldst[u]), 16, 0, 0);
+                }
             };
-            // s_waitcnt takes an immediate: wait until at most 6 * newer DMA instructions are outstanding.  Raw s_barrier, not
+            // s_waitcnt takes an immediate: wait until at most PER * newer DMA instructions are outstanding.  Raw s_barrier, not
             // __syncthreads(): the workgroup fence in front of it would drain every DMA in flight (vmcnt(0)).
             auto wait_newer = [&](int newer) {
-                if (newer >= 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-                else if (newer == 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (newer >= 2) __builtin_amdgcn_s_waitcnt(0x0F70 | (((2 * PER) & 0xF)) | ((((2 * PER) >> 4) & 0x3) << 14));
+                else if (newer == 1) __builtin_amdgcn_s_waitcnt(0x0F70 | ((PER & 0xF)) | (((PER >> 4) & 0x3) << 14));
+                else __builtin_amdgcn_s_waitcnt(0x0F70);
             };
             issue(0);
             if (ntile > 1) issue(1);
@@ -544,7 +564,8 @@ static int launch_one(const LinearArgs& a, dim3 grid, hipStream_t s) {
     return launch_epi<BM, BN, WM, WN, BK, TRANSB, EDGE, 4>(a, grid, s);
 }
 
-template <int BM, int BN, int WM, int WN, int BK>
+// BK: slab depth of the interior, untransposed path (16 = the DMA pipeline); BKR: of the register-staged paths (transposed B, edge tiles)
+template <int BM, int BN, int WM, int WN, int BK, int BKR = BK>
 static int launch_linear(const LinearArgs& a, int batch, bool transb, hipStream_t s) {
     dim3 grid((a.N + BN - 1) / BN, (a.M + BM - 1) / BM, batch);
     const bool aligned = ((a.ldx & 3) == 0) && ((a.ldw & 3) == 0) && ((a.sx & 3) == 0) && ((a.sw & 3) == 0) &&
@@ -556,13 +577,12 @@ static int launch_linear(const LinearArgs& a, int batch, bool transb, hipStream_
                              (!a.R1 || (((a.ldr1 & 3) == 0) && ((a.sr1 & 3) == 0) && al16(a.R1))) &&
                              (!a.R2 || (((a.ldr2 & 3) == 0) && ((a.sr2 & 3) == 0) && al16(a.R2))) &&
                              (!a.Mk || (((a.ldm & 3) == 0) && al16(a.Mk)));
-    const bool interior = aligned && out_aligned && (a.M % BM == 0) && (a.N % BN == 0) && (a.K % BK == 0);
-    if (interior) {
-        if (transb) return launch_one<BM, BN, WM, WN, BK, true, false>(a, grid, s);
-        return launch_one<BM, BN, WM, WN, BK, false, false>(a, grid, s);
-    }
-    if (transb) return launch_one<BM, BN, WM, WN, BK, true, true>(a, grid, s);
-    return launch_one<BM, BN, WM, WN, BK, false, true>(a, grid, s);
+    const bool tiles_ok = aligned && out_aligned && (a.M % BM == 0) && (a.N % BN == 0);
+    if (tiles_ok && !transb && (a.K % BK == 0)) return launch_one<BM, BN, WM, WN, BK, false, false>(a, grid, s);
+    if (tiles_ok && transb && (a.K % BKR == 0)) return launch_one<BM, BN, WM, WN, BKR, true, false>(a, grid, s);
+    if (BKR != BK && tiles_ok && !transb && (a.K % BKR == 0)) return launch_one<BM, BN, WM, WN, BKR, false, false>(a, grid, s);
+    if (transb) return launch_one<BM, BN, WM, WN, BKR, true, true>(a, grid, s);
+    return launch_one<BM, BN, WM, WN, BKR, false, true>(a, grid, s);
 }
 
 int linear_skinny_dispatch(int M, int K, int N, const float* X, long ldx, const float* W, long ldw, int transb, const float* bias,
@@ -575,15 +595,28 @@ using namespace dispu;
 
 // Block-tile choice of dispu_linear as BM*1000 + BN (128128, 64128, 128064, 64064): the largest tile that still
 // yields >= 256 workgroups (one per CU).  Exported so a profiler can name the kernel instantiation.
-DISPU_EXPORT int dispu_linear_tile(int batch, int M, int N) {
+static int g_tile_override = 0;     // tools/gemm_bench.py only (dispu_debug_linear_tile): force one tile for a sweep; 0 = the rule below
+DISPU_EXPORT void dispu_debug_linear_tile(int code) { g_tile_override = code; }
+
+// dma: the product can take the DMA pipeline (untransposed, K % 16 == 0; alignment assumed) -- the 64 x 128 tile only pays there
+static int linear_tile_rule(int batch, int M, int N, bool dma) {
+    if (g_tile_override > 0) return g_tile_override;
     const long mb128 = (long)((M + 127) / 128) * batch;
     if (N >= 256 && N % 256 == 0 && mb128 * (N / 256) >= 256) return 128257;   // 128x256 tile, BK 16: 64x128 per wave
     if (N > 64 && N % 128 != 0 && N % 64 == 0 && mb128 >= 64) return 64064;    // e.g. N = 320: five full 64-wide tiles beat a half-empty edge tile (64 x 64: 34 us, 128 x 64: 41 us at 32768 x 128 x 320)
-    // fewer than 512 workgroups of 64 x 128: 64 x 64 tiles (8192 rows x 128 columns: 13.8 -> 8.6 us, 2048 x 480: 22.6 -> 12.7 us)
     const long mb64 = (long)((M + 63) / 64) * batch;
-    if (N > 64) return (mb128 * ((N + 127) / 128) >= 256) ? 128128 : (mb64 * ((N + 127) / 128) >= 512 ? 64128 : 64064);
+    if (N > 64) {
+        if (mb128 * ((N + 127) / 128) >= 256) return 128128;
+        // 64 x 128 tiles once they fill the chip: 512 workgroups on the register-staged paths (round 3), 256 on the DMA pipeline
+        // (round 5, tools/gemm_bench.py: 8192 x 480 x 256 25.5 -> 22.9 us, 8192 x 256 x 256 15.8 -> 14.3 us; edge / transposed
+        // products -- 8192 x 134 x 256: 13.9 vs 18.3 us -- keep 64 x 64)
+        const long wg = mb64 * ((N + 127) / 128);
+        return (wg >= 512 || (dma && N % 128 == 0 && wg >= 256)) ? 64128 : 64064;
+    }
     return mb128 >= 256 ? 128064 : 64064;
 }
+
+DISPU_EXPORT int dispu_linear_tile(int batch, int M, int N) { return linear_tile_rule(batch, M, N, true); }
 
 static int linear_impl(int batch, int M, int K, int N, const float* X, long ldx, long sx, const float* W, long ldw, long sw, int transb,
                        const float* bias, const float* scale, const float* shift, int act, float* Y, long ldy, long sy, const float* R1,
@@ -642,14 +675,12 @@ static int linear_impl(int batch, int M, int K, int N, const float* X, long ldx,
     LinearArgs a{M, K, N, X, ldx, sx, W, ldw, sw, bias, Y, ldy, sy, R1, ldr1, sr1, R2, ldr2, sr2, act, scale, shift,
                  (Mk && mcols > 0) ? Mk : nullptr, ldm, mcols};
     const bool tb = transb != 0;
-    switch (dispu_linear_tile(batch, M, N)) {
+    switch (linear_tile_rule(batch, M, N, !tb && (K % 16) == 0)) {
+        // interior untransposed products: BK = 16 slabs through the DMA pipeline; transposed B / edge tiles: register-staged, BK = 32
         case 128257: return launch_linear<128, 256, 2, 2, 16>(a, batch, tb, s);
-        case 128258: return launch_linear<128, 256, 2, 4, 16>(a, batch, tb, s);     // 8 MFMA waves (64 x 64 each) when the DMA path applies
-        case 128256: return launch_linear<128, 256, 2, 2, 32>(a, batch, tb, s);     // benchmarking variants
-        case 128129: return launch_linear<128, 128, 2, 2, 16>(a, batch, tb, s);
-        case 128128: return launch_linear<128, 128, 2, 2, 32>(a, batch, tb, s);
-        case 64128: return launch_linear<64, 128, 2, 2, 32>(a, batch, tb, s);
-        case 128064: return launch_linear<128, 64, 2, 2, 32>(a, batch, tb, s);
-        default: return launch_linear<64, 64, 2, 2, 32>(a, batch, tb, s);
+        case 128128: return launch_linear<128, 128, 2, 2, 16, 32>(a, batch, tb, s);
+        case 64128: return launch_linear<64, 128, 2, 2, 16, 32>(a, batch, tb, s);
+        case 128064: return launch_linear<128, 64, 2, 2, 16, 32>(a, batch, tb, s);
+        default: return launch_linear<64, 64, 2, 2, 16, 32>(a, batch, tb, s);
     }
 }

@@ -203,10 +203,18 @@ class Generator(object):
         name = "linear"
         if self.profile is not None:     # "linear<BM, BN, 2, 2, BK, transb, edge, epi>[MxKxN]": the instantiation rocprofv3 reports
             t = L.dispu_linear_tile(batch, M, N)
-            bm, bn, bk = {128257: (128, 256, 16), 128256: (128, 256, 32), 128129: (128, 128, 16), 128128: (128, 128, 32),
-                          64128: (64, 128, 32), 128064: (128, 64, 32)}.get(t, (64, 64, 32))
-            edge = not (M % bm == 0 and N % bn == 0 and K % bk == 0 and ldx % 4 == 0 and ldw % 4 == 0 and sx % 4 == 0
-                        and sw % 4 == 0 and (X.data_ptr() + 4 * xoff) % 16 == 0 and (W.data_ptr() + 4 * woff) % 16 == 0)
+            bm, bn = {128257: (128, 256), 128128: (128, 128), 64128: (64, 128), 128064: (128, 64)}.get(t, (64, 64))
+            al = lambda q, o=0: q is None or (q.data_ptr() + 4 * o) % 16 == 0
+            ok = (M % bm == 0 and N % bn == 0 and ldx % 4 == 0 and ldw % 4 == 0 and sx % 4 == 0 and sw % 4 == 0 and al(X, xoff) and al(W, woff)
+                  and ldy % 4 == 0 and sy % 4 == 0 and al(Y, yoff) and al(bias) and (R1 is None or (R1.stride(0) % 4 == 0 and al(R1)))
+                  and (R2 is None or (R2.stride(0) % 4 == 0 and al(R2))))
+            bkr = 16 if t == 128257 else 32                 # register-staged paths (transposed B, edge tiles) of the smaller tiles: BK 32
+            if ok and not transb and K % 16 == 0:
+                bk, edge = 16, False                        # the DMA pipeline
+            elif ok and K % bkr == 0:
+                bk, edge = bkr, False
+            else:
+                bk, edge = bkr, True
             epi = 0 if (R1 is None and R2 is None) else 4       # epilogue variant: 0 bias/act, 4 with residual inputs
             if epi == 0 and (bm, bn, bk) == (128, 256, 16) and not transb and not edge and K >= 1024:
                 epi = 6                                          # long contractions: an instantiation of their own (csrc/linear.hip)

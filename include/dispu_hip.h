@@ -212,6 +212,8 @@ int dispu_linear_bn(int batch, int M, int K, int N, const float* X, long ldx, lo
 /* Which block tile dispu_linear picks for (batch, M, N), as BM*1000 + BN (e.g. 128128): lets a profiler map a
  * launch to the kernel instantiation name rocprofv3 reports (linear_mfma_kernel<BM, BN, transb>). */
 int dispu_linear_tile(int batch, int M, int N);
+/* benchmarking aid (tools/gemm_bench.py): force the block tile of every later dispu_linear call; 0 restores the rule.  Not used by the product path. */
+void dispu_debug_linear_tile(int code);
 /* K <= 4 inputs, N in {16, 24} outputs (feature_extraction layer0, ops.py:1449-1451). */
 int dispu_linear_small_k(long rows, int K, int N, const float* X, long ldx, const float* W, const float* bias, int act,
                          float* Y, long ldy, void* stream);

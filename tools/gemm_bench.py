@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Micro-benchmark of dispu_linear on the generator's GEMM shapes (run through gpurun).
-usage: python tools/gemm_bench.py            (GEMM_LIB=<path> times another build of the library: A/B on one box)
+usage: python tools/gemm_bench.py [tile codes ...]   e.g. 0 64064 64128 128128 128257   (GEMM_LIB=<path>: another build of the library)
 (Rounds 2 - 4 could force a tile through an environment switch; the sweeps are in profiles/r03_gemm_tile_sweep_headline_shapes.txt.)"""
 import os
 import subprocess
@@ -20,6 +20,8 @@ def run_one():
     if os.environ.get("GEMM_LIB"):                       # A/B against another build of the library
         _lib.LIB_PATH = os.environ["GEMM_LIB"]
     L = _lib.lib()
+    if os.environ.get("_GEMM_TILE"):
+        L.dispu_debug_linear_tile(int(os.environ["_GEMM_TILE"]))
     dev = torch.device("cuda:0")
     out = []
     only = os.environ.get("_GEMM_ONLY")
@@ -50,4 +52,6 @@ if __name__ == "__main__":
     if os.environ.get("_GEMM_CHILD"):
         run_one()
     else:
-        subprocess.run([sys.executable, os.path.abspath(__file__)], env=dict(os.environ, _GEMM_CHILD="1"))
+        for code in (sys.argv[1:] or ["0"]):                  # tile codes to force (dispu_debug_linear_tile); 0 = the library's rule
+            print("== tile %s" % code, flush=True)
+            subprocess.run([sys.executable, os.path.abspath(__file__)], env=dict(os.environ, _GEMM_CHILD="1", _GEMM_TILE=code))
