@@ -17,6 +17,8 @@
 //   Epilogue fuses bias, BatchNorm scale/shift, ReLU and two residual adds.
 #include "common.h"
 
+#include <type_traits>
+
 #include <cstdio>
 #include <cstdlib>
 
@@ -294,8 +296,12 @@ __global__ __launch_bounds__(64 * (WM * WN + (LinearLds<BM, BN, BK, TRANSB, EDGE
     // step's last MFMA: the wave then sits in s_waitcnt for an LDS round trip (~120 cycles) while the matrix pipe drains
     // after 64 - eight times per slab (measured: 4860 cycles per 64-MFMA slab instead of 4096).
     if constexpr (DMA) {
-        for (int t = 0; t < ntile; ++t) {
-            const float* st = lds + (t & 3) * L::STAGE;
+        // unrolled by four = one trip round the stage ring: the stage base of every slab is a compile-time offset, so the per-slab LDS
+        // address arithmetic (6 - 8 VALU instructions between the MFMAs, ~25 cycles each on an MFMA wave: tools/micro/chain_lab.hip)
+        // becomes immediates
+        auto slab = [&](auto stage_c) {
+            constexpr int SG = decltype(stage_c)::value;
+            const float* st = lds + SG * L::STAGE;
             const float* Bs = st + BK * LDA;
             // operands of k-step s+1 are requested before the MFMAs of step s (see the register path below).  A: lane
             // (row, fk) reads the dwords fk and fk + 2 of its row's float4 (one ds_read2_b32): X[row][4 kg + fk] for the
@@ -340,6 +346,12 @@ __global__ __launch_bounds__(64 * (WM * WN + (LinearLds<BM, BN, BK, TRANSB, EDGE
 #else
             __syncthreads();
 #endif
+        };
+        for (int t = 0; t < ntile; t += 4) {                         // (hand-unrolled: `#pragma unroll` is refused for this loop)
+            slab(std::integral_constant<int, 0>{});
+            if (t + 1 < ntile) slab(std::integral_constant<int, 1>{});
+            if (t + 2 < ntile) slab(std::integral_constant<int, 2>{});
+            if (t + 3 < ntile) slab(std::integral_constant<int, 3>{});
         }
     } else
     for (int t = 0; t < ntile; ++t) {
