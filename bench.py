@@ -521,6 +521,26 @@ def main():
                                 "/ time / %.1f TFLOP/s (fp32 MFMA peak); null = not an MFMA kernel (k-NN selection, gathers, 3-wide heads)"
                                 % FP32_MFMA_PEAK_TFLOPS)
 
+    if rank == 0 and world == 1:
+        # what the matrix pipe of THIS chip sustains for a GEMM-like instruction mix with real data (tools/micro/mfma_power.hip, built by
+        # __graft_entry__.build(): 8 accumulator tiles per wave, 2 A + 4 B LDS fragment reads per 8 MFMAs, random operands, no global
+        # traffic, no barriers, no loader waves): the practical ceiling next to the datasheet `peak` -- power management, not the kernel
+        mb = os.path.join(ROOT, "tools", "micro", "bin", "mfma_power")
+        if os.path.exists(mb):
+            try:
+                import subprocess
+                torch.cuda.synchronize()
+                r_ = subprocess.run([mb], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=120)
+                js = [l for l in r_.stdout.decode().splitlines() if l.startswith("{")]
+                if js:
+                    sp = json.loads(js[-1])
+                    roof["sustained_peak"] = {"tflops": sp["mfma_lds_reads_random_data_tflops"], "mfma_only_tflops": sp["mfma_only_tflops"],
+                                              "lds_reads_constant_data_tflops": sp["mfma_lds_reads_constant_data_tflops"],
+                                              "frac_of_sustained": (roof["achieved"] / sp["mfma_lds_reads_random_data_tflops"]) if roof.get("achieved") else None,
+                                              "note": "tools/micro/mfma_power.hip on this device: bare v_mfma_f32_32x32x2_f32 loop with the GEMM's LDS "
+                                                      "fragment reads and random operands, 10 launches back to back; `peak` stays the datasheet figure"}
+            except Exception as e:                             # noqa: BLE001
+                roof["sustained_peak"] = {"error": "%s: %s" % (type(e).__name__, e)}
     if rank == 0:
         # step-level fraction of the fp32 MFMA peak: every flop the step executes (dense contractions are 97 % of them)
         ms = dt / args.steps * 1e3
