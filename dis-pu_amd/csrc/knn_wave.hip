@@ -642,8 +642,11 @@ static int feat_wave_r(int b, int n, int m, int c, int k, int ldp, int ldq, cons
     return launch_feat_wave<8, CP>(b, n, m, c, k, ldp, ldq, p, q, dist, idx, st, pstride);
 }
 
+int knn_feat_big_dispatch(int b, int n, int m, int c, int k, int ldp, int ldq, const float* p, const float* q, float* dist, int* idx,
+                          hipStream_t st);
 int knn_feat_wave_dispatch(int b, int n, int m, int c, int k, int ldp, int ldq, const float* p, const float* q, float* dist,
                            int* idx, hipStream_t st, long pstride = 0) {
+    if (n > 512 && pstride == 0) return knn_feat_big_dispatch(b, n, m, c, k, ldp, ldq, p, q, dist, idx, st);
     if (n > 512 || c > 64 || k > 64) return -1;
     const int cp = (c + 3) & ~3;
     const int r = n <= 64 ? 1 : (n <= 128 ? 2 : (n <= 256 ? 4 : 8));
@@ -656,6 +659,192 @@ int knn_feat_wave_dispatch(int b, int n, int m, int c, int k, int ldp, int ldq, 
     if (c <= 32) return feat_wave_r<32>(b, n, m, c, k, ldp, ldq, p, q, dist, idx, st, pstride);
     if (c <= 48) return feat_wave_r<48>(b, n, m, c, k, ldp, ldq, p, q, dist, idx, st, pstride);
     return feat_wave_r<64>(b, n, m, c, k, ldp, ldq, p, q, dist, idx, st, pstride);
+}
+
+// ---- feature space, 512 < n <= 1024, c <= 48 (round 5): ONE pass per query over the whole cloud -----------------------------------
+// The chunked path below cuts such a cloud into four 256-candidate chunks: every chunk stages its features again for every 16
+// queries, pays the threshold / compaction / rank again, and a merge kernel follows (637 us for the three C = 48 and the one C = 24
+// call of a 1024-point dense-block pass).  Here a workgroup of 8 waves owns 64 queries.  The cloud's features pass through LDS in
+// channel halves of 24 (98 KB each, the channel-quad-major image of knn_feat_wave_kernel); the 64 x n dot products accumulate on the
+// matrix pipe ACROSS the halves (v_mfma_f32_16x16x4_f32 continues the ascending-channel fmaf chain bit for bit: 4 query tiles x 8
+// candidate tiles = 128 accumulator registers per lane), the norms continue their chains the same way.  Then, 16 queries at a time,
+// the distance words (rq - 2 dot) + rp go to LDS over the dead feature image and every wave runs the prefilter + rank ONCE over the
+// n candidates of its two queries.  Same words, same (distance, index) order as the chunked path and the lane-per-query kernel.
+constexpr int KFB_HC = 24, KFB_QB = 64, KFB_W = 8, KFB_NMAX = 1024, KFB_NP = KFB_NMAX + 4, KFB_QLD = KFB_HC / 4 + 1;
+constexpr size_t KFB_FEATS = (size_t)(KFB_HC / 4) * (KFB_NMAX + 1) * 16;                 // 98400 B, reused: dmat [16][NP] words + the full-sort scratch
+constexpr size_t KFB_SORT = (size_t)KFB_W * (16 * 64 + 4) * 8;                           // degenerate clouds: every key of two... of one query per wave
+constexpr size_t KFB_REGION_A = ((size_t)16 * KFB_NP * 4 + KFB_SORT > KFB_FEATS) ? (size_t)16 * KFB_NP * 4 + KFB_SORT : KFB_FEATS;
+constexpr size_t KFB_LDS = KFB_REGION_A + (size_t)KFB_NMAX * 4 + (size_t)KFB_QB * KFB_QLD * 16 + (size_t)KFB_QB * 4 + (size_t)KFB_W * (128 + 4) * 8;
+
+__global__ __launch_bounds__(64 * KFB_W) void knn_feat_big_kernel(int n, int m, int c, int k, int ldp, int ldq,
+                                                                  const float* __restrict__ points, const float* __restrict__ queries,
+                                                                  float* __restrict__ dist, int* __restrict__ idx) {
+    typedef float kf_f32x4 __attribute__((ext_vector_type(4)));
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int ns = KFB_NMAX + 1;
+    float4* feats = reinterpret_cast<float4*>(smem);                                     // [6][ns] (matrix phase)
+    uint32_t* dmat = reinterpret_cast<uint32_t*>(smem);                                  // [16][NP] (selection phase)
+    uint64_t* fullsort = reinterpret_cast<uint64_t*>(smem + (size_t)16 * KFB_NP * 4);    // [W][16 * 64 + 4]
+    float* norms = reinterpret_cast<float*>(smem + KFB_REGION_A);                        // [NMAX]
+    float4* qs = reinterpret_cast<float4*>(norms + KFB_NMAX);                            // [QB][QLD]
+    float* qn = reinterpret_cast<float*>(qs + KFB_QB * KFB_QLD);                         // [QB]
+    uint64_t* pbuf = reinterpret_cast<uint64_t*>(qn + KFB_QB);                           // [W][128 + 4]
+    const int cloud = blockIdx.y, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int i16 = lane & 15, q4 = lane >> 4;
+    const float* __restrict__ sp = points + (size_t)cloud * n * ldp;
+    const float* __restrict__ qp = queries + (size_t)cloud * m * ldq;
+    const int q0 = blockIdx.x * KFB_QB;
+    const bool vecp = ((c & 3) == 0) && ((ldp & 3) == 0) && ((((uintptr_t)sp) & 15) == 0);
+    const bool vecq = ((c & 3) == 0) && ((ldq & 3) == 0) && ((((uintptr_t)qp) & 15) == 0);
+    const auto load4 = [&](const float* row, int ch, bool vec) -> float4 {             // channels ch .. ch + 3 of a row, zero past c
+        float4 v = {0.f, 0.f, 0.f, 0.f};
+        if (vec) { if (ch < c) v = *reinterpret_cast<const float4*>(row + ch); }
+        else {
+            if (ch + 0 < c) v.x = row[ch + 0];
+            if (ch + 1 < c) v.y = row[ch + 1];
+            if (ch + 2 < c) v.z = row[ch + 2];
+            if (ch + 3 < c) v.w = row[ch + 3];
+        }
+        return v;
+    };
+    kf_f32x4 acc[4][8];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[t][j] = kf_f32x4{0.f, 0.f, 0.f, 0.f};
+    const int nh = (c + KFB_HC - 1) / KFB_HC;                                            // 1 or 2
+    for (int h = 0; h < nh; ++h) {
+        if (h) __syncthreads();                                                          // the previous half's operand reads are done
+        const int ch0 = h * KFB_HC;
+        {   // batches of six independent 16-byte loads per thread, then the six LDS stores
+            constexpr int UB = 6, Q4 = KFB_HC / 4;
+            const int total = Q4 * n;
+            for (int e0 = threadIdx.x; e0 < total; e0 += UB * 64 * KFB_W) {
+                float4 v[UB];
+#pragma unroll
+                for (int u = 0; u < UB; ++u) {
+                    const int e = min(e0 + u * 64 * KFB_W, total - 1);
+                    const int p = e / Q4, c4 = e - p * Q4;
+                    v[u] = load4(sp + (size_t)p * ldp, ch0 + 4 * c4, vecp);
+                }
+#pragma unroll
+                for (int u = 0; u < UB; ++u) {
+                    const int e = e0 + u * 64 * KFB_W;
+                    const int p = e / Q4, c4 = e - p * Q4;
+                    if (e < total) feats[c4 * ns + p] = v[u];
+                }
+            }
+            for (int e = threadIdx.x; e < KFB_QB * Q4; e += 64 * KFB_W) {
+                const int ql = e / Q4, c4 = e - ql * Q4;
+                const int qg = min(q0 + ql, m - 1);
+                qs[ql * KFB_QLD + c4] = load4(qp + (size_t)qg * ldq, ch0 + 4 * c4, vecq);
+            }
+        }
+        __syncthreads();
+        // |F_p|^2 and |q|^2 continue their ascending-channel chains over the halves (read after the barrier that ends the matrix phase)
+        for (int p = threadIdx.x; p < n; p += 64 * KFB_W) {
+            float r = h ? norms[p] : 0.f;
+#pragma unroll
+            for (int c4 = 0; c4 < KFB_HC / 4; ++c4) {
+                const float4 v = feats[c4 * ns + p];
+                r = __builtin_fmaf(v.x, v.x, r); r = __builtin_fmaf(v.y, v.y, r);
+                r = __builtin_fmaf(v.z, v.z, r); r = __builtin_fmaf(v.w, v.w, r);
+            }
+            norms[p] = r;
+        }
+        if (threadIdx.x < KFB_QB) {
+            float r = h ? qn[threadIdx.x] : 0.f;
+#pragma unroll
+            for (int c4 = 0; c4 < KFB_HC / 4; ++c4) {
+                const float4 v = qs[threadIdx.x * KFB_QLD + c4];
+                r = __builtin_fmaf(v.x, v.x, r); r = __builtin_fmaf(v.y, v.y, r);
+                r = __builtin_fmaf(v.z, v.z, r); r = __builtin_fmaf(v.w, v.w, r);
+            }
+            qn[threadIdx.x] = r;
+        }
+        // matrix phase: wave w owns candidate tiles w, w + 8, ..; A = 16 query rows per tile, one instruction per channel quad
+        const float* qsf = reinterpret_cast<const float*>(qs);
+        const float* ff = reinterpret_cast<const float*>(feats);
+        int cc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) cc[j] = min((wave + 8 * j) * 16 + i16, n - 1);
+#pragma unroll
+        for (int c4 = 0; c4 < KFB_HC / 4; ++c4) {
+            float a[4], bq[8];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) a[t] = qsf[((16 * t + i16) * KFB_QLD + c4) * 4 + q4];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) bq[j] = ff[(c4 * ns + cc[j]) * 4 + q4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], bq[j], acc[t][j], 0, 0, 0);
+        }
+    }
+    __syncthreads();                                                                     // feature image dead, norms complete
+    float rpj[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) rpj[j] = norms[min((wave + 8 * j) * 16 + i16, n - 1)];
+    uint64_t* buf = pbuf + (size_t)wave * (128 + 4);
+    const auto w2f = [](uint32_t w) { return ordered_to_f32(w); };
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        if (t) __syncthreads();                                                          // the previous batch's words have been read
+        float rq4[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) rq4[r] = qn[16 * t + 4 * q4 + r];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int cand = (wave + 8 * j) * 16 + i16;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {                                                // acc[r] = dot(query 4 q4 + r, candidate cand)
+                const float t0 = rq4[r] - 2.0f * acc[t][j][r];
+                const float d = (t0 + rpj[j]) + 0.0f;
+                dmat[(4 * q4 + r) * KFB_NP + cand] = (cand < n) ? f32_to_ordered(d) : 0xFFFFFFFFu;
+            }
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int s = 0; s < 2; ++s) {
+            const int ql = wave + 8 * s;                                                 // query of this batch
+            const int qg = __builtin_amdgcn_readfirstlane(q0 + 16 * t + ql);
+            if (qg >= m) continue;
+            uint32_t od[16];
+            int cp[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                cp[r] = lane + 64 * r;
+                od[r] = dmat[ql * KFB_NP + lane + 64 * r];                               // words past n are all-ones
+            }
+            const size_t o = ((size_t)cloud * m + qg) * k;
+            if (!prefilter_rank<16, true>(od, cp, buf, lane, k, 0xFFFFFFFEu, idx + o, dist ? dist + o : nullptr, w2f)) {
+                uint64_t key[16];                                                        // degenerate clouds: sort everything
+#pragma unroll
+                for (int r = 0; r < 16; ++r) key[r] = (cp[r] < n) ? (((uint64_t)od[r] << 32) | (uint32_t)cp[r]) : KEY_MAX;
+                sort_keys<16>(key);
+                const uint64_t res = select_k<16>(key, fullsort + (size_t)wave * (16 * 64 + 4), lane, k);
+                if (lane < k) {
+                    idx[o + lane] = (int)(uint32_t)res;
+                    if (dist) dist[o + lane] = ordered_to_f32((uint32_t)(res >> 32));
+                }
+            }
+        }
+    }
+}
+
+// -1: shape outside this path
+int knn_feat_big_dispatch(int b, int n, int m, int c, int k, int ldp, int ldq, const float* p, const float* q, float* dist, int* idx,
+                          hipStream_t st) {
+    if (n <= 512 || n > KFB_NMAX || c > 2 * KFB_HC || k > 64 || k > n) return -1;
+    static DevOnce attr;
+    if (attr.needed()) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(knn_feat_big_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return (int)e;
+        attr.done();
+    }
+    static_assert(KFB_LDS <= 160 * 1024, "one workgroup per CU");
+    hipLaunchKernelGGL(knn_feat_big_kernel, dim3((m + KFB_QB - 1) / KFB_QB, b), dim3(64 * KFB_W), KFB_LDS, st, n, m, c, k, ldp, ldq, p, q, dist, idx);
+    return (int)hipGetLastError();
 }
 
 // ---- feature space, 512 < n <= 4096 (the second pass of 16x upsampling runs the dense blocks on 1024-point patches): balanced
@@ -672,6 +861,10 @@ size_t knn_feat_chunked_scratch(int b, int n, int m, int c, int k) {
 
 int knn_feat_chunked_dispatch(int b, int n, int m, int c, int k, int ldp, int ldq, const float* p, const float* q, float* dist, int* idx,
                               void* scratch, size_t scratch_bytes, hipStream_t st) {
+    {
+        const int rb = knn_feat_big_dispatch(b, n, m, c, k, ldp, ldq, p, q, dist, idx, st);      // 512 < n <= 1024, c <= 48: one pass, no scratch
+        if (rb >= 0) return rb;
+    }
     const size_t need = knn_feat_chunked_scratch(b, n, m, c, k);
     if (need == 0 || !scratch || scratch_bytes < need) return -1;
     const int nc = (n + KF_CHUNK - 1) / KF_CHUNK, cs = (n + nc - 1) / nc;

@@ -647,6 +647,53 @@ def test_knn_point_2_chunked_path(ops, dev, n, m, c, k):
     assert np.array_equal(N(i2), oi2) and np.array_equal(N(d2), od)
 
 
+@pytest.mark.parametrize("n,m,c,k", [(513, 100, 24, 17), (600, 64, 48, 17), (768, 130, 30, 9), (1000, 1000, 7, 17), (1024, 1024, 48, 17),
+                                     (1024, 65, 24, 33), (1023, 200, 25, 64), (1024, 63, 3, 1)])
+def test_knn_point_2_single_pass_1024(ops, dev, n, m, c, k):
+    """Feature-space k-NN on clouds of 513 .. 1024 points with up to 48 channels: one pass (dot products accumulated over two channel
+    halves on the matrix pipe, one selection per query) == tf.nn.top_k over the full matrix (tf_grouping.py:95-114).  Ragged last
+    candidate tile / query tile / channel quad, the channel halves (c <= 24 takes one), duplicates, k up to 64."""
+    rng = np.random.default_rng(n * 3 + c)
+    a = rng.standard_normal((3, n, c)).astype(np.float32)
+    a[:, 600 % n] = a[:, 3]
+    a[:, n - 1] = a[:, 3]
+    q = np.concatenate([a[:, : m // 2], rng.standard_normal((3, m - m // 2, c)).astype(np.float32)], 1)
+    d2, i2 = ops["G"].knn_point_2(k, T(a, dev), T(q, dev))
+    od, oi2 = O.knn_point_2(k, a, q)
+    assert np.array_equal(N(i2), oi2) and np.array_equal(N(d2), od)
+
+
+def test_knn_point_2_single_pass_degenerate_clouds(ops, dev):
+    """More than 128 candidates at exactly the k-th distance (a cloud of few distinct feature rows): the threshold prefilter gives
+    up and the full sort answers -- index order within equal distances, as tf.nn.top_k."""
+    rng = np.random.default_rng(77)
+    base = rng.standard_normal((2, 5, 48)).astype(np.float32)
+    a = base[:, rng.integers(0, 5, 1024)]                                    # every row is one of five
+    a[0, :300] = 0.0
+    q = np.concatenate([a[:, :40], rng.standard_normal((2, 30, 48)).astype(np.float32)], 1)
+    for k in (17, 40):
+        d2, i2 = ops["G"].knn_point_2(k, T(a, dev), T(q, dev))
+        od, oi2 = O.knn_point_2(k, a, q)
+        assert np.array_equal(N(i2), oi2) and np.array_equal(N(d2), od)
+
+
+def test_knn_feat_strided_single_pass_column_slice(ops, dev):
+    """The dense blocks hand the k-NN a COLUMN SLICE of the wide feature buffer (row stride 120 floats, 48 channels from
+    column 24; no distances wanted): same indices as the packed call, on a 1024-point cloud."""
+    from dispu_amd import _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(9)
+    wide = rng.standard_normal((4, 1024, 120)).astype(np.float32)
+    tw = T(wide, dev)
+    idx = torch.empty(4, 1024, 17, dtype=torch.int32, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    ws = torch.empty(max(1, L.dispu_knn_feat_scratch_bytes(4, 1024, 1024, 48, 17)), dtype=torch.uint8, device=dev)
+    _lib.check(L.dispu_knn_feat_strided_ws(4, 1024, 1024, 48, 17, tw.data_ptr() + 24 * 4, 120, tw.data_ptr() + 24 * 4, 120, None,
+                                           idx.data_ptr(), ws.data_ptr(), ws.numel(), st), "knn_feat")
+    _, oi = O.knn_point_2(17, np.ascontiguousarray(wide[:, :, 24:72]), np.ascontiguousarray(wide[:, :, 24:72]))
+    assert np.array_equal(N(idx), oi[..., 1])
+
+
 # ---------------------------------------------------------------- round 3: optional ops, reference-signature entries ----
 def test_select_top_k_vs_reference_golden_and_oracle(ops, dev, golden_dir):
     """tf_grouping.select_top_k (SelectionSort): the reference's own known answer (selection_sort.cpp:65-94, golden generated by
