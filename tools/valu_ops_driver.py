@@ -11,6 +11,7 @@ import dispu_amd.tf_grouping as G            # noqa: E402
 import dispu_amd.tf_interpolate as I         # noqa: E402
 import dispu_amd.tf_nndistance as D          # noqa: E402
 import dispu_amd.tf_sampling as S            # noqa: E402
+import dispu_amd.tf_approxmatch as A         # noqa: E402
 
 dev = torch.device("cuda:0")
 g = torch.Generator(device=dev).manual_seed(1234)
@@ -27,4 +28,7 @@ for _ in range(3):
     I.three_nn(x, rand(32, 256, 3))
     D.nn_distance(x, rand(32, 1024, 3))
     S.farthest_point_sample(384, x)
+    f = torch.randn(32, 1024, 48, device=dev, generator=g)
+    G.knn_point_2(17, f, f)                                  # one pass over 1024 candidates (dense blocks of the second 16x pass)
+    A.approx_match(x4, rand(32, 4096, 3))                    # the auction at the 16x loss shape: how many vector instructions per pair
 torch.cuda.synchronize()
