@@ -170,17 +170,45 @@ __device__ __forceinline__ void am_row_body(int cloud, int rb, int c, float4* ti
     // m <= AM_CH: the one tile holds every partner of the point, so pass 1's chain IS the reference's sequential chain when it starts
     // at 1e-9f (tf_approxmatch_g.cu:60 `suml = 1e-9f`) instead of being added to it afterwards; the consumer then takes p1[0] as is
     float s3 = 0.f, s1 = (m <= AM_CH) ? 1e-9f : 0.f;
+    if constexpr (!FIRST && FMA && !PINNED) {
+        // Production arithmetic (contracted, hardware exp: tolerance-checked, not bit-pinned).  The pair loop is vector-issue bound,
+        // so ratioL[k] -- a factor of every term of the row's pass-3 sum -- multiplies the SUM once and the terms become one fma
+        // each (14.5 -> 12.5 instructions per pair, same EMD error against the oracle: tools/debug/am_check.py); the last row pass
+        // has level1 == 0, its e1 is exactly 1 and is not evaluated.  (exp(level3 d2) as the fourth power of exp(level1 d2) -- the
+        // levels descend by factors of four -- saves another exponential but makes pass 3 disagree with passes 1 - 2 of the same
+        // level by a few ulp, which the auction's clamps amplify: EMD error 7e-5 on the reference's golden clouds.  Not used.)
+        const float c1 = level1 * AM_LOG2E, c3 = level3 * AM_LOG2E;
+        if (level1 != 0.f) {
 #pragma unroll 4
-    for (int i = 0; i < len; ++i) {
-        const float4 q = tile[i];
-        const float d2 = sqdist3<FMA>(q.x - x1, q.y - y1, q.z - z1);
-        if constexpr (!FIRST) {
-            const float w = am_exp_level<PINNED>(d2, level3) * rl * q.w;      // the value `match` receives at this level
-            s3 += w;
+            for (int i = 0; i < len; ++i) {
+                const float4 q = tile[i];
+                const float d2 = sqdist3<true>(q.x - x1, q.y - y1, q.z - z1);
+                s3 = __builtin_fmaf(__builtin_amdgcn_exp2f(d2 * c3), q.w, s3);
+                s1 = __builtin_fmaf(__builtin_amdgcn_exp2f(d2 * c1), tilew[i], s1);
+            }
+        } else {
+#pragma unroll 4
+            for (int i = 0; i < len; ++i) {
+                const float4 q = tile[i];
+                const float d2 = sqdist3<true>(q.x - x1, q.y - y1, q.z - z1);
+                s3 = __builtin_fmaf(__builtin_amdgcn_exp2f(d2 * c3), q.w, s3);
+                s1 = s1 + tilew[i];
+            }
         }
-        const float e1 = am_exp_level<PINNED>(d2, level1);
-        if constexpr (FMA) s1 = __builtin_fmaf(e1, tilew[i], s1);
-        else s1 = s1 + e1 * tilew[i];
+        s3 *= rl;
+    } else {
+#pragma unroll 4
+        for (int i = 0; i < len; ++i) {
+            const float4 q = tile[i];
+            const float d2 = sqdist3<FMA>(q.x - x1, q.y - y1, q.z - z1);
+            if constexpr (!FIRST) {
+                const float w = am_exp_level<PINNED>(d2, level3) * rl * q.w;      // the value `match` receives at this level
+                s3 += w;
+            }
+            const float e1 = am_exp_level<PINNED>(d2, level1);
+            if constexpr (FMA) s1 = __builtin_fmaf(e1, tilew[i], s1);
+            else s1 = s1 + e1 * tilew[i];
+        }
     }
     if (active) {
         if constexpr (!FIRST) am_st<COH>(&v.p3[(size_t)c * n + k], s3);

@@ -121,8 +121,9 @@ int dispu_knn_feat(int b, int n, int m, int c, int k, const float* points, const
 int dispu_knn_feat_strided(int b, int n, int m, int c, int k, const float* points, int ldp, const float* queries,
                            int ldq, float* dist, int* idx, void* stream);
 /* dispu_knn_feat_strided with caller scratch (dispu_knn_feat_scratch_bytes(b,n,m,c,k) bytes, 0 = this shape needs none): clouds of
- * 513 .. 4096 points, c <= 64, k <= 32 are searched in chunks of <= 256 candidates by the wave-per-query kernel and merged
- * (the dense blocks of the second 16x pass).  Same results. */
+ * 513 .. 4096 points, c <= 64, k <= 32 are searched in chunks of <= 256 candidates by the wave-per-query kernel and merged.
+ * Clouds of 513 .. 1024 points with c <= 48 (the dense blocks of the second 16x pass) take ONE pass instead and leave the scratch
+ * untouched (both entries; dispu_knn_feat_strided needs no scratch for them either).  Same results. */
 size_t dispu_knn_feat_scratch_bytes(int b, int n, int m, int c, int k);
 int dispu_knn_feat_strided_ws(int b, int n, int m, int c, int k, const float* points, int ldp, const float* queries, int ldq,
                               float* dist, int* idx, void* scratch, size_t scratch_bytes, void* stream);
