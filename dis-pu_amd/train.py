@@ -141,6 +141,7 @@ class Trainer(object):
         # (default "auto": on up to 16 patches per step -- at 32 the chip is saturated by the chain's own kernels, side work submitted
         # later only lengthens the tail: 4.58 -> 4.63 ms; "1" / "0" force it)
         self.fused_stem = True     # one launch per dense block in the forward pass
+        self.tail_on_chain = True  # the first dense block's weight gradients (the LAST work of the backward) stay on the chain's stream: no cross-stream hop in front of Adam
         self.prep_late = True     # zeroing / W^T copies for the backward behind the non-local branch's own kernels (0: in front of them, round 3)
         self.prep_on_side = False   # ... or on a weight-gradient stream during the forward (measured slower at 8 patches in fp32: 1.79 vs 1.71 ms)   # backward's zeroing / W^T copies on a dW stream during the forward
         self._defer_mode = "auto"
@@ -569,7 +570,7 @@ class Trainer(object):
                           r1, ldr, 0, _p(mt, moff), mt.stride(0), int(mcols), self.st), "dispu_linear_masked(dX)")
 
     def _lin_bwd(self, X, xoff, K, wname, N, dY, dyoff, dX=None, dxoff=0, acc_dx=False, M=None, bias=True, W=None, dW=None, woff=0,
-                 mask=None, db=None):
+                 mask=None, db=None, side=True):
         """backward of _lin given dZ = dY[:, dyoff:dyoff+N] ALREADY multiplied by the layer's own relu' (its producer did that):
         db += colsum dZ and dW += X^T dZ on the second stream, dX[:, dxoff:dxoff+K] (+)= dZ . W^T with `mask` (see _dx)."""
         M = X.shape[0] if M is None else M
@@ -583,7 +584,7 @@ class Trainer(object):
         if dX is not None:
             WT = self.PT.get(wname + "/weights") if (wname is not None and woff == 0 and self.use_wt and K == W.shape[0]) else None
             self._dx(M, N, K, dY, dyoff, W, woff, dX, dxoff, acc_dx, mask, WT)
-        self._tn(1, M, K, N, X, xoff, X.stride(0), 0, dY, dyoff, dY.stride(0), 0, dW, woff, dW.stride(0), 0, 1, dbias=db, side=True, after=ev)
+        self._tn(1, M, K, N, X, xoff, X.stride(0), 0, dY, dyoff, dY.stride(0), 0, dW, woff, dW.stride(0), 0, 1, dbias=db, side=side, after=ev)
 
     # ----------------------------------------------------------------------------------------------- forward ----
     def forward(self, inputs):
@@ -1071,13 +1072,20 @@ class Trainer(object):
                 # the block's recomputing backward kernel (40 - 80 us) is queued: submit some of the side work deferred so far behind it
                 # (the coarse head's weight gradients, the previous blocks' reductions and prep gradients) -- a few launches per block,
                 # as many as the kernel's duration hides
-                self._flush(n=5)
-                def reduce_partials(sc=sc, scr=scr, C=C, ev=(self._fork_point() if self.overlap_dw else None)):
+                tail = self.tail_on_chain and d == 1 and self.overlap_dw
+                self._flush(n=None if tail else 5)
+                def reduce_partials(sc=sc, scr=scr, C=C, ev=(self._fork_point() if (self.overlap_dw and not tail) else None)):
                     st_r = self._fork_after(ev)[0] if ev is not None else self.st
                     _lib.check(L.dispu_edge_dense_conv_grad_reduce(rn, C, _p(scr), scr.numel(), _p(G[sc + "/l0/weights"]), _p(G[sc + "/l0/biases"]),
                                                                    _p(G[sc + "/l1/weights"]), _p(G[sc + "/l1/biases"]), _p(G[sc + "/l2/weights"]),
                                                                    _p(G[sc + "/l2/biases"]), st_r), "edge_dense_conv_grad_reduce")
-                self._defer(reduce_partials)
+                if tail:
+                    # the last block of the backward: everything deferred so far is on the side streams by now; this block's own
+                    # reduction (and layer0's weight gradient below) follow their producer on the chain's stream -- Adam waits for
+                    # them either way, and a hop to a side stream and back costs more than the two launches take
+                    reduce_partials()
+                else:
+                    self._defer(reduce_partials)
             else:
                 Eb, dE = self._edge_buffers(B, N)[0][d], self._edge_buffers(B, N)[1][d]
                 lde = dE.stride(0)
@@ -1093,7 +1101,7 @@ class Trainer(object):
                 self._act_bias_grad(rn, 48, dF, 0, ws["prep"][d], 0, 1, dF, 0, None)        # prep = relu(.): its mask (dF came from atomics)
                 self._lin_bwd(feat, in_col, 480 - in_col, fe + "layer%d_prep" % d, 48, dF, 0, dfeat, in_col, acc_dx=True)
         # layer0 (no activation, input has no gradient)
-        self._lin_bwd(self._x.view(rn, 3), 0, 3, fe + "layer0", 24, dfeat, 456, None)
+        self._lin_bwd(self._x.view(rn, 3), 0, 3, fe + "layer0", 24, dfeat, 456, None, side=not (self.tail_on_chain and self.fused_dense))
         self._join()                     # every dW is in the flat gradient buffer from here on (all-reduce, Adam)
 
     # -------------------------------------------------------------------------------------------------- step ----

@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--dtype", choices=("f32", "bf16"), default="f32",
                     help="f32: the reference's arithmetic; bf16: bf16 products / fp32 accumulation and storage (csrc/linear_bf16.hip)")
     ap.add_argument("--dw-streams", type=int, default=0, help="side streams for the weight-gradient products (0: the Trainer's default)")
+    ap.add_argument("--no-tail-on-chain", action="store_true", help="A/B: the last block's weight gradients on a side stream again")
     ap.add_argument("--tape", action="store_true", help="forward + loss + backward re-issued from a launch tape (Trainer.train_step_taped)")
     args = ap.parse_args()
     from dispu_amd import synth
@@ -48,6 +49,8 @@ def main():
     tr = Trainer(params=P, device=dev, dtype=args.dtype)
     if args.dw_streams > 0:
         tr.dw_streams = args.dw_streams
+    if args.no_tail_on_chain:
+        tr.tail_on_chain = False
     x, gt = synth.patch_with_gt(args.batch, 256, 1024, seed=5000 + rank)
     x, gt = torch.from_numpy(x).to(dev), torch.from_numpy(gt).to(dev)
     radius = torch.ones(args.batch, device=dev)
