@@ -41,7 +41,7 @@ struct ChainArgs {
     const float* Wg = nullptr; const float* bg = nullptr; const float* grid = nullptr; int n = 0; int up = 0;
 };
 
-constexpr int MC_BM = 128, MC_KMAX = 256, MC_NMAX = 256;          // MC_BM: rows per workgroup of the large-batch variant (BM = 64 below
+constexpr int MC_BM = 128, MC_KMAX = 256;                         // MC_BM: rows per workgroup of the large-batch variant (BM = 64 below
 constexpr int MC_ACT = MC_KMAX * (MC_BM + 1);                     // 8192 rows: twice the workgroups, half the rows each); floats
 // a weight slab is bk(N) = 2048 / N rows of N floats (8 / 16 / 32 rows for N = 256 / 128 / 64): every slab carries the
 // same 32 MFMAs per wave, so the barrier cadence does not depend on the layer width

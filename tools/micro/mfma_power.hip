@@ -5,6 +5,7 @@
 //   hipcc --offload-arch=gfx950 -O3 tools/micro/mfma_power.hip -o tools/micro/bin/mfma_power
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 typedef float v16f __attribute__((ext_vector_type(16)));
 
@@ -38,23 +39,24 @@ __global__ __launch_bounds__(256) void gemm_like(int slabs, const float* __restr
     if (s == 12345.678f) out[0] = s;
 }
 
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 static double g_last = 0.0;     // TFLOP/s of the last measurement
 template <bool READS, bool RANDOM>
 static void run(const char* what, const float* src, float* out) {
     const int slabs = 128, blocks = 256;                          // = one after_conv launch: 128 slabs of 64 MFMAs per wave
     const double flops = (double)blocks * 4 * slabs * 64 * 4096.0;
-    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (int reps : {1, 10, 40}) {
         hipLaunchKernelGGL((gemm_like<READS, RANDOM>), dim3(blocks), dim3(256), 0, 0, slabs, src, out);
-        hipDeviceSynchronize();
-        hipEventRecord(e0);
+        CK(hipDeviceSynchronize());
+        CK(hipEventRecord(e0));
         for (int r = 0; r < reps; ++r) hipLaunchKernelGGL((gemm_like<READS, RANDOM>), dim3(blocks), dim3(256), 0, 0, slabs, src, out);
-        hipEventRecord(e1); hipDeviceSynchronize();
-        float ms; hipEventElapsedTime(&ms, e0, e1);
+        CK(hipEventRecord(e1)); CK(hipDeviceSynchronize());
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
         printf("%-44s %2d launches back to back: %7.1f us per launch  %6.1f TFLOP/s  (%.3f of 157.3)\n", what, reps, ms * 1e3 / reps,
                flops * reps / ms / 1e9, flops * reps / ms / 1e9 / 157.3);
         if (reps == 10) g_last = flops * reps / ms / 1e9;
-        hipDeviceSynchronize();
+        CK(hipDeviceSynchronize());
     }
 }
 
@@ -63,8 +65,8 @@ int main() {
     unsigned s = 12345;
     for (auto& v : h) { s = s * 1664525u + 1013904223u; v = ((s >> 8) & 0xFFFF) / 65536.0f - 0.5f; }
     float *src, *out;
-    hipMalloc(&src, h.size() * 4); hipMalloc(&out, 4);
-    hipMemcpy(src, h.data(), h.size() * 4, hipMemcpyHostToDevice);
+    CK(hipMalloc(&src, h.size() * 4)); CK(hipMalloc(&out, 4));
+    CK(hipMemcpy(src, h.data(), h.size() * 4, hipMemcpyHostToDevice));
     run<false, false>("MFMAs only, constant operands", src, out);
     const double only = g_last;
     run<false, true>("MFMAs only, random operands", src, out);
