@@ -52,7 +52,12 @@ class Generator(object):
 
     `params` maps the TF variable names of the reference graph ('generator/feature_extraction_coarse/layer0/weights',
     ..., see oracle/generator.py:layer_shapes) to arrays: weights [C_in_total, C_out], biases [C_out], plus the
-    four BatchNorm vectors of 'refine/PointShuffle/weight_net/wconv0/bn/'."""
+    four BatchNorm vectors of 'refine/PointShuffle/weight_net/wconv0/bn/'.
+
+    Threading / streams: one Generator serves ONE caller at a time on the stream current at the call (like a session's run()).  The
+    forward forks its non-local branch onto a private auxiliary stream and joins it before it returns; workspace buffers are reused
+    by the next call with the same (B, N), and the results (return_views = False) are fresh tensors ordered on the caller's stream.
+    Use one Generator per concurrent caller (two in flight: bench.py's alt_two_in_flight holds two)."""
 
     MAX_BATCH = 2048     # patches per launch sequence: keeps every row*stride product below 2^31 and the workspace
                          # (~17 MB per patch, dominated by F' [B*1024, 2048]) at ~35 GB; larger batches run in chunks
