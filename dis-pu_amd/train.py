@@ -141,6 +141,8 @@ class Trainer(object):
         # (default "auto": on up to 16 patches per step -- at 32 the chip is saturated by the chain's own kernels, side work submitted
         # later only lengthens the tail: 4.58 -> 4.63 ms; "1" / "0" force it)
         self.fused_stem = True     # one launch per dense block in the forward pass
+        self.bf16_stream = True    # dtype="bf16": the large dense products on the streaming bf16 kernel (csrc/linear_bf16_stream.hip) where its shape rules hold
+        self._packs = {}
         self.tail_on_chain = True  # the first dense block's weight gradients (the LAST work of the backward) stay on the chain's stream: no cross-stream hop in front of Adam
         self.prep_late = True     # zeroing / W^T copies for the backward behind the non-local branch's own kernels (0: in front of them, round 3)
         self.prep_on_side = False   # ... or on a weight-gradient stream during the forward (measured slower at 8 patches in fp32: 1.79 vs 1.71 ms)   # backward's zeroing / W^T copies on a dW stream during the forward
@@ -476,6 +478,41 @@ class Trainer(object):
         operands rounded on their way into LDS) is no faster than the fp32 one, often slower (24 - 29 us vs 15 - 24 us)."""
         return self.bf16 and K > 4 and N > 4 and float(batch) * M * K * N >= self.bf16_min_macs
 
+    def _stream(self, M, K, N, X, xoff, W, woff, transpose, bias, act, Y, yoff):
+        """Y[:, yoff:yoff+N] = act(X[:, xoff:xoff+K] . B + bias) on the streaming bf16 kernel; B = W[woff..] as [K][N] (transpose = 1: the
+        forward product) or W^T with W[woff..] as [N][K] (transpose = 0: dX = dZ . W^T).  Returns False -- nothing launched -- when the
+        kernel's shape rules do not hold (the caller keeps dispu_linear_bf16).  The weight is packed to bf16 [N][K] right here, on the
+        same stream (weights change every step; 0.5 M elements at most)."""
+        if not (self.bf16 and self.bf16_stream) or M % 128 or K % 32 or N % 128:
+            return False
+        xb, yb = X.dtype == torch.bfloat16, Y.dtype == torch.bfloat16
+        es = 2 if xb else 4
+        if (X.stride(0) * es) % 16 or (xoff * es) % 16 or X.stride(1) != 1 or Y.stride(1) != 1 or W.stride(1) != 1:
+            return False
+        L = _lib.tape_lib()
+        key = (W.data_ptr() + 4 * woff, K, N, transpose)
+        bt = self._packs.get(key)
+        if bt is None:
+            bt = self._packs[key] = torch.empty((N, K), dtype=torch.bfloat16, device=self.device)
+        if transpose:
+            _lib.check(L.dispu_bf16_pack(K, N, _p(W, woff), W.stride(0), 1, _p(bt), self.st), "dispu_bf16_pack")
+        else:
+            _lib.check(L.dispu_bf16_pack(N, K, _p(W, woff), W.stride(0), 0, _p(bt), self.st), "dispu_bf16_pack")
+        tiles = (M // 128) * (N // (256 if N % 256 == 0 else 128))
+        nsp = 1
+        if tiles < 192 and not yb:
+            while nsp < 8 and tiles * nsp < 256 and K % (64 * nsp) == 0 and K // (2 * nsp) >= 256:
+                nsp *= 2
+        if nsp > 1:
+            parts = self._scratch_floats(nsp * M * N)
+            _lib.check(L.dispu_linear_bf16_stream(M, K, N, _p(X, xoff), X.stride(0), int(xb), _p(bt), K, None, 0, _p(parts), N, 0, nsp, M * N, self.st),
+                       "dispu_linear_bf16_stream")
+            _lib.check(L.dispu_linear_splitk_finish(M, N, nsp, _p(parts), M * N, _p(bias), act, _p(Y, yoff), Y.stride(0), self.st), "splitk_finish")
+        else:
+            _lib.check(L.dispu_linear_bf16_stream(M, K, N, _p(X, xoff), X.stride(0), int(xb), _p(bt), K, _p(bias), act, _p(Y, yoff), Y.stride(0),
+                                                  int(yb), 1, 0, self.st), "dispu_linear_bf16_stream")
+        return True
+
     def _lin(self, X, xoff, K, wname, act, Y, yoff, N, M=None, bias=True, W=None, woff=0):
         """Y[:, yoff:yoff+N] = act(X[:, xoff:xoff+K] . W + b)"""
         L = _lib.tape_lib()
@@ -483,6 +520,8 @@ class Trainer(object):
         W = self.P[wname + "/weights"] if W is None else W
         b = self.P[wname + "/biases"] if bias else None
         sto = (1 if X.dtype == torch.bfloat16 else 0) | (4 if Y.dtype == torch.bfloat16 else 0)
+        if (sto or self._use_bf16(1, M, K, N)) and self._stream(M, K, N, X, xoff, W, woff, 1, b, act, Y, yoff):
+            return
         if sto:
             assert xoff == 0 and yoff == 0
             _lib.check(L.dispu_linear_bf16s(1, M, K, N, _p(X), X.stride(0), 0, _p(W, woff), W.stride(0), 0, 0, _p(b), act, _p(Y), Y.stride(0), 0,
@@ -554,6 +593,8 @@ class Trainer(object):
         else:
             wp, ldw, tb = _p(W, woff), W.stride(0), 1
         sto = (1 if dY.dtype == torch.bfloat16 else 0) | (4 if dX.dtype == torch.bfloat16 else 0)
+        if (sto or bf) and mask is None and not acc and self._stream(M, N, K, dY, dyoff, W, woff, 0, None, 0, dX, dxoff):
+            return
         if sto:
             assert self.bf16 and mask is None and not acc and dyoff == 0 and dxoff == 0
             _lib.check(L.dispu_linear_bf16s(1, M, N, K, _p(dY), dY.stride(0), 0, wp, ldw, 0, tb, None, 0, _p(dX), dX.stride(0), 0, None, 0, 0,

@@ -460,6 +460,15 @@ int dispu_linear_masked(int batch, int M, int K, int N, const float* X, long ldx
 int dispu_linear_bf16_masked(int batch, int M, int K, int N, const float* X, long ldx, long sx, const float* W, long ldw, long sw,
                              int transb, const float* bias, int act, float* Y, long ldy, long sy, const float* R1, long ldr1, long sr1,
                              const float* Mk, long ldm, int mcols, void* stream);
+/* Streaming bf16-product GEMM for the step's largest dense products (Trainer(dtype="bf16"); csrc/linear_bf16_stream.hip): operands by
+ * DMA into LDS, X fp32 rounded to bf16 (nearest even) in front of the matrix pipe, B supplied as Bt [N][K] bf16 (k contiguous) by
+ * dispu_bf16_pack (transpose = 1 of W [K][N] for Y = X.W; transpose = 0 of W [N][K] for dX = dZ.W^T).  Same products as
+ * dispu_linear_bf16; x_bf16 / y_bf16: X / Y stored as bf16; splits > 1: fp32 partial products of `splits` equal k ranges to
+ * Y + s * y_split, no bias / activation (dispu_linear_splitk_finish adds them in order).  M % 128 == 0, K % (32 splits) == 0,
+ * N % 128 == 0, 16-byte aligned rows -- anything else returns hipErrorInvalidValue (the caller keeps dispu_linear_bf16). */
+int dispu_bf16_pack(int rows, int cols, const float* W, long ldw, int transpose, void* out, void* stream);
+int dispu_linear_bf16_stream(int M, int K, int N, const void* X, long ldx, int x_bf16, const void* Bt, long ldb, const float* bias, int act,
+                             void* Y, long ldy, int y_bf16, int splits, long y_split, void* stream);
 /* dispu_mlp_chain that also writes the second / third layer's outputs (Y2 [rows,N2], Y3 [rows,N3]) and the head's pre-activation
  * output Z [rows,3]: the training forward of the two head chains in one launch each (any of Y1, Y2, Y3, Z may be NULL). */
 int dispu_mlp_chain_stash(long rows, int K0, int N1, int N2, int N3, const float* X, long ldx, const float* W1, const float* b1,

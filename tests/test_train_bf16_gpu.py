@@ -244,3 +244,77 @@ def test_pair_tensor_kernels_with_bf16_storage(dev):
         _lib.check(L.dispu_ps_conv0_gather_grad_s(rows, n, k, c, p(idx), p(off), p(inv), p(t), c, flag, p(G), c, p(A), c, p(dG), c, p(dA), c, st), "gather grad")
         res.append((dG, dA))
     assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,K,N,act,ybf", [(8192, 2048, 256, 1, 0), (256, 64, 128, 0, 0), (1024, 256, 2048, 0, 1), (128, 32, 128, 1, 0), (384, 96, 384, 0, 0)])
+def test_streaming_bf16_product_equals_the_register_staged_one(M, K, N, act, ybf):
+    """dispu_linear_bf16_stream (operands by DMA, swizzled LDS image, weights packed as bf16 [N][K]) against dispu_linear_bf16 on the same
+    operands: the same roundings and the same ascending-k accumulation -> equal bit for bit (fp32 output), equal after the output
+    rounding (bf16 output); and against a float64 product of the bf16-rounded operands."""
+    from dispu_amd import _lib
+    L = _lib.lib()
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(M + K + N)
+    x = torch.randn(M, K, device=dev, generator=g)
+    w = torch.randn(K, N, device=dev, generator=g) * 0.05
+    b = torch.randn(N, device=dev, generator=g)
+    st = _lib.stream_ptr(dev)
+    ref = torch.empty(M, N, device=dev)
+    _lib.check(L.dispu_linear_bf16(1, M, K, N, x.data_ptr(), K, 0, w.data_ptr(), N, 0, 0, b.data_ptr(), act, ref.data_ptr(), N, 0, None, 0, 0, None, 0, 0, st), "ref")
+    bt = torch.empty(N, K, dtype=torch.bfloat16, device=dev)
+    _lib.check(L.dispu_bf16_pack(K, N, w.data_ptr(), N, 1, bt.data_ptr(), st), "pack")
+    assert torch.equal(bt, w.t().contiguous().to(torch.bfloat16))
+    y = torch.empty(M, N, dtype=torch.bfloat16 if ybf else torch.float32, device=dev)
+    _lib.check(L.dispu_linear_bf16_stream(M, K, N, x.data_ptr(), K, 0, bt.data_ptr(), K, b.data_ptr(), act, y.data_ptr(), N, ybf, 1, 0, st), "stream")
+    if ybf:
+        assert torch.equal(y, ref.to(torch.bfloat16))
+    else:
+        assert torch.equal(y, ref)
+    exact = x.to(torch.bfloat16).double() @ w.to(torch.bfloat16).double() + b.double()
+    if act:
+        exact = exact.clamp_min(0)
+    bound = 2e-6 * (x.abs().double() @ w.abs().double()) + 1e-6
+    tol = bound if not ybf else bound + exact.abs() * 2 ** -8
+    assert bool(((y.double() - exact).abs() <= tol).all())
+    # the straight (not transposed) pack, and shapes the streaming kernel refuses
+    wt = torch.empty(K, N, dtype=torch.bfloat16, device=dev)
+    _lib.check(L.dispu_bf16_pack(K, N, w.data_ptr(), N, 0, wt.data_ptr(), st), "pack0")
+    assert torch.equal(wt, w.to(torch.bfloat16))
+    assert L.dispu_linear_bf16_stream(M + 1, K, N, x.data_ptr(), K, 0, bt.data_ptr(), K, b.data_ptr(), act, y.data_ptr(), N, ybf, 1, 0, st) != 0
+    # X stored as bf16 (the training step's bf16 activation storage): no conversion in the kernel, same products
+    xb = x.to(torch.bfloat16)
+    y2 = torch.empty_like(y)
+    _lib.check(L.dispu_linear_bf16_stream(M, K, N, xb.data_ptr(), K, 1, bt.data_ptr(), K, b.data_ptr(), act, y2.data_ptr(), N, ybf, 1, 0, st), "stream bf16 x")
+    assert torch.equal(y2, y)
+    # k splits: fp32 partial products, added in order by dispu_linear_splitk_finish (reassociated: compared within the bound)
+    if K % 64 == 0 and not ybf:
+        nsp = 2 if K % 128 else 4
+        parts = torch.empty(nsp, M, N, device=dev)
+        _lib.check(L.dispu_linear_bf16_stream(M, K, N, x.data_ptr(), K, 0, bt.data_ptr(), K, None, 0, parts.data_ptr(), N, 0, nsp, M * N, st), "stream split")
+        y3 = torch.empty(M, N, device=dev)
+        _lib.check(L.dispu_linear_splitk_finish(M, N, nsp, parts.data_ptr(), M * N, b.data_ptr(), act, y3.data_ptr(), N, st), "finish")
+        assert bool(((y3.double() - exact).abs() <= bound).all())
+
+
+@pytest.mark.gpu
+def test_bf16_step_with_and_without_the_streaming_kernel(steps, dev):
+    """Trainer(dtype="bf16") routes its large dense products (after_conv forward / dX, the pair tensors' conv1) through
+    dispu_linear_bf16_stream; Trainer.bf16_stream = False keeps them on dispu_linear_bf16.  Same operand roundings and k order -- the
+    only difference is the k-split of after_conv's forward at few rows (fp32 partial sums added in order): coarse clouds equal to 1e-5,
+    fine ones to 1e-4, gradients to 2e-3 of their norm (float atomics in the scatter gradients are part of that)."""
+    from dispu_amd.train import Trainer
+    tx, tg, r, P = steps["data"]
+    res = {}
+    for on in (True, False):
+        tr = Trainer(params=P, device=dev, dtype="bf16")
+        tr.bf16_stream = on
+        tr.zero_grad()
+        c, f = tr.forward(tx)
+        tr.loss_backward(tg, r)
+        tr.backward()
+        torch.cuda.synchronize()
+        res[on] = (N_(c).copy(), N_(f).copy(), N_(tr.flat_g).astype(np.float64))
+    assert np.abs(res[True][0] - res[False][0]).max() <= 1e-5 and np.abs(res[True][1] - res[False][1]).max() <= 1e-4
+    ga, gb = res[True][2], res[False][2]
+    assert np.linalg.norm(ga - gb) <= 2e-3 * np.linalg.norm(gb), float(np.linalg.norm(ga - gb) / np.linalg.norm(gb))

@@ -31,6 +31,8 @@ def main():
                     help="f32: the reference's arithmetic; bf16: bf16 products / fp32 accumulation and storage (csrc/linear_bf16.hip)")
     ap.add_argument("--dw-streams", type=int, default=0, help="side streams for the weight-gradient products (0: the Trainer's default)")
     ap.add_argument("--no-tail-on-chain", action="store_true", help="A/B: the last block's weight gradients on a side stream again")
+    ap.add_argument("--no-bf16-stream", action="store_true", help="A/B: dtype bf16 without the streaming bf16 kernel (Trainer.bf16_stream = False)")
+    ap.add_argument("--bf16-min-macs", type=float, default=0.0, help="Trainer.bf16_min_macs (A/B)")
     ap.add_argument("--tape", action="store_true", help="forward + loss + backward re-issued from a launch tape (Trainer.train_step_taped)")
     args = ap.parse_args()
     from dispu_amd import synth
@@ -49,6 +51,10 @@ def main():
     tr = Trainer(params=P, device=dev, dtype=args.dtype)
     if args.dw_streams > 0:
         tr.dw_streams = args.dw_streams
+    if args.bf16_min_macs > 0:
+        tr.bf16_min_macs = args.bf16_min_macs
+    if args.no_bf16_stream:
+        tr.bf16_stream = False
     if args.no_tail_on_chain:
         tr.tail_on_chain = False
     x, gt = synth.patch_with_gt(args.batch, 256, 1024, seed=5000 + rank)
