@@ -141,6 +141,7 @@ class Trainer(object):
         # (default "auto": on up to 16 patches per step -- at 32 the chip is saturated by the chain's own kernels, side work submitted
         # later only lengthens the tail: 4.58 -> 4.63 ms; "1" / "0" force it)
         self.fused_stem = True     # one launch per dense block in the forward pass
+        self.bf16_tn = True        # dtype="bf16": weight-gradient products of fp32-stored operands on the bf16 TN kernel too (False: they stay on the fp32 one)
         self.bf16_stream = True    # dtype="bf16": the large dense products on the streaming bf16 kernel (csrc/linear_bf16_stream.hip) where its shape rules hold
         self._packs = {}
         self.tail_on_chain = True  # the first dense block's weight gradients (the LAST work of the backward) stay on the chain's stream: no cross-stream hop in front of Adam
@@ -536,7 +537,7 @@ class Trainer(object):
         L = _lib.tape_lib()
         side = side and self.overlap_dw
         sto = (1 if X.dtype == torch.bfloat16 else 0) | (2 if Zt.dtype == torch.bfloat16 else 0)
-        bf = self._use_bf16(batch, M, K, N) or bool(sto)
+        bf = (self.bf16_tn and self._use_bf16(batch, M, K, N)) or bool(sto)
         need = (L.dispu_linear_tn_bf16_scratch_floats if bf else L.dispu_linear_tn_scratch_floats)(batch, M, K, N)
 
         def launch(st, key):

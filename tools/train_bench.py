@@ -33,6 +33,7 @@ def main():
     ap.add_argument("--no-tail-on-chain", action="store_true", help="A/B: the last block's weight gradients on a side stream again")
     ap.add_argument("--no-bf16-stream", action="store_true", help="A/B: dtype bf16 without the streaming bf16 kernel (Trainer.bf16_stream = False)")
     ap.add_argument("--bf16-min-macs", type=float, default=0.0, help="Trainer.bf16_min_macs (A/B)")
+    ap.add_argument("--no-bf16-tn", action="store_true", help="A/B: Trainer.bf16_tn = False")
     ap.add_argument("--tape", action="store_true", help="forward + loss + backward re-issued from a launch tape (Trainer.train_step_taped)")
     args = ap.parse_args()
     from dispu_amd import synth
@@ -53,6 +54,8 @@ def main():
         tr.dw_streams = args.dw_streams
     if args.bf16_min_macs > 0:
         tr.bf16_min_macs = args.bf16_min_macs
+    if args.no_bf16_tn:
+        tr.bf16_tn = False
     if args.no_bf16_stream:
         tr.bf16_stream = False
     if args.no_tail_on_chain:
