@@ -90,6 +90,8 @@ SIGNATURES = {
                                  _vp, _vp]),
     "dispu_attention_project": (_i, [_i, _i, _i, _i, _vp, _l, _vp, _l, _vp, _l, C.c_float, _vp, _vp, _i, _vp, _l, _vp]),
     "dispu_softmax_rows": (_i, [_l, _i, C.c_float, _vp, _l, _vp]),
+    "dispu_linear_tn_bf16_stream_scratch_floats": (_l, [_i, _i, _i]),
+    "dispu_linear_tn_bf16_stream": (_i, [_i, _i, _i, _vp, _l, _vp, _l, _i, _vp, _l, _i, _vp, _vp, _l, _vp]),
     "dispu_bf16_pack": (_i, [_i, _i, _vp, _l, _i, _vp, _vp]),
     "dispu_linear_bf16_stream": (_i, [_i, _i, _i, _vp, _l, _i, _vp, _l, _vp, _i, _vp, _l, _i, _i, _l, _vp]),
     "dispu_linear_bf16": (_i, [_i, _i, _i, _i, _vp, _l, _l, _vp, _l, _l, _i, _vp, _i, _vp, _l, _l, _vp, _l, _l, _vp, _l, _l, _vp]),

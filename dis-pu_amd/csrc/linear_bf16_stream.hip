@@ -157,6 +157,169 @@ __global__ __launch_bounds__(512) void gemm_bf16_stream_kernel(SbArgs a) {
         }
 }
 
+// ---- weight gradients: dW[K][N] = X^T . Z over the rows m of the batch (X [M][K], Z [M][N], both fp32 or both bf16 in HBM) ----------
+// The contraction index m is the SLOW index of both operands, so a lane's 8 consecutive k of an MFMA operand are 8 rows apart in the
+// row-major tiles: slabs of 32 rows land in LDS as they are (DMA, rows of 128 X columns / BN Z columns), a lane gathers its column
+// with 8 strided reads and rounds on the way (fp32 storage; bf16 storage is taken as is).  That is 16 LDS reads per MFMA pair of a
+// 2 x 2 wave tile -- half the matrix pipe at bf16 speed, still several times what the operand stream allows.  The rows are split over
+// blockIdx.y (the output is only K x N: 16 tiles for after_conv), partial tiles go to caller scratch [split][K + 1][N] (row K = the
+// column sums of Z = the bias gradient, from the un-rounded values in LDS) and tn_stream_reduce_kernel adds them in split order.
+struct StArgs {
+    int M, K, N;                     // rows of ONE split, X columns, Z columns
+    const void* X; long ldx;
+    const void* Z; long ldz;
+    float* part; int with_colsum;
+};
+
+template <int BN, bool ST_BF16>
+__global__ __launch_bounds__(512) void gemm_bf16_tn_stream_kernel(StArgs a) {
+    constexpr int ES = ST_BF16 ? 2 : 4, XROW = 128 * ES, ZROW = BN * ES;
+    constexpr int X_BYTES = 32 * XROW, Z_BYTES = 32 * ZROW, STAGE = X_BYTES + Z_BYTES;
+    constexpr int NX = X_BYTES / 1024, NZ = Z_BYTES / 1024, PER = (NX + NZ) / 8;
+    static_assert(NX % 8 == 0 && NZ % 8 == 0, "pieces must split evenly over the eight waves");
+    constexpr int WN = BN / 64, WM = 8 / WN, TI = 128 / WM / 32, TJ = 2;
+    extern __shared__ __attribute__((aligned(16))) char sb_lds[];
+    __shared__ float colred[4][256];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN, li = lane & 31, kq = lane >> 5;
+    const int tiles_n = a.N / BN;
+    const int k0 = (blockIdx.x / tiles_n) * 128, n0 = (blockIdx.x % tiles_n) * BN;
+    const size_t mbeg = (size_t)blockIdx.y * a.M;
+    const int nt = a.M / 32;
+
+    const char* gsrc[PER];
+    int ldst[PER];
+    long gstep[PER];
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        const int p = wave + 8 * u;
+        if (u < NX / 8) {
+            const int off = p * 1024 + 16 * lane, row = off / XROW, cb = off % XROW;
+            gsrc[u] = reinterpret_cast<const char*>(a.X) + ((mbeg + row) * a.ldx + k0) * ES + cb;
+            ldst[u] = p * 1024;
+            gstep[u] = (long)32 * a.ldx * ES;
+        } else {
+            const int q = p - NX, off = q * 1024 + 16 * lane, row = off / ZROW, cb = off % ZROW;
+            gsrc[u] = reinterpret_cast<const char*>(a.Z) + ((mbeg + row) * a.ldz + n0) * ES + cb;
+            ldst[u] = X_BYTES + q * 1024;
+            gstep[u] = (long)32 * a.ldz * ES;
+        }
+    }
+    auto issue = [&](int t) {
+        char* st = sb_lds + (t % SB_NST) * STAGE;
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const float* src = reinterpret_cast<const float*>(gsrc[u] + (size_t)t * gstep[u]);
+            float* dst = reinterpret_cast<float*>(st + ldst[u]);
+            __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        }
+    };
+    sb_f32x16 acc[TI][TJ];
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const bool colsum = a.with_colsum && k0 == 0;                  // workgroup-uniform
+    constexpr int CP = 512 / BN;                                   // threads per column
+    float csum = 0.f;
+    int xcol[TI], zcol[TJ];
+#pragma unroll
+    for (int i = 0; i < TI; ++i) xcol[i] = (wm * (128 / WM) + 32 * i + li) * ES;
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) zcol[j] = X_BYTES + (wn * 64 + 32 * j + li) * ES;
+
+    issue(0);
+    if (nt > 1) issue(1);
+    for (int t = 0; t < nt; ++t) {
+        if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_barrier" ::: "memory");
+        if (t + 2 < nt) issue(t + 2);
+        const char* st = sb_lds + (t % SB_NST) * STAGE;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            sb_bf16x8 fa[TI], fb[TJ];
+            const int mrow = 16 * s2 + 8 * kq;
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    if constexpr (ST_BF16) fa[i][e] = *reinterpret_cast<const __bf16*>(st + (mrow + e) * XROW + xcol[i]);
+                    else fa[i][e] = (__bf16)*reinterpret_cast<const float*>(st + (mrow + e) * XROW + xcol[i]);
+                }
+#pragma unroll
+            for (int j = 0; j < TJ; ++j)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    if constexpr (ST_BF16) fb[j][e] = *reinterpret_cast<const __bf16*>(st + (mrow + e) * ZROW + zcol[j]);
+                    else fb[j][e] = (__bf16)*reinterpret_cast<const float*>(st + (mrow + e) * ZROW + zcol[j]);
+                }
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int j = 0; j < TJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+        if (colsum) {
+            const int col = tid % BN, part = tid / BN;
+#pragma unroll
+            for (int r = 0; r < 32 / CP; ++r) {
+                const char* q = st + X_BYTES + (part + CP * r) * ZROW + col * ES;
+                csum += ST_BF16 ? (float)*reinterpret_cast<const __bf16*>(q) : *reinterpret_cast<const float*>(q);
+            }
+        }
+    }
+    const size_t rows_p = (size_t)a.K + (a.with_colsum ? 1 : 0);
+    float* __restrict__ P = a.part + (size_t)blockIdx.y * rows_p * a.N;
+    if (colsum) {
+        colred[tid / BN][tid % BN] = csum;
+        __syncthreads();
+        if (tid < BN) {
+            float v = colred[0][tid];
+#pragma unroll
+            for (int g = 1; g < CP; ++g) v += colred[g][tid];
+            P[(size_t)a.K * a.N + n0 + tid] = v;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) {
+            const int col = n0 + wn * 64 + 32 * j + li;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = k0 + wm * (128 / WM) + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * kq;
+                P[(size_t)row * a.N + col] = acc[i][j][r];
+            }
+        }
+}
+
+// out[row][col] (+)= sum_s part[s][row][col] in split order; row K (with_colsum) -> dbias[col] (+)=
+__global__ __launch_bounds__(256) void tn_stream_reduce_kernel(int K, int N, int splits, int with_colsum, const float* __restrict__ part,
+                                                               float* __restrict__ out, long ldo, int accumulate, float* __restrict__ dbias) {
+    const long rows_p = (long)K + (with_colsum ? 1 : 0), total = rows_p * N;
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= total) return;
+    float sum = part[e];
+    for (int t = 1; t < splits; ++t) sum += part[(long)t * total + e];
+    const long row = e / N, col = e % N;
+    float* o = (row < K) ? out + row * ldo + col : dbias + col;
+    *o = accumulate ? *o + sum : sum;
+}
+
+static int tn_stream_plan(int M, int K, int N, int& splits) {
+    if (M <= 0 || K <= 0 || N <= 0 || (K % 128) || (N % 128)) return 0;
+    const int bn = (N % 256) == 0 ? 256 : 128;
+    const long tiles = (long)(K / 128) * (N / bn);
+    int s = 1;
+    while (s < 64 && tiles * s < 256) s <<= 1;
+    while (s > 1 && (M % (32 * s) != 0 || M / s < 128)) s >>= 1;
+    if (M % (32 * s) != 0) return 0;
+    splits = s;
+    return 1;
+}
+
 // out bf16 [rows][cols] = W (transpose = 0) or [cols][rows] = W^T (transpose = 1), round to nearest even; W fp32 [rows][cols], row stride ldw
 __global__ void bf16_pack_kernel(int rows, int cols, const float* __restrict__ W, long ldw, int transpose, __bf16* __restrict__ out) {
     __shared__ float t[32][33];
@@ -218,5 +381,47 @@ DISPU_EXPORT int dispu_linear_bf16_stream(int M, int K, int N, const void* X, lo
     else if (wide) hipLaunchKernelGGL((gemm_bf16_stream_kernel<256, false>), grid, blk, lds, s, a);
     else if (x_bf16) hipLaunchKernelGGL((gemm_bf16_stream_kernel<128, true>), grid, blk, lds, s, a);
     else hipLaunchKernelGGL((gemm_bf16_stream_kernel<128, false>), grid, blk, lds, s, a);
+    return (int)hipGetLastError();
+}
+
+// dW = X^T . Z on the streaming kernel (see above): X [M][K], Z [M][N] both fp32 (storage = 0) or both bf16 (storage = 3); out [K][N]
+// (+)=, dbias [N] (+)= the column sums of Z (optional).  scratch: dispu_linear_tn_bf16_stream_scratch_floats floats (0 = shape outside
+// the kernel: K % 128, N % 128, M divisible into 32-row slabs per split).  Same products as dispu_linear_tn_bf16, another split plan.
+DISPU_EXPORT long dispu_linear_tn_bf16_stream_scratch_floats(int M, int K, int N) {
+    int splits;
+    if (!tn_stream_plan(M, K, N, splits)) return 0;
+    return (long)splits * ((long)K + 1) * N;
+}
+
+DISPU_EXPORT int dispu_linear_tn_bf16_stream(int M, int K, int N, const void* X, long ldx, const void* Z, long ldz, int storage, float* out,
+                                             long ldo, int accumulate, float* dbias, float* scratch, long scratch_floats, void* stream) {
+    int splits;
+    const bool bf = storage == 3;
+    if (!(storage == 0 || storage == 3) || !tn_stream_plan(M, K, N, splits) || !X || !Z || !out || !scratch ||
+        scratch_floats < (long)splits * ((long)K + 1) * N || ldx < K || ldz < N || (ldx & (bf ? 7 : 3)) || (ldz & (bf ? 7 : 3)) ||
+        (((uintptr_t)X) & 15) || (((uintptr_t)Z) & 15))
+        return (int)hipErrorInvalidValue;
+    hipStream_t s = (hipStream_t)stream;
+    const bool wide = (N % 256) == 0;
+    const int bn = wide ? 256 : 128, es = bf ? 2 : 4;
+    StArgs a{M / splits, K, N, X, ldx, Z, ldz, scratch, dbias ? 1 : 0};
+    const size_t lds = (size_t)SB_NST * 32 * (128 + bn) * es;
+    static DevOnce attr;
+    if (attr.needed()) {
+        DISPU_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_tn_stream_kernel<256, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));   // + 4 KB static
+        DISPU_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_tn_stream_kernel<128, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));   // + 4 KB static
+        DISPU_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_tn_stream_kernel<256, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));   // + 4 KB static
+        DISPU_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_tn_stream_kernel<128, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));   // + 4 KB static
+        attr.done();
+    }
+    const dim3 grid((K / 128) * (N / bn), splits), blk(512);
+    if (wide && bf) hipLaunchKernelGGL((gemm_bf16_tn_stream_kernel<256, true>), grid, blk, lds, s, a);
+    else if (wide) hipLaunchKernelGGL((gemm_bf16_tn_stream_kernel<256, false>), grid, blk, lds, s, a);
+    else if (bf) hipLaunchKernelGGL((gemm_bf16_tn_stream_kernel<128, true>), grid, blk, lds, s, a);
+    else hipLaunchKernelGGL((gemm_bf16_tn_stream_kernel<128, false>), grid, blk, lds, s, a);
+    DISPU_CHECK_LAUNCH();
+    const long total = ((long)K + (dbias ? 1 : 0)) * N;
+    hipLaunchKernelGGL(tn_stream_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, K, N, splits, dbias ? 1 : 0, scratch, out, ldo,
+                       accumulate, dbias);
     return (int)hipGetLastError();
 }

@@ -539,9 +539,20 @@ class Trainer(object):
         sto = (1 if X.dtype == torch.bfloat16 else 0) | (2 if Zt.dtype == torch.bfloat16 else 0)
         bf = (self.bf16_tn and self._use_bf16(batch, M, K, N)) or bool(sto)
         need = (L.dispu_linear_tn_bf16_scratch_floats if bf else L.dispu_linear_tn_scratch_floats)(batch, M, K, N)
+        # wide outputs (>= 4 tiles of 128 x 256: after_conv's 2048 x 256) on the streaming TN kernel: 36 vs 58 us at 8192 rows; outputs of one
+        # or two tiles cannot fill the chip with <= 64 row splits and stay on the register-staged kernel (131072 x 128 x 128: 47 vs 63 us)
+        tn_stream = 0
+        if (bf and self.bf16_stream and batch == 1 and sto in (0, 3) and K % 128 == 0 and N % 128 == 0 and xoff == 0 and zoff == 0
+                and (K // 128) * (N // (256 if N % 256 == 0 else 128)) >= 4 and ldo == N):
+            tn_stream = L.dispu_linear_tn_bf16_stream_scratch_floats(M, K, N)
+            need = max(need, tn_stream)
 
         def launch(st, key):
             sc = self._scratch_floats(need, key)
+            if tn_stream:
+                _lib.check(L.dispu_linear_tn_bf16_stream(M, K, N, _p(X), ldx, _p(Zt), ldz, sto, _p(out, ooff), ldo, accumulate, _p(dbias), _p(sc),
+                                                         sc.numel(), st), "dispu_linear_tn_bf16_stream")
+                return
             if sto:
                 assert bf and xoff == 0 and zoff == 0
                 _lib.check(L.dispu_linear_tn_bf16s(batch, M, K, N, _p(X), ldx, sx, _p(Zt), ldz, sz, _p(out, ooff), ldo, so, accumulate, _p(dbias), _p(sc),

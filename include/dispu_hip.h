@@ -467,6 +467,12 @@ int dispu_linear_bf16_masked(int batch, int M, int K, int N, const float* X, lon
  * Y + s * y_split, no bias / activation (dispu_linear_splitk_finish adds them in order).  M % 128 == 0, K % (32 splits) == 0,
  * N % 128 == 0, 16-byte aligned rows -- anything else returns hipErrorInvalidValue (the caller keeps dispu_linear_bf16). */
 int dispu_bf16_pack(int rows, int cols, const float* W, long ldw, int transpose, void* out, void* stream);
+/* dW = X^T . Z on the streaming kernel: X [M][K], Z [M][N] both fp32 (storage = 0) or both bf16 (storage = 3); out [K][N] (+)=, dbias [N]
+ * (+)= column sums of Z (optional).  scratch: dispu_linear_tn_bf16_stream_scratch_floats(M, K, N) floats; 0 = shape outside the kernel
+ * (K % 128, N % 128, rows divisible into 32-row slabs per split) -- dispu_linear_tn_bf16_stream then returns hipErrorInvalidValue. */
+long dispu_linear_tn_bf16_stream_scratch_floats(int M, int K, int N);
+int dispu_linear_tn_bf16_stream(int M, int K, int N, const void* X, long ldx, const void* Z, long ldz, int storage, float* out, long ldo,
+                                int accumulate, float* dbias, float* scratch, long scratch_floats, void* stream);
 int dispu_linear_bf16_stream(int M, int K, int N, const void* X, long ldx, int x_bf16, const void* Bt, long ldb, const float* bias, int act,
                              void* Y, long ldy, int y_bf16, int splits, long y_split, void* stream);
 /* dispu_mlp_chain that also writes the second / third layer's outputs (Y2 [rows,N2], Y3 [rows,N3]) and the head's pre-activation

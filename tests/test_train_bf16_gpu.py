@@ -318,3 +318,32 @@ def test_bf16_step_with_and_without_the_streaming_kernel(steps, dev):
     assert np.abs(res[True][0] - res[False][0]).max() <= 1e-5 and np.abs(res[True][1] - res[False][1]).max() <= 1e-4
     ga, gb = res[True][2], res[False][2]
     assert np.linalg.norm(ga - gb) <= 2e-3 * np.linalg.norm(gb), float(np.linalg.norm(ga - gb) / np.linalg.norm(gb))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,K,N,st,acc", [(8192, 2048, 256, 0, 1), (4096, 128, 128, 3, 0), (131072, 128, 128, 3, 1), (1024, 256, 384, 0, 0), (8192, 256, 2048, 0, 1)])
+def test_streaming_bf16_weight_gradient(M, K, N, st, acc):
+    """dispu_linear_tn_bf16_stream: dW = X^T . Z with fp32- or bf16-stored operands against a float64 product of the bf16-rounded
+    operands (the bound of test_linear_tn_bf16), accumulation into out, the bias gradient from the un-rounded Z."""
+    from dispu_amd import _lib
+    L = _lib.lib()
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(M + K + N)
+    x = torch.randn(M, K, device=dev, generator=g)
+    z = torch.randn(M, N, device=dev, generator=g) * 0.1
+    xs, zs = (x.to(torch.bfloat16), z.to(torch.bfloat16)) if st == 3 else (x, z)
+    out0 = torch.randn(K, N, device=dev, generator=g)
+    db0 = torch.randn(N, device=dev, generator=g)
+    out, db = out0.clone(), db0.clone()
+    need = L.dispu_linear_tn_bf16_stream_scratch_floats(M, K, N)
+    assert need > 0
+    sc = torch.empty(need, device=dev)
+    _lib.check(L.dispu_linear_tn_bf16_stream(M, K, N, xs.data_ptr(), K, zs.data_ptr(), N, st, out.data_ptr(), N, acc, db.data_ptr(), sc.data_ptr(), need,
+                                             _lib.stream_ptr(dev)), "tn stream")
+    xr, zr = x.to(torch.bfloat16).double(), z.to(torch.bfloat16).double()
+    want = xr.t() @ zr + (out0.double() if acc else 0)
+    bound = 4e-6 * (xr.abs().t() @ zr.abs()) + 1e-6 * (1 + want.abs())
+    assert bool(((out.double() - want).abs() <= bound).all()), float((out.double() - want).abs().max())
+    zsum = (zs.double() if st == 3 else z.double()).sum(0) + (db0.double() if acc else 0)
+    assert bool(((db.double() - zsum).abs() <= 1e-5 * (1 + z.abs().double().sum(0))).all())
+    assert L.dispu_linear_tn_bf16_stream_scratch_floats(M, K + 1, N) == 0
