@@ -295,17 +295,29 @@ __global__ __launch_bounds__(512) void gemm_bf16_tn_stream_kernel(StArgs a) {
         }
 }
 
-// out[row][col] (+)= sum_s part[s][row][col] in split order; row K (with_colsum) -> dbias[col] (+)=
+// out[row][col] (+)= sum_s part[s][row][col]; row K (with_colsum) -> dbias[col] (+)=.  32 elements x 8 split groups per workgroup: group g
+// adds splits g, g + 8, .. in ascending order, the eight group sums are added g = 0 .. 7: a fixed association (deterministic), with
+// chains 8x shorter than one thread per element (up to 256 splits for the one-tile outputs).
 __global__ __launch_bounds__(256) void tn_stream_reduce_kernel(int K, int N, int splits, int with_colsum, const float* __restrict__ part,
                                                                float* __restrict__ out, long ldo, int accumulate, float* __restrict__ dbias) {
+    __shared__ float red[8][32];
+    const int el = threadIdx.x & 31, g = threadIdx.x >> 5;
     const long rows_p = (long)K + (with_colsum ? 1 : 0), total = rows_p * N;
-    const long e = (long)blockIdx.x * 256 + threadIdx.x;
-    if (e >= total) return;
-    float sum = part[e];
-    for (int t = 1; t < splits; ++t) sum += part[(long)t * total + e];
-    const long row = e / N, col = e % N;
-    float* o = (row < K) ? out + row * ldo + col : dbias + col;
-    *o = accumulate ? *o + sum : sum;
+    const long e = (long)blockIdx.x * 32 + el;
+    float sum = 0.f;
+    if (e < total)
+#pragma unroll 4
+        for (int t = g; t < splits; t += 8) sum += part[(long)t * total + e];
+    red[g][el] = sum;
+    __syncthreads();
+    if (g == 0 && e < total) {
+        float r = red[0][el];
+#pragma unroll
+        for (int q = 1; q < 8; ++q) r += red[q][el];
+        const long row = e / N, col = e % N;
+        float* o = (row < K) ? out + row * ldo + col : dbias + col;
+        *o = accumulate ? *o + r : r;
+    }
 }
 
 static int tn_stream_plan(int M, int K, int N, int& splits) {
@@ -313,7 +325,7 @@ static int tn_stream_plan(int M, int K, int N, int& splits) {
     const int bn = (N % 256) == 0 ? 256 : 128;
     const long tiles = (long)(K / 128) * (N / bn);
     int s = 1;
-    while (s < 64 && tiles * s < 256) s <<= 1;
+    while (s < 256 && tiles * s < 256) s <<= 1;
     while (s > 1 && (M % (32 * s) != 0 || M / s < 128)) s >>= 1;
     if (M % (32 * s) != 0) return 0;
     splits = s;
@@ -421,7 +433,7 @@ DISPU_EXPORT int dispu_linear_tn_bf16_stream(int M, int K, int N, const void* X,
     else hipLaunchKernelGGL((gemm_bf16_tn_stream_kernel<128, false>), grid, blk, lds, s, a);
     DISPU_CHECK_LAUNCH();
     const long total = ((long)K + (dbias ? 1 : 0)) * N;
-    hipLaunchKernelGGL(tn_stream_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, K, N, splits, dbias ? 1 : 0, scratch, out, ldo,
+    hipLaunchKernelGGL(tn_stream_reduce_kernel, dim3((unsigned)((total + 31) / 32)), dim3(256), 0, s, K, N, splits, dbias ? 1 : 0, scratch, out, ldo,
                        accumulate, dbias);
     return (int)hipGetLastError();
 }

@@ -539,11 +539,10 @@ class Trainer(object):
         sto = (1 if X.dtype == torch.bfloat16 else 0) | (2 if Zt.dtype == torch.bfloat16 else 0)
         bf = (self.bf16_tn and self._use_bf16(batch, M, K, N)) or bool(sto)
         need = (L.dispu_linear_tn_bf16_scratch_floats if bf else L.dispu_linear_tn_scratch_floats)(batch, M, K, N)
-        # wide outputs (>= 4 tiles of 128 x 256: after_conv's 2048 x 256) on the streaming TN kernel: 36 vs 58 us at 8192 rows; outputs of one
-        # or two tiles cannot fill the chip with <= 64 row splits and stay on the register-staged kernel (131072 x 128 x 128: 47 vs 63 us)
+        # the streaming TN kernel where its shape rules hold (after_conv's 2048 x 256: 37 vs 59 us at 8192 rows; the pair tensors' 128 x 128
+        # over 131072 bf16-stored rows: 22 vs 47 us)
         tn_stream = 0
-        if (bf and self.bf16_stream and batch == 1 and sto in (0, 3) and K % 128 == 0 and N % 128 == 0 and xoff == 0 and zoff == 0
-                and (K // 128) * (N // (256 if N % 256 == 0 else 128)) >= 4 and ldo == N):
+        if (bf and self.bf16_stream and batch == 1 and sto in (0, 3) and K % 128 == 0 and N % 128 == 0 and xoff == 0 and zoff == 0):
             tn_stream = L.dispu_linear_tn_bf16_stream_scratch_floats(M, K, N)
             need = max(need, tn_stream)
 
