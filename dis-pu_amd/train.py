@@ -161,8 +161,12 @@ class Trainer(object):
     def _invalidate_recordings(self):
         """Launch tapes hold RAW device pointers (flat parameter / gradient / moment buffers, W^T copies,
         scratch, workspaces).  Whenever one of those buffers is re-allocated every recording is dropped, so the next
-        train_step_taped records afresh instead of replaying launches onto freed memory."""
+        train_step_taped records afresh instead of replaying launches onto freed memory.  The bf16 images of the weights
+        (_stream) are keyed by the weight's address: dropped with the tapes that point at them."""
         self._tapes.clear()
+        if getattr(self, "_packs", None):
+            torch.cuda.synchronize(self.device)
+            self._packs.clear()
 
     def load_params(self, params):
         dev = self.device
