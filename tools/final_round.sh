@@ -18,5 +18,9 @@ bash tools/prof_train.sh ${TAG}_train 8 > gpurun_out/$TAG/prof_train.log 2>&1
 timeout 300 python tools/emd_bench.py > gpurun_out/$TAG/emd_bench.txt 2>> gpurun_out/$TAG/ops.log
 timeout 300 python tools/train_bench.py --dtype bf16 > gpurun_out/$TAG/train_b8_bf16_bench.json 2>> gpurun_out/$TAG/ops.log
 timeout 300 python tools/fps_bench.py > gpurun_out/$TAG/fps_bench.txt 2>> gpurun_out/$TAG/ops.log
+for b in 32 64; do timeout 300 python tools/train_bench.py --dtype bf16 --batch $b > gpurun_out/$TAG/train_b${b}_bf16_bench.json 2>> gpurun_out/$TAG/ops.log; done
+timeout 300 python tools/train_bench.py --batch 64 > gpurun_out/$TAG/train_b64_f32_bench.json 2>> gpurun_out/$TAG/ops.log
+timeout 300 python tools/debug/bf16_gemm_bench.py > gpurun_out/$TAG/bf16_gemm_bench.txt 2>&1
+timeout 300 python tools/debug/bf16_tn_bench.py > gpurun_out/$TAG/bf16_tn_bench.txt 2>&1
 bash tools/trace_train.sh ${TAG}_trace 8 f32 > gpurun_out/$TAG/trace.log 2>&1
 echo done
