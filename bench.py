@@ -129,7 +129,7 @@ def cpu_baseline(target_seconds=14.0, with_ops=True):
     return out
 
 
-def train_step_table(dev, steps=20, warmup=4):
+def train_step_table(dev, steps=20, warmup=12):
     """Side table `roofline.train_step` (BASELINE configs[4]'s per-GPU share: 8 patches per GPU, full train step = training-mode forward,
     pu_loss, backward, gradient all-reduce (a no-op on one rank), Adam): ms per step (eager launches), fp32 and bf16, plus the
     B = 32 step; `mfma_frac` prices 3 x the forward's executed flops against the fp32 MFMA peak (a lower bound on the work: the backward
@@ -149,13 +149,17 @@ def train_step_table(dev, steps=20, warmup=4):
             out[key] = {"error": r.stderr.decode(errors="replace")[-300:]}
             continue
         d = json.loads(r.stdout.decode().strip().splitlines()[-1])
-        ms = d["ms_per_step"]
+        # the MEDIAN of the five K-step loops train_bench.py times (after `warmup` untimed steps): a single 20-step loop of this
+        # ~30 ms region scatters by +-4 % (first loop 1.706 vs median 1.644 ms in round 5), min / max ride along
+        rep = d["ms_per_step_repeats"]
+        ms = rep["median"]
         flops = 3.0 * 2.0 * step_macs_per_patch() * B
-        out[key] = {"ms_per_step": round(ms, 4), "patches_per_s": round(B / ms * 1e3, 1),
+        out[key] = {"ms_per_step": round(ms, 4), "ms_min": round(rep["min"], 4), "ms_max": round(rep["max"], 4),
+                    "ms_first_loop": round(d["ms_per_step"], 4), "patches_per_s": round(B / ms * 1e3, 1),
                     "mfma_frac": round(flops / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
                     "forward_ms": d.get("forward_ms"), "loss_ms": d.get("loss_ms"), "backward_ms": d.get("backward_ms")}
     out["note"] = ("full train step (forward in training mode + pu_loss + backward + Adam) on one GPU, each row tools/train_bench.py in its own "
-                   "process; mfma_frac = 3 x forward flops / time / %.1f TFLOP/s fp32 MFMA peak; bf16 = bf16 products AND bf16 storage of the "
+                   "process; ms_per_step = median of 5 loops of %d steps after %d warm-up steps (ms_min / ms_max / ms_first_loop beside it);" % (steps, warmup) + "  mfma_frac = 3 x forward flops / time / %.1f TFLOP/s fp32 MFMA peak; bf16 = bf16 products AND bf16 storage of the "
                    "local cell's pair tensors" % FP32_MFMA_PEAK_TFLOPS)
     return out
 
@@ -203,6 +207,7 @@ def main():
     ap.add_argument("--graph-only", action="store_true", help="always replay the hipGraph (default: setup picks the faster of replay and eager launches)")
     ap.add_argument("--split-bf16", action="store_true",
                     help="EXPLORATORY, not the headline: after_conv's products as 3-way split-bf16 MFMAs (fp32-accurate, fp32 accumulate)")
+    ap.add_argument("--one-stream", action="store_true", help="Generator.branches = False: the non-local cell on the launch stream (profiling passes)")
     ap.add_argument("--no-ops", action="store_true", help="skip the per-op roofline table (roofline.ops, cpu_baseline.ops)")
     args = ap.parse_args()
 
@@ -228,14 +233,28 @@ def main():
     local_dev = local % max(ndev, 1)
     torch.cuda.set_device(local_dev)
     dev = torch.device("cuda", local_dev)
-    if world > 1:
+    # DISPU_BENCH_COLLECTIVES=1 with --gpus 1: a ONE-rank process group, so that the N > 1 code (comm lane, events, the collective calls
+    # themselves -- a 1-rank RCCL communicator really enqueues them) runs on the single GPU a test box has; the side tables are skipped
+    force1 = world == 1 and os.environ.get("DISPU_BENCH_COLLECTIVES", "0") == "1"
+    comm = world > 1 or force1
+    solo = world == 1 and not force1
+    if comm:
+        kw = {}
+        if force1 and "MASTER_ADDR" not in os.environ:
+            import socket
+            sk = socket.socket()
+            sk.bind(("127.0.0.1", 0))
+            kw = dict(init_method="tcp://127.0.0.1:%d" % sk.getsockname()[1], rank=0, world_size=1)
+            sk.close()
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, **kw)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, **kw)
 
     params = init_params(seed=1234)                           # Xavier-uniform, zero biases (reference init)
     gen = Generator(params=params, device=dev)
+    if args.one_stream:
+        gen.branches = False
     gen.return_views = True                                   # results stay in the workspace: no copy kernels in the step
     gen.split_bf16 = bool(args.split_bf16)
     x = torch.from_numpy(synth.patches(PATCHES_PER_GPU, NPOINT, seed=1000 * 2 + rank)).to(dev)   # 1000*config + rank
@@ -245,7 +264,7 @@ def main():
     # the fine head writes its clouds into the slot's own [32, 1024, 3] buffer (Generator.fine_out), nothing waits on the compute
     # stream.  DISPU_BENCH_GATHER=sync keeps round 4's exposed gather (A/B), =off drops the collective (the compute-only reference the
     # two-rank dry run compares against).
-    gather_mode = os.environ.get("DISPU_BENCH_GATHER", "overlap") if world > 1 else "off"
+    gather_mode = os.environ.get("DISPU_BENCH_GATHER", "overlap") if comm else "off"
     pipe = parallel.GatherPipeline((PATCHES_PER_GPU, NPOINT * UP, 3), dev) if gather_mode == "overlap" else None
     gathered = torch.empty((world * PATCHES_PER_GPU, NPOINT * UP, 3), dtype=torch.float32, device=dev) if gather_mode == "sync" else None
 
@@ -317,7 +336,7 @@ def main():
     if graphs is not None and not args.graph_only:
         def _time(fn, n=40):
             torch.cuda.synchronize()
-            if world > 1:
+            if comm:
                 dist.barrier()
             t = time.perf_counter()
             for _ in range(n):
@@ -331,7 +350,7 @@ def main():
             _eager_step()
         t_graph, t_eager = _time(step), _time(_eager_step)
         pick = torch.tensor([1.0 if t_eager < 0.995 * t_graph else 0.0], device=dev)
-        if world > 1:                                          # every rank must take the same path
+        if comm:                                          # every rank must take the same path
             dist.all_reduce(pick, op=dist.ReduceOp.MIN)
         calib = {"hipgraph_ms": t_graph * 1e3, "eager_ms": t_eager * 1e3}
         if float(pick.item()) > 0.5:
@@ -342,7 +361,7 @@ def main():
     for _ in range(args.warmup):
         step()
     drain()
-    if world > 1:
+    if comm:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -350,10 +369,10 @@ def main():
         step()
     drain()                                                    # the K-th step's gather is inside the timed region too
     torch.cuda.synchronize()
-    if world > 1:
+    if comm:
         dist.barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if comm:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -361,7 +380,7 @@ def main():
     # loop's (the contract's timed region), min / median / max of all five ride along
     loops = [dt]
     for _ in range(4):
-        if world > 1:
+        if comm:
             dist.barrier()
         torch.cuda.synchronize()
         t1 = time.perf_counter()
@@ -369,10 +388,10 @@ def main():
             step()
         drain()
         torch.cuda.synchronize()
-        if world > 1:
+        if comm:
             dist.barrier()
         d1 = time.perf_counter() - t1
-        if world > 1:
+        if comm:
             tt = torch.tensor([d1], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             d1 = float(tt.item())
@@ -382,7 +401,7 @@ def main():
     # k, fp32 accumulate: csrc/linear_bf16x3.hip).  fp32-accurate (tests/test_headline_gpu.py) but NOT the fmaf chain of the strict path,
     # so it rides along as a second figure; `value` above stays the strict-fp32 step.
     alt = None
-    if rank == 0 and world == 1 and not args.split_bf16 and not args.eager:
+    if rank == 0 and solo and not args.split_bf16 and not args.eager:
         try:
             g2 = Generator(params=params, device=dev)
             g2.return_views = True
@@ -433,7 +452,7 @@ def main():
     # batch's latency-bound feature extractor fills the tail of the previous one.  Strict fp32, same kernels, same results per batch;
     # NOT `value` (the contract's step is one batch from its first kernel to its last) -- reported beside it.
     alt2 = None
-    if rank == 0 and world == 1 and not args.split_bf16 and not args.eager:
+    if rank == 0 and solo and not args.split_bf16 and not args.eager:
         try:
             gens = [gen, Generator(params=params, device=dev)]
             gens[1].return_views = True
@@ -470,7 +489,7 @@ def main():
         acc = {}
         # every kernel ALONE on the device: the step's second stream (Generator.branches: the non-local cell beside the local cell) is
         # folded back into the launch stream for this pass, so a kernel's time is its own and not that of two kernels sharing the CUs
-        # (same kernels, same data; tools/prof_bench.sh runs its rocprofv3 pass the same way, DISPU_BRANCHES=0)
+        # (same kernels, same data; tools/prof_bench.sh runs its rocprofv3 pass the same way, --one-stream)
         two_streams, gen.branches = gen.branches, False
         for _ in range(reps):
             gen.profile = []
@@ -521,7 +540,7 @@ def main():
                                 "/ time / %.1f TFLOP/s (fp32 MFMA peak); null = not an MFMA kernel (k-NN selection, gathers, 3-wide heads)"
                                 % FP32_MFMA_PEAK_TFLOPS)
 
-    if rank == 0 and world == 1:
+    if rank == 0 and solo:
         # what the matrix pipe of THIS chip sustains for a GEMM-like instruction mix with real data (tools/micro/mfma_power.hip, built by
         # __graft_entry__.build(): 8 accumulator tiles per wave, 2 A + 4 B LDS fragment reads per 8 MFMAs, random operands, no global
         # traffic, no barriers, no loader waves): the practical ceiling next to the datasheet `peak` -- power management, not the kernel
@@ -553,7 +572,7 @@ def main():
                              "per patch (work removed by exact algebra counted as done)"
                              % (step_macs_per_patch() / 1e9, PATCHES_PER_GPU, FP32_MFMA_PEAK_TFLOPS, REFERENCE_FLOPS_PER_PATCH / 1e9))
         side = {}
-        if world == 1 and not args.no_ops:
+        if solo and not args.no_ops:
             sys.path.insert(0, os.path.join(ROOT, "tools"))
             import ops_bench
             try:
@@ -578,10 +597,10 @@ def main():
                "data": "synthetic",
                "config": {"workload": "BASELINE configs[%d]: %d patches x %d points per GPU, generator forward 256->1024 (4x), "
                                       "fp32%s" % (1 if world == 1 else 2, PATCHES_PER_GPU, NPOINT,
-                                                  "" if world == 1 else ", + %s all-gather of the upsampled clouds" % ("RCCL" if backend == "nccl" else backend)),
+                                                  "" if not comm else ", + %s all-gather of the upsampled clouds" % ("RCCL" if backend == "nccl" else backend)),
                           "patches_per_gpu": PATCHES_PER_GPU, "global_patches": world * PATCHES_PER_GPU,
                           "points_out_per_step": pts, "launch": launch, "launch_calibration_ms": calib,
-                          "collective": (None if world == 1 else
+                          "collective": (None if not comm else
                                          {"overlap": "all-gather of step i on a comm lane while step i + 1 computes (two result slots, "
                                                      "parallel.GatherPipeline); the K-th gather completes inside the timed region",
                                           "sync": "all-gather on the compute stream after every step (round-4 behaviour)",
@@ -596,7 +615,7 @@ def main():
         srt = sorted(loops)
         out["ms_per_step_repeats"] = {"n": len(loops), "min": srt[0] / args.steps * 1e3, "median": srt[len(srt) // 2] / args.steps * 1e3,
                                       "max": srt[-1] / args.steps * 1e3, "note": "the timed K-step loop run 5 times; value / ms_per_step = the first"}
-        if world == 1 and not args.no_cpu_baseline:
+        if solo and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(with_ops=not args.no_ops)
             except Exception as e:                             # noqa: BLE001
@@ -611,22 +630,24 @@ def main():
             side["cpu_baseline_ops"] = out["cpu_baseline"].pop("ops")
         if "train_step" in side and isinstance(side["train_step"], dict):
             roof["train_step_ms"] = {k: v.get("ms_per_step") for k, v in side["train_step"].items() if isinstance(v, dict)}
+            roof["train_step_ms_min_median_max"] = {k: [v.get("ms_min"), v.get("ms_per_step"), v.get("ms_max")]
+                                                    for k, v in side["train_step"].items() if isinstance(v, dict) and "ms_min" in v}
         side["headline"] = {k: out[k] for k in ("value", "ms_per_step", "steps", "warmup", "n_gpus")}
         # only the full run writes the side file: the profiled / counter passes (--no-ops, timings inflated by the profiler) must not
         # overwrite it
-        for d in ((os.path.join(ROOT, "profiles"), os.path.join(ROOT, "gpurun_out")) if (world == 1 and not args.no_ops) else ()):
+        for d in ((os.path.join(ROOT, "profiles"), os.path.join(ROOT, "gpurun_out")) if (solo and not args.no_ops) else ()):
             try:
                 os.makedirs(d, exist_ok=True)
                 with open(os.path.join(d, "bench_side_tables.json"), "w") as f:
                     json.dump(side, f, indent=1)
             except OSError:
                 pass
-        if world == 1 and not args.no_ops:
+        if solo and not args.no_ops:
             roof["side_tables"] = "profiles/bench_side_tables.json (keys: kernels, ops, train_step, ops_peaks, cpu_baseline_ops)"
         print(json.dumps(out))
     if pipe is not None:
         pipe.close()
-    if world > 1:
+    if comm:
         dist.destroy_process_group()
 
 

@@ -8,7 +8,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libdispu_hip.so")
 
-ABI_VERSION = 4       # include/dispu_hip.h: dispu_version()
+ABI_VERSION = 5       # include/dispu_hip.h: dispu_version()
 ARITH_PLAIN = 0
 ARITH_CONTRACT = 1
 ARITH_PINNED_EXP = 2   # OR-able, approx_match only (bit-reproducible exp; parity mode)
@@ -47,6 +47,7 @@ SIGNATURES = {
     "dispu_nn_distance_grad": (_i, [_i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "dispu_approx_match_scratch_bytes": (_sz, [_i, _i, _i]),
     "dispu_approx_match": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp]),
+    "dispu_approx_match_ws": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _sz, _i, _vp]),
     "dispu_match_cost_scratch_bytes": (_sz, [_i, _i, _i]),
     "dispu_match_cost": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp]),
     "dispu_match_cost_ws": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
@@ -57,6 +58,7 @@ SIGNATURES = {
     "dispu_linear_bn": (_i, [_i, _i, _i, _i, _vp, _l, _l, _vp, _l, _l, _i, _vp, _vp, _vp, _i, _vp, _l, _l, _vp, _l, _l, _vp, _l, _l,
                              _vp]),
     "dispu_linear_tile": (_i, [_i, _i, _i]),
+    "dispu_linear_tile2": (_i, [_i, _i, _i, _i, _i]),
     "dispu_debug_linear_tile": (None, [_i]),
     "dispu_sa_fused": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "dispu_edge_conv_fused": (_i, [_i, _i, _i, _i, _vp, _l, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
@@ -207,7 +209,7 @@ class Tape(object):
 
 
 _TAPE = None                     # the Tape being recorded, if any
-_NO_TAPE = ("dispu_version", "dispu_error_string", "dispu_linear_tile")
+_NO_TAPE = ("dispu_version", "dispu_error_string", "dispu_linear_tile", "dispu_linear_tile2")
 
 
 class _TapeLib(object):

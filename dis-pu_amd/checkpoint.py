@@ -471,15 +471,23 @@ def save_train_state(log_dir, trainer, epoch=None):
     return prefix
 
 
-def _update_state_file(log_dir, base, max_to_keep=5):
-    """The `checkpoint` state file as tf.train.Saver(max_to_keep=5) maintains it: the newest prefix first as
-    model_checkpoint_path, then the last `max_to_keep` prefixes oldest-first as all_model_checkpoint_paths."""
+def _update_state_file(log_dir, base, max_to_keep=None):
+    """The `checkpoint` state file as the reference's tf.train.Saver(max_to_keep=None) (DisPU/model.py:184) maintains it: the newest
+    prefix first as model_checkpoint_path, then EVERY prefix saved so far, oldest first, as all_model_checkpoint_paths -- nothing on
+    disk drops out of the list.  A finite `max_to_keep` behaves like TF's: prefixes that fall off the list have their bundle files
+    (`<prefix>.index`, `<prefix>.data-*`) deleted too."""
     path = os.path.join(log_dir, "checkpoint")
     prev = []
     if os.path.exists(path):
         with open(path) as f:
             prev = re.findall(r'all_model_checkpoint_paths:\s*"([^"]+)"', f.read())
-    keep = ([p for p in prev if p != base] + [base])[-max_to_keep:]
+    keep = [p for p in prev if p != base] + [base]
+    if max_to_keep:
+        for gone in keep[:-max_to_keep]:
+            for f in os.listdir(log_dir):
+                if f == gone + ".index" or f.startswith(gone + ".data-"):
+                    os.remove(os.path.join(log_dir, f))
+        keep = keep[-max_to_keep:]
     with open(path, "w") as f:
         f.write('model_checkpoint_path: "%s"\n' % base)
         for p in keep:

@@ -326,6 +326,113 @@ __global__ __launch_bounds__(AM_ROWS) void am_assemble_kernel(int n, int m, AmLe
     am_assemble_body<FMA, PINNED>(blockIdx.z, blockIdx.x, blockIdx.y, tile, n, m, lv, xyz1, xyz2, temp, match);
 }
 
+// ---- the auction inside the reference op's own temp ---------------------------------------------------------------------------
+// approxmatchLauncher's caller allocates temp as [b, 2 (n + m)] floats (tf_approxmatch.cpp:164-170) and nothing more.  This form
+// needs exactly that: ONE workgroup per cloud (as the reference's kernel, tf_approxmatch_g.cu:180: <<<32,512>>> over clouds), a lane
+// per point, the partners streamed through an LDS tile in ascending order, so every sum is the reference's sequential chain
+// (oracle/dispu_oracle.c:orc_approx_match, chunk = 0: bit for bit in DISPU_ARITH_PINNED_EXP mode) and `match` is zeroed and then
+// read-modify-written once per level like the reference's `match += w` (:16,152).  Latency bound by construction (10 levels x 3 passes
+// x (n / 1024) x m dependent steps per workgroup): dispu_approx_match_ws is the fast path.
+constexpr int AMC_T = 1024;    // lanes per cloud, also partners per LDS tile
+
+template <bool FMA, bool PINNED>
+__global__ __launch_bounds__(AMC_T) void am_cloud_kernel(int b, int n, int m, AmLevels lv, float multiL, float multiR,
+                                                          const float* __restrict__ xyz1, const float* __restrict__ xyz2,
+                                                          float* __restrict__ match, float* __restrict__ temp) {
+    __shared__ float4 tile[AMC_T];
+    const int tid = threadIdx.x;
+    for (int cloud = blockIdx.x; cloud < b; cloud += gridDim.x) {
+        float* __restrict__ remL = temp + (size_t)cloud * 2 * ((size_t)n + m);
+        float* __restrict__ remR = remL + n;
+        float* __restrict__ ratL = remR + m;
+        float* __restrict__ ratR = ratL + n;
+        const float* __restrict__ p1 = xyz1 + (size_t)cloud * n * 3;
+        const float* __restrict__ p2 = xyz2 + (size_t)cloud * m * 3;
+        float* __restrict__ mt = match + (size_t)cloud * n * m;
+        for (size_t e = tid; e < (size_t)n * m; e += AMC_T) mt[e] = 0.f;
+        for (int k = tid; k < n; k += AMC_T) remL[k] = multiL;
+        for (int l = tid; l < m; l += AMC_T) remR[l] = multiR;
+        __syncthreads();
+        for (int t = 0; t < AM_LEVELS; ++t) {
+            const float level = lv.v[t];
+            // pass 1 (:56-78): ratioL[k] = remainL[k] / (1e-9 + sum_l e remainR[l]), the chain starting AT 1e-9f
+            for (int k0 = 0; k0 < n; k0 += AMC_T) {
+                const int k = k0 + tid;
+                float x1 = 0.f, y1 = 0.f, z1 = 0.f;
+                if (k < n) { x1 = p1[k * 3 + 0]; y1 = p1[k * 3 + 1]; z1 = p1[k * 3 + 2]; }
+                float s = 1e-9f;
+                for (int l0 = 0; l0 < m; l0 += AMC_T) {
+                    const int len = min(AMC_T, m - l0);
+                    __syncthreads();
+                    if (tid < len) tile[tid] = make_float4(p2[(l0 + tid) * 3 + 0], p2[(l0 + tid) * 3 + 1], p2[(l0 + tid) * 3 + 2], remR[l0 + tid]);
+                    __syncthreads();
+                    if (k < n)
+                        for (int i = 0; i < len; ++i) {
+                            const float4 q = tile[i];
+                            const float e = am_exp_level<PINNED>(sqdist3<FMA>(q.x - x1, q.y - y1, q.z - z1), level);
+                            if constexpr (FMA) s = __builtin_fmaf(e, q.w, s);
+                            else s = s + e * q.w;
+                        }
+                }
+                if (k < n) ratL[k] = remL[k] / s;
+            }
+            __syncthreads();
+            // pass 2 (:80-112): sumr = (sum_k e ratioL[k]) remainR[l]; ratioR = min(remainR / (sumr + 1e-9), 1) remainR; remainR -= sumr, >= 0
+            for (int l0 = 0; l0 < m; l0 += AMC_T) {
+                const int l = l0 + tid;
+                float x2 = 0.f, y2 = 0.f, z2 = 0.f;
+                if (l < m) { x2 = p2[l * 3 + 0]; y2 = p2[l * 3 + 1]; z2 = p2[l * 3 + 2]; }
+                float s = 0.f;
+                for (int k0 = 0; k0 < n; k0 += AMC_T) {
+                    const int len = min(AMC_T, n - k0);
+                    __syncthreads();
+                    if (tid < len) tile[tid] = make_float4(p1[(k0 + tid) * 3 + 0], p1[(k0 + tid) * 3 + 1], p1[(k0 + tid) * 3 + 2], ratL[k0 + tid]);
+                    __syncthreads();
+                    if (l < m)
+                        for (int i = 0; i < len; ++i) {
+                            const float4 q = tile[i];
+                            const float e = am_exp_level<PINNED>(sqdist3<FMA>(x2 - q.x, y2 - q.y, z2 - q.z), level);
+                            if constexpr (FMA) s = __builtin_fmaf(e, q.w, s);
+                            else s = s + e * q.w;
+                        }
+                }
+                if (l < m) {
+                    const float rr = remR[l];
+                    const float sumr = s * rr;
+                    const float consumption = fminf(rr / (sumr + 1e-9f), 1.0f);
+                    ratR[l] = consumption * rr;
+                    remR[l] = fmaxf(0.0f, rr - sumr);
+                }
+            }
+            __syncthreads();
+            // pass 3 (:114-160): w = e ratioL[k] ratioR[l]; match[l][k] += w; remainL[k] = max(0, remainL[k] - sum_l w)
+            for (int k0 = 0; k0 < n; k0 += AMC_T) {
+                const int k = k0 + tid;
+                float x1 = 0.f, y1 = 0.f, z1 = 0.f, rl = 0.f;
+                if (k < n) { x1 = p1[k * 3 + 0]; y1 = p1[k * 3 + 1]; z1 = p1[k * 3 + 2]; rl = ratL[k]; }
+                float s = 0.f;
+                for (int l0 = 0; l0 < m; l0 += AMC_T) {
+                    const int len = min(AMC_T, m - l0);
+                    __syncthreads();
+                    if (tid < len) tile[tid] = make_float4(p2[(l0 + tid) * 3 + 0], p2[(l0 + tid) * 3 + 1], p2[(l0 + tid) * 3 + 2], ratR[l0 + tid]);
+                    __syncthreads();
+                    if (k < n) {
+                        float* __restrict__ col = mt + (size_t)l0 * n + k;
+                        for (int i = 0; i < len; ++i) {
+                            const float4 q = tile[i];
+                            const float w = am_exp_level<PINNED>(sqdist3<FMA>(q.x - x1, q.y - y1, q.z - z1), level) * rl * q.w;
+                            col[(size_t)i * n] += w;
+                            s += w;
+                        }
+                    }
+                }
+                if (k < n) remL[k] = fmaxf(0.0f, remL[k] - s);
+            }
+            __syncthreads();
+        }
+    }
+}
+
 // (Rounds 3 - 4 also carried the whole auction as ONE persistent launch with per-cloud software barriers -- bit-identical and slower: an
 // in-kernel barrier across XCDs costs more than a kernel boundary; removed in round 5, see profiles/EXPERIMENTS.md.)
 
@@ -518,11 +625,8 @@ __global__ __launch_bounds__(256) void match_grad2_kernel(int n, int m, const fl
     if (lane == 0) { float* g = grad + ((size_t)cloud * m + l) * 3; g[0] = gx; g[1] = gy; g[2] = gz; }
 }
 
-template <bool FMA, bool PINNED>
-static int run_approx_match(int b, int n, int m, const float* xyz1, const float* xyz2, float* match, float* temp,
-                            hipStream_t s) {
-    const float multiL = (n >= m) ? 1.0f : (float)(m / n);
-    const float multiR = (n >= m) ? (float)(n / m) : 1.0f;
+// level_t = -(4^(7 - t)), t = 0 .. 8, and 0 for the last (tf_approxmatch_g.cu:50-53: j = 7 .. -2, level = -powf(4, j), 0 at j = -2)
+static AmLevels am_levels() {
     AmLevels lv;
     for (int t = 0; t < AM_LEVELS; ++t) {
         const int j = 7 - t;
@@ -533,6 +637,15 @@ static int run_approx_match(int b, int n, int m, const float* xyz1, const float*
         }
         lv.v[t] = level;
     }
+    return lv;
+}
+
+template <bool FMA, bool PINNED>
+static int run_approx_match(int b, int n, int m, const float* xyz1, const float* xyz2, float* match, float* temp,
+                            hipStream_t s) {
+    const float multiL = (n >= m) ? 1.0f : (float)(m / n);
+    const float multiR = (n >= m) ? (float)(n / m) : 1.0f;
+    const AmLevels lv = am_levels();
     const dim3 blk(AM_ROWS);
     const dim3 grow((n + AM_ROWS - 1) / AM_ROWS, am_chunks(m), b), gcol((m + AM_ROWS - 1) / AM_ROWS, am_chunks(n), b);
     hipLaunchKernelGGL(am_init_kernel, dim3(8, b), dim3(256), 0, s, n, m, multiL, multiR, temp);
@@ -556,18 +669,44 @@ DISPU_EXPORT size_t dispu_approx_match_scratch_bytes(int b, int n, int m) {
     return sizeof(float) * (size_t)b * am_cloud_floats(n, m) + sizeof(unsigned) * ((size_t)b + 1);   // + per-cloud stage counters, fail flag
 }
 
-DISPU_EXPORT int dispu_approx_match(int b, int n, int m, const float* xyz1, const float* xyz2, float* match,
-                                    float* temp, int arith, void* stream) {
+static int am_check_args(int b, int n, int m) {
     if (b < 0 || n <= 0 || m <= 0) return (int)hipErrorInvalidValue;
-    if (b == 0) return 0;
-    if (!temp) return (int)hipErrorInvalidValue;
     if (b > 65535 || (size_t)n * 3 > 0x7fffffffull || (size_t)m * 3 > 0x7fffffffull) return (int)hipErrorInvalidValue;
+    return 0;
+}
+
+// The fast path: 2-D tiled passes, `temp` = dispu_approx_match_scratch_bytes(b,n,m) bytes; a smaller scratch is refused, untouched.
+DISPU_EXPORT int dispu_approx_match_ws(int b, int n, int m, const float* xyz1, const float* xyz2, float* match,
+                                       float* temp, size_t temp_bytes, int arith, void* stream) {
+    if (const int e = am_check_args(b, n, m)) return e;
+    if (b == 0) return 0;
+    if (!temp || temp_bytes < dispu_approx_match_scratch_bytes(b, n, m)) return (int)hipErrorInvalidValue;
     hipStream_t s = (hipStream_t)stream;
     const bool fma = (arith & DISPU_ARITH_CONTRACT) != 0, pin = (arith & DISPU_ARITH_PINNED_EXP) != 0;
     if (fma && pin) return run_approx_match<true, true>(b, n, m, xyz1, xyz2, match, temp, s);
     if (fma) return run_approx_match<true, false>(b, n, m, xyz1, xyz2, match, temp, s);
     if (pin) return run_approx_match<false, true>(b, n, m, xyz1, xyz2, match, temp, s);
     return run_approx_match<false, false>(b, n, m, xyz1, xyz2, match, temp, s);
+}
+
+// approxmatchLauncher(b,n,m,xyz1,xyz2,match,temp) (tf_approxmatch.cpp:141): `temp` is the op's own [b, 2 (n + m)] float allocation
+// (:164-170) and nothing behind it is touched.  One workgroup per cloud, the reference's sequential association.
+DISPU_EXPORT int dispu_approx_match(int b, int n, int m, const float* xyz1, const float* xyz2, float* match,
+                                    float* temp, int arith, void* stream) {
+    if (const int e = am_check_args(b, n, m)) return e;
+    if (b == 0) return 0;
+    if (!temp) return (int)hipErrorInvalidValue;
+    hipStream_t s = (hipStream_t)stream;
+    const bool fma = (arith & DISPU_ARITH_CONTRACT) != 0, pin = (arith & DISPU_ARITH_PINNED_EXP) != 0;
+    const float multiL = (n >= m) ? 1.0f : (float)(m / n);
+    const float multiR = (n >= m) ? (float)(n / m) : 1.0f;
+    const AmLevels lv = am_levels();
+    const dim3 grid(b), blk(AMC_T);
+    if (fma && pin) hipLaunchKernelGGL((am_cloud_kernel<true, true>), grid, blk, 0, s, b, n, m, lv, multiL, multiR, xyz1, xyz2, match, temp);
+    else if (fma) hipLaunchKernelGGL((am_cloud_kernel<true, false>), grid, blk, 0, s, b, n, m, lv, multiL, multiR, xyz1, xyz2, match, temp);
+    else if (pin) hipLaunchKernelGGL((am_cloud_kernel<false, true>), grid, blk, 0, s, b, n, m, lv, multiL, multiR, xyz1, xyz2, match, temp);
+    else hipLaunchKernelGGL((am_cloud_kernel<false, false>), grid, blk, 0, s, b, n, m, lv, multiL, multiR, xyz1, xyz2, match, temp);
+    return (int)hipGetLastError();
 }
 
 DISPU_EXPORT size_t dispu_match_cost_scratch_bytes(int b, int n, int m) {

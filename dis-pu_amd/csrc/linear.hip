@@ -588,7 +588,8 @@ static int launch_linear(const LinearArgs& a, int batch, bool transb, hipStream_
                              (!a.scale || (al16(a.scale) && al16(a.shift))) &&
                              (!a.R1 || (((a.ldr1 & 3) == 0) && ((a.sr1 & 3) == 0) && al16(a.R1))) &&
                              (!a.R2 || (((a.ldr2 & 3) == 0) && ((a.sr2 & 3) == 0) && al16(a.R2))) &&
-                             (!a.Mk || (((a.ldm & 3) == 0) && al16(a.Mk)));
+                             (!a.Mk || (((a.ldm & 3) == 0) && al16(a.Mk) && a.mcols >= a.N));   // the vector epilogue loads whole TN-wide mask rows:
+                                                                                                   // a mask narrower than the product keeps the guarded per-column path
     const bool tiles_ok = aligned && out_aligned && (a.M % BM == 0) && (a.N % BN == 0);
     if (tiles_ok && !transb && (a.K % BK == 0)) return launch_one<BM, BN, WM, WN, BK, false, false>(a, grid, s);
     if (tiles_ok && transb && (a.K % BKR == 0)) return launch_one<BM, BN, WM, WN, BKR, true, false>(a, grid, s);
@@ -629,6 +630,9 @@ static int linear_tile_rule(int batch, int M, int N, bool dma) {
 }
 
 DISPU_EXPORT int dispu_linear_tile(int batch, int M, int N) { return linear_tile_rule(batch, M, N, true); }
+// The tile the launch of THIS product takes: transposed-B products and K % 16 != 0 never use the DMA pipeline, and with 256 - 511
+// workgroups that changes the choice (64 x 64 instead of 64 x 128).  dispu_linear_tile (ABI <= 4) assumes the DMA pipeline.
+DISPU_EXPORT int dispu_linear_tile2(int batch, int M, int K, int N, int transb) { return linear_tile_rule(batch, M, N, !transb && (K % 16) == 0); }
 
 static int linear_impl(int batch, int M, int K, int N, const float* X, long ldx, long sx, const float* W, long ldw, long sw, int transb,
                        const float* bias, const float* scale, const float* shift, int act, float* Y, long ldy, long sy, const float* R1,

@@ -1,7 +1,7 @@
 // Version / error-string entry points of libdispu_hip.so.
 #include "common.h"
 
-DISPU_EXPORT int dispu_version(void) { return 4; }   // history: include/dispu_hip.h
+DISPU_EXPORT int dispu_version(void) { return 5; }   // history: include/dispu_hip.h
 DISPU_EXPORT const char* dispu_error_string(int code) { return hipGetErrorString((hipError_t)code); }
 
 // ---- launch-tape helpers (dis-pu_amd/_lib.py:Tape): the training step's eager launch sequence, recorded once and re-issued from a

@@ -16,7 +16,6 @@ Everything up to and including `coarse` is bit-identical to oracle/generator.py 
 """
 import contextlib
 import math
-import os
 
 import numpy as np
 import torch
@@ -87,7 +86,7 @@ class Generator(object):
         self.split_up3 = True        # the N = 320 product as 256 + 64 columns (each launch reads up128 once)
         # non-local cell on a second stream next to the grouping / skip / local cell (round 4: on by default, -1 % since the head chains
         # form their own inputs -- the branch now joins right before the fine chain; rounds 1 - 3 measured it +1 %)
-        self.branches = bool(int(os.environ.get('DISPU_BRANCHES', '1')))
+        self.branches = True           # False: everything on the launch stream (profiling passes: every kernel alone on the device)
         self._aux = None
         self.fused_residual = True
         self.fused_heads = True      # one launch per head chain
@@ -207,7 +206,7 @@ class Generator(object):
         p = lambda t, off=0: _lib.C.c_void_p(t.data_ptr() + 4 * off) if t is not None else _lib.C.c_void_p(0)
         name = "linear"
         if self.profile is not None:     # "linear<BM, BN, 2, 2, BK, transb, edge, epi>[MxKxN]": the instantiation rocprofv3 reports
-            t = L.dispu_linear_tile(batch, M, N)
+            t = L.dispu_linear_tile2(batch, M, K, N, int(bool(transb)))
             bm, bn = {128257: (128, 256), 128128: (128, 128), 64128: (64, 128), 128064: (128, 64)}.get(t, (64, 64))
             al = lambda q, o=0: q is None or (q.data_ptr() + 4 * o) % 16 == 0
             ok = (M % bm == 0 and N % bn == 0 and ldx % 4 == 0 and ldw % 4 == 0 and sx % 4 == 0 and sw % 4 == 0 and al(X, xoff) and al(W, woff)

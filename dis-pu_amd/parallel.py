@@ -140,21 +140,35 @@ class _Ticket(object):
 
 
 class _Lane(object):
-    """Asynchronous collectives, issued strictly in submission order."""
+    """Asynchronous collectives, issued strictly in submission order.
 
-    def __init__(self, device, group=None):
+    Failure model: a job that raises on one rank never enters its collective, so the peers would sit in the matching call for
+    the transport's timeout.  The lane therefore breaks loudly: the failing rank tears its lane group down (the peers' pending
+    operations then fail with a connection error instead of hanging), every later submit / wait on this lane re-raises the first
+    error, the lane's own gloo group carries a finite timeout (`timeout_s`) as the backstop, and close() raises if the background
+    thread cannot be drained instead of abandoning it."""
+
+    def __init__(self, device, group=None, timeout_s=300.0):
         self.group = group
         self.backend = dist.get_backend(group)
         self.device = torch.device(device)
         self.cuda = self.device.type == "cuda"
         self.stream = torch.cuda.Stream(device=self.device) if self.cuda else None
         self.threaded = self.backend == "gloo"
+        self.timeout_s = float(timeout_s)
+        self.broken = None                      # the first exception of a job: the lane is unusable afterwards
+        self._own_group = False
         self._q, self._thread = None, None
         if self.threaded:
             # the background thread's collectives must not interleave with the launching thread's on one gloo context (the pairing
             # of sends and receives is by call order): the lane talks over a group of its own.  (RCCL needs none: there every
             # collective, the lane's included, is ENQUEUED by the launching thread, in program order on every rank.)
-            self.group = dist.new_group(ranks=dist.get_process_group_ranks(group if group is not None else dist.group.WORLD), backend="gloo")
+            # dist.new_group is itself a collective over the parent group: lanes are built where every rank passes in the same
+            # order (GatherPipeline / BucketedAllReduce constructors; Trainer builds its reducer when the parameters are loaded).
+            import datetime
+            self.group = dist.new_group(ranks=dist.get_process_group_ranks(group if group is not None else dist.group.WORLD), backend="gloo",
+                                        timeout=datetime.timedelta(seconds=self.timeout_s))
+            self._own_group = True
             self._q = queue.Queue()
             self._thread = threading.Thread(target=self._run, name="dispu-comm", daemon=True)
             self._thread.start()
@@ -180,9 +194,28 @@ class _Lane(object):
             if scale is not None:
                 t.mul_(scale)
 
+    # ---- failure ----
+    def _abort(self, err):
+        """first failure on this rank: remember it and drop the lane's own group, so that peers blocked in the collective this rank
+        never entered fail at once (connection closed) instead of waiting for the timeout."""
+        if self.broken is None:
+            self.broken = err
+            if self._own_group:
+                self._own_group = False
+                try:
+                    dist.destroy_process_group(self.group)
+                except Exception:              # noqa: BLE001 -- already failing; the original error is the one to report
+                    pass
+
+    def _check(self):
+        if self.broken is not None:
+            raise RuntimeError("the collective lane of this rank is broken by an earlier failure: %s: %s"
+                               % (type(self.broken).__name__, self.broken)) from self.broken
+
     # ---- submission ----
     def submit(self, job, after=()):
         """`job()` issues collectives; it starts once the HIP events in `after` have completed.  Returns a ticket for wait()."""
+        self._check()
         ticket = _Ticket()
         if self.threaded:
             self._q.put((job, tuple(after), ticket))
@@ -190,7 +223,11 @@ class _Lane(object):
         with torch.cuda.stream(self.stream):
             for ev in after:
                 self.stream.wait_event(ev)
-            job()                                  # RCCL: enqueued behind the waits; the lane stream is blocked until it completes
+            try:
+                job()                              # RCCL: enqueued behind the waits; the lane stream is blocked until it completes
+            except BaseException as e:             # noqa: BLE001
+                self._abort(e)
+                raise
             ticket.event = torch.cuda.Event()
             ticket.event.record(self.stream)
         ticket.flag.set()
@@ -204,6 +241,10 @@ class _Lane(object):
             if item is None:
                 return
             job, after, ticket = item
+            if self.broken is not None:            # jobs behind a failed one are not attempted: their collectives have no partner
+                ticket.error = self.broken
+                ticket.flag.set()
+                continue
             try:
                 if self.cuda:
                     with torch.cuda.stream(self.stream):
@@ -216,13 +257,17 @@ class _Lane(object):
                     job()
             except BaseException as e:             # noqa: BLE001 -- re-raised in the thread that waits for the ticket
                 ticket.error = e
+                self._abort(e)
             ticket.flag.set()
 
     def wait(self, ticket):
         """the CURRENT stream (and, under gloo, the calling thread) waits for the job behind `ticket`."""
         if ticket is None:
             return
-        ticket.flag.wait()
+        if not ticket.flag.wait(timeout=self.timeout_s + 30.0 if self.threaded else None):
+            err = TimeoutError("a collective job did not finish within %.0f s" % self.timeout_s)
+            self._abort(err)
+            raise err
         if ticket.error is not None:
             raise ticket.error
         if ticket.event is not None:
@@ -231,8 +276,12 @@ class _Lane(object):
     def close(self):
         if self._thread is not None:
             self._q.put(None)
-            self._thread.join(timeout=30)
-            self._thread = None
+            self._thread.join(timeout=self.timeout_s + 30.0)
+            alive, self._thread = self._thread.is_alive(), None
+            if alive:
+                err = RuntimeError("the collective lane's thread is still inside a collective after %.0f s" % self.timeout_s)
+                self._abort(err)
+                raise err
 
 
 def _here(device):

@@ -15,9 +15,10 @@ def approx_match(xyz1, xyz2, arith=_lib.ARITH_CONTRACT):
     m = xyz2.shape[1]
     L = _lib.lib()
     match = torch.empty((b, m, n), dtype=torch.float32, device=xyz1.device)
-    temp = torch.empty((L.dispu_approx_match_scratch_bytes(b, n, m) // 4,), dtype=torch.float32, device=xyz1.device)
-    _lib.check(L.dispu_approx_match(b, n, m, _lib.ptr(xyz1), _lib.ptr(xyz2), _lib.ptr(match), _lib.ptr(temp), int(arith),
-                                    _lib.stream_ptr(xyz1.device)), "dispu_approx_match")
+    nbytes = L.dispu_approx_match_scratch_bytes(b, n, m)
+    temp = torch.empty((nbytes // 4,), dtype=torch.float32, device=xyz1.device)
+    _lib.check(L.dispu_approx_match_ws(b, n, m, _lib.ptr(xyz1), _lib.ptr(xyz2), _lib.ptr(match), _lib.ptr(temp), nbytes, int(arith),
+                                       _lib.stream_ptr(xyz1.device)), "dispu_approx_match_ws")
     return match
 
 

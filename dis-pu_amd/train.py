@@ -74,7 +74,8 @@ def learning_rate(opts, epoch):
 
 
 def _p(t, off=0):
-    return _lib.C.c_void_p(t.data_ptr() + 4 * off) if t is not None else _lib.C.c_void_p(0)
+    """Device pointer of element `off` of t's storage (in t's own element size: a bf16-stored activation advances 2 bytes per column)."""
+    return _lib.C.c_void_p(t.data_ptr() + t.element_size() * off) if t is not None else _lib.C.c_void_p(0)
 
 
 class Trainer(object):
@@ -109,6 +110,9 @@ class Trainer(object):
         self.dw_streams = 2                   # side streams the weight-gradient products are spread over (round-robin)
         self._ar = None                       # parallel.BucketedAllReduce over flat_g (data parallel only, see _reducer)
         self._ar_armed = False                # True inside train_step(): backward() may start a bucket's all-reduce as soon as it is complete
+        # a ONE-rank process group normally means "no collectives".  True keeps them (a 1-rank RCCL communicator executes the real
+        # stream / event ordering of the data-parallel step: the dry run of tests/test_distributed_gpu.py on the one GPU a test box has)
+        self.collectives_at_world_1 = False
         # weight-gradient products (dW = X^T dZ) are off the backward chain: only Adam reads them.  They run on a second
         # HIP stream next to the dX products that ARE the chain (both read dZ; at 8 patches neither fills 256 CUs alone).
         self.overlap_dw = True
@@ -206,6 +210,9 @@ class Trainer(object):
         self.moving_var = torch.from_numpy(np.ascontiguousarray(params[BN + "moving_variance"], np.float32)).to(dev)
         self.grid = torch.from_numpy(gen_grid(self.up_ratio)).to(dev)
         self.adam_t = 0
+        # data parallel: the reducer (and, under gloo, its lane's process group -- dist.new_group is a collective) is built HERE, where
+        # every rank passes in the same order, not lazily inside whichever of train_step / all_reduce_grads a rank reaches first
+        self._reducer()
 
     def params(self):
         """current parameters as the name -> numpy mapping Generator.load_params / the oracle take."""
@@ -1179,7 +1186,7 @@ class Trainer(object):
         the compute streams (parallel.BucketedAllReduce).  None without a process group."""
         if self._ar is None:
             import torch.distributed as dist
-            if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(self.pg) == 1:
+            if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(self.pg) == 1 and not self.collectives_at_world_1):
                 return None
             from . import parallel
             first = next(k for k in self.names if k.startswith("refine/"))

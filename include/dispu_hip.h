@@ -48,7 +48,9 @@ extern "C" {
  * 3 = round 3: dispu_match_cost / dispu_match_cost_grad are the reference's launcher signatures again (as in version 1, no
  * scratch) and the scratch-taking fast paths are dispu_match_cost_ws / dispu_match_cost_grad_ws; dispu_fps_ws (scratch with an
  * explicit size), dispu_prob_sample, dispu_selection_sort; the fused training kernels.  A symbol never changes signature again:
- * new forms get new names.  4 = round 4: additions only (dispu_attention_fwd_lse / dispu_attention_bwd, ...). */
+ * new forms get new names.  4 = round 4: additions only (dispu_attention_fwd_lse / dispu_attention_bwd, ...).
+ * 5 = round 6: dispu_approx_match works inside the reference op's own temp ([b, 2(n+m)] floats; until 4 it needed
+ * dispu_approx_match_scratch_bytes and had no way to refuse less); the tiled fast path is dispu_approx_match_ws with an explicit size. */
 int dispu_version(void);
 /* Stream / event / memset operations on raw HIP handles (hipEventRecord, hipStreamWaitEvent, hipMemsetAsync): what a host that
  * re-issues a recorded launch sequence needs beside the kernels (dis-pu_amd/_lib.py:Tape; no reference counterpart: TF's executor). */
@@ -170,12 +172,18 @@ int dispu_nn_distance_grad(int b, int n, const float* xyz1, int m, const float* 
 /* ---- tf_ops/approxmatch --------------------------------------------------------------------- */
 
 /* approxmatchLauncher(b,n,m,xyz1,xyz2,match,temp)   tf_ops/approxmatch/tf_approxmatch.cpp:141,164-170;
- * kernel tf_approxmatch_g.cu:1-182.  match [b,m,n].  `temp`: dispu_approx_match_scratch_bytes(b,n,m) bytes (the reference's
- * temp is [b, 2*(n+m)] floats; here it also holds the per-level ratio vectors and the per-chunk partial sums of the 2-D
- * tiled passes).  Sums are associated in chunks of 128 partners (csrc/approxmatch.hip; oracle chunk = 128). */
+ * kernel tf_approxmatch_g.cu:1-182.  match [b,m,n].
+ * dispu_approx_match: the launcher's own contract -- `temp` is the op's [b, 2*(n+m)] float allocation
+ * (tf_approxmatch.cpp:164-170) and nothing behind it is written.  One workgroup per cloud like the reference's kernel, every sum in
+ * the reference's sequential order (bit-exact to oracle/dispu_oracle.c:orc_approx_match with DISPU_ARITH_PINNED_EXP); slow.
+ * dispu_approx_match_ws: the fast path (2-D tiled passes, csrc/approxmatch.hip).  `temp`: dispu_approx_match_scratch_bytes(b,n,m)
+ * bytes -- the per-level ratio vectors and the per-chunk partial sums; `temp_bytes` is what the caller really allocated and a smaller
+ * scratch is refused (hipErrorInvalidValue) without being touched.  Sums are associated in chunks of 128 partners (oracle chunk = 128). */
 size_t dispu_approx_match_scratch_bytes(int b, int n, int m);
 int dispu_approx_match(int b, int n, int m, const float* xyz1, const float* xyz2, float* match, float* temp, int arith,
                        void* stream);
+int dispu_approx_match_ws(int b, int n, int m, const float* xyz1, const float* xyz2, float* match, float* temp,
+                          size_t temp_bytes, int arith, void* stream);
 /* matchcostLauncher(b,n,m,xyz1,xyz2,match,out)   tf_approxmatch.cpp:142; kernel tf_approxmatch_g.cu:183-228.
  * dispu_match_cost: the launcher's own signature, no scratch (one workgroup per cloud, like the reference's kernel).
  * dispu_match_cost_ws: the fast path; `scratch`: dispu_match_cost_scratch_bytes(b,n,m) bytes (one partial per tile of `match`).
@@ -213,6 +221,9 @@ int dispu_linear_bn(int batch, int M, int K, int N, const float* X, long ldx, lo
 /* Which block tile dispu_linear picks for (batch, M, N), as BM*1000 + BN (e.g. 128128): lets a profiler map a
  * launch to the kernel instantiation name rocprofv3 reports (linear_mfma_kernel<BM, BN, transb>). */
 int dispu_linear_tile(int batch, int M, int N);
+/* The same for a given K and transb (ABI 5): transposed-B products and K % 16 != 0 never take the DMA pipeline, which changes the
+ * choice at 256 - 511 workgroups (64064 instead of 64128); dispu_linear_tile assumes the DMA pipeline. */
+int dispu_linear_tile2(int batch, int M, int K, int N, int transb);
 /* benchmarking aid (tools/gemm_bench.py): force the block tile of every later dispu_linear call; 0 restores the rule.  Not used by the product path. */
 void dispu_debug_linear_tile(int code);
 /* K <= 4 inputs, N in {16, 24} outputs (feature_extraction layer0, ops.py:1449-1451). */

@@ -41,7 +41,7 @@ def test_library_loads_and_binding_is_complete(built_lib):
     from dispu_amd import _lib
     assert sorted(_lib.SIGNATURES) == header_symbols()
     lib = _lib.lib()
-    assert lib.dispu_version() == 4
+    assert lib.dispu_version() == 5
     assert lib.dispu_fps_scratch_bytes(2, 1000, 10) == 0
     assert lib.dispu_fps_scratch_bytes(2, 30000, 10) == 2 * 30000 * 4
     assert lib.dispu_approx_match_scratch_bytes(3, 10, 20) == 3 * (20 * 30 + 2 * 10 + 20) * 4 + 4 * 4   # ratio vectors + chunk partials + stage counters

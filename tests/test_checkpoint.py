@@ -249,11 +249,21 @@ def test_adam_steps_saturate_when_both_powers_underflowed_and_explicit_counter_w
     assert CK.adam_steps_from_bundle({}, 0.9) == 0             # a test-graph bundle: a fresh optimizer
 
 
-def test_state_file_keeps_the_last_five_prefixes_like_tf_saver(tmp_path):
+def test_state_file_lists_every_prefix_like_the_reference_saver(tmp_path):
+    """DisPU/model.py:184 is tf.train.Saver(max_to_keep=None): the state file lists every checkpoint still on disk.  A finite limit
+    (TF's own behaviour) drops the oldest from the list AND from the disk."""
     P = PP.init_params(2)
-    for ep in (20, 40, 60, 80, 100, 120):
+    eps = (20, 40, 60, 80, 100, 120)
+    for ep in eps:
         CK.save_generator_params(str(tmp_path / "model"), P, step=ep)
     txt = (tmp_path / "checkpoint").read_text().splitlines()
     assert txt[0] == 'model_checkpoint_path: "model-120"'
-    assert txt[1:] == ['all_model_checkpoint_paths: "model-%d"' % e for e in (40, 60, 80, 100, 120)]
+    assert txt[1:] == ['all_model_checkpoint_paths: "model-%d"' % e for e in eps]
+    assert all((tmp_path / ("model-%d.index" % e)).exists() for e in eps)
+    assert CK.pre_load_checkpoint(str(tmp_path))[0] == 120
+    CK._update_state_file(str(tmp_path), "model-120", max_to_keep=2)
+    txt = (tmp_path / "checkpoint").read_text().splitlines()
+    assert txt[1:] == ['all_model_checkpoint_paths: "model-%d"' % e for e in (100, 120)]
+    left = sorted(f for f in os.listdir(tmp_path) if f.startswith("model-"))
+    assert left and all(f.startswith(("model-100.", "model-120.")) for f in left)
     assert CK.pre_load_checkpoint(str(tmp_path))[0] == 120

@@ -182,3 +182,67 @@ def test_overlapped_collectives_gloo_world2():
     assert all(r[1] for r in res), "pipelined all-gather differs from the blocking one"
     assert all(r[2] for r in res), "bucketed all-reduce differs from the single-bucket one"
     assert all(r[3] == 0.5 and r[4] == 10.5 for r in res)
+
+
+# ---- round 6: a failing job on one rank must not hang its peers ------------------------------------------------------------
+def _failing_lane_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import sys
+    import time
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from dispu_amd import parallel
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        lane = parallel._Lane("cpu", timeout_s=20.0)
+        t = torch.ones(4)
+        good = lane.submit(lambda: lane.all_reduce(t))
+        lane.wait(good)
+        ok_first = bool(torch.equal(t, torch.full((4,), float(world))))
+
+        def job():
+            if rank == 1:
+                raise ValueError("rank 1's producer failed before the collective")
+            lane.all_reduce(t)
+
+        t0 = time.time()
+        kind = None
+        try:
+            lane.wait(lane.submit(job))
+        except ValueError as e:
+            kind = "own:" + str(e)
+        except Exception as e:                    # noqa: BLE001 -- the peer: a transport error, not a hang
+            kind = "peer:" + type(e).__name__
+        waited = time.time() - t0
+        later = None
+        try:
+            lane.submit(lambda: None)
+        except RuntimeError as e:
+            later = str(e)
+        try:
+            lane.close()
+        except RuntimeError:
+            pass
+        q.put((rank, ok_first, kind, waited, later))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_lane_failure_is_loud_on_every_rank_gloo_world2():
+    """a job that raises on one rank never enters its collective.  The failing rank re-raises its own error and
+    tears its lane group down; the peer's pending all-reduce then fails with a transport error well inside the lane's timeout (20 s
+    here) instead of hanging; afterwards the lane refuses further work on both ranks."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_failing_lane_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(r[1] for r in res)
+    assert res[1][2] == "own:rank 1's producer failed before the collective"
+    assert res[0][2] is not None and res[0][2].startswith("peer:"), res[0]
+    assert res[0][3] < 60.0 and res[1][3] < 60.0, "a rank sat in the dead collective: %r" % (res,)
+    assert all(r[4] is not None and "broken" in r[4] for r in res), res

@@ -410,3 +410,147 @@ def test_bench_two_ranks_overlapped_gather_costs_nothing(dev):
         json.dump(ms, f)
     # two processes time-sharing one GPU and host-staged gloo: noisy; the exposed gather costs +25 %, the pipelined one must stay well below
     assert ms["overlap"] <= 1.15 * ms["off"] + 0.02 and ms["overlap"] < ms["sync"], ms
+
+
+# ------------------------------------------------------------------------ round 6: the RCCL branch itself, on one GPU ----
+def _rccl_world1_worker(rank, world, port, q):
+    """A ONE-rank `nccl` (= RCCL) process group: the collectives are really enqueued on the comm lane's HIP stream behind the
+    producers' events (parallel._Lane.submit, the non-threaded branch no gloo test reaches), only the transport is trivial."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import sys
+    import time
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda:0")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        from dispu_amd import parallel, synth
+        from dispu_amd.generator import Generator
+        from dispu_amd.params import init_params
+        from dispu_amd.train import Trainer
+        P = init_params(seed=1234)
+        # ---- inference: pipelined gather of the real generator's clouds
+        b = 8
+        gen, ref = Generator(params=P, device=dev), Generator(params=P, device=dev)
+        gen.return_views = True
+        xs = [torch.from_numpy(synth.patches(b, 256, seed=90 + i)).to(dev) for i in range(6)]
+        pipe = parallel.GatherPipeline((b, 1024, 3), dev)
+        assert not pipe.lane.threaded and pipe.lane.backend == "nccl"
+        same, pending = True, []
+        for i, x in enumerate(xs):
+            slot, gen.fine_out = pipe.acquire()
+            gen(x)
+            pipe.launch(slot)
+            if pending:
+                j, s = pending.pop()
+                same = same and bool(torch.equal(pipe.result(s), ref(xs[j])[1]))
+            pending.append((i, slot))
+        j, s = pending.pop()
+        same = same and bool(torch.equal(pipe.result(s), ref(xs[j])[1]))
+
+        def loop(with_gather, n=40):
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            for _ in range(n):
+                if with_gather:
+                    slot, gen.fine_out = pipe.acquire()
+                    gen(xs[0])
+                    pipe.launch(slot)
+                else:
+                    gen.fine_out = None
+                    gen(xs[0])
+            if with_gather:
+                pipe.drain()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t) / n * 1e3
+        for w in (False, True):
+            loop(w, 10)
+        t_plain = sorted(loop(False) for _ in range(5))[2]
+        t_gather = sorted(loop(True) for _ in range(5))[2]
+        pipe.close()
+        gen.fine_out = None
+        # ---- training: bucketed all-reduce launched from inside backward() on the comm lane's stream
+        x, gt = synth.patch_with_gt(8, 256, 1024, seed=43)
+        x, gt = torch.from_numpy(x).to(dev), torch.from_numpy(gt).to(dev)
+        radius = torch.ones(8, device=dev)
+        a, c = Trainer(params=P, device=dev), Trainer(params=P, device=dev)
+        assert a._reducer() is None and c._reducer() is None          # one rank: no collectives unless asked for
+        c.collectives_at_world_1 = True
+        ar = c._reducer()
+        assert ar is not None and not ar.lane.threaded
+        early = []
+        orig = ar.launch
+        def spy(i, after=None):
+            early.append((i, after is not None))
+            return orig(i, after)
+        ar.launch = spy
+        rel = []
+        for step in range(3):
+            a.train_step(x, gt, radius)
+            c.train_step(x, gt, radius)
+            torch.cuda.synchronize()
+            rel.append(float((c.flat_p - a.flat_p).norm() / a.flat_p.norm()))
+            c.flat_p.copy_(a.flat_p); c.flat_m.copy_(a.flat_m); c.flat_v.copy_(a.flat_v)
+            c.moving_mean.copy_(a.moving_mean); c.moving_var.copy_(a.moving_var)
+
+        def tloop(t, n=20):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                t.train_step(x, gt, radius)
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / n * 1e3
+        for t in (a, c):
+            tloop(t, 10)
+        s_plain = sorted(tloop(a) for _ in range(5))[2]
+        s_coll = sorted(tloop(c) for _ in range(5))[2]
+        q.put((0, same, t_plain, t_gather, early, rel, s_plain, s_coll))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_branch_on_one_rank(dev):
+    """the `nccl` branch of parallel._Lane.submit / BucketedAllReduce / GatherPipeline has never executed (the
+    test box has one GPU, the gloo tests take the threaded branch).  A one-rank RCCL communicator runs the real stream / event
+    ordering: gathered clouds bit-identical to the plain forward, the data-parallel train step equal to the single-process one
+    (float atomics: 1e-5), the refine bucket launched from inside backward(), and neither collective slows its step."""
+    res = _spawn(_rccl_world1_worker, (), world=1)
+    _, same, t_plain, t_gather, early, rel, s_plain, s_coll = res[0]
+    print("one-rank RCCL dry run: forward %.4f ms, + pipelined all-gather %.4f ms; train step %.4f ms, + bucketed all-reduce %.4f ms"
+          % (t_plain, t_gather, s_plain, s_coll))
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    import json
+    with open(os.path.join(ROOT, "gpurun_out", "rccl_world1_dry_run.json"), "w") as f:
+        json.dump({"forward_ms": t_plain, "forward_with_pipelined_all_gather_ms": t_gather, "train_step_ms": s_plain,
+                   "train_step_with_bucketed_all_reduce_ms": s_coll, "param_rel_diff_per_step": rel}, f)
+    assert same, "gathered clouds differ from the plain forward"
+    assert early[:6] == [(0, True), (1, False)] * 3, early[:8]       # per step: refine bucket from inside backward(), the rest from finish()
+    assert max(rel) <= 1e-5, rel
+    assert t_gather <= 1.03 * t_plain + 0.01, (t_plain, t_gather)            # 8 patches: ~0.4 ms steps, eager launches
+    assert s_coll <= 1.05 * s_plain + 0.02, (s_plain, s_coll)
+
+
+def test_bench_one_rank_rccl_dry_run(dev):
+    """`bench.py --gpus 1` with DISPU_BENCH_COLLECTIVES=1 DISPU_BENCH_BACKEND=nccl: the N > 1 code of the bench (process group,
+    comm lane on a side HIP stream, one hipGraph per result slot, barriers, max-over-ranks) with a real RCCL communicator of one
+    rank.  The pipelined gather must cost the step nothing (median of the five timed loops within 1 % + 5 us of the no-collective run)."""
+    import json
+    import subprocess
+    import sys
+    ms, launch = {}, {}
+    for mode in ("off", "overlap"):
+        env = dict(os.environ, DISPU_BENCH_BACKEND="nccl", DISPU_BENCH_COLLECTIVES="1", DISPU_BENCH_GATHER=mode, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+            env.pop(k, None)
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "3"]
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, cwd=ROOT, timeout=900)
+        assert r.returncode == 0, r.stderr.decode(errors="replace")[-2000:]
+        d = json.loads([l for l in r.stdout.decode().splitlines() if l.startswith("{")][0])
+        assert d["n_gpus"] == 1 and d["config"]["collective"] is not None and "RCCL" in d["config"]["workload"]
+        assert "cpu_baseline" not in d
+        ms[mode], launch[mode] = d["ms_per_step_repeats"]["median"], d["config"]["launch"][:8]
+    print("one-rank RCCL bench: compute-only %.4f ms (%s), pipelined all-gather %.4f ms (%s)" % (ms["off"], launch["off"], ms["overlap"], launch["overlap"]))
+    with open(os.path.join(ROOT, "gpurun_out", "rccl_world1_bench.json"), "w") as f:
+        json.dump({"ms": ms, "launch": launch}, f)
+    assert ms["overlap"] <= 1.01 * ms["off"] + 0.005, ms

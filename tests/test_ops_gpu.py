@@ -838,6 +838,46 @@ def test_approx_match_4096_against_the_sequential_order(ops, dev):
     assert np.allclose(prod, c_seq, rtol=1e-5)
 
 
+@pytest.mark.parametrize("b,n,m", [(3, 300, 200), (2, 1100, 1030), (1, 2048, 512), (40, 64, 96), (2, 1, 5), (1, 1024, 1025)])
+@pytest.mark.parametrize("arith", [PLAIN, CONTRACT])
+def test_approx_match_reference_signature_with_reference_sized_temp(dev, b, n, m, arith):
+    """dispu_approx_match keeps the reference launcher's contract: temp is the op's [b, 2 (n + m)] float allocation
+    (tf_approxmatch.cpp:164-170).  Nothing behind it is written (canary), every sum is the reference's sequential chain -- bit-exact
+    to the oracle's chunk = 0 order in pinned-exp mode at ANY size -- and the hardware-exp EMD is within 1e-5 of the oracle's.
+    dispu_approx_match_ws refuses a scratch smaller than dispu_approx_match_scratch_bytes without touching it or `match`."""
+    from dispu_amd import _lib
+    L = _lib.lib()
+    if min(n, m) < 8:
+        rng = np.random.default_rng(b * 7919 + n * 31 + m)
+        x1, x2 = rng.random((b, n, 3), dtype=np.float32), rng.random((b, m, 3), dtype=np.float32)
+    else:
+        x1, x2 = synth_patches(b, n, seed=n + 5), synth_patches(b, m, seed=m + 6)
+    t1, t2, st = T(x1, dev), T(x2, dev), _lib.stream_ptr(dev)
+    nt = b * 2 * (n + m)
+    contract = 1 if arith == CONTRACT else 0
+    temp = torch.full((nt + 4096,), -7.0, dtype=torch.float32, device=dev)
+    match = torch.full((b, m, n), -3.0, dtype=torch.float32, device=dev)            # the entry zeroes it itself (tf_approxmatch_g.cu:16)
+    _lib.check(L.dispu_approx_match(b, n, m, t1.data_ptr(), t2.data_ptr(), match.data_ptr(), temp.data_ptr(), arith | PINNED_EXP, st),
+               "dispu_approx_match")
+    assert bool((temp[nt:] == -7.0).all()), "dispu_approx_match wrote behind the reference's [b, 2(n+m)] temp"
+    assert np.array_equal(N(match), O.approx_match(x1, x2, contract=contract, pinned_exp=True, chunk=0))
+    _lib.check(L.dispu_approx_match(b, n, m, t1.data_ptr(), t2.data_ptr(), match.data_ptr(), temp.data_ptr(), arith, st), "dispu_approx_match")
+    assert bool((temp[nt:] == -7.0).all())
+    mo = O.approx_match(x1, x2, contract=contract)
+    assert np.allclose(O.match_cost(x1, x2, N(match)), O.match_cost(x1, x2, mo), rtol=1e-5)
+    need = L.dispu_approx_match_scratch_bytes(b, n, m)
+    assert need > nt * 4
+    sc = torch.full((need // 4 + 1024,), -7.0, dtype=torch.float32, device=dev)
+    mw = torch.full((b, m, n), -3.0, dtype=torch.float32, device=dev)
+    for nbytes in (need - 4, nt * 4, 0):
+        assert L.dispu_approx_match_ws(b, n, m, t1.data_ptr(), t2.data_ptr(), mw.data_ptr(), sc.data_ptr(), nbytes, arith, st) != 0
+        assert bool((sc == -7.0).all()) and bool((mw == -3.0).all()), "a refused call must not touch scratch or match"
+    _lib.check(L.dispu_approx_match_ws(b, n, m, t1.data_ptr(), t2.data_ptr(), mw.data_ptr(), sc.data_ptr(), need, arith | PINNED_EXP, st),
+               "dispu_approx_match_ws")
+    assert bool((sc[(need + 3) // 4:] == -7.0).all())
+    assert np.array_equal(N(mw), O.approx_match(x1, x2, contract=contract, pinned_exp=True, chunk=O.AM_CHUNK))
+
+
 @pytest.mark.parametrize("b,n,m", [(4, 1024, 1024), (2, 300, 700), (3, 1, 5), (7, 129, 127)])
 def test_approx_match_is_run_to_run_identical(ops, dev, b, n, m):
     """The 22 launches of the auction combine their partial sums in a fixed order (no atomics): two calls give the same bits, in

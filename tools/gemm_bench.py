@@ -44,7 +44,7 @@ def run_one():
         e1.record()
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) * 1e3 / reps
-        out.append("%7dx%4dx%3d tile=%6d %8.1f us %6.1f TF/s" % (M, K, N, L.dispu_linear_tile(1, M, N), us, 2.0 * M * K * N / us / 1e6))
+        out.append("%7dx%4dx%3d tile=%6d %8.1f us %6.1f TF/s" % (M, K, N, L.dispu_linear_tile2(1, M, K, N, 0), us, 2.0 * M * K * N / us / 1e6))
     print("\n".join(out))
 
 

@@ -7,9 +7,9 @@ OUT=$PWD/gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-# DISPU_BRANCHES=0: one stream, every kernel alone on the device -- the per-kernel averages then are the kernels' own times, comparable
+# --one-stream: one stream, every kernel alone on the device -- the per-kernel averages then are the kernels' own times, comparable
 # with bench.py's HIP-event pass (which folds the second stream back the same way); the timed step itself runs two streams
-DISPU_BRANCHES=0 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/raw -o prof -- python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-ops --eager > $OUT/bench_profiled.json 2> $OUT/rocprof.log || true
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/raw -o prof -- python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-ops --eager --one-stream > $OUT/bench_profiled.json 2> $OUT/rocprof.log || true
 cd $GRAFT_REPO_ROOT
 find $OUT/raw -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/kernel_stats.csv
 python bench.py --steps 50 --warmup 5 > $OUT/bench.json 2>> $OUT/rocprof.log

@@ -15,6 +15,7 @@ from dispu_amd.params import init_params
 dev = torch.device("cuda:0")
 gen = Generator(params=init_params(1234), device=dev)
 gen.return_views = True
+gen.branches = False                  # one stream: every kernel alone on the device
 x = torch.from_numpy(synth.patches(32, 1024, seed=3000)).to(dev)      # what the first pass hands over: 32 clouds of 1024 points
 for _ in range(3):
     gen(x)
@@ -26,7 +27,7 @@ torch.cuda.synchronize()
 print("second pass (32, 1024 -> 4096): %.3f ms per call" % ((time.perf_counter() - t) * 100))
 PY
 cd /tmp
-DISPU_BRANCHES=0 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/raw -o prof -- python /tmp/c4_pass2.py > $OUT/log.txt 2>&1 || true
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/raw -o prof -- python /tmp/c4_pass2.py > $OUT/log.txt 2>&1 || true
 cd $GRAFT_REPO_ROOT
 find $OUT/raw -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/kernel_stats.csv
 rm -rf $OUT/raw
