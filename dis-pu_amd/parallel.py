@@ -148,13 +148,16 @@ class _Lane(object):
     error, the lane's own gloo group carries a finite timeout (`timeout_s`) as the backstop, and close() raises if the background
     thread cannot be drained instead of abandoning it."""
 
-    def __init__(self, device, group=None, timeout_s=300.0):
+    def __init__(self, device, group=None, timeout_s=300.0, threaded=None):
+        """threaded: None = the transport's default (gloo: a background thread, it has no streams; RCCL: enqueue from the launching
+        thread).  True under RCCL moves the ~30 us of host time every collective call costs (c10d + RCCL enqueue) off the thread that
+        launches the step's kernels -- worth it for launch-bound steps (the 8-patch train step); the lane then owns a communicator."""
         self.group = group
         self.backend = dist.get_backend(group)
         self.device = torch.device(device)
         self.cuda = self.device.type == "cuda"
         self.stream = torch.cuda.Stream(device=self.device) if self.cuda else None
-        self.threaded = self.backend == "gloo"
+        self.threaded = (self.backend == "gloo") if threaded is None else bool(threaded)
         self.timeout_s = float(timeout_s)
         self.broken = None                      # the first exception of a job: the lane is unusable afterwards
         self._own_group = False
@@ -166,7 +169,8 @@ class _Lane(object):
             # dist.new_group is itself a collective over the parent group: lanes are built where every rank passes in the same
             # order (GatherPipeline / BucketedAllReduce constructors; Trainer builds its reducer when the parameters are loaded).
             import datetime
-            self.group = dist.new_group(ranks=dist.get_process_group_ranks(group if group is not None else dist.group.WORLD), backend="gloo",
+            # (a threaded RCCL lane needs its own communicator for the same reason: two threads enqueueing on one communicator race.)
+            self.group = dist.new_group(ranks=dist.get_process_group_ranks(group if group is not None else dist.group.WORLD), backend=self.backend,
                                         timeout=datetime.timedelta(seconds=self.timeout_s))
             self._own_group = True
             self._q = queue.Queue()
@@ -249,7 +253,10 @@ class _Lane(object):
                 if self.cuda:
                     with torch.cuda.stream(self.stream):
                         for ev in after:
-                            ev.synchronize()       # blocks this thread only
+                            if self.backend == "gloo":
+                                ev.synchronize()   # host-staged transport: blocks this thread only
+                            else:
+                                self.stream.wait_event(ev)     # RCCL: enqueued behind the producers, nothing blocks
                         job()
                         ticket.event = torch.cuda.Event()
                         ticket.event.record(self.stream)
@@ -307,12 +314,12 @@ class GatherPipeline(object):
     last used it (finished long before -- it never stalls a steady-state loop).  Equal shards only (the sharded bench / serving
     loop); ragged batches go through all_gather_clouds."""
 
-    def __init__(self, local_shape, device, dtype=torch.float32, depth=2, group=None):
+    def __init__(self, local_shape, device, dtype=torch.float32, depth=2, group=None, threaded=None):
         if not (dist.is_available() and dist.is_initialized()):
             raise RuntimeError("GatherPipeline needs an initialised process group")
         self.world = dist.get_world_size(group)
         self.device = torch.device(device)
-        self.lane = _Lane(self.device, group)
+        self.lane = _Lane(self.device, group, threaded=threaded)
         local_shape = tuple(int(s) for s in local_shape)
         self.local = [torch.empty(local_shape, dtype=dtype, device=self.device) for _ in range(depth)]
         self.out = [torch.empty((self.world * local_shape[0],) + local_shape[1:], dtype=dtype, device=self.device) for _ in range(depth)]
@@ -351,7 +358,7 @@ class BucketedAllReduce(object):
     1/world average is the caller's: Trainer folds it into the Adam launch).  Summation order inside a bucket is the
     transport's, exactly as for the single-bucket all_reduce_gradients: same values, sooner."""
 
-    def __init__(self, flat, bounds, group=None):
+    def __init__(self, flat, bounds, group=None, threaded=None):
         if not (dist.is_available() and dist.is_initialized()):
             raise RuntimeError("BucketedAllReduce needs an initialised process group")
         bounds = [(int(lo), int(hi)) for lo, hi in bounds]
@@ -360,7 +367,7 @@ class BucketedAllReduce(object):
             raise ValueError("buckets %r do not tile the %d-element buffer" % (bounds, flat.numel()))
         self.flat, self.bounds, self.group = flat, bounds, group
         self.world = dist.get_world_size(group)
-        self.lane = _Lane(flat.device, group)
+        self.lane = _Lane(flat.device, group, threaded=threaded)
         self.tickets = [None] * len(bounds)
 
     def launch(self, i, after=None):

@@ -30,6 +30,7 @@ from .generator import BN_EPS, DENSE_BLOCKS, GROWTH, K_NEIGH, _Opts, gen_grid
 
 BN_DECAY = 0.95      # DisPU/generator.py:39 bn_decay
 BN = "refine/PointShuffle/weight_net/wconv0/bn/"
+BN_CH = 16            # its channels (the weight net's 3 -> 16 conv, Common/ops.py:181-191)
 
 
 class TrainOpts(_Opts):
@@ -83,7 +84,7 @@ class Trainer(object):
 
     `params`: the same name -> array mapping Generator.load_params takes (oracle/generator.py:layer_shapes names)."""
 
-    def __init__(self, opts=None, params=None, device=None, process_group=None, dtype="f32"):
+    def __init__(self, opts=None, params=None, device=None, process_group=None, dtype="f32", comm_thread=None, collectives_at_world_1=False):
         """dtype "f32": the reference's arithmetic (every product on the fp32 matrix pipe, bit-equal to an fmaf chain).
         dtype "bf16" (BASELINE configs[4]): mixed precision -- master weights, activations and gradients stay fp32 in HBM,
         the dense products (forward, dX, dW) round their operands to bf16 and run on v_mfma_f32_32x32x16_bf16 with fp32
@@ -112,7 +113,10 @@ class Trainer(object):
         self._ar_armed = False                # True inside train_step(): backward() may start a bucket's all-reduce as soon as it is complete
         # a ONE-rank process group normally means "no collectives".  True keeps them (a 1-rank RCCL communicator executes the real
         # stream / event ordering of the data-parallel step: the dry run of tests/test_distributed_gpu.py on the one GPU a test box has)
-        self.collectives_at_world_1 = False
+        self.collectives_at_world_1 = bool(collectives_at_world_1)
+        # None: the transport's default (RCCL: the launching thread enqueues the collectives).  True: a background thread does -- the step
+        # is launch-bound at 8 patches per GPU and a collective call costs ~30 us of host time (parallel._Lane)
+        self.comm_thread = comm_thread
         # weight-gradient products (dW = X^T dZ) are off the backward chain: only Adam reads them.  They run on a second
         # HIP stream next to the dX products that ARE the chain (both read dZ; at 8 patches neither fills 256 CUs alone).
         self.overlap_dw = True
@@ -187,7 +191,11 @@ class Trainer(object):
             offs.append(total)
             total += (s + 3) & ~3
         self.flat_p = torch.zeros(total, dtype=torch.float32, device=dev)
-        self.flat_g = torch.zeros_like(self.flat_p)
+        # gradients and, behind them, the 2 x 16 BatchNorm moving statistics in ONE buffer: data parallel, both are reduced over the
+        # replicas by the same two bucket collectives (a collective call costs ~30 us of host time whatever its size -- two more for
+        # 128 bytes of statistics were 4 % of the 8-patch step, tests/test_distributed_gpu.py:test_rccl_branch_on_one_rank)
+        self._red = torch.zeros(total + 2 * BN_CH, dtype=torch.float32, device=dev)
+        self.flat_g = self._red[:total]
         self.flat_m = torch.zeros_like(self.flat_p)
         self.flat_v = torch.zeros_like(self.flat_p)
         self.P, self.G, self.names = OrderedDict(), OrderedDict(), names
@@ -206,8 +214,10 @@ class Trainer(object):
                 self.PT[k] = self.flat_pT[o:o + s].view(shp[1], shp[0])
                 desc += [o, shp[0], shp[1]]
         self._t_desc = torch.tensor(desc, dtype=torch.int32, device=dev)
-        self.moving_mean = torch.from_numpy(np.ascontiguousarray(params[BN + "moving_mean"], np.float32)).to(dev)
-        self.moving_var = torch.from_numpy(np.ascontiguousarray(params[BN + "moving_variance"], np.float32)).to(dev)
+        self._stats = self._red[total:]
+        self.moving_mean, self.moving_var = self._stats[:BN_CH], self._stats[BN_CH:]
+        self.moving_mean.copy_(torch.from_numpy(np.ascontiguousarray(params[BN + "moving_mean"], np.float32)))
+        self.moving_var.copy_(torch.from_numpy(np.ascontiguousarray(params[BN + "moving_variance"], np.float32)))
         self.grid = torch.from_numpy(gen_grid(self.up_ratio)).to(dev)
         self.adam_t = 0
         # data parallel: the reducer (and, under gloo, its lane's process group -- dist.new_group is a collective) is built HERE, where
@@ -1192,7 +1202,7 @@ class Trainer(object):
             first = next(k for k in self.names if k.startswith("refine/"))
             split = (self.P[first].data_ptr() - self.flat_p.data_ptr()) // 4
             assert all(k.startswith("refine/") == ((self.P[k].data_ptr() - self.flat_p.data_ptr()) // 4 >= split) for k in self.names)
-            self._ar = parallel.BucketedAllReduce(self.flat_g, [(split, self.flat_g.numel()), (0, split)], self.pg)
+            self._ar = parallel.BucketedAllReduce(self._red, [(split, self._red.numel()), (0, split)], self.pg, threaded=self.comm_thread)
         return self._ar
 
     def _bucket_point(self, i):
@@ -1215,11 +1225,14 @@ class Trainer(object):
     def all_reduce_grads(self):
         """gradient all-reduce (RCCL over xGMI) of the 4.2 MB buffer, in the buckets of _reducer(): whatever backward() has not
         launched yet is launched here, then the current stream waits for all of it.  The 1/world average is folded into the Adam
-        launch.  BN moving statistics (per-rank batch statistics) are averaged behind the last bucket."""
+        launch.  BN moving statistics (per-rank batch statistics) ride at the tail of the refine bucket and are averaged here."""
         ar = self._reducer()
         if ar is None:
             return 1
-        return ar.finish(extra=[self.moving_mean, self.moving_var])
+        world = ar.finish()
+        if world > 1:
+            self._stats.mul_(1.0 / world)                # summed with the refine bucket; the gradients' 1/world rides in the Adam launch
+        return world
 
     def adam(self, world=1):
         """tf.train.AdamOptimizer(lr, beta1=opts.beta) (model.py:178)."""
