@@ -103,6 +103,8 @@ SIGNATURES = {
     "dispu_linear_bf16x3": (_i, [_i, _i, _i, _vp, _l, _vp, _vp, _i, _vp, _l, _vp, _l, _vp, _l, _vp]),
     "dispu_linear_tn_scratch_floats": (_l, [_i, _i, _i, _i]),
     "dispu_linear_tn": (_i, [_i, _i, _i, _i, _vp, _l, _l, _vp, _l, _l, _vp, _l, _l, _i, _vp, _vp, _l, _vp]),
+    "dispu_tn_defer": (_i, [_vp]),
+    "dispu_tn_reduce_grouped": (_i, [_i, _vp, _vp, _vp]),
     "dispu_act_bias_grad_scratch_floats": (_l, [_l, _i]),
     "dispu_act_bias_grad": (_i, [_l, _i, _vp, _l, _vp, _l, _i, _vp, _l, _vp, _i, _vp, _l, _vp]),
     "dispu_max_k": (_i, [_l, _i, _i, _vp, _l, _vp, _l, _vp]),
@@ -159,6 +161,12 @@ SIGNATURES = {
     "dispu_augment": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "dispu_adam": (_i, [_l, _vp, _vp, _vp, _vp, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _vp]),
 }
+
+class TnReduceDesc(C.Structure):
+    """include/dispu_hip.h: dispu_tn_reduce_desc (72 bytes)."""
+    _fields_ = [("part", _vp), ("out", _vp), ("dbias", _vp), ("ldo", _l), ("stride", _l), ("K", _i), ("N", _i), ("splits", _i),
+                ("rows_p", _i), ("accumulate", _i), ("bias_accumulate", _i), ("assoc", _i), ("reserved", _i)]
+
 
 _LIB = None
 

@@ -26,9 +26,22 @@
         if (e__ != hipSuccess) return (int)e__;      \
     } while (0)
 
+// A split reduction a TN (weight-gradient) product leaves undone when the caller asked for that (dispu_tn_defer, include/dispu_hip.h):
+// out[k][n] (+)= sum_s part[s][k][n], row K of the partials (rows_p == K + 1) -> dbias[n].  Mirrors dispu_tn_reduce_desc.
+struct dispu_tn_reduce_desc {
+    const float* part; float* out; float* dbias;
+    long ldo, stride;                       // row stride of out; floats between consecutive partials
+    int K, N, splits, rows_p;
+    int accumulate, bias_accumulate, assoc, reserved;   // assoc 0: the fp32 kernels' order (tn_reduce_kernel), 1: the bf16 kernels'
+};
+static_assert(sizeof(dispu_tn_reduce_desc) == 72, "descriptor layout is part of the C-ABI");
+
 namespace dispu {
 
 constexpr int kWave = 64;
+
+// the one-shot sink dispu_tn_defer arms for the NEXT TN product on this thread (train_gemm.hip); taking it disarms it
+dispu_tn_reduce_desc* tn_take_defer();
 
 // "done once per DEVICE" flag for hipFuncSetAttribute (function attributes are per device: a process that drives several
 // GPUs must opt every one of them in to > 64 KB of dynamic LDS).  Two threads racing through the first call both set the

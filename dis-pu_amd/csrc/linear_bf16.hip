@@ -410,6 +410,9 @@ DISPU_EXPORT int dispu_linear_tn_bf16s(int batch, int M, int K, int N, const voi
     const float* X = (const float*)Xv;
     const float* Z = (const float*)Zv;
     const int xa = (storage & 1) ? 1 : 0, zb = (storage & 2) ? 1 : 0;
+    dispu_tn_reduce_desc* sink = tn_take_defer();                 // dispu_tn_defer (train_gemm.hip): describe the reduction, do not launch it
+    if (sink) sink->splits = 0;
+    if (batch != 1) sink = nullptr;
     if (batch < 0 || M < 0 || K < 0 || N < 0 || !out || (dbias && batch != 1)) return (int)hipErrorInvalidValue;
     if (batch == 0 || K == 0 || N == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
@@ -434,6 +437,10 @@ DISPU_EXPORT int dispu_linear_tn_bf16s(int batch, int M, int K, int N, const voi
     const int rc = gb_launch<false, false>(a, batch, s);
     if (rc != 0) return rc;
     const long total = rows_p * N;
+    if (sink) {
+        *sink = dispu_tn_reduce_desc{scratch, out, dbias, ldo, total, K, N, splits, (int)rows_p, accumulate, accumulate, 1, 0};
+        return 0;
+    }
     hipLaunchKernelGGL(gemm_bf16_reduce_kernel, dim3((unsigned)((total + 31) / 32), batch), dim3(256), 0, s, K, N, splits, dbias ? 1 : 0,
                        scratch, out, ldo, so, accumulate, dbias);
     return (int)hipGetLastError();

@@ -409,6 +409,8 @@ DISPU_EXPORT int dispu_linear_tn_bf16_stream(int M, int K, int N, const void* X,
                                              long ldo, int accumulate, float* dbias, float* scratch, long scratch_floats, void* stream) {
     int splits;
     const bool bf = storage == 3;
+    dispu_tn_reduce_desc* sink = tn_take_defer();                 // dispu_tn_defer (train_gemm.hip): describe the reduction, do not launch it
+    if (sink) sink->splits = 0;
     if (!(storage == 0 || storage == 3) || !tn_stream_plan(M, K, N, splits) || !X || !Z || !out || !scratch ||
         scratch_floats < (long)splits * ((long)K + 1) * N || ldx < K || ldz < N || (ldx & (bf ? 7 : 3)) || (ldz & (bf ? 7 : 3)) ||
         (((uintptr_t)X) & 15) || (((uintptr_t)Z) & 15))
@@ -433,6 +435,10 @@ DISPU_EXPORT int dispu_linear_tn_bf16_stream(int M, int K, int N, const void* X,
     else hipLaunchKernelGGL((gemm_bf16_tn_stream_kernel<128, false>), grid, blk, lds, s, a);
     DISPU_CHECK_LAUNCH();
     const long total = ((long)K + (dbias ? 1 : 0)) * N;
+    if (sink) {
+        *sink = dispu_tn_reduce_desc{scratch, out, dbias, ldo, total, K, N, splits, K + (dbias ? 1 : 0), accumulate, accumulate, 1, 0};
+        return 0;
+    }
     hipLaunchKernelGGL(tn_stream_reduce_kernel, dim3((unsigned)((total + 31) / 32)), dim3(256), 0, s, K, N, splits, dbias ? 1 : 0, scratch, out, ldo,
                        accumulate, dbias);
     return (int)hipGetLastError();

@@ -44,16 +44,19 @@ constexpr size_t MB_LDS_BYTES = (size_t)(MB_ACT + 2 * MB_WST) * sizeof(float);
 template <int K, int N, int BM, bool LAST, bool RES = false>
 __device__ __forceinline__ void chain_layer_bwd(float* act, const float* wst, int g0, const ChainBwdArgs& a, const float* Mk,
                                                 long ldmk, float* D, long ldd, long row0, int wm, int wn, int fi, int fk) {
-    constexpr int TNW = N / 64, LDW = N + 4, BK = mb_bk(N), RT = BM / 64, LDA = BM + 1;
-    static_assert(RT == 1, "the epilogue operands of a layer are prefetched into registers: 64-row workgroups only");
+    // the four MFMA waves as WMW x WNW: 64-row workgroups 2 x 2 (32 rows x N / 2 columns per wave), 32-row workgroups 1 x 4 (32 rows x
+    // N / 4 columns) -- the latter doubles the workgroup count where 64-row tiles leave half the chip idle (8 training patches: 8192 rows)
+    constexpr int WMW = BM / 32, WNW = 4 / WMW, NW = N / WNW, TNW = NW / 32, LDW = N + 4, BK = mb_bk(N), LDA = BM + 1;
+    static_assert(BM == 32 || BM == 64, "the epilogue operands of a layer are prefetched into registers: 32- or 64-row workgroups only");
+    static_assert(TNW >= 1, "layer too narrow for the wave grid");
     f32x16 acc[TNW];
     // the epilogue's mask (and residual) values, requested BEFORE the product loop: they arrive while the MFMAs run.  (Loaded inside
     // the epilogue the compiler serialised load -> wait -> store per element: the stores may alias the next loads for all it knows.)
     float mk[TNW][16], rr[RES ? TNW : 1][16], rr2[RES ? TNW : 1][16];
-    const size_t rbase = (size_t)(row0 + wm * (BM / 2) + 4 * fk);
+    const size_t rbase = (size_t)(row0 + wm * 32 + 4 * fk);
 #pragma unroll
     for (int j = 0; j < TNW; ++j) {
-        const int n = wn * (N / 2) + j * 32 + fi;
+        const int n = wn * NW + j * 32 + fi;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const size_t gr = rbase + (r & 3) + 8 * (r >> 2);
@@ -72,14 +75,14 @@ __device__ __forceinline__ void chain_layer_bwd(float* act, const float* wst, in
             for (int j = 0; j < TNW; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    rr[j][r] = a.R[(rbase + (r & 3) + 8 * (r >> 2)) * a.ldr + wn * (N / 2) + j * 32 + fi];
+                    rr[j][r] = a.R[(rbase + (r & 3) + 8 * (r >> 2)) * a.ldr + wn * NW + j * 32 + fi];
         }
         if (a.R2) {
 #pragma unroll
             for (int j = 0; j < TNW; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    rr2[j][r] = a.R2[(rbase + (r & 3) + 8 * (r >> 2)) * a.ldr2 + wn * (N / 2) + j * 32 + fi];
+                    rr2[j][r] = a.R2[(rbase + (r & 3) + 8 * (r >> 2)) * a.ldr2 + wn * NW + j * 32 + fi];
         }
     }
     for (int s = 0; s < K / BK; ++s) {
@@ -88,9 +91,9 @@ __device__ __forceinline__ void chain_layer_bwd(float* act, const float* wst, in
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 2) {
             float bf[TNW];
-            const float af = as[(kk + fk) * LDA + wm * (BM / 2) + fi];
+            const float af = as[(kk + fk) * LDA + wm * 32 + fi];
 #pragma unroll
-            for (int j = 0; j < TNW; ++j) bf[j] = ws[(kk + fk) * LDW + wn * (N / 2) + j * 32 + fi];
+            for (int j = 0; j < TNW; ++j) bf[j] = ws[(kk + fk) * LDW + wn * NW + j * 32 + fi];
 #pragma unroll
             for (int j = 0; j < TNW; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bf[j], acc[j], 0, 0, 0);
         }
@@ -100,10 +103,10 @@ __device__ __forceinline__ void chain_layer_bwd(float* act, const float* wst, in
     if constexpr (!LAST) {
 #pragma unroll
         for (int j = 0; j < TNW; ++j) {
-            const int n = wn * (N / 2) + j * 32 + fi;
+            const int n = wn * NW + j * 32 + fi;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = wm * (BM / 2) + (r & 3) + 8 * (r >> 2) + 4 * fk;
+                const int row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
                 float v = acc[j][r];
                 if constexpr (RES) v = (v + rr[j][r]) + rr2[j][r];
                 if (mk[j][r] <= 0.f) v = 0.f;
@@ -115,7 +118,7 @@ __device__ __forceinline__ void chain_layer_bwd(float* act, const float* wst, in
         // dX through its masks: Ma was prefetched; Mb / Mc (the fine head: three masked copies) are loaded as a block each
 #pragma unroll
         for (int j = 0; j < TNW; ++j) {
-            const int n = wn * (N / 2) + j * 32 + fi;
+            const int n = wn * NW + j * 32 + fi;
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 a.Da[(rbase + (r & 3) + 8 * (r >> 2)) * a.ldd0 + n] = (mk[j][r] <= 0.f) ? 0.f : acc[j][r];
@@ -123,13 +126,13 @@ __device__ __forceinline__ void chain_layer_bwd(float* act, const float* wst, in
         if (a.Db) {
 #pragma unroll
             for (int j = 0; j < TNW; ++j) {
-                const int n = wn * (N / 2) + j * 32 + fi;
+                const int n = wn * NW + j * 32 + fi;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) mk[j][r] = a.Mb[(rbase + (r & 3) + 8 * (r >> 2)) * a.ldm + n];
             }
 #pragma unroll
             for (int j = 0; j < TNW; ++j) {
-                const int n = wn * (N / 2) + j * 32 + fi;
+                const int n = wn * NW + j * 32 + fi;
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
                     a.Db[(rbase + (r & 3) + 8 * (r >> 2)) * a.ldd0 + n] = (mk[j][r] <= 0.f) ? 0.f : acc[j][r];
@@ -138,13 +141,13 @@ __device__ __forceinline__ void chain_layer_bwd(float* act, const float* wst, in
         if (a.Dc) {
 #pragma unroll
             for (int j = 0; j < TNW; ++j) {
-                const int n = wn * (N / 2) + j * 32 + fi;
+                const int n = wn * NW + j * 32 + fi;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) mk[j][r] = a.Mc[(rbase + (r & 3) + 8 * (r >> 2)) * a.ldm + n];
             }
 #pragma unroll
             for (int j = 0; j < TNW; ++j) {
-                const int n = wn * (N / 2) + j * 32 + fi;
+                const int n = wn * NW + j * 32 + fi;
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
                     a.Dc[(rbase + (r & 3) + 8 * (r >> 2)) * a.ldd0 + n] = (mk[j][r] <= 0.f) ? 0.f : acc[j][r];
@@ -257,7 +260,7 @@ __global__ __launch_bounds__(512) void mlp_chain_bwd_kernel(ChainBwdArgs a) {
     }
 
     // ------------------------------------------------------------------------------------------ MFMA waves
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = (BM == 64) ? (wave >> 1) : 0, wn = (BM == 64) ? (wave & 1) : wave;
     const int fi = lane & 31, fk = lane >> 5;
     __syncthreads();
     chain_layer_bwd<64, N2, BM, false>(act, wst, 0, a, a.Y2, a.ldy2, a.D2, a.ldd2, row0, wm, wn, fi, fk);
@@ -269,14 +272,14 @@ __global__ __launch_bounds__(512) void mlp_chain_bwd_kernel(ChainBwdArgs a) {
 
 using namespace dispu;
 
-// Backward of dispu_mlp_chain(_stash): see the header.  rows % 64 == 0; (K0, N1, N2) in {(256,128,256), (256,256,256)}; every pointer
+// Backward of dispu_mlp_chain(_stash): see the header.  rows % 32 == 0; (K0, N1, N2) in {(256,128,256), (256,256,256)}; every pointer
 // 16-byte aligned, every leading dimension a multiple of 4 (except lddz).  D1 may alias R (same element read then written by one lane).
 DISPU_EXPORT int dispu_mlp_chain_grad(long rows, int K0, int N1, int N2, const float* dZ, long lddz, const float* W4, const float* Wt3,
                                       const float* Wt2, const float* Wt1, const float* Y3, long ldy3, const float* Y2, long ldy2,
                                       const float* Y1, long ldy1, const float* R, long ldr, const float* R2, long ldr2, float* D3, long ldd3,
                                       float* D2, long ldd2, float* D1, long ldd1, const float* Ma, const float* Mb, const float* Mc, long ldm, float* Da, float* Db,
                                       float* Dc, long ldd0, void* stream) {
-    if (rows < 0 || (rows % 64) != 0 || !dZ || !W4 || !Wt3 || !Wt2 || !Wt1 || !Y3 || !Y2 || !Y1 || !D3 || !D2 || !D1 || !Da ||
+    if (rows < 0 || (rows % 32) != 0 || !dZ || !W4 || !Wt3 || !Wt2 || !Wt1 || !Y3 || !Y2 || !Y1 || !D3 || !D2 || !D1 || !Da ||
         (Db && !Mb) || (Dc && !Mc) || ((ldy3 | ldd3) & 3) ||
         ((((uintptr_t)W4) | ((uintptr_t)Wt3) | ((uintptr_t)Wt2) | ((uintptr_t)Wt1) | ((uintptr_t)Y3) | ((uintptr_t)D3)) & 15))
         return (int)hipErrorInvalidValue;
@@ -286,9 +289,11 @@ DISPU_EXPORT int dispu_mlp_chain_grad(long rows, int K0, int N1, int N2, const f
     ChainBwdArgs a{rows, dZ, lddz, W4, Wt3, Wt2, Wt1, Y3, ldy3, Y2, ldy2, Y1, ldy1, R, ldr, R2, ldr2, D3, ldd3, D2, ldd2, D1, ldd1,
                    Ma, Mb, Mc, ldm, Da, Db, Dc, ldd0};
     hipStream_t s = (hipStream_t)stream;
-    // 64-row workgroups at every size: a layer's epilogue operands (masks, residual) wait in registers during its product loop, which
-    // leaves no room for the 128-row tile's accumulators
-    const dim3 grid((unsigned)(rows / 64));
+    // 64-row workgroups (a layer's epilogue operands -- masks, residual -- wait in registers during its product loop, which leaves no room
+    // for a 128-row tile's accumulators); 32-row workgroups while 64-row ones would leave CUs idle (fewer than 192 of them: the 8-patch
+    // training step's 8192 rows are 128) or the row count demands it
+    const bool half = (rows % 64) != 0 || rows / 64 < 192;
+    const dim3 grid((unsigned)(rows / (half ? 32 : 64)));
     auto launch = [&](auto kern) -> int {
         static DevOnce once;
         if (once.needed()) {
@@ -300,6 +305,10 @@ DISPU_EXPORT int dispu_mlp_chain_grad(long rows, int K0, int N1, int N2, const f
     };
     const bool res = R || R2;
     if (res && !coarse) return (int)hipErrorInvalidValue;      // residual inputs: the 128-wide Y1 only (register budget of the prefetch)
+    if (half) {
+        if (coarse) return res ? launch(mlp_chain_bwd_kernel<256, 128, 256, 32, true>) : launch(mlp_chain_bwd_kernel<256, 128, 256, 32, false>);
+        return launch(mlp_chain_bwd_kernel<256, 256, 256, 32, false>);
+    }
     if (coarse) return res ? launch(mlp_chain_bwd_kernel<256, 128, 256, 64, true>) : launch(mlp_chain_bwd_kernel<256, 128, 256, 64, false>);
     return launch(mlp_chain_bwd_kernel<256, 256, 256, 64, false>);
 }

@@ -288,6 +288,94 @@ __global__ __launch_bounds__(256) void tn_reduce4_kernel(int batch, int K, int N
     }
 }
 
+// ---- deferred reductions, one grouped launch -------------------------------------------------------------------------------------
+// The training step runs ~20 weight-gradient products of very different sizes, each followed by its own split reduction: 20 more
+// launches of 4 - 25 us that only Adam waits for.  dispu_tn_defer(&desc) arms a one-shot sink: the next TN product on this thread
+// launches its product kernel only and describes the reduction it left undone; dispu_tn_reduce_grouped runs any number of described
+// reductions as ONE launch (a workgroup looks its descriptor up by block index), in exactly the association the single launches use.
+static thread_local dispu_tn_reduce_desc* tl_tn_defer = nullptr;
+dispu_tn_reduce_desc* tn_take_defer() {
+    dispu_tn_reduce_desc* d = tl_tn_defer;
+    tl_tn_defer = nullptr;
+    return d;
+}
+
+__device__ __forceinline__ float4 f4_add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float f4_add(float a, float b) { return a + b; }
+template <typename T> __device__ __forceinline__ T f4_zero();
+template <> __device__ __forceinline__ float f4_zero<float>() { return 0.f; }
+template <> __device__ __forceinline__ float4 f4_zero<float4>() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+
+__host__ __device__ inline bool tn_desc_vec(const dispu_tn_reduce_desc& d) {
+    return (d.N % 4 == 0) && (d.ldo % 4 == 0) && (d.stride % 4 == 0) &&
+           (((((uintptr_t)d.part) | ((uintptr_t)d.out) | ((uintptr_t)d.dbias)) & 15) == 0);
+}
+__host__ __device__ inline unsigned tn_desc_chunks(const dispu_tn_reduce_desc& d) {
+    const size_t e = (size_t)d.rows_p * d.N;
+    return (unsigned)(((tn_desc_vec(d) ? e / 4 : e) + 31) / 32);
+}
+
+// one 32-element (32-quad) chunk of one descriptor: 8 split groups x 32 lanes, the associations of tn_reduce(4)_kernel (assoc 0: group g
+// adds splits g, g + 8, ... alternating between two running sums) and of gemm_bf16_reduce_kernel / tn_stream_reduce_kernel (assoc 1: one
+// running sum per group); the eight group sums are added in group order
+template <typename T>
+__device__ __forceinline__ void tn_reduce_chunk(const dispu_tn_reduce_desc& d, unsigned chunk, T (*red)[32]) {
+    constexpr int W = sizeof(T) / 4;
+    const int lane = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    const size_t q1 = (size_t)d.rows_p * d.N / W, q = (size_t)chunk * 32 + lane;
+    const size_t sq = (size_t)d.stride / W;
+    T v = f4_zero<T>();
+    if (q < q1) {
+        const T* __restrict__ p = reinterpret_cast<const T*>(d.part) + q;
+        if (d.assoc == 0) {
+            T v0 = f4_zero<T>(), v1 = f4_zero<T>();
+            for (int s = grp; s < d.splits; s += 64) {
+                T b[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) b[j] = (s + 8 * j < d.splits) ? p[(size_t)(s + 8 * j) * sq] : f4_zero<T>();
+#pragma unroll
+                for (int j = 0; j < 8; j += 2) {
+                    if (s + 8 * j < d.splits) v0 = f4_add(v0, b[j]);
+                    if (s + 8 * (j + 1) < d.splits) v1 = f4_add(v1, b[j + 1]);
+                }
+            }
+            v = f4_add(v0, v1);
+        } else {
+#pragma unroll 4
+            for (int t = grp; t < d.splits; t += 8) v = f4_add(v, p[(size_t)t * sq]);
+        }
+    }
+    red[grp][lane] = v;
+    __syncthreads();
+    if (grp == 0 && q < q1) {
+        T t = red[0][lane];
+#pragma unroll
+        for (int g = 1; g < 8; ++g) t = f4_add(t, red[g][lane]);
+        const size_t r = q * W;
+        const int k = (int)(r / d.N), n = (int)(r - (size_t)k * d.N);
+        T* o;
+        bool acc;
+        if (k < d.K) { o = reinterpret_cast<T*>(d.out + (size_t)k * d.ldo + n); acc = d.accumulate != 0; }
+        else { o = reinterpret_cast<T*>(d.dbias + n); acc = d.bias_accumulate != 0; }
+        if (k < d.K || d.dbias) *o = acc ? f4_add(*o, t) : t;
+    }
+}
+
+__global__ __launch_bounds__(256) void tn_reduce_grouped_kernel(int count, const dispu_tn_reduce_desc* __restrict__ tab) {
+    __shared__ float4 red[8][32];
+    unsigned b = blockIdx.x;
+    int i = 0;
+    dispu_tn_reduce_desc d = tab[0];
+    for (;;) {                                                    // uniform: block index -> (descriptor, chunk)
+        const unsigned c = tn_desc_chunks(d);
+        if (b < c || i + 1 >= count) break;
+        b -= c;
+        d = tab[++i];
+    }
+    if (tn_desc_vec(d)) tn_reduce_chunk<float4>(d, b, red);
+    else tn_reduce_chunk<float>(d, b, reinterpret_cast<float(*)[32]>(red));
+}
+
 static void launch_tn_reduce(int batch, int K, int N, int splits, const float* part, float* out, long ldo, long so, int accumulate,
                              float* dbias, hipStream_t s) {
     const bool vec = (N % 4 == 0) && (ldo % 4 == 0) && (so % 4 == 0) && ((((uintptr_t)part) | ((uintptr_t)out)) & 15) == 0;
@@ -497,6 +585,9 @@ DISPU_EXPORT long dispu_linear_tn_scratch_floats(int batch, int M, int K, int N)
 DISPU_EXPORT int dispu_linear_tn(int batch, int M, int K, int N, const float* X, long ldx, long sx, const float* Z, long ldz,
                                  long sz, float* out, long ldo, long so, int accumulate, float* dbias, float* scratch,
                                  long scratch_floats, void* stream) {
+    dispu_tn_reduce_desc* sink = tn_take_defer();                 // armed by dispu_tn_defer: describe the reduction instead of launching it
+    if (sink) sink->splits = 0;
+    if (batch != 1) sink = nullptr;                               // batched products (the unfused attention backward) reduce themselves
     if (batch < 0 || M < 0 || K < 0 || N < 0) return (int)hipErrorInvalidValue;
     if (batch == 0 || K == 0 || N == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
@@ -516,6 +607,10 @@ DISPU_EXPORT int dispu_linear_tn(int batch, int M, int K, int N, const float* X,
             hipLaunchKernelGGL(linear_tn_narrow_kernel, dim3(nchunks, (jobs + wpb - 1) / wpb), dim3(64 * wpb), 0, s, M, K, N, nrows, KT, NT,
                                X, ldx, Z, ldz, scratch);
             DISPU_CHECK_LAUNCH();
+            if (sink) {
+                *sink = dispu_tn_reduce_desc{scratch, out, dbias, ldo, (long)(K + 1) * N, K, N, nchunks, K + 1, accumulate, 1, 0, 0};
+                return 0;
+            }
             launch_tn_reduce(1, K, N, nchunks, scratch, out, ldo, so, accumulate, dbias, s);
             DISPU_CHECK_LAUNCH();
             return 0;
@@ -541,10 +636,37 @@ DISPU_EXPORT int dispu_linear_tn(int batch, int M, int K, int N, const float* X,
     else rc = launch_tn_e<2, 4>(a, grid, edge, s);
     if (rc != 0) return rc;
     if (!direct) {
+        if (sink) {
+            *sink = dispu_tn_reduce_desc{scratch, out, dbias, ldo, (long)(K + 1) * N, K, N, splits, K + 1, accumulate, 1, 0, 0};
+            return 0;
+        }
         launch_tn_reduce(batch, K, N, splits, scratch, out, ldo, so, accumulate, dbias, s);
         DISPU_CHECK_LAUNCH();
     }
     return 0;
+}
+
+DISPU_EXPORT int dispu_tn_defer(dispu_tn_reduce_desc* desc) {
+    if (!desc) return (int)hipErrorInvalidValue;
+    desc->splits = 0;
+    tl_tn_defer = desc;
+    return 0;
+}
+
+DISPU_EXPORT int dispu_tn_reduce_grouped(int count, const dispu_tn_reduce_desc* table_host, const dispu_tn_reduce_desc* table_device,
+                                         void* stream) {
+    if (count < 0 || (count > 0 && (!table_host || !table_device))) return (int)hipErrorInvalidValue;
+    unsigned long chunks = 0;
+    for (int i = 0; i < count; ++i) {
+        const dispu_tn_reduce_desc& d = table_host[i];
+        if (d.splits <= 0 || !d.part || !d.out || d.K <= 0 || d.N <= 0 || d.rows_p < d.K || d.rows_p > d.K + 1 || (unsigned)d.assoc > 1u)
+            return (int)hipErrorInvalidValue;
+        chunks += tn_desc_chunks(d);
+    }
+    if (chunks == 0) return 0;
+    if (chunks > 0x7fffffffUL) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(tn_reduce_grouped_kernel, dim3((unsigned)chunks), dim3(256), 0, (hipStream_t)stream, count, table_device);
+    return (int)hipGetLastError();
 }
 
 DISPU_EXPORT long dispu_act_bias_grad_scratch_floats(long rows, int n) {

@@ -152,6 +152,12 @@ class Trainer(object):
         self.bf16_tn = True        # dtype="bf16": weight-gradient products of fp32-stored operands on the bf16 TN kernel too (False: they stay on the fp32 one)
         self.bf16_stream = True    # dtype="bf16": the large dense products on the streaming bf16 kernel (csrc/linear_bf16_stream.hip) where its shape rules hold
         self._packs = {}
+        # the split reductions of the weight-gradient products are not launched one by one: every product describes the reduction it left
+        # undone (dispu_tn_defer) and a stream's descriptors run as ONE launch when that stream is joined (_join, _bucket_point): ~20
+        # launches of 4 - 25 us per step become 3.  False: every product reduces itself (A/B; bit-identical)
+        self.group_reduce = True
+        self._rg = {}                      # stream pointer -> [host descriptor array, entries pending, stream c_void_p]
+        self._rg_dev = {}                  # descriptor table bytes -> device copy (content-addressed: tapes keep pointing at theirs)
         self.tail_on_chain = True  # the first dense block's weight gradients (the LAST work of the backward) stay on the chain's stream: no cross-stream hop in front of Adam
         self.prep_late = True     # zeroing / W^T copies for the backward behind the non-local branch's own kernels (0: in front of them, round 3)
         self.prep_on_side = False   # ... or on a weight-gradient stream during the forward (measured slower at 8 patches in fp32: 1.79 vs 1.71 ms)   # backward's zeroing / W^T copies on a dW stream during the forward
@@ -435,9 +441,51 @@ class Trainer(object):
         self._side_busy[i] = True
         return ctypes.c_void_p(self._sides[i].cuda_stream), "dw%d" % i
 
+    # ---- grouped split reductions (dispu_tn_defer / dispu_tn_reduce_grouped) ----
+    _RG_MAX = 64
+
+    def _rg_slot(self, st, out_ptr, bias_ptr):
+        """-> (address of the next free descriptor of stream `st`, its group, out pointer, bias pointer).  A product whose destination
+        another pending reduction also accumulates into flushes that group first (two descriptors of one launch must not alias)."""
+        for g in self._rg.values():
+            if g[1] and any(o == out_ptr or (bias_ptr and b == bias_ptr) for o, b in g[3]):
+                self._rg_flush_group(g)
+        g = self._rg.get(st.value)
+        if g is None:
+            g = self._rg[st.value] = [(_lib.TnReduceDesc * self._RG_MAX)(), 0, ctypes.c_void_p(st.value), []]
+        if g[1] >= self._RG_MAX:
+            self._rg_flush_group(g)
+        return (ctypes.c_void_p(ctypes.addressof(g[0]) + g[1] * ctypes.sizeof(_lib.TnReduceDesc)), g, out_ptr, bias_ptr)
+
+    def _rg_commit(self, slot):
+        _, g, out_ptr, bias_ptr = slot
+        if g[0][g[1]].splits > 0:                        # the product left a reduction behind (0: it wrote its result itself)
+            g[1] += 1
+            g[3].append((out_ptr, bias_ptr))
+
+    def _rg_flush_group(self, g):
+        n = g[1]
+        if not n:
+            return
+        raw = ctypes.string_at(ctypes.addressof(g[0]), n * ctypes.sizeof(_lib.TnReduceDesc))
+        dev = self._rg_dev.get(raw)
+        if dev is None:                                  # first step with this table (steady state: the same pointers every step)
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("a new reduction table inside a hipGraph capture: run one eager step with this batch shape first")
+            dev = self._rg_dev[raw] = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.device)
+        _lib.check(_lib.tape_lib().dispu_tn_reduce_grouped(n, ctypes.c_void_p(ctypes.addressof(g[0])), ctypes.c_void_p(dev.data_ptr()), g[2]),
+                   "dispu_tn_reduce_grouped")
+        g[1] = 0
+        g[3] = []
+
+    def _rg_flush(self):
+        for g in self._rg.values():
+            self._rg_flush_group(g)
+
     def _join(self):
         """the current stream waits for every dW product queued so far (before a buffer they read is overwritten, before Adam)."""
         self._flush()
+        self._rg_flush()                                 # each stream's pending split reductions: one launch per stream, behind its products
         for i, busy in enumerate(self._side_busy if self._sides else []):
             if busy:
                 ev = self._ev(self._join_evs[i])
@@ -552,9 +600,12 @@ class Trainer(object):
         _lib.check(self._dl(1, M, K, N, _p(X, xoff), X.stride(0), 0, _p(W, woff), W.stride(0), 0, 0, _p(b), act,
                                   _p(Y, yoff), Y.stride(0), 0, None, 0, 0, None, 0, 0, self.st), "dispu_linear")
 
-    def _tn(self, batch, M, K, N, X, xoff, ldx, sx, Zt, zoff, ldz, sz, out, ooff, ldo, so, accumulate, dbias=None, side=False, after=None):
+    def _tn(self, batch, M, K, N, X, xoff, ldx, sx, Zt, zoff, ldz, sz, out, ooff, ldo, so, accumulate, dbias=None, side=False, after=None,
+            wgrad=False):
         """out (+)= X^T . Zt.  side=True: on a side stream (the caller guarantees nothing overwrites X / Zt before _join), ordered after
-        `after` / the enclosing _fork_group's event / this point of the current stream; the launch itself may be deferred (_defer)."""
+        `after` / the enclosing _fork_group's event / this point of the current stream; the launch itself may be deferred (_defer).
+        wgrad=True: `out` is a weight gradient -- nothing reads it before _join(), so its split reduction may wait for the stream's
+        grouped launch (Trainer.group_reduce)."""
         L = _lib.tape_lib()
         side = side and self.overlap_dw
         sto = (1 if X.dtype == torch.bfloat16 else 0) | (2 if Zt.dtype == torch.bfloat16 else 0)
@@ -568,7 +619,21 @@ class Trainer(object):
             need = max(need, tn_stream)
 
         def launch(st, key):
+            slot = None
+            if self.group_reduce and wgrad and batch == 1 and (key is not None or self._cur == "main"):
+                # a scratch buffer of this product's own (it must survive until the grouped reduction) and a descriptor slot of its stream
+                key = ("tn", out.data_ptr() + 4 * ooff, K, N)
+                slot = self._rg_slot(st, out.data_ptr() + 4 * ooff, dbias.data_ptr() if dbias is not None else 0)
             sc = self._scratch_floats(need, key)
+            if slot is not None:
+                _lib.check(L.dispu_tn_defer(slot[0]), "dispu_tn_defer")
+            try:
+                launch_product(st, sc)
+            finally:
+                if slot is not None:
+                    self._rg_commit(slot)
+
+        def launch_product(st, sc):
             if tn_stream:
                 _lib.check(L.dispu_linear_tn_bf16_stream(M, K, N, _p(X), ldx, _p(Zt), ldz, sto, _p(out, ooff), ldo, accumulate, _p(dbias), _p(sc),
                                                          sc.numel(), st), "dispu_linear_tn_bf16_stream")
@@ -657,7 +722,8 @@ class Trainer(object):
         if dX is not None:
             WT = self.PT.get(wname + "/weights") if (wname is not None and woff == 0 and self.use_wt and K == W.shape[0]) else None
             self._dx(M, N, K, dY, dyoff, W, woff, dX, dxoff, acc_dx, mask, WT)
-        self._tn(1, M, K, N, X, xoff, X.stride(0), 0, dY, dyoff, dY.stride(0), 0, dW, woff, dW.stride(0), 0, 1, dbias=db, side=side, after=ev)
+        self._tn(1, M, K, N, X, xoff, X.stride(0), 0, dY, dyoff, dY.stride(0), 0, dW, woff, dW.stride(0), 0, 1, dbias=db, side=side, after=ev,
+                 wgrad=True)
 
     # ----------------------------------------------------------------------------------------------- forward ----
     def forward(self, inputs):
@@ -1108,7 +1174,7 @@ class Trainer(object):
                 self._lin_bwd(ws["up256"], 0, 256, c2, 128, dup128, 0)
                 w1, dw1 = P["generator/upshuffle_0/conv1/weights"], G["generator/upshuffle_0/conv1/weights"]
                 self._tn(1, rm, 2, 256, ws["gcode"], 0, 2, 0, ws["dup256"], 0, 256, 0, dw1, 480 * 256, 256, 0, 1,
-                         dbias=G["generator/upshuffle_0/conv1/biases"], side=True)     # read by Adam only: off the chain like every other dW
+                         dbias=G["generator/upshuffle_0/conv1/biases"], side=True, wgrad=True)   # read by Adam only: off the chain like every other dW
         else:
             self._lin_bwd(ws["c64"], 0, 64, cs + "fc_layer2", 3, dcoarse, 0, ws["dc64"], mask=(ws["c64"], 0, 64))
             self._lin_bwd(ws["c256"], 0, 256, cs + "fc_layer1", 64, ws["dc64"], 0, ws["dc256"], mask=(ws["c256"], 0, 256))
@@ -1215,6 +1281,7 @@ class Trainer(object):
         if ar is None or _lib.taping() is not None or torch.cuda.is_current_stream_capturing() or ar.launched(i):
             return
         self._flush()                                    # deferred weight gradients of the bucket go to their streams first
+        self._rg_flush()                                 # ... and their pending split reductions
         evs = []
         for s in [torch.cuda.current_stream(self.device)] + list(self._sides):
             ev = torch.cuda.Event()

@@ -398,6 +398,21 @@ long dispu_linear_tn_scratch_floats(int batch, int M, int K, int N);
 int dispu_linear_tn(int batch, int M, int K, int N, const float* X, long ldx, long sx, const float* Z, long ldz, long sz,
                     float* out, long ldo, long so, int accumulate, float* dbias, float* scratch, long scratch_floats,
                     void* stream);
+/* Deferred split reductions (ABI 5; csrc/train_gemm.hip).  The training step has ~20 weight-gradient products, each followed by its own
+ * 4 - 25 us reduction launch that only Adam waits for.  dispu_tn_defer(&desc) arms a ONE-SHOT, per-thread sink: the next dispu_linear_tn /
+ * dispu_linear_tn_bf16(s) / dispu_linear_tn_bf16_stream call on this thread (batch == 1) launches its product only and fills `desc` with the
+ * reduction it left undone (desc.splits == 0: it left none); its `scratch` must then stay untouched until dispu_tn_reduce_grouped has run
+ * those descriptors -- any number of them in ONE launch, `table_device` being a device copy of `table_host` (count entries), on a stream
+ * ordered after the products.  Same association as the products' own reductions: bit-identical results.  Descriptors of one call must not
+ * alias each other's `out` rows or `dbias`. */
+typedef struct dispu_tn_reduce_desc {
+    const float* part; float* out; float* dbias;
+    long ldo, stride;
+    int K, N, splits, rows_p;
+    int accumulate, bias_accumulate, assoc, reserved;
+} dispu_tn_reduce_desc;
+int dispu_tn_defer(dispu_tn_reduce_desc* desc);
+int dispu_tn_reduce_grouped(int count, const dispu_tn_reduce_desc* table_host, const dispu_tn_reduce_desc* table_device, void* stream);
 long dispu_act_bias_grad_scratch_floats(long rows, int n);
 /* dZ = dY * (act ? Y > 0 : 1) (relu_grad; dZ may alias dY or be NULL), dbias (+)= column sums of dZ (bias_add_grad;
  * dbias may be NULL).  tf_util.py:100-115,170-185. */

@@ -327,7 +327,9 @@ def test_mlp_chain_stash_equals_separate_launches(dev, L, shape, mode):
 
 
 @pytest.mark.parametrize("shape,fine,rows", [((256, 128, 256), False, 384), ((256, 256, 256), True, 384), ((256, 128, 256), False, 8192),
-                                             ((256, 256, 256), True, 64)])
+                                             ((256, 256, 256), True, 64),
+                                             # 64-row workgroups (>= 192 of them) and a row count only 32-row workgroups tile
+                                             ((256, 256, 256), True, 16384), ((256, 128, 256), False, 12288), ((256, 128, 256), False, 96)])
 def test_mlp_chain_grad(dev, L, shape, fine, rows):
     """dispu_mlp_chain_grad (csrc/mlp_chain_bwd.hip): the four dX products of a head chain's backward in one launch against float64
     autograd of the chain X -> relu(X W1) -> relu(. W2) -> relu(. W3) -> . W4 (ops.py:1186-1192, 1089-1108, 1079-1083).  coarse: the
@@ -509,3 +511,102 @@ def test_attention_train_refuses_unsupported_shapes(dev, L):
     assert bad != 0
     bad = L.lib().dispu_attention_fwd_lse(1, 64, 64, 64, p(t), 66, p(t), 64, p(t), 64, 0.125, p(t), 64, p(v), st)     # unaligned rows
     assert bad != 0
+
+
+# ---------------------------------------------------------------------------------------- round 6: grouped split reductions ----
+def test_deferred_reductions_in_one_grouped_launch_equal_the_products_own(dev, L):
+    """dispu_tn_defer + dispu_tn_reduce_grouped (csrc/train_gemm.hip): five weight-gradient products of the four TN kernels (tiled fp32,
+    narrow fp32, bf16, streaming bf16 with fp32- and bf16-stored operands; accumulate on and off, with and without a bias gradient,
+    a non-multiple-of-4 width) leave their reductions to ONE grouped launch -- bit-identical to each product reducing itself.  The sink is
+    one-shot: the call after a deferred one reduces itself again; batched products ignore it."""
+    lib = L.lib()
+    st = L.stream_ptr(dev)
+    rng = np.random.default_rng(66)
+    jobs = [  # (kind, M, K, N, accumulate, bias)
+        ("f32", 8192, 256, 128, 1, True), ("f32", 8192, 64, 24, 1, True), ("f32", 5000, 134, 255, 0, False),
+        ("bf16", 8192, 256, 64, 1, True), ("stream", 8192, 2048, 256, 1, True), ("stream16", 16384, 128, 128, 0, True)]
+    descs = (L.TnReduceDesc * len(jobs))()
+    want, got, keep = [], [], []
+    for i, (kind, M, K, N, acc, bias) in enumerate(jobs):
+        x = dv(rng.standard_normal((M, K)).astype(np.float32), dev)
+        z = dv(rng.standard_normal((M, N)).astype(np.float32), dev)
+        if kind == "stream16":
+            x, z = x.to(torch.bfloat16), z.to(torch.bfloat16)
+            keep += [x, z]
+        o0 = rng.standard_normal((K, N)).astype(np.float32)
+        b0 = rng.standard_normal(N).astype(np.float32)
+
+        def call(out, db, sc, kind=kind, M=M, K=K, N=N, acc=acc, x=x, z=z):
+            if kind == "f32":
+                return lib.dispu_linear_tn(1, M, K, N, p(x), K, 0, p(z), N, 0, p(out), N, 0, acc, p(db), p(sc), sc.numel(), st)
+            if kind == "bf16":
+                return lib.dispu_linear_tn_bf16(1, M, K, N, p(x), K, 0, p(z), N, 0, p(out), N, 0, acc, p(db), p(sc), sc.numel(), st)
+            return lib.dispu_linear_tn_bf16_stream(M, K, N, p(x), K, p(z), N, 3 if kind == "stream16" else 0, p(out), N, acc, p(db), p(sc), sc.numel(), st)
+        need = max({"f32": lib.dispu_linear_tn_scratch_floats(1, M, K, N), "bf16": lib.dispu_linear_tn_bf16_scratch_floats(1, M, K, N)}.get(
+            kind, lib.dispu_linear_tn_bf16_stream_scratch_floats(M, K, N)), 4)
+        res = []
+        for deferred in (False, True):
+            out, db = dv(o0, dev), (dv(b0, dev) if bias else None)
+            sc = torch.empty(need, dtype=torch.float32, device=dev)
+            keep.append(sc)
+            if deferred:
+                L.check(lib.dispu_tn_defer(C.c_void_p(C.addressof(descs) + i * C.sizeof(L.TnReduceDesc))), "defer")
+            L.check(call(out, db, sc), kind)
+            res.append((out, db))
+        assert descs[i].splits > 1 and descs[i].K == K and descs[i].N == N, (kind, descs[i].splits)
+        want.append(res[0])
+        got.append(res[1])
+    raw = C.string_at(C.addressof(descs), C.sizeof(descs))
+    table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev)
+    torch.cuda.synchronize()
+    for (o, b), (kind, M, K, N, acc, bias) in zip(got, jobs):          # nothing reduced yet: the destinations still hold their start values
+        assert not torch.equal(o, want[jobs.index((kind, M, K, N, acc, bias))][0])
+    L.check(lib.dispu_tn_reduce_grouped(len(jobs), C.c_void_p(C.addressof(descs)), C.c_void_p(table.data_ptr()), st), "grouped")
+    torch.cuda.synchronize()
+    for (wo, wb), (go, gb), job in zip(want, got, jobs):
+        assert torch.equal(wo, go), job
+        assert wb is None or torch.equal(wb, gb), job
+    # one-shot: with nothing armed the product reduces itself; a batched product disarms the sink and reduces itself too
+    d1 = (L.TnReduceDesc * 1)()
+    x = dv(rng.standard_normal((2, 512, 64)).astype(np.float32), dev)
+    z = dv(rng.standard_normal((2, 512, 32)).astype(np.float32), dev)
+    o1, o2 = torch.zeros((2, 64, 32), device=dev), torch.zeros((2, 64, 32), device=dev)
+    sc = torch.empty(max(lib.dispu_linear_tn_scratch_floats(2, 512, 64, 32), 4), dtype=torch.float32, device=dev)
+    L.check(lib.dispu_linear_tn(2, 512, 64, 32, p(x), 64, 512 * 64, p(z), 32, 512 * 32, p(o1), 32, 64 * 32, 0, None, p(sc), sc.numel(), st), "tn")
+    L.check(lib.dispu_tn_defer(C.c_void_p(C.addressof(d1))), "defer")
+    L.check(lib.dispu_linear_tn(2, 512, 64, 32, p(x), 64, 512 * 64, p(z), 32, 512 * 32, p(o2), 32, 64 * 32, 0, None, p(sc), sc.numel(), st), "tn")
+    torch.cuda.synchronize()
+    assert d1[0].splits == 0 and torch.equal(o1, o2)
+    close(N_(o1), np.einsum("bmk,bmn->bkn", N_(x).astype(np.float64), N_(z).astype(np.float64)), 1e-5, "batched TN")
+    assert lib.dispu_tn_reduce_grouped(1, C.c_void_p(C.addressof(d1)), C.c_void_p(table.data_ptr()), st) != 0      # splits == 0: refused
+    assert lib.dispu_tn_reduce_grouped(0, None, None, st) == 0
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_trainer_grouped_reductions_equal_single_ones(dev, dtype):
+    """Trainer.group_reduce (the step's ~20 split reductions as one launch per stream) against every product reducing itself: the same
+    gradients (float atomics elsewhere in the backward move the last bits: 1e-6 of the largest gradient), taped steps included."""
+    from dispu_amd import synth
+    from dispu_amd.params import init_params
+    from dispu_amd.train import Trainer
+    P = init_params(1234)
+    x, gt = synth.patch_with_gt(8, 256, 1024, seed=11)
+    x, gt = torch.from_numpy(x).to(dev), torch.from_numpy(gt).to(dev)
+    radius = torch.ones(8, device=dev)
+    g = {}
+    for on in (False, True):
+        tr = Trainer(params=P, device=dev, dtype=dtype)
+        tr.group_reduce = on
+        tr.zero_grad()
+        tr.forward(x)
+        tr.loss_backward(gt, radius)
+        tr.backward()
+        torch.cuda.synchronize()
+        g[on] = tr.flat_g.clone()
+        if on:
+            assert len(tr._rg_dev) >= 1 and all(grp[1] == 0 for grp in tr._rg.values())
+            for _ in range(3):
+                terms = tr.train_step_taped(x, gt, radius)
+            assert np.isfinite(float(terms["pu_loss"]))
+    scale = float(g[False].abs().max())
+    assert float((g[True] - g[False]).abs().max()) <= 5e-6 * scale

@@ -34,6 +34,7 @@ def main():
     ap.add_argument("--no-bf16-stream", action="store_true", help="A/B: dtype bf16 without the streaming bf16 kernel (Trainer.bf16_stream = False)")
     ap.add_argument("--bf16-min-macs", type=float, default=0.0, help="Trainer.bf16_min_macs (A/B)")
     ap.add_argument("--no-bf16-tn", action="store_true", help="A/B: Trainer.bf16_tn = False")
+    ap.add_argument("--no-group-reduce", action="store_true", help="A/B: every weight-gradient product launches its own split reduction (Trainer.group_reduce = False)")
     ap.add_argument("--tape", action="store_true", help="forward + loss + backward re-issued from a launch tape (Trainer.train_step_taped)")
     args = ap.parse_args()
     from dispu_amd import synth
@@ -60,6 +61,8 @@ def main():
         tr.bf16_stream = False
     if args.no_tail_on_chain:
         tr.tail_on_chain = False
+    if args.no_group_reduce:
+        tr.group_reduce = False
     x, gt = synth.patch_with_gt(args.batch, 256, 1024, seed=5000 + rank)
     x, gt = torch.from_numpy(x).to(dev), torch.from_numpy(gt).to(dev)
     radius = torch.ones(args.batch, device=dev)
