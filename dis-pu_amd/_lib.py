@@ -101,6 +101,7 @@ SIGNATURES = {
     "dispu_linear_tn_bf16": (_i, [_i, _i, _i, _i, _vp, _l, _l, _vp, _l, _l, _vp, _l, _l, _i, _vp, _vp, _l, _vp]),
     "dispu_bf16x3_split_weights": (_i, [_i, _i, _vp, _l, _vp, _vp]),
     "dispu_linear_bf16x3": (_i, [_i, _i, _i, _vp, _l, _vp, _vp, _i, _vp, _l, _vp, _l, _vp, _l, _vp]),
+    "dispu_debug_x3_kernel": (None, [_i]),
     "dispu_linear_tn_scratch_floats": (_l, [_i, _i, _i, _i]),
     "dispu_linear_tn": (_i, [_i, _i, _i, _i, _vp, _l, _l, _vp, _l, _l, _vp, _l, _l, _i, _vp, _vp, _l, _vp]),
     "dispu_tn_defer": (_i, [_vp]),

@@ -356,12 +356,182 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_ws_kernel(X3Args a) {
         }
 }
 
+// ---- round 6: the same products as operand STREAMS (the design of csrc/linear_bf16_stream.hip) ------------------------------------
+// gemm_bf16x3_ws_kernel spends its time in the loader waves: 1.2 M fp32 values per launch and CU are split into three bf16 terms by
+// four waves that also carry every operand byte through registers (~200 us for the after_conv shape, 6 MFMAs per 16 k notwithstanding).
+// Here nothing is carried: a 32-k slab of X (128 rows x 128 B of fp32) and the slab image of the three W planes (48 KB, already in its
+// swizzled stage layout: dispu_bf16x3_split_weights) go global -> LDS by DMA (global_load_lds_dwordx4), two stages, one slab in flight;
+// ALL eight waves compute (4 x 2 wave grid: 32 rows x 128 columns each) and a wave splits its own A fragment -- 8 consecutive k of one
+// row, two ds_read_b128 -- on the VALU, in the shadow of the 24 MFMAs the fragment feeds.  The X bank swizzle is applied on the global
+// side (the lane that lands at 16-byte position p of row r fetches chunk p ^ (r & 7)).  Same products in the same order per
+// accumulator as the kernels above: bit-identical results.
+constexpr int S3_BM = 128, S3_BN = 256, S3_BK = 32, S3_NST = 2;
+constexpr int S3_A_BYTES = S3_BM * S3_BK * 4;             // 16 KB
+constexpr int S3_B_BYTES = W3_B_STAGE * 2;                // 48 KB
+constexpr int S3_STAGE = S3_A_BYTES + S3_B_BYTES;         // 64 KB
+constexpr size_t S3_LDS_BYTES = (size_t)S3_NST * S3_STAGE;
+static_assert(S3_BN == W3_BN && S3_BK == W3_BK, "the stream kernel reads the wave-specialised kernel's slab-major planes");
+
+__global__ __launch_bounds__(512) void gemm_bf16x3_stream_kernel(X3Args a) {
+    extern __shared__ __attribute__((aligned(16))) char s3_lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1, li = lane & 31, kq = lane >> 5;
+    const int m0 = blockIdx.y * S3_BM, n0 = blockIdx.x * S3_BN;
+    const int nt = a.K / S3_BK;
+
+    // this wave's 1 KB pieces of a slab: X pieces wave, wave + 8 (8 rows x 128 B each), W pieces wave + 8 u, u < 6 (contiguous)
+    const char* gx[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int q = wave + 8 * u, r = 8 * q + (lane >> 3), p = lane & 7;
+        gx[u] = reinterpret_cast<const char*>(a.X + (size_t)(m0 + r) * a.ldx + 4 * (p ^ (r & 7)));
+    }
+    const char* gw = reinterpret_cast<const char*>(a.Wp + (size_t)blockIdx.x * nt * W3_B_STAGE) + (size_t)wave * 1024 + lane * 16;
+    auto issue = [&](int t) {
+        char* st = s3_lds + (t & 1) * S3_STAGE;
+#ifdef S3_NOX                                                 // lab (tools/debug/x3_lab.py): only the first two slabs' X / W pieces are fetched --
+        if (t < 2)                                            // wrong results, the time that is left is what the OTHER operand's stream costs
+#endif
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {   // (float pointers: with char* operands to the DMA builtin the host pass silently drops the kernel's stub)
+            const float* src = reinterpret_cast<const float*>(gx[u] + (size_t)t * (S3_BK * 4));
+            float* dst = reinterpret_cast<float*>(st + (wave + 8 * u) * 1024);
+            __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        }
+#ifdef S3_NOW
+        if (t < 2)
+#endif
+#pragma unroll
+        for (int u = 0; u < 6; ++u) {
+            const float* src = reinterpret_cast<const float*>(gw + (size_t)t * S3_B_BYTES + u * 8192);
+            float* dst = reinterpret_cast<float*>(st + S3_A_BYTES + (wave + 8 * u) * 1024);
+            __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        }
+    };
+
+    x3_f32x16 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+    // fragment addresses inside a stage (bytes)
+    const int arow = wm * 32 + li, a_row = arow * 128, a_sw = arow & 7;
+    int boff[4][2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int col = wn * 128 + j * 32 + li;
+            boff[j][ks] = S3_A_BYTES + 2 * (col * W3_BK + (((2 * ks + kq) ^ ((col >> 2) & 3)) * 8));
+        }
+    constexpr int PLANE = W3_BN * W3_BK * 2;                  // bytes between the planes of a stage
+
+    // The split of a fragment on the VALU, two values per step, as explicit instructions: v_cvt_pk_bf16_f32 packs (first, second) value into
+    // (low, high) half -- the element order of the MFMA operand, no permutes -- and the subtractions stay single v_sub_f32 (left to the
+    // compiler they are SLP-packed into v_pk_add_f32, which costs ~25 extra cycles apiece next to MFMAs: MI355X_MICROARCH.md).  Same
+    // arithmetic as x3_split, element for element.
+    typedef unsigned int s3_u32x4 __attribute__((ext_vector_type(4)));
+    auto cvt_pk = [](float x0, float x1) -> unsigned int {
+        unsigned int r;
+        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(x0), "v"(x1));
+        return r;
+    };
+    auto sub = [](float x, float y) -> float {
+        float r;
+        asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
+        return r;
+    };
+    auto split8 = [&](const float4& lo, const float4& hi, x3_bf16x8 (&fa)[3]) {
+        const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        s3_u32x4 p0, p1, p2;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const unsigned int q0 = cvt_pk(v[2 * e], v[2 * e + 1]);
+            const float r0 = sub(v[2 * e], __uint_as_float(q0 << 16)), r1 = sub(v[2 * e + 1], __uint_as_float(q0 & 0xffff0000u));
+            const unsigned int q1 = cvt_pk(r0, r1);
+            const float s0 = sub(r0, __uint_as_float(q1 << 16)), s1 = sub(r1, __uint_as_float(q1 & 0xffff0000u));
+            p0[e] = q0; p1[e] = q1; p2[e] = cvt_pk(s0, s1);
+        }
+        fa[0] = __builtin_bit_cast(x3_bf16x8, p0);
+        fa[1] = __builtin_bit_cast(x3_bf16x8, p1);
+        fa[2] = __builtin_bit_cast(x3_bf16x8, p2);
+    };
+    const int a_off[2][2] = {{a_row + (((2 * kq) ^ a_sw) << 4), a_row + (((2 * kq + 1) ^ a_sw) << 4)},
+                             {a_row + (((4 + 2 * kq) ^ a_sw) << 4), a_row + (((5 + 2 * kq) ^ a_sw) << 4)}};
+
+    issue(0);
+    for (int t = 0; t < nt; ++t) {
+        // slab t has landed (this wave's pieces: vmcnt, everybody's: barrier); everybody has finished reading slab t - 1, whose stage
+        // slab t + 1 may now overwrite
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_barrier" ::: "memory");
+        if (t + 1 < nt) issue(t + 1);
+        const char* st = s3_lds + (t & 1) * S3_STAGE;
+        // k-step 0: its A fragment is read and split in the open (nothing of this slab could be read before the barrier); k-step 1's is
+        // read right away and split between the MFMAs of step 0
+        x3_bf16x8 fa0[3], fa1[3], fb[4][3];
+        {
+            const float4 lo = *reinterpret_cast<const float4*>(st + a_off[0][0]), hi = *reinterpret_cast<const float4*>(st + a_off[0][1]);
+            split8(lo, hi, fa0);
+        }
+#ifndef S3_NOSCHED
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+        const float4 lo1 = *reinterpret_cast<const float4*>(st + a_off[1][0]), hi1 = *reinterpret_cast<const float4*>(st + a_off[1][1]);
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) fb[j][p] = *reinterpret_cast<const x3_bf16x8*>(st + p * PLANE + boff[j][0]);
+        // six rounds over the four blocks, smallest partial products first: consecutive MFMAs never share an accumulator
+#define S3_ROUND(FA, PA, PB)                                                                                         \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                                \
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[PA], fb[j][PB], acc[j], 0, 0, 0);
+        S3_ROUND(fa0, 2, 0) S3_ROUND(fa0, 1, 1) S3_ROUND(fa0, 0, 2) S3_ROUND(fa0, 1, 0) S3_ROUND(fa0, 0, 1) S3_ROUND(fa0, 0, 0)
+        split8(lo1, hi1, fa1);
+#ifndef S3_NOSCHED
+        // pin: the 12 B reads in front, then every MFMA of step 0 followed by two of the 44 split instructions of step 1
+        __builtin_amdgcn_sched_group_barrier(0x100, 14, 0);
+#pragma unroll
+        for (int i = 0; i < 24; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) fb[j][p] = *reinterpret_cast<const x3_bf16x8*>(st + p * PLANE + boff[j][1]);
+        S3_ROUND(fa1, 2, 0) S3_ROUND(fa1, 1, 1) S3_ROUND(fa1, 0, 2) S3_ROUND(fa1, 1, 0) S3_ROUND(fa1, 0, 1) S3_ROUND(fa1, 0, 0)
+#undef S3_ROUND
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int col = n0 + wn * 128 + j * 32 + li;
+        const float bv = a.bias ? a.bias[col] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * kq;
+            float v = acc[j][r] + bv;
+            if (a.act == 1) v = fmaxf(v, 0.f);
+            if (a.R1) v += a.R1[(long)row * a.ldr1 + col];
+            if (a.R2) v += a.R2[(long)row * a.ldr2 + col];
+            a.Y[(long)row * a.ldy + col] = v;
+        }
+    }
+}
+
 }  // namespace dispu
 
 using namespace dispu;
 
 // the wave-specialised kernel and its slab-major planes wherever the shape allows (round 2's single-role kernel otherwise)
 static bool x3_use_ws() { return true; }
+// which kernel takes the slab-major shapes: 0 = the streaming kernel of round 6, 1 = round 4's wave-specialised one (A/B: tools/debug/x3_lab.py,
+// tests); same planes, bit-identical results
+static int g_x3_kernel = 0;
+DISPU_EXPORT void dispu_debug_x3_kernel(int which) { g_x3_kernel = which; }
 
 // planes: 3 * K * N bf16 values (6 K N bytes), [plane][n][k]
 DISPU_EXPORT int dispu_bf16x3_split_weights(int K, int N, const float* W, long ldw, void* planes, void* stream) {
@@ -396,6 +566,15 @@ DISPU_EXPORT int dispu_linear_bf16x3(int M, int K, int N, const float* X, long l
         if (attr2.needed()) {
             DISPU_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x3_ws_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)W3_LDS_BYTES));
             attr2.done();
+        }
+        if (g_x3_kernel == 0 && (((uintptr_t)planes) & 15) == 0) {
+            static DevOnce attr3;
+            if (attr3.needed()) {
+                DISPU_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16x3_stream_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)S3_LDS_BYTES));
+                attr3.done();
+            }
+            hipLaunchKernelGGL(gemm_bf16x3_stream_kernel, dim3((unsigned)(N / S3_BN), (unsigned)(M / S3_BM)), dim3(512), S3_LDS_BYTES, (hipStream_t)stream, a);
+            return (int)hipGetLastError();
         }
         hipLaunchKernelGGL(gemm_bf16x3_ws_kernel, dim3((unsigned)(N / W3_BN), (unsigned)(M / W3_BM)), dim3(512), W3_LDS_BYTES, (hipStream_t)stream, a);
         return (int)hipGetLastError();

@@ -1149,6 +1149,10 @@ class Trainer(object):
             _lib.check(L.dispu_ps_skip_max_grad(rm, M, k, 128, _p(ws["psidx"]), _p(coarse), _p(ws["up128"]), 128, _p(ws["gmax"]), 144,
                                                 _p(ws["dgmax"]), 136, _p(dcoarse), _p(dup128), 128, 1, self.st), "ps_skip_max_grad")
         self._merge(2)                                   # the weight net's share of dcoarse
+        # the refine branch's weight-gradient products submitted so far (after_conv's 2048 x 256 with its ~100 MB of partials among them)
+        # get their grouped reduction HERE, in the shadow of the coarse chain's backward; whatever is left at _join() is small.  (All of
+        # them at _join(): 35 us of reductions between the last product and Adam.)
+        self._rg_flush()
         self._bucket_point(0)                            # data parallel: every refine/* gradient is queued -> its all-reduce starts
 
         # coarse regressor

@@ -31,7 +31,7 @@ for Cc in (48, 24):
     st = torch.cuda.current_stream().cuda_stream
     for it in range(3):
         rc = L.dispu_stem_block(npts, n, Cc, vp(F.data_ptr()), C.c_long(Cc), 17, 1, *[vp(w.data_ptr()) for w in W], vp(Y.data_ptr()), C.c_long(ld),
-                                vp(idx.data_ptr()), vp(Wp.data_ptr()), vp(Wp.data_ptr()), k_old, vp(Pb.data_ptr()), C.c_long(48), vp(st))
+                                vp(idx.data_ptr()), vp(Wp.data_ptr()), vp(Wp.data_ptr()), k_old, vp(Pb.data_ptr()), C.c_long(48), None, None, None, None, C.c_long(0), vp(st))
         assert rc == 0, rc
     torch.cuda.synchronize()
     stamps = Y[npts * ld:npts * ld + 8 * 16 * 2].cpu().numpy().view(np.uint64).reshape(8, 16)
@@ -43,7 +43,7 @@ for Cc in (48, 24):
     e0.record()
     for it in range(50):
         L.dispu_stem_block(npts, n, Cc, vp(F.data_ptr()), C.c_long(Cc), 17, 1, *[vp(w.data_ptr()) for w in W], vp(Y.data_ptr()), C.c_long(ld),
-                           None, vp(Wp.data_ptr()), vp(Wp.data_ptr()), k_old, vp(Pb.data_ptr()), C.c_long(48), vp(st))
+                           None, vp(Wp.data_ptr()), vp(Wp.data_ptr()), k_old, vp(Pb.data_ptr()), C.c_long(48), None, None, None, None, C.c_long(0), vp(st))
     e1.record()
     torch.cuda.synchronize()
     print("  %.2f us per launch (back to back)" % (e0.elapsed_time(e1) * 1000 / 50))

@@ -27,20 +27,26 @@ assert L.dispu_bf16x3_split_weights(K, N, vp(w.data_ptr()), C.c_long(N), vp(plan
 def run():
     return L.dispu_linear_bf16x3(M, K, N, vp(x.data_ptr()), C.c_long(K), vp(planes.data_ptr()), vp(b.data_ptr()), 1, vp(y.data_ptr()), C.c_long(N),
                                  None, C.c_long(0), None, C.c_long(0), vp(st))
-for _ in range(5):
-    assert run() == 0
-torch.cuda.synchronize()
-e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-ts = []
-for rep in range(5):
-    e0.record()
-    for _ in range(10):
-        run()
-    e1.record()
+L.dispu_debug_x3_kernel.restype = None
+outs = {}
+for which, name in (((1, "wave-specialised (round 4)"),) if not sys.argv[1:] else ()) + ((0, "streaming (round 6)"),):
+    L.dispu_debug_x3_kernel(which)
+    for _ in range(5):
+        assert run() == 0
     torch.cuda.synchronize()
-    ts.append(e0.elapsed_time(e1) * 100)
-print(" ".join(sys.argv[1:]) or "(production)", "us per launch:", " ".join("%.1f" % t for t in ts),
-      "| %.0f TFLOP/s fp32-equivalent" % (2.0 * M * K * N / min(ts) / 1e6))
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ts = []
+    for rep in range(5):
+        e0.record()
+        for _ in range(10):
+            run()
+        e1.record()
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1) * 100)
+    outs[which] = y.clone()
+    print("%-28s" % name, " ".join(sys.argv[1:]) or "(production)", "us per launch:", " ".join("%.1f" % t for t in ts),
+          "| %.0f TFLOP/s fp32-equivalent" % (2.0 * M * K * N / min(ts) / 1e6))
 if not sys.argv[1:]:
     want = torch.relu(x.double() @ w.double() + b.double())
-    print("max |err| vs float64:", float((y.double() - want).abs().max()), "of max", float(want.abs().max()))
+    print("max |err| vs float64:", float((y.double() - want).abs().max()), "of max", float(want.abs().max()),
+          "| the two kernels bit-identical:", bool(torch.equal(outs[0], outs[1])))
