@@ -69,9 +69,23 @@ __device__ unsigned long long mc_clock_ticks[4];
 template <int K, int N, int BM>
 __device__ __forceinline__ void chain_layer(float* act, const float* wst, int g0, const float* __restrict__ bias, float* __restrict__ Yg,
                                             long ldy, long row0, int wm, int wn, int fi, int fk MC_WAIT_PARAM) {
-    constexpr int TNW = N / 64;                                   // 32-wide column blocks per wave (2 x 2 waves over BM x N)
+    // the four MFMA waves as WMW x WNW over BM x N: 2 x 2 (a wave owns BM / 2 rows, N / 2 columns), or 1 x 4 for the 32-row workgroups
+    // of small batches (round 6: 8192 rows as 256 workgroups instead of 128) -- where a layer is narrower than 4 x 32 columns (N3 = 64)
+    // only its first N / 32 waves work, the others keep the barrier count
+    constexpr int WMW = (BM >= 64) ? 2 : 1, WNW = 4 / WMW;
+    constexpr int COLS = (N / WNW >= 32) ? N / WNW : 32, NACT = N / COLS;      // columns per wave, waves along N that have columns
+    constexpr int TNW = COLS / 32;                                // 32-wide column blocks per wave
     constexpr int LDW = N + 4, BK = mc_bk(N);
-    constexpr int RT = BM / 64, MC_LDA = BM + 1;                  // 32-row tiles per wave (a wave owns BM / 2 rows)
+    constexpr int RT = BM / (32 * WMW), MC_LDA = BM + 1, ROWS = BM / WMW;   // 32-row tiles per wave
+    constexpr int NS = K / BK, NSTEP = BK / 2;
+    if constexpr (NACT < WNW) {
+        if (wn >= NACT) {                                         // wave-uniform: no columns in this layer
+            for (int s = 0; s < NS; ++s) __syncthreads();
+            __syncthreads();
+            __syncthreads();
+            return;
+        }
+    }
     f32x16 acc[RT][TNW];
 #pragma unroll
     for (int i = 0; i < RT; ++i)
@@ -85,7 +99,6 @@ __device__ __forceinline__ void chain_layer(float* act, const float* wst, int g0
     // pipe drained (2600 - 2750 cycles of its own per slab, tools/micro/chain_lab.hip).  Reading ahead over the barrier needs slab
     // s + 1 COMPLETE while slab s is consumed: three weight stages, the loaders store slab g + 2 during slab g (and the input chunk
     // of slab g + 2 likewise).
-    constexpr int NS = K / BK, NSTEP = BK / 2;
     static_assert(NSTEP % 2 == 0, "the fragment double buffer starts every slab in set 0");
     float af[2][RT], bf[2][TNW];
 #ifdef MC_X_NOA
@@ -115,8 +128,8 @@ __device__ __forceinline__ void chain_layer(float* act, const float* wst, int g0
     {
         const float* ws = wst + st * MC_WST;
 #pragma unroll
-        for (int i = 0; i < RT; ++i) af[0][i] = MC_RDA(act[fk * MC_LDA + wm * (BM / 2) + i * 32 + fi]);
-        MC_RDB(bf[0], ws + fk * LDW + wn * (N / 2) + fi);
+        for (int i = 0; i < RT; ++i) af[0][i] = MC_RDA(act[fk * MC_LDA + wm * ROWS + i * 32 + fi]);
+        MC_RDB(bf[0], ws + fk * LDW + wn * COLS + fi);
     }
 #endif
     // unrolled by 4: the per-slab LDS addresses become immediates (one base per four slabs) instead of 6 - 8 VALU instructions per slab
@@ -136,12 +149,12 @@ __device__ __forceinline__ void chain_layer(float* act, const float* wst, int g0
             if (s2 + 1 < NSTEP) {
                 const int kk = 2 * (s2 + 1);
 #pragma unroll
-                for (int i = 0; i < RT; ++i) af[nxt][i] = MC_RDA(as[(kk + fk) * MC_LDA + wm * (BM / 2) + i * 32 + fi]);
-                MC_RDB(bf[nxt], ws + (kk + fk) * LDW + wn * (N / 2) + fi);
+                for (int i = 0; i < RT; ++i) af[nxt][i] = MC_RDA(as[(kk + fk) * MC_LDA + wm * ROWS + i * 32 + fi]);
+                MC_RDB(bf[nxt], ws + (kk + fk) * LDW + wn * COLS + fi);
             } else if (more) {                                     // first step of the next slab (uniform branch; its stage is complete)
 #pragma unroll
-                for (int i = 0; i < RT; ++i) af[nxt][i] = MC_RDA(as[(BK + fk) * MC_LDA + wm * (BM / 2) + i * 32 + fi]);
-                MC_RDB(bf[nxt], wsn + fk * LDW + wn * (N / 2) + fi);
+                for (int i = 0; i < RT; ++i) af[nxt][i] = MC_RDA(as[(BK + fk) * MC_LDA + wm * ROWS + i * 32 + fi]);
+                MC_RDB(bf[nxt], wsn + fk * LDW + wn * COLS + fi);
             }
 #endif
 #pragma unroll
@@ -179,13 +192,13 @@ __device__ __forceinline__ void chain_layer(float* act, const float* wst, int g0
     __syncthreads();                                              // every wave has finished reading this layer's input
 #pragma unroll
     for (int j = 0; j < TNW; ++j) {
-        const int n = wn * (N / 2) + j * 32 + fi;
+        const int n = wn * COLS + j * 32 + fi;
         const float bv = bias[n];
 #pragma unroll
         for (int i = 0; i < RT; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
+                const int row = wm * ROWS + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
                 const float v = fmaxf(acc[i][j][r] + bv, 0.f);
                 act[n * MC_LDA + row] = v;
                 if (Yg) Yg[(size_t)(row0 + row) * ldy + n] = v;
@@ -381,7 +394,7 @@ __global__ __launch_bounds__(512) void mlp_chain_kernel(ChainArgs a) {
     }
 
     // ------------------------------------------------------------------------------------------ MFMA waves
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = (BM >= 64) ? (wave >> 1) : 0, wn = (BM >= 64) ? (wave & 1) : wave;
     const int fi = lane & 31, fk = lane >> 5;
 #ifdef MC_CLOCK
     unsigned long long mc_wait_local = 0;
@@ -492,19 +505,22 @@ DISPU_EXPORT int dispu_mlp_chain_stash(long rows, int K0, int N1, int N2, int N3
                                        const float* W2, const float* b2, const float* W3, const float* b3, const float* W4, const float* b4,
                                        float* Y1, long ldy1, float* Y2, long ldy2, float* Y3, long ldy3, float* Z, long ldz, int mode,
                                        const float* R, long ldr, float* out, long ldo, void* stream) {
-    if (rows < 0 || (rows % 64) != 0 || (ldx & 3) || !X || !W1 || !W2 || !W3 || !W4 || !b1 || !b2 || !b3 || !b4 || !out ||
+    const bool stash = Y2 || Y3 || Z;
+    if (rows < 0 || (rows % (stash ? 32 : 64)) != 0 || (ldx & 3) || !X || !W1 || !W2 || !W3 || !W4 || !b1 || !b2 || !b3 || !b4 || !out ||
         (mode == 1 && !R) || ((((uintptr_t)X) | ((uintptr_t)W1) | ((uintptr_t)W2) | ((uintptr_t)W3)) & 15))
         return (int)hipErrorInvalidValue;
     if (rows == 0) return 0;
     ChainArgs a{rows, X, ldx, W1, b1, W2, b2, W3, b3, W4, b4, Y1, ldy1, Y2, ldy2, Y3, ldy3, Z, ldz, R, ldr, out, ldo, mode};
     hipStream_t s = (hipStream_t)stream;
-    const bool stash = Y2 || Y3 || Z;
     // 128-row workgroups once they fill the chip (>= 192 of them); below that (the training step's 8 patches = 8192 rows) 64-row
     // workgroups: twice as many, each streaming the same weights for half the rows.  Same arithmetic, bit-identical results.
     const bool small = (rows % MC_BM) != 0 || rows / MC_BM < 192;
+    // round 6, the stashing (training) variant: 32-row workgroups while 64-row ones would leave CUs idle (fewer than 192 of them: the
+    // 8-patch training step's 8192 rows are 128), or where the row count demands it
+    const bool tiny = stash && small && ((rows % 64) != 0 || rows / 64 < 192);
     const bool coarse = (K0 == 256 && N1 == 128 && N2 == 256 && N3 == 64), fine = (K0 == 256 && N1 == 256 && N2 == 256 && N3 == 64);
     if (!coarse && !fine) return (int)hipErrorInvalidValue;
-    const dim3 grid((unsigned)(rows / (small ? 64 : MC_BM)));
+    const dim3 grid((unsigned)(rows / (tiny ? 32 : small ? 64 : MC_BM)));
     auto launch = [&](auto kern) -> int {
         static DevOnce once;                                   // per instantiation of this generic lambda, per device
         if (once.needed()) {
@@ -515,8 +531,9 @@ DISPU_EXPORT int dispu_mlp_chain_stash(long rows, int K0, int N1, int N2, int N3
         return (int)hipGetLastError();
     };
 #define MC_PICK(K0_, N1_) \
+    tiny ? launch(mlp_chain_kernel<K0_, N1_, 256, 64, 32, true>) : \
     (small ? (stash ? launch(mlp_chain_kernel<K0_, N1_, 256, 64, 64, true>) : launch(mlp_chain_kernel<K0_, N1_, 256, 64, 64, false>)) \
            : (stash ? launch(mlp_chain_kernel<K0_, N1_, 256, 64, 128, true>) : launch(mlp_chain_kernel<K0_, N1_, 256, 64, 128, false>)))
-    return coarse ? MC_PICK(256, 128) : MC_PICK(256, 256);
+    return coarse ? (MC_PICK(256, 128)) : (MC_PICK(256, 256));
 #undef MC_PICK
 }

@@ -295,12 +295,12 @@ def test_point_matmul_grad_relu(dev, L):
     close(N_(dwv).reshape(rows, k, t), wt.grad.numpy(), 1e-5, "dwv")
 
 
+@pytest.mark.parametrize("rows", [384, 96, 12288, 24576])       # 32-row workgroups (< 192 of 64 rows; 96: only 32 divides), 64-row, 128-row
 @pytest.mark.parametrize("shape,mode", [((256, 128, 256, 64), 0), ((256, 256, 256, 64), 1)])
-def test_mlp_chain_stash_equals_separate_launches(dev, L, shape, mode):
+def test_mlp_chain_stash_equals_separate_launches(dev, L, shape, mode, rows):
     """dispu_mlp_chain_stash: the stashed Y1 / Y2 / Y3 / Z and the head output are bit-identical to the dispu_linear /
     dispu_linear_small_n launches of the same layers (the training forward of the two head chains, ops.py:1089-1110, 1186-1192)."""
     rng = np.random.default_rng(sum(shape))
-    rows = 384
     K0, N1, N2, N3 = shape
     X = rng.standard_normal((rows, K0)).astype(np.float32)
     Ws = [(rng.standard_normal((a, b)) / np.sqrt(a)).astype(np.float32) for a, b in ((K0, N1), (N1, N2), (N2, N3), (N3, 3))]
