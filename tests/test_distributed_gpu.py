@@ -514,7 +514,14 @@ def _rccl_world1_worker(rank, world, port, q):
         s_plain = sorted(tloop(a) for _ in range(5))[2]
         s_coll = sorted(tloop(c) for _ in range(5))[2]
         s_thr = sorted(tloop(d) for _ in range(5))[2]
-        rel_d = float((d.flat_p - a.flat_p).norm() / a.flat_p.norm())     # 85 steps each from the same start: same trajectory up to float atomics
+        for t in (c, d):                                                  # one more step from a's exact state: the comm-thread trainer too
+            t.flat_p.copy_(a.flat_p); t.flat_m.copy_(a.flat_m); t.flat_v.copy_(a.flat_v)
+            t.moving_mean.copy_(a.moving_mean); t.moving_var.copy_(a.moving_var)
+            t.adam_t = a.adam_t
+        a.train_step(x, gt, radius)
+        d.train_step(x, gt, radius)
+        torch.cuda.synchronize()
+        rel_d = float((d.flat_p - a.flat_p).norm() / a.flat_p.norm())
         d._reducer().close()
         q.put((0, same, t_plain, t_gather, early, rel, s_plain, s_coll, s_thr, rel_d, t_gather_thr))
     finally:
@@ -541,7 +548,7 @@ def test_rccl_branch_on_one_rank(dev):
     assert same, "gathered clouds differ from the plain forward"
     assert early[:6] == [(0, True), (1, False)] * 3, early[:8]       # per step: refine bucket from inside backward(), the rest from finish()
     assert max(rel) <= 1e-4, rel                     # parameters after Adam; float atomics in the gradients (two evaluations of ONE trainer differ as much)
-    assert rel_d <= 1e-3, rel_d
+    assert rel_d <= 1e-4, rel_d
     # a collective call costs ~30 us of host time; these steps are launch-bound (8 patches, eager): one call per forward, two per train
     # step.  Bounds = that price + noise; the 32-patch bench step (host idle most of the time) must not move at all (next test).
     assert min(t_gather, t_gather_thr) <= t_plain + 0.045, (t_plain, t_gather, t_gather_thr)
