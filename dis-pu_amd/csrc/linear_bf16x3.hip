@@ -528,9 +528,11 @@ using namespace dispu;
 
 // the wave-specialised kernel and its slab-major planes wherever the shape allows (round 2's single-role kernel otherwise)
 static bool x3_use_ws() { return true; }
-// which kernel takes the slab-major shapes: 0 = the streaming kernel of round 6, 1 = round 4's wave-specialised one (A/B: tools/debug/x3_lab.py,
-// tests); same planes, bit-identical results
-static int g_x3_kernel = 0;
+// which kernel takes the slab-major shapes: 1 = round 4's wave-specialised one (the default), 0 = the streaming kernel of round 6; same planes,
+// bit-identical results.  On uniform random operands the streaming kernel is the faster one by a few per cent (205 - 216 vs 210 - 243 us at the
+// after_conv shape, tools/debug/x3_lab.py); inside the generator step, on the local cell's real F' tensor, it is 34 us SLOWER (0.880 vs 0.846 ms
+// per step on one stream, tools/debug/x3_step_ab.py) -- both sit at the chip's sustained bf16 matrix rate, see profiles/EXPERIMENTS.md
+static int g_x3_kernel = 1;
 DISPU_EXPORT void dispu_debug_x3_kernel(int which) { g_x3_kernel = which; }
 
 // planes: 3 * K * N bf16 values (6 K N bytes), [plane][n][k]

@@ -390,8 +390,8 @@ int dispu_linear_tn_bf16(int batch, int M, int K, int N, const float* X, long ld
 int dispu_bf16x3_split_weights(int K, int N, const float* W, long ldw, void* planes, void* stream);
 int dispu_linear_bf16x3(int M, int K, int N, const float* X, long ldx, const void* planes, const float* bias, int act, float* Y,
                         long ldy, const float* R1, long ldr1, const float* R2, long ldr2, void* stream);
-/* benchmarking aid (tools/debug/x3_lab.py, tests): 0 = the streaming kernel (default, round 6), 1 = round 4's wave-specialised kernel for
- * the N % 256 == 0 shapes; same planes, bit-identical results.  Not used by the product path. */
+/* benchmarking aid (tools/debug/x3_lab.py, x3_step_ab.py, tests): 1 = round 4's wave-specialised kernel (default), 0 = round 6's streaming kernel
+ * for the N % 256 == 0 shapes; same planes, bit-identical results.  Not used by the product path. */
 void dispu_debug_x3_kernel(int which);
 /* floats of scratch dispu_linear_tn needs for (batch, M, K, N). */
 long dispu_linear_tn_scratch_floats(int batch, int M, int K, int N);

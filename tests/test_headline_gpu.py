@@ -173,6 +173,39 @@ def test_split_bf16_gemm_shapes(dev, M, K, Nn):
         assert (N(y)[:, Nn:] == -3.0).all()
 
 
+@pytest.mark.parametrize("M,K,Nn", [(256, 2048, 256), (384, 160, 512)])
+def test_split_bf16_streaming_kernel_equals_wave_specialised(dev, M, K, Nn):
+    """Round 6's streaming split-bf16 kernel (operands by DMA, all eight waves compute, fragment split pipelined between the MFMAs;
+    dispu_debug_x3_kernel(0)) issues the same products in the same order per accumulator as round 4's wave-specialised kernel (the
+    default, 1): bit-identical outputs, with residuals and bias."""
+    from dispu_amd import _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(M + K)
+    x = np.maximum(rng.standard_normal((M, K)), 0).astype(np.float32)
+    w = (rng.standard_normal((K, Nn)) * 0.1).astype(np.float32)
+    b = rng.standard_normal(Nn).astype(np.float32)
+    r1 = rng.standard_normal((M, Nn)).astype(np.float32)
+    tx, tw, tb, t1 = (torch.from_numpy(a).to(dev) for a in (x, w, b, r1))
+    planes = torch.empty(3 * K * Nn, dtype=torch.bfloat16, device=dev)
+    st = _lib.stream_ptr(dev)
+    _lib.check(L.dispu_bf16x3_split_weights(K, Nn, tw.data_ptr(), Nn, planes.data_ptr(), st), "split")
+    ys = {}
+    try:
+        for which in (1, 0):
+            L.dispu_debug_x3_kernel(which)
+            y = torch.zeros((M, Nn), device=dev)
+            _lib.check(L.dispu_linear_bf16x3(M, K, Nn, tx.data_ptr(), K, planes.data_ptr(), tb.data_ptr(), 1, y.data_ptr(), Nn, t1.data_ptr(), Nn,
+                                             None, 0, st), "dispu_linear_bf16x3")
+            ys[which] = y
+        torch.cuda.synchronize()
+    finally:
+        L.dispu_debug_x3_kernel(1)
+    assert torch.equal(ys[0], ys[1])
+    want = np.maximum(x.astype(np.float64) @ w.astype(np.float64) + b, 0) + r1
+    scale = (np.abs(x).astype(np.float64) @ np.abs(w).astype(np.float64)).max()
+    assert np.abs(N(ys[0]) - want).max() / scale <= 4e-7
+
+
 def test_generator_split_bf16_mode_within_tolerance(bench_setup, dev):
     """Generator.split_bf16 (exploratory): after_conv through the split-bf16 GEMM.  coarse (decided before the refinement branch)
     stays bit-exact, fine stays within the 1e-5 tolerance against the oracle and within 2e-6 of the strict-fp32 run."""

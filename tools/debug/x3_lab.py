@@ -29,7 +29,7 @@ def run():
                                  None, C.c_long(0), None, C.c_long(0), vp(st))
 L.dispu_debug_x3_kernel.restype = None
 outs = {}
-for which, name in (((1, "wave-specialised (round 4)"),) if not sys.argv[1:] else ()) + ((0, "streaming (round 6)"),):
+for which, name in (((1, "wave-specialised (round 4, default)"),) if not sys.argv[1:] else ()) + ((0, "streaming (round 6)"),):
     L.dispu_debug_x3_kernel(which)
     for _ in range(5):
         assert run() == 0
