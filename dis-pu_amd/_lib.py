@@ -104,6 +104,7 @@ SIGNATURES = {
     "dispu_debug_x3_kernel": (None, [_i]),
     "dispu_linear_tn_scratch_floats": (_l, [_i, _i, _i, _i]),
     "dispu_linear_tn": (_i, [_i, _i, _i, _i, _vp, _l, _l, _vp, _l, _l, _vp, _l, _l, _i, _vp, _vp, _l, _vp]),
+    "dispu_ps_local_grad": (_i, [_l, _i] + [_vp] * 3 + [_l] + [_vp] * 14),
     "dispu_tn_defer": (_i, [_vp]),
     "dispu_tn_reduce_grouped": (_i, [_i, _vp, _vp, _vp]),
     "dispu_act_bias_grad_scratch_floats": (_l, [_l, _i]),

@@ -156,6 +156,10 @@ class Trainer(object):
         # undone (dispu_tn_defer) and a stream's descriptors run as ONE launch when that stream is joined (_join, _bucket_point): ~20
         # launches of 4 - 25 us per step become 3.  False: every product reduces itself (A/B; bit-identical)
         self.group_reduce = True
+        # the local cell's backward (feature x weight gradient, conv1's dX, conv0's gather) as ONE recomputing launch (csrc/ps_local_bwd.hip,
+        # fp32 storage only): h1 / dz0 / wv / the inverted neighbour graph never exist in HBM.  Correct and tested, but 40 us slower per 8-patch
+        # step than the five-launch path (1.595 vs 1.555 ms): OFF by default
+        self.fused_local_bwd = False
         self._rg = {}                      # stream pointer -> [host descriptor array, entries pending, stream c_void_p]
         self._rg_dev = {}                  # descriptor table bytes -> device copy (content-addressed: tapes keep pointing at theirs)
         self.tail_on_chain = True  # the first dense block's weight gradients (the LAST work of the backward) stay on the chain's stream: no cross-stream hop in front of Adam
@@ -940,18 +944,26 @@ class Trainer(object):
         P = self.P
         ps = "refine/PointShuffle/"
         coarse = ws["coarse"].view(rm, 3)
-        _lib.check(L.dispu_knn_invert(B, M, k, _p(ws["psidx"]), _p(ws["inv_off"]), _p(ws["inv"]), self.st), "knn_invert")
+        fused = self._fused_local_bwd_ok(ws)
+        if not fused:
+            _lib.check(L.dispu_knn_invert(B, M, k, _p(ws["psidx"]), _p(ws["inv_off"]), _p(ws["inv"]), self.st), "knn_invert")
         if ws["h0"].dtype == torch.bfloat16:
             _lib.check(L.dispu_ps_gather_sub_relu_bf16(rm, M, k, 128, _p(ws["psidx"]), _p(ws["gm"]), 128, _p(ws["am"]), 128, _p(ws["h0"]), 128,
                                                        self.st), "gather_sub_relu_bf16")
         else:
             _lib.check(L.dispu_ps_gather_sub_relu(rm, M, k, 128, _p(ws["psidx"]), _p(ws["gm"]), 128, _p(ws["am"]), 128, _p(ws["h0"]), 128, self.st),
                        "gather_sub_relu")
-        self._lin(ws["h0"], 0, 128, ps + "conv1", 1, ws["h1"], 0, 128)
-        _lib.check(L.dispu_ps_weight_net(rm, M, k, 16, _p(ws["psidx"]), _p(coarse), _p(P[ps + "weight_net/wconv0/weights"]),
-                                         _p(P[ps + "weight_net/wconv0/biases"]), _p(ws["bn_scale"]), _p(ws["bn_shift"]), _p(ws["wv"]), self.st),
-                   "weight_net")
+        if not fused:                                    # (fused backward: only h0 is needed in HBM -- the dW1 = h0^T . dz1 product reads it)
+            self._lin(ws["h0"], 0, 128, ps + "conv1", 1, ws["h1"], 0, 128)
+            _lib.check(L.dispu_ps_weight_net(rm, M, k, 16, _p(ws["psidx"]), _p(coarse), _p(P[ps + "weight_net/wconv0/weights"]),
+                                             _p(P[ps + "weight_net/wconv0/biases"]), _p(ws["bn_scale"]), _p(ws["bn_shift"]), _p(ws["wv"]), self.st),
+                       "weight_net")
         self._stash_ready = True
+
+    def _fused_local_bwd_ok(self, ws):
+        """the one-launch backward of the local cell: fp32 pair-tensor storage, whole 8-point groups, transposed weight copies at hand."""
+        return (self.fused_local_bwd and ws["h0"].dtype == torch.float32 and ws["h0"].shape[0] % 64 == 0 and self.use_wt
+                and ("refine/PointShuffle/conv1/weights" in self.PT))
 
     # -------------------------------------------------------------------------------------------------- loss ----
     def _chamfer(self, pred, gt, radius, coef, dpred, slot):
@@ -1119,9 +1131,18 @@ class Trainer(object):
         self._flush(prio=0)
         if not (self._sched & 2):
             self._merge(2)                               # h0 / h1 / wv / the inverted graph are in place
-        _lib.check(L.dispu_ps_point_matmul_grad_relu_s(rm, k, 128, 16, _p(ws["h1"]), 128, _p(ws["wv"]), _p(ws["dhp"]), 2048, _p(ws["dz1"]),
-                                                       128, _p(ws["dwv"]), 1 if ws["h1"].dtype == torch.bfloat16 else 0, self.st),
-                   "point_matmul_grad")
+        fused_lb = self._fused_local_bwd_ok(ws)
+        if fused_lb:
+            # one launch: dwv, dz1 (for the side-stream dW1), dG (atomics into the zeroed buffer) and -dA; h1 / dz0 / wv stay on chip
+            self._zero(ws["dG"])
+            _lib.check(L.dispu_ps_local_grad(rm, M, _p(ws["psidx"]), _p(coarse), _p(ws["gm"]), 128, _p(ws["am"]), _p(P[ps + "conv1/weights"]),
+                                             _p(P[ps + "conv1/biases"]), _p(self.PT[ps + "conv1/weights"]), _p(P[ps + "weight_net/wconv0/weights"]),
+                                             _p(P[ps + "weight_net/wconv0/biases"]), _p(ws["bn_scale"]), _p(ws["bn_shift"]), _p(ws["dhp"]),
+                                             _p(ws["dz1"]), _p(ws["dwv"]), _p(ws["dG"]), _p(ws["dAneg"]), self.st), "ps_local_grad")
+        else:
+            _lib.check(L.dispu_ps_point_matmul_grad_relu_s(rm, k, 128, 16, _p(ws["h1"]), 128, _p(ws["wv"]), _p(ws["dhp"]), 2048, _p(ws["dz1"]),
+                                                           128, _p(ws["dwv"]), 1 if ws["h1"].dtype == torch.bfloat16 else 0, self.st),
+                       "point_matmul_grad")
         # the weight net's backward (dwv -> BatchNorm -> 3 -> 16 conv -> atomics into dcoarse) next to the conv1 / conv0 gradients
         def wnet_backward():
             ww, bw = P[ps + "weight_net/wconv0/weights"], P[ps + "weight_net/wconv0/biases"]
@@ -1130,11 +1151,14 @@ class Trainer(object):
                                             _p(G[ps + "weight_net/wconv0/biases"]), _p(G[BN + "gamma"]), _p(G[BN + "beta"]), _p(dcoarse),
                                             _p(ws["bn_sums"]), _p(self._bn_scratch), self._bn_scratch.numel() * 8, self.st), "ps_wnet_grad")
         self._defer_branch(2, wnet_backward)
-        self._lin_bwd(ws["h0"], 0, 128, ps + "conv1", 128, ws["dz1"], 0, ws["dz0"])          # dz0 holds dh0: conv0's relu' rides in the gather
-        # conv0 in its per-source-point form: dh0 * (G[j] - A[i] > 0) -> dG (gather through the inverted graph), -dA; then [B*M, 128] products
-        _lib.check(L.dispu_ps_conv0_gather_grad_s(rm, M, k, 128, _p(ws["psidx"]), _p(ws["inv_off"]), _p(ws["inv"]), _p(ws["dz0"]), 128,
-                                                  1 if ws["dz0"].dtype == torch.bfloat16 else 0, _p(ws["gm"]), 128, _p(ws["am"]), 128,
-                                                  _p(ws["dG"]), 128, _p(ws["dAneg"]), 128, self.st), "conv0_gather_grad")
+        if fused_lb:
+            self._lin_bwd(ws["h0"], 0, 128, ps + "conv1", 128, ws["dz1"], 0, None)            # dW1, db1 only: the dX product ran inside the fused launch
+        else:
+            self._lin_bwd(ws["h0"], 0, 128, ps + "conv1", 128, ws["dz1"], 0, ws["dz0"])      # dz0 holds dh0: conv0's relu' rides in the gather
+            # conv0 in its per-source-point form: dh0 * (G[j] - A[i] > 0) -> dG (gather through the inverted graph), -dA; then [B*M, 128] products
+            _lib.check(L.dispu_ps_conv0_gather_grad_s(rm, M, k, 128, _p(ws["psidx"]), _p(ws["inv_off"]), _p(ws["inv"]), _p(ws["dz0"]), 128,
+                                                      1 if ws["dz0"].dtype == torch.bfloat16 else 0, _p(ws["gm"]), 128, _p(ws["am"]), 128,
+                                                      _p(ws["dG"]), 128, _p(ws["dAneg"]), 128, self.st), "conv0_gather_grad")
         # the main queue now holds after_conv's dX, the feature x weight gradient, conv1's dX and the gather (~0.35 ms of kernels at 8
         # patches): time to submit the side work that piled up behind them (five weight gradients, the non-local and skip branches)
         self._flush()

@@ -522,6 +522,15 @@ int dispu_mlp_chain_grad(long rows, int K0, int N1, int N2, const float* dZ, lon
                          const float* Y1, long ldy1, const float* R, long ldr, const float* R2, long ldr2, float* D3, long ldd3,
                          float* D2, long ldd2, float* D1, long ldd1, const float* Ma, const float* Mb, const float* Mc, long ldm, float* Da, float* Db,
                          float* Dc, long ldd0, void* stream);
+/* Backward of dispu_ps_local in one recomputing launch (csrc/ps_local_bwd.hip; what TF autodiff derives from Common/ops.py:1055-1067):
+ * given dF [npoints, 2048] = d loss / d F', per 8-point group h0 = relu(G[j] - A[i]) and h1 = relu(h0.W1 + b1) are rebuilt on chip with the
+ * forward's arithmetic and   dwv[(i,s),t] = sum_c dF[i,c,t] h1[(i,s),c]   (-> dispu_ps_wnet_grad),
+ * dz1 = (sum_t dF[i,c,t] wv[(i,s),t]) [h1 > 0]  [npoints*16, 128]  (-> the dW1 = h0^T.dz1 product),   dz0 = (dz1.W1^T) [h0 > 0],
+ * dG[j] += dz0[(i,s)] (float atomics: dG must be ZERO on entry),   dAneg[i] = -sum_s dz0[(i,s)].
+ * W1t = W1^T row-major [128, 128]; scale / shift = the weight net's folded BatchNorm of this step; k = 16, c = 128, t = 16. */
+int dispu_ps_local_grad(long npoints, int n_per_cloud, const int* idx, const float* xyz, const float* Gm, long ldg, const float* Am,
+                        const float* W1, const float* b1, const float* W1t, const float* Ww, const float* bw, const float* scale,
+                        const float* shift, const float* dF, float* dz1, float* dwv, float* dG, float* dAneg, void* stream);
 /* o_i = dY * (Y_i > 0), i = 1..3: the gradients of sum = relu(after_conv) + relu(skip) + relu(non-local) (ops.py:1072-1075). */
 int dispu_mask3(long rows, int n, const float* dY, long lddy, const float* Y1, long ld1, const float* Y2, long ld2, const float* Y3,
                 long ld3, float* o1, float* o2, float* o3, long ldo, void* stream);

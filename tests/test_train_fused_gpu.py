@@ -610,3 +610,80 @@ def test_trainer_grouped_reductions_equal_single_ones(dev, dtype):
             assert np.isfinite(float(terms["pu_loss"]))
     scale = float(g[False].abs().max())
     assert float((g[True] - g[False]).abs().max()) <= 5e-6 * scale
+
+
+# ---------------------------------------------------------------------------------- round 6: local cell backward in one launch ----
+@pytest.mark.parametrize("B,n", [(2, 256), (3, 64), (1, 1024)])
+def test_ps_local_grad_equals_the_five_launch_path(dev, L, B, n):
+    """dispu_ps_local_grad (csrc/ps_local_bwd.hip) against the launches it replaces, on the same inputs: gather_sub_relu -> dispu_linear
+    (conv1) -> weight_net -> ps_point_matmul_grad_relu -> dispu_linear(transb) -> knn_invert + ps_conv0_gather_grad.  dz1 (recomputed conv1,
+    its ReLU mask and the t-ascending contraction are the same arithmetic) bit-identical; dwv / dAneg re-associated sums and dG float atomics:
+    1e-5 of the largest entry."""
+    rng = np.random.default_rng(B * 1000 + n)
+    k, c, t = 16, 128, 16
+    xyz, idx = _cloud(rng, B, n, k)
+    rows = B * n
+    Gm = rng.standard_normal((rows, c)).astype(np.float32)
+    Am = rng.standard_normal((rows, c)).astype(np.float32)
+    W1 = (rng.standard_normal((c, c)) * 0.15).astype(np.float32)
+    b1 = (rng.standard_normal(c) * 0.1).astype(np.float32)
+    Ww, bw = rng.standard_normal((3, t)).astype(np.float32), rng.standard_normal(t).astype(np.float32)
+    sc, sh = (1 + 0.1 * rng.standard_normal(t)).astype(np.float32), (0.1 * rng.standard_normal(t)).astype(np.float32)
+    dF = rng.standard_normal((rows, c * t)).astype(np.float32)
+    lib, st = L.lib(), L.stream_ptr(dev)
+    di, dx = dv(idx, dev, torch.int32), dv(xyz.reshape(rows, 3), dev)
+    tG, tA, tW1, tb1, tW1t = dv(Gm, dev), dv(Am, dev), dv(W1, dev), dv(b1, dev), dv(np.ascontiguousarray(W1.T), dev)
+    tWw, tbw, tsc, tsh, tdF = dv(Ww, dev), dv(bw, dev), dv(sc, dev), dv(sh, dev), dv(dF, dev)
+    E = lambda r, w: torch.empty((r, w), dtype=torch.float32, device=dev)
+    # the five-launch path
+    h0, h1, wv, dz1, dwv, dz0 = E(rows * k, c), E(rows * k, c), E(rows * k, t), E(rows * k, c), E(rows * k, t), E(rows * k, c)
+    L.check(lib.dispu_ps_gather_sub_relu(rows, n, k, c, p(di), p(tG), c, p(tA), c, p(h0), c, st), "gather_sub_relu")
+    L.check(lib.dispu_linear(1, rows * k, c, c, p(h0), c, 0, p(tW1), c, 0, 0, p(tb1), 1, p(h1), c, 0, None, 0, 0, None, 0, 0, st), "conv1")
+    L.check(lib.dispu_ps_weight_net(rows, n, k, t, p(di), p(dx), p(tWw), p(tbw), p(tsc), p(tsh), p(wv), st), "weight_net")
+    L.check(lib.dispu_ps_point_matmul_grad_relu(rows, k, c, t, p(h1), c, p(wv), p(tdF), c * t, p(dz1), c, p(dwv), st), "point_matmul_grad_relu")
+    L.check(lib.dispu_linear(1, rows * k, c, c, p(dz1), c, 0, p(tW1), c, 0, 1, None, 0, p(dz0), c, 0, None, 0, 0, None, 0, 0, st), "conv1 dX")
+    off = torch.empty((B, n + 1), dtype=torch.int32, device=dev)
+    inv = torch.empty((B, n * k), dtype=torch.int32, device=dev)
+    L.check(lib.dispu_knn_invert(B, n, k, p(di), p(off), p(inv), st), "knn_invert")
+    dG, dA = E(rows, c), E(rows, c)
+    L.check(lib.dispu_ps_conv0_gather_grad(rows, n, k, c, p(di), p(off), p(inv), p(dz0), c, p(tG), c, p(tA), c, p(dG), c, p(dA), c, st), "gather_grad")
+    # one launch
+    fz1, fwv, fG, fA = E(rows * k, c), E(rows * k, t), torch.zeros((rows, c), dtype=torch.float32, device=dev), E(rows, c)
+    L.check(lib.dispu_ps_local_grad(rows, n, p(di), p(dx), p(tG), c, p(tA), p(tW1), p(tb1), p(tW1t), p(tWw), p(tbw), p(tsc), p(tsh), p(tdF),
+                                    p(fz1), p(fwv), p(fG), p(fA), st), "ps_local_grad")
+    torch.cuda.synchronize()
+    _KEEP.extend([h0, h1, wv, dz1, dwv, dz0, off, inv, dG, dA, fz1, fwv, fG, fA])
+    assert torch.equal(fz1, dz1), "dz1 differs from the unfused path"
+    close(N_(fwv), N_(dwv).astype(np.float64), 1e-5, "dwv")
+    close(N_(fG), N_(dG).astype(np.float64), 1e-5, "dG")
+    close(N_(fA), N_(dA).astype(np.float64), 1e-5, "dAneg")
+    assert lib.dispu_ps_local_grad(rows - 2, n, p(di), p(dx), p(tG), c, p(tA), p(tW1), p(tb1), p(tW1t), p(tWw), p(tbw), p(tsc), p(tsh), p(tdF),
+                                   p(fz1), p(fwv), p(fG), p(fA), st) != 0           # whole 4-point groups only
+
+
+def test_trainer_fused_local_backward_equals_the_unfused_one(dev):
+    """Trainer.fused_local_bwd against the five-launch path inside the real step: the same gradients up to float atomics / re-associated
+    sums (1e-5 of the largest gradient), and the side effects the unfused path has no more (h1, wv, the inverted graph) are not needed."""
+    from dispu_amd import synth
+    from dispu_amd.params import init_params
+    from dispu_amd.train import Trainer
+    P = init_params(1234)
+    x, gt = synth.patch_with_gt(8, 256, 1024, seed=17)
+    x, gt = torch.from_numpy(x).to(dev), torch.from_numpy(gt).to(dev)
+    radius = torch.ones(8, device=dev)
+    g = {}
+    for on in (False, True):
+        tr = Trainer(params=P, device=dev)
+        tr.fused_local_bwd = on
+        tr.zero_grad()
+        tr.forward(x)
+        tr.loss_backward(gt, radius)
+        tr.backward()
+        torch.cuda.synchronize()
+        g[on] = tr.flat_g.clone()
+        if on:
+            for _ in range(2):
+                terms = tr.train_step(x, gt, radius)
+            assert np.isfinite(float(terms["pu_loss"]))
+    scale = float(g[False].abs().max())
+    assert float((g[True] - g[False]).abs().max()) <= 1e-5 * scale
