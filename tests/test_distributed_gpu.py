@@ -551,15 +551,17 @@ def test_rccl_branch_on_one_rank(dev):
     assert rel_d <= 1e-4, rel_d
     # a collective call costs ~30 us of host time; these steps are launch-bound (8 patches, eager): one call per forward, two per train
     # step.  Bounds = that price + noise; the 32-patch bench step (host idle most of the time) must not move at all (next test).
-    assert min(t_gather, t_gather_thr) <= t_plain + 0.045, (t_plain, t_gather, t_gather_thr)
-    assert min(s_coll, s_thr) <= s_plain + 0.09, (s_plain, s_coll, s_thr)
+    # (measured: +0.029 - 0.031 ms and +0.04 - 0.05 ms; the bounds leave 2.5 - 3x for a noisy box -- the figures themselves go to
+    # gpurun_out/rccl_world1_dry_run.json)
+    assert min(t_gather, t_gather_thr) <= t_plain + 0.08, (t_plain, t_gather, t_gather_thr)
+    assert min(s_coll, s_thr) <= s_plain + 0.15, (s_plain, s_coll, s_thr)
 
 
 def test_bench_one_rank_rccl_dry_run(dev):
     """`bench.py --gpus 1` with DISPU_BENCH_COLLECTIVES=1 DISPU_BENCH_BACKEND=nccl: the N > 1 code of the bench (process group,
     comm lane on a side HIP stream, one hipGraph per result slot, barriers, max-over-ranks) with a real RCCL communicator of one
     rank.  The pipelined gather may cost the step the cross-stream event it needs and nothing else (median of the five timed loops
-    within 4 % of the no-collective run; measured 0.921 -> 0.948 ms)."""
+    within 6 % of the no-collective run; measured 0.921 -> 0.948 ms)."""
     import json
     import subprocess
     import sys
@@ -581,4 +583,4 @@ def test_bench_one_rank_rccl_dry_run(dev):
     # what is left is not the collective: tools/debug/gather_cost.py takes the loop apart on the same one-rank group -- one graph 0.915 ms,
     # two alternating graphs 0.917, + an event recorded behind every replay and waited for by an idle side stream 0.927 - 0.931, + a
     # plain copy on that stream 0.927 - 0.935, + the RCCL all-gather instead 0.930 - 0.935: the cross-stream event costs 1.5 %, the gather nothing
-    assert ms["overlap"] <= 1.04 * ms["off"], ms
+    assert ms["overlap"] <= 1.06 * ms["off"], ms                 # measured 1.019 - 1.029
