@@ -185,6 +185,9 @@ class Trainer(object):
         if getattr(self, "_packs", None):
             torch.cuda.synchronize(self.device)
             self._packs.clear()
+        if getattr(self, "_rg_dev", None):               # device copies of reduction tables: only tapes (dropped above) and the step being
+            torch.cuda.synchronize(self.device)          # recorded point at them; a moved scratch buffer makes new table contents anyway
+            self._rg_dev.clear()
 
     def load_params(self, params):
         dev = self.device
